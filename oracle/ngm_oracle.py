@@ -1,0 +1,432 @@
+"""CPU oracle for the per-field NeRF render/train hot path of neural_graph_mapping.
+
+*** TEST INFRASTRUCTURE -- NOT PRODUCT CODE ***
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product path (``neural_graph_mapping_amd``)
+never routes through it; it fails loudly when the HIP library is missing.
+
+This is a from-scratch restatement (plain PyTorch on CPU, fp32 by default, fp64
+on request) of the reference algorithm.  Every function cites the reference
+file:line it follows (paths relative to /root/reference/src/neural_graph_mapping,
+``rm.py`` = ``run_mapping.py``).  Randomness is an *input* (``u_coarse`` /
+``u_guided`` are the ``torch.rand`` draws of camera.py:274) so that results can
+be compared sample-for-sample.
+
+Parity pin: ``tests/test_oracle_golden.py`` checks every function below against
+fixtures generated from the real reference (``tests/golden/make_golden.py``);
+``tests/test_oracle_vs_reference.py`` additionally compares against the live
+reference whenever /root/reference is present.  Hash (permutohedral) encoding
+is **parity unpinned**: its arithmetic lives in an un-vendored CUDA dependency
+(permutohedral_encoding @ bf445adb, pyproject.toml:21).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+# ----------------------------------------------------------------------------------------
+# specs
+# ----------------------------------------------------------------------------------------
+
+
+@dataclass
+class CameraSpec:
+    """Pinhole intrinsics; principal point given for pixel_center 0 (camera.py:22-80,98-116).
+
+    The reference stores cx at pixel centre 0.5 (camera.py:69-70) and converts back with
+    get_pinhole_camera_parameters(0.0) inside ijs_to_directions (camera.py:188), i.e. the
+    effective principal point is ``cx_cfg - pixel_center_cfg``.
+    """
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+    @staticmethod
+    def from_config(width, height, fx, fy, cx, cy, pixel_center=0.0, **_):
+        return CameraSpec(width, height, fx, fy, cx - pixel_center, cy - pixel_center)
+
+
+@dataclass
+class FieldSpec:
+    """Architecture of one NeuralField (models.py:69-128)."""
+    encoding: str = "fourier"          # "fourier" | "nerf" | "none"
+    dim_enc: int = 64                  # encoding width D
+    raw_coords: bool = True            # Fourier: cat(x, sin(Wx)) (positional_encodings.py:208-212)
+    num_octaves: int = 8               # NeRF octaves (positional_encodings.py:230)
+    start_octave: int = 0
+    num_layers: int = 2                # hidden layers L
+    dim_hidden: Optional[int] = None   # H; None -> D (models.py:99-100)
+    dim_out: int = 4
+
+    def __post_init__(self):
+        if self.encoding == "nerf":
+            self.dim_enc = 3 * self.num_octaves * 2
+        if self.dim_hidden is None:
+            self.dim_hidden = self.dim_enc
+
+    def layer_dims(self):
+        dims_in = [self.dim_enc] + [self.dim_hidden] * self.num_layers
+        dims_out = [self.dim_hidden] * self.num_layers + [self.dim_out]
+        return list(zip(dims_in, dims_out))
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Names as in the reference's stacked state dict."""
+        shapes = {}
+        if self.encoding == "fourier":
+            n = self.dim_enc - 3 if self.raw_coords else self.dim_enc
+            shapes["_encoding._linear.weight"] = (n, 3)
+        for i, (di, do) in enumerate(self.layer_dims()):
+            shapes[f"_linears.{i}.weight"] = (do, di)
+            shapes[f"_linears.{i}.bias"] = (do,)
+        return shapes
+
+
+@dataclass
+class RenderSpec:
+    """Renderer constants (rm.py:116-220; defaults of config/neural_graph_map.yaml)."""
+    geometry_mode: str = "nrgbd"
+    geometry_factor: float = 20.0
+    color_factor: float = 1.0
+    truncation_distance: float = 0.1
+    range_depth_guided: Optional[float] = None     # None -> truncation (rm.py:169-170)
+    num_samples_coarse: int = 8
+    num_samples_depth_guided: int = 16
+    field_radius: float = 1.0
+    scale_mode: str = "unit_cube"
+    freespace_weight: float = 40.0
+    tsdf_weight: float = 50.0
+    termination_weight: float = 0.0
+    photometric_weight: float = 1.0
+    depth_weight: float = 1.0
+    huber_delta: float = 0.05                       # losses.py:63
+
+    def __post_init__(self):
+        if self.range_depth_guided is None:
+            self.range_depth_guided = self.truncation_distance
+
+
+# ----------------------------------------------------------------------------------------
+# ray sampler (camera.py:186-292, rm.py:513-547)
+# ----------------------------------------------------------------------------------------
+
+
+def ijs_to_directions(ijs: torch.Tensor, cam: CameraSpec, dtype=torch.float32) -> torch.Tensor:
+    """Unit view directions, OpenGL convention (camera.py:186-203)."""
+    dx = (ijs[..., 1] - cam.cx) / cam.fx
+    dy = -((ijs[..., 0] - cam.cy) / cam.fy)
+    dz = -torch.ones_like(dx)
+    d = torch.stack([dx, dy, dz], -1).to(dtype)
+    return torch.nn.functional.normalize(d, dim=-1)
+
+
+def stratified_distances(near, far, n: int, u):
+    """``t_k = (delta*u_k + lin_k*(far-near)) + near`` (camera.py:269-276)."""
+    delta = (far - near) / n
+    lin = torch.linspace(0.0, 1.0, steps=n + 1, dtype=near.dtype)
+    bounds = lin[None] * (far - near)[..., None]
+    return (delta[..., None] * u + bounds[..., :-1]) + near[..., None]
+
+
+def sample_rays(ijs, cam: CameraSpec, near, far, gt, spec: RenderSpec, u_coarse, u_guided=None,
+                num_samples=None):
+    """Coarse stratum + depth-guided stratum, merged ascending (rm.py:513-545).
+
+    Returns points_cam (...,S,3), distances (...,S) sorted, dirs (...,3)."""
+    n_c = spec.num_samples_coarse if num_samples is None else num_samples
+    dirs = ijs_to_directions(ijs, cam, near.dtype)
+    t = stratified_distances(near, far, n_c, u_coarse)
+    n_g = spec.num_samples_depth_guided
+    if gt is not None and n_g > 0 and u_guided is not None:
+        invalid = (gt == 0.0) | (near > gt) | (far < gt)            # rm.py:522-526
+        g_near = torch.where(invalid, near, gt - spec.range_depth_guided)
+        g_far = torch.where(invalid, far, gt + spec.range_depth_guided)
+        t_g = stratified_distances(g_near, g_far, n_g, u_guided)
+        t = torch.sort(torch.cat([t, t_g], -1), dim=-1)[0]          # rm.py:538-545
+    pts = dirs.unsqueeze(-2) * t.unsqueeze(-1)                      # camera.py:291
+    return pts, t, dirs
+
+
+def transform_points(p, T):
+    """p_w = R p + t (utils.py:276-286, non-inverse branch)."""
+    return torch.einsum("...dk,...k->...d", T[..., :3, :3], p) + T[..., :3, 3]
+
+
+# ----------------------------------------------------------------------------------------
+# world -> field-local (models.py:329-339, 278-285; pytorch3d quaternion math restated)
+# ----------------------------------------------------------------------------------------
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz,
+                        aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx,
+                        aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def quat_invert(q):
+    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+
+
+def quat_apply(q, p):
+    p4 = torch.cat((p.new_zeros(p.shape[:-1] + (1,)), p), -1)
+    return quat_mul(quat_mul(q, p4), quat_invert(q))[..., 1:]
+
+
+def scale_local(p, radius, scale_mode):
+    if scale_mode == "unit_cube":
+        return p / (2 * radius) + 0.5
+    if scale_mode == "unit_ball":
+        return p / radius
+    if scale_mode == "no":
+        return p
+    raise NotImplementedError(scale_mode)
+
+
+def world_to_field(p_world, pos, quat, radius, scale_mode):
+    """p_world (F,P,3), pos (F,3), quat (F,4) real-first -> local scaled (F,P,3)."""
+    local = p_world - pos.unsqueeze(-2)
+    local = quat_apply(quat_invert(quat).unsqueeze(-2), local)
+    return scale_local(local, radius, scale_mode)
+
+
+# ----------------------------------------------------------------------------------------
+# encodings + MLP (positional_encodings.py:164-276, models.py:143-182)
+# ----------------------------------------------------------------------------------------
+
+
+def encode(x, params, fs: FieldSpec):
+    """x (F,P,3) -> (F,P,D)."""
+    if fs.encoding == "fourier":
+        W = params["_encoding._linear.weight"]                      # (F, D-3, 3)
+        feat = torch.sin(torch.einsum("fpc,fdc->fpd", x, W))
+        return torch.cat((x, feat), -1) if fs.raw_coords else feat
+    if fs.encoding == "nerf":
+        octs = torch.arange(fs.start_octave, fs.start_octave + fs.num_octaves, dtype=x.dtype)
+        mult = 2 ** octs * math.pi
+        sp = x.unsqueeze(-1) * mult                                 # (F,P,3,O)
+        lead = x.shape[:-1]
+        return torch.cat((torch.sin(sp).reshape(*lead, -1), torch.cos(sp).reshape(*lead, -1)), -1)
+    if fs.encoding == "none":
+        return x
+    raise NotImplementedError(fs.encoding)
+
+
+def field_mlp(h, params, fs: FieldSpec):
+    """skip_mode 'no' (models.py:148-157): relu on all but the last layer."""
+    n = fs.num_layers
+    for i in range(n + 1):
+        W = params[f"_linears.{i}.weight"]
+        b = params[f"_linears.{i}.bias"]
+        h = torch.einsum("fpi,foi->fpo", h, W) + b.unsqueeze(-2)
+        if i < n:
+            h = torch.relu(h)
+    return h
+
+
+def field_forward_local(x_local, params, fs: FieldSpec):
+    return field_mlp(encode(x_local, params, fs), params, fs)
+
+
+def field_set_forward_vmap(query_points, pos, quat, params, fs: FieldSpec, radius=1.0,
+                           scale_mode="unit_cube"):
+    """NeuralFieldSet.forward(use_vmap=True) (models.py:329-345)."""
+    if pos is not None:
+        x = world_to_field(query_points, pos, quat, radius, scale_mode)
+    else:
+        x = scale_local(query_points, radius, scale_mode)
+    return field_forward_local(x, params, fs)
+
+
+def field_set_forward_knn(points, pos, quat, params, fs: FieldSpec, radius=1.0,
+                          scale_mode="unit_cube", num_knn=2, distance_factor=10.0,
+                          outside_value=1.0):
+    """NeuralFieldSet.forward(use_vmap=False) (models.py:347-405). points (P,3)."""
+    P = points.shape[0]
+    K = min(num_knn, pos.shape[0])
+    d2 = ((points[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+    d2k, idx = torch.topk(d2, K, dim=-1, largest=False, sorted=True)
+    dist = torch.sqrt(d2k)
+    inside = dist[:, 0] < radius
+    out = torch.full((P, fs.dim_out), outside_value, dtype=points.dtype)
+    if inside.any():
+        pi, di, ii = points[inside], dist[inside], idx[inside]
+        w = torch.softmax(-distance_factor * di, dim=-1)
+        acc = torch.zeros(pi.shape[0], fs.dim_out, dtype=points.dtype)
+        for k in range(K):
+            fk = ii[:, k]
+            loc = quat_apply(quat_invert(quat[fk]), pi - pos[fk])
+            loc = scale_local(loc, radius, scale_mode)
+            # evaluate each point with its own field's parameters
+            pk = {n: v[fk] for n, v in params.items()}
+            o = field_forward_local(loc.unsqueeze(1), pk, fs).squeeze(1)
+            acc = acc + w[:, k:k + 1] * o
+        out[inside] = acc
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# volume renderer (rm.py:709-799) and render_ijs (rm.py:439-666)
+# ----------------------------------------------------------------------------------------
+
+
+def occupancy_probs(mode, geoms, dists, geometry_factor, neus_isds=None):
+    if mode == "density":                                           # rm.py:746-749
+        deltas = dists[..., 1:] - dists[..., :-1]
+        return 1 - torch.exp(-deltas * torch.relu(geoms[..., :-1])), -1
+    if mode == "occupancy":                                         # rm.py:750-752
+        return torch.sigmoid(geometry_factor * geoms), None
+    if mode == "neus":                                              # rm.py:753-758
+        tno = torch.sigmoid(neus_isds * geometry_factor * geoms)
+        return torch.clamp_min((tno[..., :-1] - tno[..., 1:]) / (tno[..., :-1] + 1e-5), 0), -1
+    if mode == "nrgbd":                                             # rm.py:759-762
+        x = geometry_factor * geoms
+        return 4 * torch.sigmoid(x) * torch.sigmoid(-x), None
+    raise NotImplementedError(mode)
+
+
+def quadrature(mode, colors, geoms, dists, depths, geometry_factor=20.0, neus_isds=None):
+    """Returns colors(...,3), depth, color_var(...,3), depth_var, term_prob, weights."""
+    occ, last = occupancy_probs(mode, geoms, dists, geometry_factor, neus_isds)
+    lead = geoms.shape[:-1]
+    T = torch.cat([occ.new_ones(*lead, 1), torch.cumprod(1 - occ[..., :-1], -1)], -1)
+    w = occ * T
+    bg = 1 - w.sum(-1)
+    c = colors[..., :last, :]
+    d = depths[..., :last]
+    C = (c * w[..., None]).sum(-2)
+    D = (d * w).sum(-1)
+    Cv = (w[..., None] * (C.unsqueeze(-2) - c) ** 2).sum(-2)
+    Dv = (w * (D[..., None] - d) ** 2).sum(-1)
+    return C, D, Cv, Dv, 1.0 - bg, w
+
+
+def render_ijs(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs: RenderSpec,
+               near, far, gt=None, u_coarse=None, u_guided=None, num_samples=None,
+               neus_isds=None, return_samples=False):
+    """Training-style render (use_vmap=True) of rm.py:439-666.
+
+    ijs (F,R,2), c2ws (F,R,4,4) or (4,4), pos (F,3), quat (F,4), near/far/gt (F,R).
+    Returns a dict with the Prediction fields (rm.py:59-69)."""
+    if c2ws.dim() == 2:
+        c2ws = c2ws[None, None]
+    pts_cam, t, dirs = sample_rays(ijs, cam, near, far, gt, rs, u_coarse, u_guided, num_samples)
+    pts_w = transform_points(pts_cam, c2ws.unsqueeze(-3))
+    F, R, S = t.shape
+    out = field_set_forward_vmap(pts_w.reshape(F, R * S, 3), pos, quat, params, fs,
+                                 rs.field_radius, rs.scale_mode).view(F, R, S, -1)
+    colors = rs.color_factor * out[..., :3]
+    geoms = out[..., 3]
+    depths = -pts_cam[..., 2]
+    tau = rs.truncation_distance
+    fs_vec = ts_vec = fs_mask = ts_mask = None
+    if rs.freespace_weight != 0.0 and gt is not None:               # rm.py:624-630
+        fs_mask = t < (gt[..., None] - tau) * (gt[..., None] != 0.0)
+        fs_vec = geoms[fs_mask] * tau
+    if rs.tsdf_weight != 0.0 and gt is not None:                    # rm.py:632-639
+        deltas = gt[..., None] - t
+        ts_mask = (deltas.abs() < tau) & (gt[..., None] != 0.0)
+        ts_vec = geoms[ts_mask] * tau - deltas[ts_mask]
+    C, D, Cv, Dv, term, w = quadrature(rs.geometry_mode, colors, geoms, t, depths,
+                                       rs.geometry_factor, neus_isds)
+    pred = dict(rgbds=torch.cat([C, D[..., None]], -1), color_vars=Cv, depth_vars=Dv,
+                term_probs=term, freespace_geometry=fs_vec, tsdf_residuals=ts_vec)
+    if return_samples:
+        pred.update(sample_distances=t, sample_outs=out, sample_weights=w, points_world=pts_w,
+                    freespace_mask=fs_mask, tsdf_mask=ts_mask)
+    return pred
+
+
+# ----------------------------------------------------------------------------------------
+# losses (rm.py:1769-1872, losses.py:10-75)
+# ----------------------------------------------------------------------------------------
+
+
+def compute_losses(pred, target_rgbds, depth_mask, term_mask, term_target, rs: RenderSpec):
+    """Global masked means over all fields (rm.py:1787-1872); l1 photometric + huber depth."""
+    m = depth_mask & (pred["term_probs"] > 0.8)                     # rm.py:1787-1788
+    loss = {}
+    loss["termination"] = ((pred["term_probs"][term_mask] - term_target[term_mask]) ** 2).mean()
+    loss["photometric_l1"] = (target_rgbds[m][:, :3] - pred["rgbds"][m][:, :3]).abs().mean()
+    loss["depth_huber"] = torch.nn.functional.huber_loss(
+        pred["rgbds"][m][:, 3], target_rgbds[m][:, 3], delta=rs.huber_delta)
+    total = (rs.termination_weight * loss["termination"]
+             + rs.photometric_weight * loss["photometric_l1"]
+             + rs.depth_weight * loss["depth_huber"])
+    if pred["freespace_geometry"] is not None:
+        loss["freespace"] = ((pred["freespace_geometry"] - rs.truncation_distance) ** 2).mean()
+        total = total + rs.freespace_weight * loss["freespace"]
+    if pred["tsdf_residuals"] is not None:
+        loss["tsdf"] = (pred["tsdf_residuals"] ** 2).mean()
+        total = total + rs.tsdf_weight * loss["tsdf"]
+    loss["combined"] = total
+    return loss
+
+
+# ----------------------------------------------------------------------------------------
+# Adam with L2 weight decay and one shared step counter (rm.py:347-389, 668-707, 1183-1221)
+# ----------------------------------------------------------------------------------------
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=1e-3, beta1=0.9, beta2=0.999,
+              eps=1e-15, weight_decay=1e-5):
+    """One torch.optim.Adam (non-amsgrad, L2-coupled wd) update; `step` is the new count."""
+    g = grad + weight_decay * param
+    exp_avg = beta1 * exp_avg + (1 - beta1) * g
+    exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = exp_avg_sq.sqrt() / math.sqrt(bc2) + eps
+    param = param - (lr / bc1) * exp_avg / denom
+    return param, exp_avg, exp_avg_sq
+
+
+# ----------------------------------------------------------------------------------------
+# PSNR (evaluation.py:46-56; torchmetrics PSNR with data_range=1 restated)
+# ----------------------------------------------------------------------------------------
+
+
+def psnr(pred_rgb, target_rgb, crop=0):
+    if crop > 0:
+        pred_rgb = pred_rgb[crop:-crop, crop:-crop]
+        target_rgb = target_rgb[crop:-crop, crop:-crop]
+    p = pred_rgb.clamp(0.0, 1.0)
+    t = target_rgb.clamp(0.0, 1.0)
+    mse = ((p - t) ** 2).mean()
+    return float(10.0 * torch.log10(1.0 / mse))
+
+
+# ----------------------------------------------------------------------------------------
+# helpers used by tests / bench
+# ----------------------------------------------------------------------------------------
+
+
+def init_params(fs: FieldSpec, num_fields: int, seed=0, mu=0.0, sigma=4.0,
+                identical=False, dtype=torch.float32):
+    """Random parameters in the reference's stacked layout.
+
+    ``identical=True`` mimics add_fields (clone of one prototype, models.py:254-257)."""
+    g = torch.Generator().manual_seed(seed)
+    n = 1 if identical else num_fields
+    params = {}
+    for name, shape in fs.param_shapes().items():
+        if name == "_encoding._linear.weight":
+            v = torch.randn(n, *shape, generator=g) * sigma + mu
+        elif name.endswith("weight"):
+            bound = 1.0 / math.sqrt(shape[1])
+            v = (torch.rand(n, *shape, generator=g) * 2 - 1) * bound
+        else:
+            fan_in = dict(fs.param_shapes())[name.replace("bias", "weight")][1]
+            bound = 1.0 / math.sqrt(fan_in)
+            v = (torch.rand(n, *shape, generator=g) * 2 - 1) * bound
+        if identical:
+            v = v.expand(num_fields, *shape).clone()
+        params[name] = v.to(dtype)
+    return params

@@ -1,0 +1,344 @@
+"""Generate golden fixtures from the REAL reference (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference on CPU through ``_ref_import`` (third-party stubs only), runs the
+reference's own functions on seeded inputs and stores inputs + expected outputs as small
+``.npz`` files next to this script.  The random numbers the reference draws with
+``torch.rand`` (camera.py:274) are recorded by re-seeding and re-drawing the same shapes in
+the same order (coarse stratum first, then depth-guided).  Fixtures are data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_import import NRGBD_CAMERA, build_map, import_reference, make_config  # noqa: E402
+
+rm, models, camera, pe, losses, utils = import_reference()
+
+
+def npy(d):
+    out = {}
+    for k, v in d.items():
+        if v is None:
+            continue
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **npy(arrays))
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def rand_quats(n, gen):
+    return torch.nn.functional.normalize(torch.randn(n, 4, generator=gen), dim=-1)
+
+
+def look_at_c2w(eye, target, gen):
+    """OpenGL camera-to-world looking from eye to target (-z forward), random roll-free."""
+    fwd = torch.nn.functional.normalize(target - eye, dim=-1)
+    up = torch.tensor([0.0, 1.0, 0.0]).expand_as(fwd)
+    right = torch.nn.functional.normalize(torch.linalg.cross(fwd, up), dim=-1)
+    up2 = torch.linalg.cross(right, fwd)
+    T = torch.eye(4).repeat(*eye.shape[:-1], 1, 1)
+    T[..., :3, 0] = right
+    T[..., :3, 1] = up2
+    T[..., :3, 2] = -fwd
+    T[..., :3, 3] = eye
+    return T
+
+
+def synth_target(F, R, cam, pos, gen, radius=1.0, invalid_frac=0.15):
+    """Synthetic Target in the spirit of _sample_target_mv (rm.py:1383-1459)."""
+    ijs = torch.stack([torch.randint(0, cam.height, (F, R), generator=gen),
+                       torch.randint(0, cam.width, (F, R), generator=gen)], -1)
+    eye_dir = torch.nn.functional.normalize(torch.randn(F, R, 3, generator=gen), dim=-1)
+    dist = 2.0 + torch.rand(F, R, 1, generator=gen)
+    eye = pos[:, None, :] + eye_dir * dist
+    tgt = pos[:, None, :] + 0.3 * torch.randn(F, R, 3, generator=gen)
+    c2ws = look_at_c2w(eye, tgt, gen)
+    dirs = cam.ijs_to_directions(ijs)
+    pos_c = utils.transform_points(pos[:, None, :], c2ws, inv=True)
+    center = (pos_c * dirs).sum(-1)
+    near = (center - radius).clamp_min(0.0)
+    far = (center + radius).clamp_min(0.0)
+    gt = near + (far - near) * (0.1 + 0.8 * torch.rand(F, R, generator=gen))
+    sel = torch.rand(F, R, generator=gen)
+    gt = torch.where(sel < invalid_frac, torch.zeros_like(gt), gt)           # missing depth
+    gt = torch.where((sel >= invalid_frac) & (sel < invalid_frac + 0.05), far + 0.3, gt)
+    gt = torch.where((sel >= invalid_frac + 0.05) & (sel < invalid_frac + 0.1),
+                     (near - 0.2).clamp_min(0.01), gt)
+    rgb = torch.rand(F, R, 3, generator=gen)
+    depth = gt * dirs[..., 2].abs()
+    rgbds = torch.cat([rgb, depth[..., None]], -1)
+    valid = gt != 0.0
+    depth_mask = (gt > near) & (gt < far) & valid
+    term_probs = (gt < far).float()
+    term_mask = (gt > near) & valid
+    return dict(ijs=ijs, c2ws=c2ws, near=near, far=far, gt=gt, rgbds=rgbds,
+                depth_mask=depth_mask, term_probs=term_probs, term_mask=term_mask)
+
+
+def make_target(t, field_ids):
+    return rm.Target(ijs=t["ijs"], c2ws=t["c2ws"], near_distances=t["near"],
+                     far_distances=t["far"], gt_distances=t["gt"], field_ids=field_ids,
+                     rgbds=t["rgbds"], rgb_mask=t["depth_mask"], depth_mask=t["depth_mask"],
+                     term_probs=t["term_probs"], term_mask=t["term_mask"])
+
+
+def draw_u(seed, F, R, n_c, n_g):
+    torch.manual_seed(seed)
+    u_c = torch.rand(F, R, n_c)
+    u_g = torch.rand(F, R, n_g) if n_g > 0 else None
+    return u_c, u_g
+
+
+# ------------------------------------------------------------------------------------------
+def g1_directions():
+    cam = camera.Camera(**NRGBD_CAMERA)
+    gen = torch.Generator().manual_seed(1)
+    ijs = torch.stack([torch.randint(0, 480, (60,), generator=gen),
+                       torch.randint(0, 640, (60,), generator=gen)], -1)
+    corners = torch.tensor([[0, 0], [0, 639], [479, 0], [479, 639]])
+    ijs = torch.cat([corners, ijs])
+    save("g1_directions", ijs=ijs, dirs=cam.ijs_to_directions(ijs))
+
+
+def g2_g3_sampling():
+    cam = camera.Camera(**NRGBD_CAMERA)
+    gen = torch.Generator().manual_seed(2)
+    F, R, n_c, n_g = 2, 8, 4, 4
+    ijs = torch.stack([torch.randint(0, 480, (F, R), generator=gen),
+                       torch.randint(0, 640, (F, R), generator=gen)], -1)
+    near = 1.0 + torch.rand(F, R, generator=gen)
+    far = near + 2.0
+    # G2: plain stratified sampling with recorded draws
+    torch.manual_seed(20)
+    pts, t = cam.sample_ijs_uniform(ijs, n_c, near, far, convention="opengl")
+    torch.manual_seed(20)
+    u_c = torch.rand(F, R, n_c)
+    save("g2_sample_uniform", ijs=ijs, near=near, far=far, u=u_c, points=pts, distances=t)
+    # G3: merged coarse + guided incl. gt=0, gt<near, gt>far.  Statements of rm.py:521-545
+    # are methods of NeuralGraphMap._render_ijs; their effect is captured through the sorted
+    # sample distances recovered from the rendered free-space mask in g6; here we pin the two
+    # camera calls and torch.sort on the concatenation.
+    gt = near + (far - near) * torch.rand(F, R, generator=gen)
+    gt[0, 0] = 0.0
+    gt[0, 1] = near[0, 1] - 0.5
+    gt[1, 0] = far[1, 0] + 0.5
+    rho = 0.1
+    mask = (gt == 0.0) + (near > gt) + (far < gt)
+    gn, gf = gt - rho, gt + rho
+    gn[mask] = near[mask]
+    gf[mask] = far[mask]
+    torch.manual_seed(30)
+    pts_c, t_c = cam.sample_ijs_uniform(ijs, n_c, near, far, convention="opengl")
+    pts_g, t_g = cam.sample_ijs_uniform(ijs, n_g, gn, gf, convention="opengl")
+    t_all, order = torch.sort(torch.cat([t_c, t_g], -1), dim=-1)
+    pts_all = torch.gather(torch.cat([pts_c, pts_g], -2), -2,
+                           order.unsqueeze(-1).expand(-1, -1, -1, 3))
+    u_c, u_g = draw_u(30, F, R, n_c, n_g)
+    save("g3_sample_merged", ijs=ijs, near=near, far=far, gt=gt, rho=np.float32(rho),
+         u_coarse=u_c, u_guided=u_g, points=pts_all, distances=t_all)
+
+
+def g4_field_forward():
+    gen = torch.Generator().manual_seed(4)
+    F, P = 3, 40
+    pos = torch.randn(F, 3, generator=gen)
+    quat = rand_quats(F, gen)
+    q = pos[:, None, :] + 0.6 * torch.randn(F, P, 3, generator=gen)
+    for enc in ("fourier", "nerf"):
+        cfg = make_config(encoding=enc, num_octaves=8)
+        ngm = build_map(rm, cfg, F, pos, quat, seed=40)
+        model = ngm._model
+        # de-correlate the fields (add_fields clones one prototype)
+        for k, v in model.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn(v.shape, generator=gen))
+        model.set_vmap_fields(torch.arange(F))
+        with torch.no_grad():
+            out = model(q, pos, quat, torch.arange(F), True)
+        arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+        save(f"g4_field_forward_{enc}", query=q, pos=pos, quat=quat, out=out, **arrays)
+
+
+def g5_quadrature():
+    gen = torch.Generator().manual_seed(5)
+    for mode in ("nrgbd", "occupancy", "density", "neus"):
+        for S in (2, 24, 128):
+            cfg = make_config(geometry_mode=mode)
+            ngm = build_map(rm, cfg, 1, torch.zeros(1, 3), torch.tensor([[1.0, 0, 0, 0]]), seed=50)
+            lead = (2, 5)
+            colors = torch.rand(*lead, S, 3, generator=gen)
+            geoms = 0.1 * torch.randn(*lead, S, generator=gen)
+            geoms[0, 0, 0] = 0.0                       # occ = 1 for nrgbd
+            geoms[0, 1] = 5.0                          # |g| large
+            geoms[0, 2] = -5.0
+            dists = torch.sort(torch.rand(*lead, S, generator=gen) * 3 + 0.5, -1)[0]
+            depths = dists * 0.9
+            isds = (1.0 / (0.5 + torch.rand(2, 1, 1, generator=gen))) if mode == "neus" else None
+            C, D, Cv, Dv, term, w = ngm._quadrature(colors, geoms, dists, depths, isds)
+            save(f"g5_quadrature_{mode}_S{S}", colors=colors, geoms=geoms, dists=dists,
+                 depths=depths, isds=isds, C=C, D=D, Cv=Cv, Dv=Dv, term=term, w=w,
+                 geometry_factor=np.float32(cfg["geometry_factor"]))
+
+
+def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, dim_enc=64,
+                termination_weight=0.0, perturb=True, save_samples=False):
+    cam = camera.Camera(**NRGBD_CAMERA)
+    gen = torch.Generator().manual_seed(seed)
+    pos = 0.5 * torch.randn(F, 3, generator=gen)
+    quat = rand_quats(F, gen)
+    cfg = make_config(encoding=encoding, dim_enc=dim_enc, num_layers=num_layers,
+                      num_samples_coarse=n_c, num_samples_depth_guided=n_g,
+                      termination_weight=termination_weight)
+    ngm = build_map(rm, cfg, F, pos, quat, seed=seed)
+    ngm._camera = cam
+    model = ngm._model
+    if perturb:
+        for k, v in model.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn(v.shape, generator=gen))
+        # make geometry non-trivial: larger last-layer weights
+        model.all_fields_params[f"_linears.{num_layers}.weight"].mul_(2.0)
+    t = synth_target(F, R, cam, pos, gen)
+    fids = torch.arange(F)
+    target = make_target(t, fids)
+    torch.manual_seed(seed + 1000)
+    pred = ngm._render_ijs(t["ijs"], t["c2ws"], cam, field_ids=fids, use_vmap=True,
+                           near_distances=t["near"], far_distances=t["far"],
+                           gt_distances=t["gt"])
+    u_c, u_g = draw_u(seed + 1000, F, R, n_c, n_g)
+    loss = ngm._compute_losses(target, pred)
+    loss["combined"].backward()
+    vp = model.vmap_fields_params
+    arrays = {"p::" + k: v for k, v in vp.items()}
+    arrays.update({"g::" + k: v.grad for k, v in vp.items() if v.grad is not None})
+    arrays.update({"t::" + k: v for k, v in t.items()})
+    arrays.update({"loss::" + k: v for k, v in loss.items()})
+    save(name, pos=pos, quat=quat, u_coarse=u_c, u_guided=u_g,
+         pred_rgbds=pred.rgbds, pred_color_vars=pred.color_vars, pred_depth_vars=pred.depth_vars,
+         pred_term_probs=pred.term_probs, pred_freespace=pred.freespace_geometry,
+         pred_tsdf=pred.tsdf_residuals, **arrays)
+
+
+def g6_train():
+    _train_case("g6_train_cfg0", F=1, R=256, n_c=16, n_g=16, seed=60)
+    _train_case("g6_train_3field", F=3, R=24, n_c=8, n_g=16, seed=61, termination_weight=0.5)
+    _train_case("g6_train_nerf_l1", F=2, R=16, n_c=8, n_g=8, seed=62, encoding="nerf",
+                num_layers=1)
+
+
+def g7_adam():
+    """10 iterations of the reference's sparse-Adam plumbing with changing active sets."""
+    cam = camera.Camera(**NRGBD_CAMERA)
+    gen = torch.Generator().manual_seed(7)
+    NF, R, n_c, n_g = 4, 16, 4, 8
+    pos = 0.5 * torch.randn(NF, 3, generator=gen)
+    quat = rand_quats(NF, gen)
+    cfg = make_config(num_samples_coarse=n_c, num_samples_depth_guided=n_g, dim_enc=32)
+    torch.manual_seed(70)
+    ngm = rm.NeuralGraphMap(cfg)
+    ngm._camera = cam
+    ngm._optimizer = torch.optim.Adam([torch.zeros((), requires_grad=True)],
+                                      lr=cfg["learning_rate"], eps=cfg["adam_eps"],
+                                      weight_decay=cfg["adam_weight_decay"])
+    ngm._global_map_dict["num"] = NF
+    ngm._global_map_dict["positions"][:NF] = pos
+    ngm._global_map_dict["orientations"][:NF] = quat
+    ngm._add_fields(NF)
+    with torch.no_grad():
+        for k, v in ngm._model.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    p0 = {"p0::" + k: v.clone() for k, v in ngm._model.all_fields_params.items()}
+    active_sets = [[0, 1], [1, 2], [0, 1], [3, 2], [0, 3], [1, 2], [2, 3], [0, 1], [1, 3], [0, 2]]
+    steps = {}
+    for it, ids in enumerate(active_sets):
+        fids = torch.tensor(ids)
+        t = synth_target(len(ids), R, cam, pos[fids], gen)
+        target = make_target(t, fids)
+        torch.manual_seed(700 + it)
+        pred = ngm._render_ijs(t["ijs"], t["c2ws"], cam, field_ids=fids, use_vmap=True,
+                               near_distances=t["near"], far_distances=t["far"],
+                               gt_distances=t["gt"])
+        u_c, u_g = draw_u(700 + it, len(ids), R, n_c, n_g)
+        loss = ngm._compute_losses(target, pred)
+        ngm._update_step(loss, fids)
+        steps.update({f"it{it}::" + k: v for k, v in t.items()})
+        steps[f"it{it}::u_coarse"] = u_c
+        steps[f"it{it}::u_guided"] = u_g
+        steps[f"it{it}::field_ids"] = fids
+        steps[f"it{it}::loss"] = loss["combined"]
+    p1 = {"p1::" + k: v for k, v in ngm._model.all_fields_params.items()}
+    m1 = {"m1::" + k: ngm._optim_state[k]["exp_avg"] for k in ngm._optim_state}
+    v1 = {"v1::" + k: ngm._optim_state[k]["exp_avg_sq"] for k in ngm._optim_state}
+    save("g7_adam", pos=pos, quat=quat, num_iters=np.int64(len(active_sets)),
+         **p0, **p1, **m1, **v1, **steps)
+
+
+def g8_knn():
+    gen = torch.Generator().manual_seed(8)
+    NF, P = 3, 200
+    pos = torch.tensor([[0.0, 0.0, 0.0], [0.9, 0.1, 0.0], [0.2, 1.0, -0.3]])
+    quat = rand_quats(NF, gen)
+    cfg = make_config()
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=80)
+    model = ngm._model
+    for k, v in model.all_fields_params.items():
+        if v.dim() > 1:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    pts = 2.2 * (torch.rand(P, 3, generator=gen) - 0.5) + torch.tensor([0.4, 0.4, -0.1])
+    pts[:5] += 10.0                                  # far outside every field
+    with torch.no_grad():
+        out = model(pts, pos, quat, None, False)
+    arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+    save("g8_knn", points=pts, pos=pos, quat=quat, out=out, **arrays)
+
+
+def g9_render_image():
+    gen = torch.Generator().manual_seed(9)
+    cam_kw = dict(width=32, height=24, fx=27.7, fy=27.7, cx=15.5, cy=11.5, pixel_center=0.0)
+    cam = camera.Camera(**cam_kw)
+    NF = 3
+    pos = torch.tensor([[0.0, 0.0, -2.5], [0.9, 0.1, -2.8], [-0.7, 0.3, -2.2]])
+    quat = rand_quats(NF, gen)
+    cfg = make_config(eval_far_distance=5.0, eval_num_samples=48)
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=90)
+    model = ngm._model
+    for k, v in model.all_fields_params.items():
+        if v.dim() > 1:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    model.all_fields_params["_linears.2.weight"].mul_(3.0)
+    c2w = torch.eye(4)
+    ngm.eval()
+    torch.manual_seed(900)
+    rgbd, dvar = ngm.render_image(c2w, cam)
+    torch.manual_seed(900)
+    u = torch.rand(24 * 32, 48)
+    target = torch.rand(24, 32, 3, generator=gen)
+    arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+    save("g9_render_image", pos=pos, quat=quat, c2w=c2w, u=u, rgbd=rgbd, dvar=dvar,
+         target_rgb=target, cam=np.array([cam_kw[k] for k in
+                                         ("width", "height", "fx", "fy", "cx", "cy")]),
+         eval_far=np.float32(5.0), eval_num_samples=np.int64(48), **arrays)
+
+
+if __name__ == "__main__":
+    g1_directions()
+    g2_g3_sampling()
+    g4_field_forward()
+    g5_quadrature()
+    g6_train()
+    g7_adam()
+    g8_knn()
+    g9_render_image()

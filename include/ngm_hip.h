@@ -1,0 +1,245 @@
+/*
+ * ngm_hip.h -- C ABI of the MI355X-native (gfx950) render/train hot path of Neural Graph Mapping.
+ *
+ * The reference (KTH-RPL/neural_graph_mapping) is pure Python and has no FFI; its boundary is a
+ * Python method contract.  Each entry point below replaces the reference interface cited next to
+ * it (paths relative to /root/reference/src/neural_graph_mapping, rm.py = run_mapping.py).  The
+ * reference-side binding (a ctypes stub a maintainer would add) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, opaque device pointers + explicit sizes; no torch types, no allocation inside:
+ *    the caller owns and pre-allocates every output and the workspace;
+ *  - all floating point tensors are contiguous row-major fp32, indices int64 (as the reference);
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *  - return value: 0 = ok, negative = NGM_E_* (ngm_last_error() holds a message); never throws.
+ *  - F = active fields in the batch, R = rays per field, S = S_c + S_g samples per ray,
+ *    P = points per field, D = encoding width, H = hidden width, L = hidden layers.
+ */
+#ifndef NGM_HIP_H
+#define NGM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGM_ABI_VERSION 1
+#define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
+#define NGM_NUM_LOSS_SUMS 16
+
+enum ngm_status {
+  NGM_OK = 0,
+  NGM_E_INVALID = -1,     /* bad argument / inconsistent sizes          */
+  NGM_E_UNSUPPORTED = -2, /* configuration has no compiled kernel       */
+  NGM_E_WORKSPACE = -3,   /* workspace too small                        */
+  NGM_E_HIP = -4          /* HIP runtime error (launch / device)        */
+};
+
+enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3 };
+enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
+enum ngm_geometry_mode { NGM_GEO_NRGBD = 0, NGM_GEO_OCCUPANCY = 1, NGM_GEO_DENSITY = 2, NGM_GEO_NEUS = 3 };
+
+/* slots of the loss partial-sum vector (rm.py:1769-1872); counts are stored as floats */
+enum ngm_loss_slot {
+  NGM_LS_PHOTO_SUM = 0, /* sum |rgb - rgb*| over masked rays, 3 channels     */
+  NGM_LS_PHOTO_CNT = 1, /* number of masked rays (mean divides by 3*cnt)      */
+  NGM_LS_DEPTH_SUM = 2, /* sum huber(depth - depth*)                          */
+  NGM_LS_DEPTH_CNT = 3,
+  NGM_LS_FS_SUM = 4,    /* sum (g*tau - tau)^2 over free-space samples        */
+  NGM_LS_FS_CNT = 5,
+  NGM_LS_TSDF_SUM = 6,  /* sum (g*tau - (gt - t))^2 over truncation samples   */
+  NGM_LS_TSDF_CNT = 7,
+  NGM_LS_TERM_SUM = 8,  /* sum (term - term*)^2 over term_mask rays           */
+  NGM_LS_TERM_CNT = 9
+};
+
+/* NeuralField architecture: models.py:69-128, positional_encodings.py:167-195,222-243 */
+typedef struct ngm_field_cfg {
+  int32_t encoding;     /* ngm_encoding */
+  int32_t dim_enc;      /* D: encoding output width (Fourier: dim_out; NeRF: 6*octaves)      */
+  int32_t raw_coords;   /* Fourier: 1 -> cat(x, sin(Wx)), W is (D-3,3); 0 -> sin(Wx), (D,3)  */
+  int32_t num_octaves;  /* NeRF */
+  int32_t start_octave; /* NeRF */
+  int32_t num_layers;   /* L hidden Linear+ReLU layers (skip_mode "no")                     */
+  int32_t dim_hidden;   /* H (= D when dim_mlp_out is null, models.py:99-100)               */
+  int32_t dim_out;      /* 4: r,g,b,geometry                                                */
+  int32_t scale_mode;   /* ngm_scale_mode, models.py:278-285                                */
+  float field_radius;
+} ngm_field_cfg;
+
+/* Stacked per-field parameters, models.py:245-276 (`all_fields_params` / `vmap_fields_params`).
+ * One device pointer per tensor plus the element stride between consecutive fields, so both a
+ * dict of separate (N,...) tensors and views into one arena are accepted.  `field_index`
+ * (optional, int64[F]) selects rows: batch field f uses row field_index[f] (NULL: row f). */
+typedef struct ngm_params {
+  const float* enc_w; /* "_encoding._linear.weight" (N, D-3|D, 3); NULL unless Fourier */
+  int64_t enc_w_stride;
+  const float* w[NGM_MAX_LAYERS + 1]; /* "_linears.{i}.weight" (N, out_i, in_i) */
+  int64_t w_stride[NGM_MAX_LAYERS + 1];
+  const float* b[NGM_MAX_LAYERS + 1]; /* "_linears.{i}.bias" (N, out_i) */
+  int64_t b_stride[NGM_MAX_LAYERS + 1];
+  const int64_t* field_index;
+} ngm_params;
+
+/* Gradient outputs, same layout rules as ngm_params (row f of each tensor = batch field f). */
+typedef struct ngm_grads {
+  float* enc_w;
+  int64_t enc_w_stride;
+  float* w[NGM_MAX_LAYERS + 1];
+  int64_t w_stride[NGM_MAX_LAYERS + 1];
+  float* b[NGM_MAX_LAYERS + 1];
+  int64_t b_stride[NGM_MAX_LAYERS + 1];
+} ngm_grads;
+
+/* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */
+typedef struct ngm_render_cfg {
+  int32_t geometry_mode;       /* ngm_geometry_mode, rm.py:746-762            */
+  int32_t num_samples_coarse;  /* S_c                                         */
+  int32_t num_samples_guided;  /* S_g (0: single stratum, eval style)         */
+  int32_t reserved0;
+  float geometry_factor;       /* gamma                                       */
+  float color_factor;
+  float truncation_distance;   /* tau                                         */
+  float range_depth_guided;    /* rho (rm.py:169-170)                         */
+  float fx, fy, cx, cy;        /* intrinsics at pixel centre 0 (camera.py:188) */
+  float w_termination, w_photometric, w_depth, w_freespace, w_tsdf; /* rm.py:129-135 */
+  float huber_delta;           /* 0.05, losses.py:63                          */
+  float term_threshold;        /* 0.8, rm.py:1787                             */
+} ngm_render_cfg;
+
+/* One batch of rays: the reference's Target record (rm.py:43-58) in device memory. */
+typedef struct ngm_rays {
+  int32_t F, R;
+  const int64_t* ijs;      /* (F,R,2) [row, col]                                            */
+  const float* c2ws;       /* (F,R,4,4) when c2w_per_ray != 0 else (4,4) shared              */
+  int32_t c2w_per_ray;
+  int32_t reserved0;
+  const float* near;       /* (F,R) or NULL -> near_const                                    */
+  const float* far;        /* (F,R) or NULL -> far_const                                     */
+  const float* gt;         /* (F,R) or NULL; 0.0 = no depth                                  */
+  float near_const, far_const;
+  const float* field_pos;  /* (F,3) field positions in the world frame                       */
+  const float* field_quat; /* (F,4) real-first quaternions                                   */
+  const float* u_coarse;   /* (F,R,S_c) torch.rand draws of camera.py:274, or NULL -> Philox */
+  const float* u_guided;   /* (F,R,S_g) or NULL -> Philox                                    */
+  const float* lin_coarse; /* (S_c+1) torch.linspace(0,1) table of camera.py:271 or NULL     */
+  const float* lin_guided; /* (S_g+1) or NULL                                                */
+  uint64_t philox_seed;    /* used when u_* is NULL                                          */
+  uint64_t philox_offset;
+} ngm_rays;
+
+/* Supervision of one batch (rm.py:43-58, 1769-1872); masks are uint8 0/1. */
+typedef struct ngm_targets {
+  const float* rgbds;        /* (F,R,4) r,g,b,depth                 */
+  const uint8_t* depth_mask; /* (F,R)                               */
+  const uint8_t* term_mask;  /* (F,R) or NULL (all false)           */
+  const float* term_probs;   /* (F,R) or NULL                       */
+} ngm_targets;
+
+/* Per-ray outputs: the reference's Prediction (rm.py:59-69) minus the data-dependent vectors. */
+typedef struct ngm_prediction {
+  float* rgbds;      /* (F,R,4) */
+  float* color_vars; /* (F,R,3) */
+  float* depth_vars; /* (F,R)   */
+  float* term_probs; /* (F,R)   */
+} ngm_prediction;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int ngm_abi_version(void);
+const char* ngm_last_error(void);
+/* number of compute units / device name of the current device (for launch sizing, bench) */
+int ngm_device_info(int* num_cus, char* name, int name_len);
+
+/* ---- K1: ray sampler ----------------------------------------------------------------------
+ * Replaces Camera.ijs_to_directions + Camera.sample_ijs_uniform (camera.py:186-292), the
+ * depth-guided merge + sort + gather (rm.py:521-545).  Outputs the sorted samples in the camera
+ * frame: points_cam (F,R,S,3), distances (F,R,S), dirs (F,R,3) (any may be NULL). */
+int ngm_sample_rays(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam,
+                    float* distances, float* dirs, void* stream);
+
+/* ---- K2+K3: NeuralFieldSet.forward(use_vmap=True) -----------------------------------------
+ * models.py:329-345: world -> field-local transform, scaling, encoding, MLP; points (F,P,3)
+ * (world frame when field_pos/field_quat are given, local otherwise), out (F,P,4). */
+int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
+                       const float* points, const float* field_pos, const float* field_quat,
+                       float* out, void* stream);
+/* Backward of the above w.r.t. every parameter: d_out (F,P,4) -> grads.  workspace: see
+ * ngm_field_eval_bwd_workspace(). */
+int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
+                       const float* points, const float* field_pos, const float* field_quat,
+                       const float* d_out, const ngm_grads* grads, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int64_t ngm_field_eval_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64_t P);
+
+/* ---- K4: volume renderer -------------------------------------------------------------------
+ * NeuralGraphMap._quadrature (rm.py:709-799) on N rays x S samples: colors (N,S,3), geoms (N,S),
+ * dists (N,S), depths (N,S), neus_isds (N) or NULL.  Outputs: C (N,3), D (N), Cvar (N,3),
+ * Dvar (N), term (N), weights (N,S_eff) (any may be NULL). */
+int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors,
+                      const float* geoms, const float* dists, const float* depths,
+                      const float* neus_isds, float* C, float* D, float* Cvar, float* Dvar,
+                      float* term, float* weights, void* stream);
+/* Backward of C, D, term (and optionally a direct per-sample seed) w.r.t. colors and geoms. */
+int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors,
+                      const float* geoms, const float* dists, const float* depths,
+                      const float* neus_isds, const float* dC, const float* dD,
+                      const float* dterm, float* d_colors, float* d_geoms, void* stream);
+
+/* ---- fused render / train step -------------------------------------------------------------
+ * ngm_render_fwd replaces NeuralGraphMap._render_ijs(use_vmap=True) (rm.py:439-666): sampler ->
+ * world->local -> encoding -> MLP -> compositing in ONE kernel.  When `targets` is non-NULL it
+ * also accumulates the loss partial sums of _compute_losses (rm.py:1769-1872) into
+ * loss_sums[NGM_NUM_LOSS_SUMS] (device, overwritten) and fills the saved-for-backward part of
+ * the workspace.  sample_stash (optional, (F,R,S,6): r,g,b,geometry,t,T) exposes the per-sample
+ * values for callers that need the compacted free-space / TSDF vectors of the Prediction. */
+int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F,
+                             int32_t R, int32_t train);
+int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
+                   const ngm_params* params, const ngm_rays* rays, const ngm_targets* targets,
+                   const ngm_prediction* pred, float* loss_sums, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* Backward of loss["combined"] (rm.py:1871) w.r.t. every field parameter.  loss_sums are the
+ * GLOBAL sums/counts (after the caller's cross-GPU all-reduce of ngm_render_fwd's output);
+ * workspace must be the one filled by the matching ngm_render_fwd call.  loss_out (optional,
+ * device float[8]): combined, termination, photometric, depth, freespace, tsdf. */
+int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
+                   const ngm_params* params, const ngm_rays* rays, const ngm_targets* targets,
+                   const ngm_prediction* pred, const float* loss_sums, const ngm_grads* grads,
+                   float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Generic-seed variant used by the autograd wrapper of render_ijs: explicit dL/d(rgbds) (F,R,4),
+ * dL/d(term_probs) (F,R) and optional per-sample dL/d(geometry) (F,R,S). */
+int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
+                          const ngm_params* params, const ngm_rays* rays, const float* d_rgbds,
+                          const float* d_term, const float* d_geom_samples,
+                          const ngm_grads* grads, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+/* read access to the per-sample values saved by ngm_render_fwd(train): copies geometry (F,R,S)
+ * and sorted distances (F,R,S) out of the workspace (for Prediction.freespace_geometry /
+ * tsdf_residuals, rm.py:624-639). */
+int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F,
+                            int32_t R, const void* workspace, float* geoms, float* dists,
+                            void* stream);
+
+/* ---- sparse per-field Adam (rm.py:347-389, 668-707, 1183-1221) ---------------
+ * torch.optim.Adam (L2-coupled weight decay) applied in place to rows field_index[f] of one
+ * stacked tensor of `numel_per_field` elements: param/exp_avg/exp_avg_sq have `stride` elements
+ * between fields, grad is (F, numel_per_field) with grad_stride.  `step` is the NEW shared step
+ * count (one counter for all fields, rm.py:380-385). */
+int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t stride,
+                    const float* grad, int64_t grad_stride, const int64_t* field_index, int32_t F,
+                    int64_t numel_per_field, int64_t step, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, void* stream);
+
+/* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
+ * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
+ * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4. */
+int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields,
+                       int64_t P, const float* points, const float* field_pos,
+                       const float* field_quat, int32_t num_knn, float distance_factor,
+                       float outside_value, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGM_HIP_H */

@@ -1,0 +1,203 @@
+"""ctypes binding of the C ABI in include/ngm_hip.h (libngm_hip.so).
+
+Torch-free: every call takes raw device addresses (ints) and a stream handle, so it serves both
+the torch layer (``tensor.data_ptr()``) and the torch-free harness (``hiprt.DeviceArray.ptr``).
+The product path has NO CPU fallback: if the library is missing, importing this module's `lib()`
+raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libngm_hip.so")
+
+NGM_MAX_LAYERS = 4
+NGM_NUM_LOSS_SUMS = 16
+ENC = {"none": 0, "fourier": 1, "nerf": 2, "permuto": 3}
+SCALE = {"no": 0, "unit_ball": 1, "unit_cube": 2}
+GEO = {"nrgbd": 0, "occupancy": 1, "density": 2, "neus": 3}
+LS = dict(PHOTO_SUM=0, PHOTO_CNT=1, DEPTH_SUM=2, DEPTH_CNT=3, FS_SUM=4, FS_CNT=5, TSDF_SUM=6,
+          TSDF_CNT=7, TERM_SUM=8, TERM_CNT=9)
+
+f32p = C.c_void_p
+LArr = C.c_void_p * (NGM_MAX_LAYERS + 1)
+SArr = C.c_int64 * (NGM_MAX_LAYERS + 1)
+
+
+class FieldCfg(C.Structure):
+    _fields_ = [("encoding", C.c_int32), ("dim_enc", C.c_int32), ("raw_coords", C.c_int32),
+                ("num_octaves", C.c_int32), ("start_octave", C.c_int32), ("num_layers", C.c_int32),
+                ("dim_hidden", C.c_int32), ("dim_out", C.c_int32), ("scale_mode", C.c_int32),
+                ("field_radius", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
+                ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
+                ("b", LArr), ("b_stride", SArr)]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("geometry_mode", C.c_int32), ("num_samples_coarse", C.c_int32),
+                ("num_samples_guided", C.c_int32), ("reserved0", C.c_int32),
+                ("geometry_factor", C.c_float), ("color_factor", C.c_float),
+                ("truncation_distance", C.c_float), ("range_depth_guided", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("w_termination", C.c_float), ("w_photometric", C.c_float), ("w_depth", C.c_float),
+                ("w_freespace", C.c_float), ("w_tsdf", C.c_float), ("huber_delta", C.c_float),
+                ("term_threshold", C.c_float)]
+
+
+class Rays(C.Structure):
+    _fields_ = [("F", C.c_int32), ("R", C.c_int32), ("ijs", C.c_void_p), ("c2ws", f32p),
+                ("c2w_per_ray", C.c_int32), ("reserved0", C.c_int32), ("near", f32p), ("far", f32p),
+                ("gt", f32p), ("near_const", C.c_float), ("far_const", C.c_float),
+                ("field_pos", f32p), ("field_quat", f32p), ("u_coarse", f32p), ("u_guided", f32p),
+                ("lin_coarse", f32p), ("lin_guided", f32p), ("philox_seed", C.c_uint64),
+                ("philox_offset", C.c_uint64)]
+
+
+class Targets(C.Structure):
+    _fields_ = [("rgbds", f32p), ("depth_mask", C.c_void_p), ("term_mask", C.c_void_p),
+                ("term_probs", f32p)]
+
+
+class Prediction(C.Structure):
+    _fields_ = [("rgbds", f32p), ("color_vars", f32p), ("depth_vars", f32p), ("term_probs", f32p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libngm_hip.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -m neural_graph_mapping_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    P = C.POINTER
+    L.ngm_abi_version.restype = C.c_int
+    L.ngm_last_error.restype = C.c_char_p
+    L.ngm_device_info.argtypes = [P(C.c_int), C.c_char_p, C.c_int]
+    L.ngm_sample_rays.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp]
+    L.ngm_field_eval_fwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, vp]
+    L.ngm_field_eval_bwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp]
+    L.ngm_field_eval_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
+    L.ngm_field_eval_bwd_workspace.restype = i64
+    L.ngm_composite_fwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 11 + [vp]
+    L.ngm_composite_bwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 10 + [vp]
+    L.ngm_render_workspace.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, i32]
+    L.ngm_render_workspace.restype = i64
+    L.ngm_render_fwd.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), P(Targets),
+                                 P(Prediction), vp, vp, i64, vp]
+    L.ngm_render_bwd.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), P(Targets),
+                                 P(Prediction), vp, P(Grads), vp, vp, i64, vp]
+    L.ngm_render_bwd_seeded.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), vp, vp, vp,
+                                        P(Grads), vp, i64, vp]
+    L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
+    L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
+    L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp]
+    for name in ("ngm_sample_rays", "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_composite_fwd",
+                 "ngm_composite_bwd", "ngm_render_fwd", "ngm_render_bwd", "ngm_render_bwd_seeded",
+                 "ngm_render_read_samples", "ngm_adam_sparse", "ngm_field_eval_knn", "ngm_device_info"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_rays",
+            "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
+            "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
+            "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
+            "ngm_field_eval_knn"]
+
+
+class NgmError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ngm_last_error().decode(errors="replace")
+        raise NgmError(f"{what} failed with status {rc}: {msg}")
+
+
+# ------------------------------------------------------------------------------------------------
+# struct builders from plain python values / raw device addresses
+# ------------------------------------------------------------------------------------------------
+def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,
+              num_layers=2, dim_hidden=None, dim_out=4, scale_mode="unit_cube", field_radius=1.0):
+    if encoding == "nerf":
+        dim_enc = 6 * num_octaves
+    if encoding == "none":
+        dim_enc = 3
+    if dim_hidden is None:
+        dim_hidden = dim_enc
+    return FieldCfg(ENC[encoding], dim_enc, int(bool(raw_coords)), num_octaves, start_octave,
+                    num_layers, dim_hidden, dim_out, SCALE[scale_mode], float(field_radius))
+
+
+def param_names(fc: FieldCfg):
+    names = []
+    if fc.encoding == ENC["fourier"]:
+        names.append("_encoding._linear.weight")
+    for i in range(fc.num_layers + 1):
+        names += [f"_linears.{i}.weight", f"_linears.{i}.bias"]
+    return names
+
+
+def param_shapes(fc: FieldCfg):
+    shapes = {}
+    if fc.encoding == ENC["fourier"]:
+        shapes["_encoding._linear.weight"] = ((fc.dim_enc - 3) if fc.raw_coords else fc.dim_enc, 3)
+    for i in range(fc.num_layers + 1):
+        din = fc.dim_enc if i == 0 else fc.dim_hidden
+        dout = fc.dim_out if i == fc.num_layers else fc.dim_hidden
+        shapes[f"_linears.{i}.weight"] = (dout, din)
+        shapes[f"_linears.{i}.bias"] = (dout,)
+    return shapes
+
+
+def _fill_ptrs(struct, fc, ptrs, strides):
+    """ptrs/strides: dict name -> device address / element stride between fields."""
+    if fc.encoding == ENC["fourier"]:
+        struct.enc_w = ptrs["_encoding._linear.weight"]
+        struct.enc_w_stride = strides["_encoding._linear.weight"]
+    for i in range(fc.num_layers + 1):
+        struct.w[i] = ptrs[f"_linears.{i}.weight"]
+        struct.w_stride[i] = strides[f"_linears.{i}.weight"]
+        struct.b[i] = ptrs[f"_linears.{i}.bias"]
+        struct.b_stride[i] = strides[f"_linears.{i}.bias"]
+    return struct
+
+
+def params_struct(fc, ptrs, strides, field_index=None):
+    p = _fill_ptrs(Params(), fc, ptrs, strides)
+    p.field_index = field_index
+    return p
+
+
+def grads_struct(fc, ptrs, strides):
+    return _fill_ptrs(Grads(), fc, ptrs, strides)
+
+
+def render_cfg(geometry_mode="nrgbd", num_samples_coarse=8, num_samples_guided=16,
+               geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1,
+               range_depth_guided=None, fx=554.2562584220408, fy=554.2562584220408, cx=319.5,
+               cy=239.5, w_termination=0.0, w_photometric=1.0, w_depth=1.0, w_freespace=40.0,
+               w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8):
+    if range_depth_guided is None:
+        range_depth_guided = truncation_distance
+    return RenderCfg(GEO[geometry_mode], num_samples_coarse, num_samples_guided, 0, geometry_factor,
+                     color_factor, truncation_distance, range_depth_guided, fx, fy, cx, cy,
+                     w_termination, w_photometric, w_depth, w_freespace, w_tsdf, huber_delta,
+                     term_threshold)

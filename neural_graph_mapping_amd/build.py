@@ -1,0 +1,75 @@
+"""Build the gfx950 C-ABI library (libngm_hip.so) in-tree with hipcc.
+
+    python -m neural_graph_mapping_amd.build [--fast] [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects are cached under csrc/_obj (keyed by a hash
+of the sources + flags); the shared library lands in neural_graph_mapping_amd/lib/ and travels to
+the GPU box with the repo snapshot.
+"""
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libngm_hip.so")
+SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_composite.hip", "ngm_knn.hip"]
+HEADERS = ["ngm_device.h", "ngm_field.h", "ngm_launch.h", "../../include/ngm_hip.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest(src, flags):
+    h = hashlib.sha256()
+    for f in [src] + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()[:16]
+
+
+def _compile(src, flags):
+    obj = os.path.join(OBJ, src.replace(".hip", "") + "-" + _digest(src, flags) + ".o")
+    if not os.path.exists(obj):
+        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build(fast=False, force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    flags = FLAGS + (["-DNGM_FAST_BUILD"] if fast else [])
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, flags), SOURCES))
+    stamp = os.path.join(OBJ, "link.stamp")
+    key = " ".join(objs)
+    if force or not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != key:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        with open(stamp, "w") as fh:
+            fh.write(key)
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(fast="--fast" in sys.argv, force="--force" in sys.argv)

@@ -1,0 +1,389 @@
+// C ABI of the gfx950 hot path (declared in include/ngm_hip.h): argument validation, launch planning,
+// workspace carving.  No allocation, no synchronisation; everything is enqueued on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ngm_hip.h"
+#include "ngm_launch.h"
+
+int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
+                       float* dirs, hipStream_t st);
+int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st);
+int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st);
+int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists, hipStream_t st);
+int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
+                    const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
+                    float eps, float wd, hipStream_t st);
+int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
+                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
+                   hipStream_t st);
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return NGM_E_HIP;
+  }
+  return NGM_OK;
+}
+static int num_cus() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cached = prop.multiProcessorCount;
+  else
+    cached = 256;  // MI355X
+  (void)hipGetLastError();
+  return cached;
+}
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+static int check_field_cfg(const ngm_field_cfg* fc) {
+  if (!fc) return fail(NGM_E_INVALID, "field cfg is NULL");
+  if (fc->dim_out != 4) return fail(NGM_E_UNSUPPORTED, "dim_out must be 4 (r,g,b,geometry)");
+  if (fc->num_layers < 1 || fc->num_layers > NGM_MAX_LAYERS) return fail(NGM_E_UNSUPPORTED, "num_layers out of range");
+  if (fc->encoding == NGM_ENC_PERMUTO) return fail(NGM_E_UNSUPPORTED, "permutohedral encoding: not built yet");
+  if (fc->encoding == NGM_ENC_NERF && fc->dim_enc != 6 * fc->num_octaves) return fail(NGM_E_INVALID, "nerf: dim_enc != 6*octaves");
+  if (fc->encoding == NGM_ENC_NONE && fc->dim_enc != 3) return fail(NGM_E_INVALID, "no encoding: dim_enc must be 3");
+  if (fc->dim_enc < 1 || fc->dim_enc > 64 || fc->dim_hidden < 1 || fc->dim_hidden > 64)
+    return fail(NGM_E_UNSUPPORTED, "dim_enc / dim_hidden must be <= 64");
+  if (((fc->dim_enc + 31) / 32) != ((fc->dim_hidden + 31) / 32) && !(fc->dim_enc <= 32 && fc->dim_hidden <= 32))
+    return fail(NGM_E_UNSUPPORTED, "dim_enc and dim_hidden must pad to the same multiple of 32");
+  return NGM_OK;
+}
+static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
+  if (!pr) return fail(NGM_E_INVALID, "params is NULL");
+  if (fc->encoding == NGM_ENC_FOURIER && !pr->enc_w) return fail(NGM_E_INVALID, "fourier encoding needs enc_w");
+  for (int l = 0; l <= fc->num_layers; ++l)
+    if (!pr->w[l] || !pr->b[l]) return fail(NGM_E_INVALID, "missing layer weight/bias pointer");
+  return NGM_OK;
+}
+
+extern "C" {
+
+int ngm_abi_version(void) { return NGM_ABI_VERSION; }
+const char* ngm_last_error(void) { return g_err; }
+
+int ngm_device_info(int* ncu, char* name, int name_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(NGM_E_HIP, "no HIP device");
+  }
+  if (ncu) *ncu = prop.multiProcessorCount;
+  if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  return NGM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int ngm_sample_rays(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam, float* distances, float* dirs,
+                    void* stream) {
+  if (!cfg || !rays || !rays->ijs) return fail(NGM_E_INVALID, "ngm_sample_rays: NULL argument");
+  const int S = cfg->num_samples_coarse + (rays->gt ? cfg->num_samples_guided : 0);
+  if (S < 1) return fail(NGM_E_INVALID, "no samples");
+  ngm_launch_sampler(cfg, rays, S, points_cam, distances, dirs, (hipStream_t)stream);
+  return check_launch("ngm_sample_rays");
+}
+
+// ------------------------------------------------------------------------------------------------
+int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                       const float* field_pos, const float* field_quat, float* out, void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !out || F < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_field_eval_fwd: bad argument");
+  if ((field_pos == nullptr) != (field_quat == nullptr)) return fail(NGM_E_INVALID, "pos/quat must both be given");
+  if (P == 0) return NGM_OK;
+  PointsFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = F; a.P = P; a.points = points; a.pos = field_pos; a.quat = field_quat; a.out = out;
+  const int ncu = num_cus();
+  int64_t bpf = (ncu + F - 1) / F;                         // workgroups per field
+  int64_t per = align_up((P + bpf - 1) / bpf, NGM_BLOCK);
+  bpf = (P + per - 1) / per;
+  a.per_block = per;
+  rc = ngm_launch_points_fwd(a, (int)(bpf * F), (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_field_eval_fwd: no kernel for this (D,H,L)");
+  return check_launch("ngm_field_eval_fwd");
+}
+
+static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf) {
+  const int ncu = num_cus();
+  int64_t b = (ncu + F - 1) / F;
+  int64_t per = align_up((P + b - 1) / b, 32 * NGM_WAVES_PER_BLOCK);
+  if (per < 32 * NGM_WAVES_PER_BLOCK) per = 32 * NGM_WAVES_PER_BLOCK;
+  *per_block = per;
+  *bpf = (int)((P + per - 1) / per);
+}
+static int64_t param_pad(const ngm_field_cfg* fc) {
+  int64_t e, w[NGM_MAX_LAYERS + 1], b[NGM_MAX_LAYERS + 1];
+  return align_up(ngm_param_offsets(fc, &e, w, b), 64);
+}
+
+int64_t ngm_field_eval_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64_t P) {
+  if (check_field_cfg(fcfg)) return NGM_E_INVALID;
+  int64_t per; int bpf;
+  plan_bwd(F, P, &per, &bpf);
+  return (int64_t)F * bpf * param_pad(fcfg) * 4 + 256;
+}
+
+int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                       const float* field_pos, const float* field_quat, const float* d_out, const ngm_grads* grads,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !d_out || !grads || F < 1 || P < 1) return fail(NGM_E_INVALID, "ngm_field_eval_bwd: bad argument");
+  if (workspace_bytes < ngm_field_eval_bwd_workspace(fcfg, F, P) || !workspace) return fail(NGM_E_WORKSPACE, "workspace too small");
+  FieldBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = F; a.P = P; a.points = points; a.pos = field_pos; a.quat = field_quat;
+  a.d_out = reinterpret_cast<const float4*>(d_out);
+  plan_bwd(F, P, &a.per_block, &a.blocks_per_field);
+  a.p_pad = param_pad(fcfg);
+  a.partials = reinterpret_cast<float*>(align_up((int64_t)workspace, 256));
+  rc = ngm_launch_field_bwd(a, a.blocks_per_field * F, (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_field_eval_bwd: no kernel for this (D,H,L)");
+  rc = check_launch("ngm_field_eval_bwd");
+  if (rc) return rc;
+  GradReduceArgs g;
+  g.fc = *fcfg; g.gr = *grads; g.F = F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
+  ngm_launch_grad_reduce(g, (hipStream_t)stream);
+  return check_launch("ngm_grad_reduce");
+}
+
+// ------------------------------------------------------------------------------------------------
+int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors, const float* geoms,
+                      const float* dists, const float* depths, const float* neus_isds, float* C, float* D, float* Cvar,
+                      float* Dvar, float* term, float* weights, void* stream) {
+  if (!cfg || !colors || !geoms || !dists || !depths || N < 0) return fail(NGM_E_INVALID, "ngm_composite_fwd: bad argument");
+  if (N == 0) return NGM_OK;
+  CompositeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rc = *cfg; a.N = N; a.S = S; a.colors = colors; a.geoms = geoms; a.dists = dists; a.depths = depths; a.isds = neus_isds;
+  a.C = C; a.D = D; a.Cv = Cvar; a.Dv = Dvar; a.term = term; a.weights = weights;
+  const int rc = ngm_launch_composite_fwd(a, (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_composite_fwd: unsupported S (max 1024)");
+  return check_launch("ngm_composite_fwd");
+}
+
+int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors, const float* geoms,
+                      const float* dists, const float* depths, const float* neus_isds, const float* dC, const float* dD,
+                      const float* dterm, float* d_colors, float* d_geoms, void* stream) {
+  if (!cfg || !colors || !geoms || !dists || !depths || N < 0) return fail(NGM_E_INVALID, "ngm_composite_bwd: bad argument");
+  if (N == 0) return NGM_OK;
+  CompositeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rc = *cfg; a.N = N; a.S = S; a.colors = colors; a.geoms = geoms; a.dists = dists; a.depths = depths; a.isds = neus_isds;
+  a.dC = dC; a.dD = dD; a.dterm = dterm; a.d_colors = d_colors; a.d_geoms = d_geoms;
+  const int rc = ngm_launch_composite_bwd(a, (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_composite_bwd: unsupported mode (nrgbd/occupancy only) or S > 1024");
+  return check_launch("ngm_composite_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused render / train step
+// ------------------------------------------------------------------------------------------------
+struct RenderPlan {
+  int S, rays_per_block, blocks_fwd;
+  int64_t per_block_bwd; int blocks_per_field_bwd;
+  int64_t p_pad;
+  int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, total;
+};
+static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {
+  RenderPlan p;
+  memset(&p, 0, sizeof(p));
+  p.S = rc->num_samples_coarse + (guided ? rc->num_samples_guided : 0);
+  const int ncu = num_cus();
+  int ch = (ncu + F - 1) / F;
+  const int max_ch = (R + NGM_WAVES_PER_BLOCK - 1) / NGM_WAVES_PER_BLOCK;
+  if (ch > max_ch) ch = max_ch;
+  if (ch < 1) ch = 1;
+  int rpb = (R + ch - 1) / ch;
+  rpb = (int)align_up(rpb, NGM_WAVES_PER_BLOCK);
+  p.rays_per_block = rpb;
+  p.blocks_fwd = F * ((R + rpb - 1) / rpb);
+  p.p_pad = param_pad(fc);
+  int64_t o = 0;
+  if (train) {
+    const int64_t NR = (int64_t)F * R, NS = NR * p.S;
+    p.off_raytab = o; o = align_up(o + NR * 8 * 4, 256);
+    p.off_stashA = o; o = align_up(o + NS * 16, 256);
+    p.off_stashB = o; o = align_up(o + NS * 8, 256);
+    p.off_losspart = o; o = align_up(o + (int64_t)p.blocks_fwd * NGM_NUM_LOSS_SUMS * 4, 256);
+    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
+    p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
+  }
+  p.total = o + 256;
+  return p;
+}
+
+int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F, int32_t R, int32_t train) {
+  if (check_field_cfg(fcfg) || !rcfg || F < 1 || R < 1) return NGM_E_INVALID;
+  // sized for the guided case (S_c + S_g), the larger of the two
+  return plan_render(fcfg, rcfg, F, R, true, train != 0).total;
+}
+
+static int check_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const ngm_params* pr, const ngm_rays* rays) {
+  int e = check_field_cfg(fc);
+  if (e) return e;
+  e = check_params(fc, pr);
+  if (e) return e;
+  if (!rc || !rays || !rays->ijs || !rays->c2ws || !rays->field_pos || !rays->field_quat)
+    return fail(NGM_E_INVALID, "render: NULL ray argument");
+  if (rays->F < 1 || rays->R < 1) return fail(NGM_E_INVALID, "render: empty batch");
+  if (rc->geometry_mode != NGM_GEO_NRGBD && rc->geometry_mode != NGM_GEO_OCCUPANCY)
+    return fail(NGM_E_UNSUPPORTED, "fused render: geometry modes nrgbd / occupancy only");
+  const int S = rc->num_samples_coarse + (rays->gt ? rc->num_samples_guided : 0);
+  if (S < 1 || S > 1024) return fail(NGM_E_UNSUPPORTED, "fused render: samples per ray must be in [1,1024]");
+  return NGM_OK;
+}
+
+int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params, const ngm_rays* rays,
+                   const ngm_targets* targets, const ngm_prediction* pred, float* loss_sums, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  int e = check_render(fcfg, rcfg, params, rays);
+  if (e) return e;
+  if (!pred) return fail(NGM_E_INVALID, "render_fwd: pred is NULL");
+  const bool train = targets != nullptr;
+  if (train && (!targets->rgbds || !targets->depth_mask || !loss_sums)) return fail(NGM_E_INVALID, "render_fwd: incomplete targets");
+  if (train && targets->term_mask && !targets->term_probs) return fail(NGM_E_INVALID, "render_fwd: term_mask without term_probs");
+  if (train && (!pred->rgbds || !pred->term_probs)) return fail(NGM_E_INVALID, "render_fwd(train): pred.rgbds/term_probs required");
+  const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, train);
+  if (train && (!workspace || workspace_bytes < p.total)) return fail(NGM_E_WORKSPACE, "render_fwd: workspace too small");
+  char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
+  RenderFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.rc = *rcfg; a.rays = *rays; a.pred = *pred;
+  a.has_targets = train ? 1 : 0;
+  if (train) a.tg = *targets;
+  a.S = p.S; a.rays_per_block = p.rays_per_block;
+  if (train) {
+    a.raytab = reinterpret_cast<float*>(ws + p.off_raytab);
+    a.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
+    a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
+    a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
+  }
+  e = ngm_launch_render_fwd(a, p.blocks_fwd, (hipStream_t)stream);
+  if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");
+  e = check_launch("ngm_render_fwd");
+  if (e) return e;
+  if (train) {
+    ngm_launch_loss_reduce(a.loss_partials, p.blocks_fwd, loss_sums, (hipStream_t)stream);
+    e = check_launch("ngm_loss_reduce");
+  }
+  return e;
+}
+
+static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
+                             const ngm_rays* rays, StashBwdArgs& sb, const ngm_grads* grads, void* workspace,
+                             int64_t workspace_bytes, hipStream_t st) {
+  const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, true);
+  if (!workspace || workspace_bytes < p.total) return fail(NGM_E_WORKSPACE, "render_bwd: workspace too small");
+  char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
+  sb.rc = *rcfg; sb.F = rays->F; sb.R = rays->R; sb.S = p.S;
+  sb.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
+  sb.stashB = reinterpret_cast<const float2*>(ws + p.off_stashB);
+  sb.raytab = reinterpret_cast<const float*>(ws + p.off_raytab);
+  int e = ngm_launch_stash_bwd(sb, st);
+  if (e) return fail(e, "render_bwd: unsupported geometry mode");
+  e = check_launch("ngm_stash_bwd");
+  if (e) return e;
+  FieldBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
+  a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
+  a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = sb.stashA;
+  a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
+  e = ngm_launch_field_bwd(a, a.blocks_per_field * a.F, st);
+  if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
+  e = check_launch("ngm_field_bwd");
+  if (e) return e;
+  GradReduceArgs g;
+  g.fc = *fcfg; g.gr = *grads; g.F = rays->F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
+  ngm_launch_grad_reduce(g, st);
+  return check_launch("ngm_grad_reduce");
+}
+
+int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params, const ngm_rays* rays,
+                   const ngm_targets* targets, const ngm_prediction* pred, const float* loss_sums, const ngm_grads* grads,
+                   float* loss_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  int e = check_render(fcfg, rcfg, params, rays);
+  if (e) return e;
+  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !loss_sums || !grads)
+    return fail(NGM_E_INVALID, "render_bwd: NULL argument");
+  StashBwdArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.seed_mode = 0; sb.tg = *targets; sb.pred = *pred; sb.loss_sums = loss_sums;
+  e = render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
+  if (e) return e;
+  if (loss_out) {
+    ngm_launch_loss_values(rcfg, loss_sums, loss_out, (hipStream_t)stream);
+    e = check_launch("ngm_loss_values");
+  }
+  return e;
+}
+
+int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
+                          const ngm_rays* rays, const float* d_rgbds, const float* d_term, const float* d_geom_samples,
+                          const ngm_grads* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+  int e = check_render(fcfg, rcfg, params, rays);
+  if (e) return e;
+  if (!d_rgbds || !grads) return fail(NGM_E_INVALID, "render_bwd_seeded: NULL argument");
+  StashBwdArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.seed_mode = 1; sb.d_rgbds = d_rgbds; sb.d_term = d_term; sb.d_geom_samples = d_geom_samples;
+  return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F, int32_t R,
+                            const void* workspace, float* geoms, float* dists, void* stream) {
+  if (check_field_cfg(fcfg) || !rcfg || !workspace) return fail(NGM_E_INVALID, "render_read_samples: bad argument");
+  // the stash of a guided (training) render
+  const RenderPlan p = plan_render(fcfg, rcfg, F, R, true, true);
+  const char* ws = reinterpret_cast<const char*>(align_up((int64_t)workspace, 256));
+  ngm_launch_read_stash(reinterpret_cast<const float4*>(ws + p.off_stashA), reinterpret_cast<const float2*>(ws + p.off_stashB),
+                        (int64_t)F * R * p.S, geoms, dists, (hipStream_t)stream);
+  return check_launch("ngm_render_read_samples");
+}
+
+// ------------------------------------------------------------------------------------------------
+int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t stride, const float* grad,
+                    int64_t grad_stride, const int64_t* field_index, int32_t F, int64_t numel_per_field, int64_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  if (!param || !exp_avg || !exp_avg_sq || !grad || F < 1 || numel_per_field < 1 || step < 1)
+    return fail(NGM_E_INVALID, "ngm_adam_sparse: bad argument");
+  ngm_launch_adam(param, exp_avg, exp_avg_sq, stride, grad, grad_stride, field_index, F, numel_per_field, step, lr, beta1,
+                  beta2, eps, weight_decay, (hipStream_t)stream);
+  return check_launch("ngm_adam_sparse");
+}
+
+int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields, int64_t P,
+                       const float* points, const float* field_pos, const float* field_quat, int32_t num_knn,
+                       float distance_factor, float outside_value, float* out, void* stream) {
+  int e = check_field_cfg(fcfg);
+  if (e) return e;
+  e = check_params(fcfg, params);
+  if (e) return e;
+  if (!points || !field_pos || !field_quat || !out || num_fields < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_field_eval_knn: bad argument");
+  if (P == 0) return NGM_OK;
+  const int K = num_knn < num_fields ? num_knn : num_fields;
+  if (K < 1 || K > 4) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_knn: K must be in [1,4]");
+  e = ngm_launch_knn(fcfg, params, num_fields, P, points, field_pos, field_quat, K, distance_factor, outside_value, out,
+                     (hipStream_t)stream);
+  if (e) return fail(e, "ngm_field_eval_knn: not available for this configuration");
+  return check_launch("ngm_field_eval_knn");
+}
+
+}  // extern "C"

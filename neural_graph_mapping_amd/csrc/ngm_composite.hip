@@ -1,0 +1,444 @@
+// HBM-bound stages of the hot path (gfx950): standalone ray sampler, volume-rendering quadrature
+// forward / backward (wave segmented prefix scans over flat samples), backward of the compositing on
+// the fused kernel's per-sample stash, and the sparse per-field Adam update.
+#include "ngm_device.h"
+#include "ngm_launch.h"
+#include <algorithm>
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+__device__ __forceinline__ int fdiv_idx2(int idx, float inv_s, int S) {
+  int q = (int)(((float)idx + 0.5f) * inv_s);
+  if (q * S > idx) --q;
+  if ((q + 1) * S <= idx) ++q;
+  return q;
+}
+
+// ================================================================================================
+// K1 standalone sampler: one thread per source element; rank-scatter into the sorted slot.
+// ================================================================================================
+struct SamplerArgs {
+  ngm_render_cfg rc;
+  ngm_rays rays;
+  int S;
+  float* points_cam; float* distances; float* dirs;
+};
+
+__global__ void k_sample_rays(SamplerArgs a) {
+  const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
+  const int S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = g / a.S;
+    const int e = (int)(g - ray * a.S);
+    const RayGeom rg = ray_geom(a.rc, a.rays, ray, S_g > 0);
+    float t; int rank;
+    sample_rank(a.rc, a.rays, rg, ray, e, S_c, S_g, &t, &rank);
+    const int64_t o = ray * a.S + rank;
+    if (a.distances) a.distances[o] = t;
+    if (a.points_cam) {
+      a.points_cam[3 * o] = __fmul_rn(rg.dx, t); a.points_cam[3 * o + 1] = __fmul_rn(rg.dy, t);
+      a.points_cam[3 * o + 2] = __fmul_rn(rg.dz, t);
+    }
+    if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
+  }
+}
+
+int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
+                       float* dirs, hipStream_t st) {
+  SamplerArgs a{*rc, *rays, S, points_cam, distances, dirs};
+  const int64_t total = (int64_t)rays->F * rays->R * S;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_sample_rays, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ================================================================================================
+// K4 quadrature forward (rm.py:709-799), all four geometry modes.
+// Each wave owns a contiguous run of rays and walks their flat samples 64 at a time; transmittance
+// is a segmented inclusive product scan carried from step to step; the per-ray sums are segmented
+// sum scans whose segment tails accumulate into a small LDS ray table.
+// ================================================================================================
+#define CQ_BR 32
+#define CQ_MAXS 1024
+struct CompWaveLds {
+  float ra[CQ_BR][12];
+  float wbuf[CQ_MAXS];
+};
+
+__device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int k, int S, float* docc = nullptr) {
+  const int mode = a.rc.geometry_mode;
+  const int64_t g = ray * S + k;
+  const float gm = a.geoms[g];
+  if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY) return occ_pointwise(mode, a.rc.geometry_factor, gm, docc);
+  if (k >= S - 1) return 0.f;   // density / neus drop the last sample (rm.py:749,758)
+  if (mode == NGM_GEO_DENSITY) {
+    const float dl = a.dists[g + 1] - a.dists[g];
+    return 1.0f - expf(-dl * fmaxf(gm, 0.f));
+  }
+  const float isd = a.isds ? a.isds[ray] : 1.0f;
+  const float t0 = ngm_sigmoid(isd * a.rc.geometry_factor * gm);
+  const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * a.geoms[g + 1]);
+  return fmaxf((t0 - t1) / (t0 + 1e-5f), 0.f);
+}
+
+__global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, int rays_per_wave) {
+  __shared__ CompWaveLds lds[NGM_WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  CompWaveLds& wl = lds[wave];
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
+  const int S = a.S;
+  const int mode = a.rc.geometry_mode;
+  const int S_eff = (mode == NGM_GEO_DENSITY || mode == NGM_GEO_NEUS) ? S - 1 : S;
+  const float inv_s = 1.0f / (float)S;
+  const int BR = max(1, min(CQ_BR, CQ_MAXS / S));
+  for (int64_t rb = r_beg; rb < r_end; rb += BR) {
+    const int nb = (int)min<int64_t>(BR, r_end - rb);
+    const int nsamp = nb * S;
+    if (lane < nb) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) wl.ra[lane][c] = 0.f;
+    }
+    WAVE_SYNC();
+    float carry = 1.0f;
+    for (int base = 0; base < nsamp; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      const int64_t g = (rb + rl) * S + k;
+      const bool act = valid && k < S_eff;
+      const float occ = act ? occ_at(a, rb + rl, k, S) : 0.f;
+      float q = seg_scan_mul(1.0f - occ, k, lane);
+      if (k > lane) q *= carry;
+      const float up = __shfl_up(q, 1, 64);
+      const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
+      carry = __shfl(q, 63, 64);
+      const float w = act ? occ * T_excl : 0.f;
+      float c0 = 0, c1 = 0, c2 = 0, dp = 0;
+      if (act) { c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g]; }
+      if (valid) wl.wbuf[idx] = w;
+      if (act && a.weights) a.weights[(rb + rl) * S_eff + k] = w;
+      const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
+                  s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * dp, k, lane),
+                  s4 = seg_scan_add(w, k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+      if (tail) { float* ra = wl.ra[rl]; ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4; }
+      WAVE_SYNC();
+    }
+    for (int base = 0; base < nsamp; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      const int64_t g = (rb + rl) * S + k;
+      const bool act = valid && k < S_eff;
+      const float* ra = wl.ra[rl];
+      const float w = valid ? wl.wbuf[idx] : 0.f;
+      float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+      if (act) { e0 = ra[0] - a.colors[3 * g]; e1 = ra[1] - a.colors[3 * g + 1]; e2 = ra[2] - a.colors[3 * g + 2]; e3 = ra[3] - a.depths[g]; }
+      const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
+                  v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+      WAVE_SYNC();
+      if (tail) { float* rw = wl.ra[rl]; rw[5] += v0; rw[6] += v1; rw[7] += v2; rw[8] += v3; }
+      WAVE_SYNC();
+    }
+    if (lane < nb) {
+      const int64_t ray = rb + lane;
+      const float* ra = wl.ra[lane];
+      if (a.C) { a.C[3 * ray] = ra[0]; a.C[3 * ray + 1] = ra[1]; a.C[3 * ray + 2] = ra[2]; }
+      if (a.D) a.D[ray] = ra[3];
+      if (a.Cv) { a.Cv[3 * ray] = ra[5]; a.Cv[3 * ray + 1] = ra[6]; a.Cv[3 * ray + 2] = ra[7]; }
+      if (a.Dv) a.Dv[ray] = ra[8];
+      if (a.term) a.term[ray] = 1.0f - (1.0f - ra[4]);
+    }
+    WAVE_SYNC();
+  }
+}
+
+static int comp_grid(int64_t N, int S, int* rays_per_wave) {
+  // enough waves to fill the chip (256 CUs x 8 waves), whole rays per wave
+  const int64_t target_waves = 256 * 8;
+  int64_t rpw = (N + target_waves - 1) / target_waves;
+  if (rpw < 1) rpw = 1;
+  *rays_per_wave = (int)rpw;
+  const int64_t waves = (N + rpw - 1) / rpw;
+  return (int)((waves + NGM_WAVES_PER_BLOCK - 1) / NGM_WAVES_PER_BLOCK);
+}
+
+int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
+  if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
+  int rpw;
+  const int blocks = comp_grid(a.N, a.S, &rpw);
+  hipLaunchKernelGGL(k_composite_fwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  return 0;
+}
+
+// ================================================================================================
+// quadrature backward (pointwise geometry modes): dL/dcolour_k = w_k dC ; dL/docc_k = T_k (a_k - Q_k)
+// with a_k = dC.c_k + dD d_k + dterm and the suffix recursion Q_{k-1} = a_k o_k + (1-o_k) Q_k, evaluated
+// as a REVERSE segmented scan of affine maps (exact also when 1-o_k = 0, unlike the division form).
+// ================================================================================================
+struct CompBwdLds {
+  float tex[CQ_MAXS];   // exclusive transmittance
+  float occ[CQ_MAXS];
+  float doc[CQ_MAXS];   // d occ / d geom
+};
+
+__global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, int rays_per_wave) {
+  __shared__ CompBwdLds lds[NGM_WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  CompBwdLds& wl = lds[wave];
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
+  const int S = a.S;
+  const float inv_s = 1.0f / (float)S;
+  const int BR = max(1, min(CQ_BR, CQ_MAXS / S));
+  for (int64_t rb = r_beg; rb < r_end; rb += BR) {
+    const int nb = (int)min<int64_t>(BR, r_end - rb);
+    const int nsamp = nb * S;
+    // forward sweep: occupancy + exclusive transmittance
+    float carry = 1.0f;
+    for (int base = 0; base < nsamp; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      float dodg0 = 0.f;
+      const float occ = valid ? occ_at(a, rb + rl, k, S, &dodg0) : 0.f;
+      float q = seg_scan_mul(1.0f - occ, k, lane);
+      if (k > lane) q *= carry;
+      const float up = __shfl_up(q, 1, 64);
+      const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
+      carry = __shfl(q, 63, 64);
+      if (valid) { wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0; }
+    }
+    WAVE_SYNC();
+    // reverse sweep
+    float carryQ = 0.f;
+    const int nsteps = (nsamp + 63) / 64;
+    for (int st = nsteps - 1; st >= 0; --st) {
+      const int idx = st * 64 + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      const int kr = valid ? S - 1 - k : 0;
+      const int64_t ray = rb + rl, g = ray * S + k;
+      float c0 = 0, c1 = 0, c2 = 0, dp = 0, T = 0, occ = 0, dodg = 0;
+      float dC0 = 0, dC1 = 0, dC2 = 0, dD = 0, dT = 0;
+      if (valid) {
+        c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g];
+        T = wl.tex[idx]; occ = wl.occ[idx]; dodg = wl.doc[idx];
+        if (a.dC) { dC0 = a.dC[3 * ray]; dC1 = a.dC[3 * ray + 1]; dC2 = a.dC[3 * ray + 2]; }
+        if (a.dD) dD = a.dD[ray];
+        if (a.dterm) dT = a.dterm[ray];
+      }
+      const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * dp + dT;
+      float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
+      seg_rscan_affine(A, B, kr, lane);
+      const bool extends = valid && (kr > 63 - lane);
+      const float Qend = extends ? carryQ : 0.f;
+      const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);
+      const float Qk = (kr >= 1 && lane < 63) ? fmaf(nB, Qend, nA) : Qend;
+      const float Qbefore = fmaf(B, Qend, A);
+      carryQ = __shfl(Qbefore, 0, 64);
+      if (valid) {
+        const float w = occ * T;
+        if (a.d_colors) { a.d_colors[3 * g] = w * dC0; a.d_colors[3 * g + 1] = w * dC1; a.d_colors[3 * g + 2] = w * dC2; }
+        if (a.d_geoms) a.d_geoms[g] = T * (ak - Qk) * dodg;
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+
+int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
+  if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
+  if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
+  int rpw;
+  const int blocks = comp_grid(a.N, a.S, &rpw);
+  hipLaunchKernelGGL(k_composite_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  return 0;
+}
+
+// ================================================================================================
+// Backward of compositing + losses on the fused forward's stash.  Reads (colour, geometry | t, T),
+// overwrites stashA with dL/d(raw MLP outputs) for the MFMA backward kernel.
+// ================================================================================================
+__global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int rays_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t N = (int64_t)a.F * a.R;
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(N, gw * rays_per_wave), r_end = min(N, r_beg + rays_per_wave);
+  const int S = a.S;
+  const float inv_s = 1.0f / (float)S;
+  const float tau = a.rc.truncation_distance, gamma = a.rc.geometry_factor, cf = a.rc.color_factor;
+  const int mode = a.rc.geometry_mode;
+  // global loss normalisers (after the caller's all-reduce)
+  float k_photo = 0, k_depth = 0, k_term = 0, k_fs = 0, k_ts = 0;
+  if (a.seed_mode == 0) {
+    const float n_m = a.loss_sums[NGM_LS_PHOTO_CNT], n_d = a.loss_sums[NGM_LS_DEPTH_CNT], n_t = a.loss_sums[NGM_LS_TERM_CNT],
+                n_fs = a.loss_sums[NGM_LS_FS_CNT], n_ts = a.loss_sums[NGM_LS_TSDF_CNT];
+    k_photo = n_m > 0 ? a.rc.w_photometric / (3.0f * n_m) : 0.f;
+    k_depth = n_d > 0 ? a.rc.w_depth / n_d : 0.f;
+    k_term = n_t > 0 ? a.rc.w_termination * 2.0f / n_t : 0.f;
+    k_fs = n_fs > 0 ? a.rc.w_freespace * 2.0f / n_fs : 0.f;
+    k_ts = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
+  }
+  const int64_t nsamp_all = (r_end - r_beg) * S;
+  float carryQ = 0.f;
+  const int64_t nsteps = (nsamp_all + 63) / 64;
+  for (int64_t st = nsteps - 1; st >= 0; --st) {
+    const int64_t idx = st * 64 + lane;
+    const bool valid = idx < nsamp_all;
+    // idx / S with idx possibly large: exact integer division (one per lane per step)
+    const int64_t rl = valid ? idx / S : 0;
+    const int k = valid ? (int)(idx - rl * S) : 0;
+    const int kr = valid ? S - 1 - k : 0;
+    const int64_t ray = r_beg + rl, g = ray * S + k;
+    float c0 = 0, c1 = 0, c2 = 0, geom = 0, t = 0, T = 0, dzc = 0, gt = 0;
+    float dC0 = 0, dC1 = 0, dC2 = 0, dD = 0, dT = 0;
+    if (valid) {
+      const float4 sa = a.stashA[g];
+      const float2 sb = a.stashB[g];
+      c0 = sa.x; c1 = sa.y; c2 = sa.z; geom = sa.w; t = sb.x; T = sb.y;
+      const float4 r1 = reinterpret_cast<const float4*>(a.raytab)[2 * ray + 1];
+      dzc = r1.z; gt = r1.w;
+      if (a.seed_mode == 0) {
+        const float4 pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
+        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
+        const float term = a.pred.term_probs[ray];
+        const bool m = a.tg.depth_mask[ray] && (term > a.rc.term_threshold);
+        if (m) {
+          const float e0 = pr.x - tg.x, e1 = pr.y - tg.y, e2 = pr.z - tg.z;
+          dC0 = k_photo * ((e0 > 0.f) - (e0 < 0.f)); dC1 = k_photo * ((e1 > 0.f) - (e1 < 0.f));
+          dC2 = k_photo * ((e2 > 0.f) - (e2 < 0.f));
+          const float e = pr.w - tg.w, dl = a.rc.huber_delta;
+          dD = k_depth * ((fabsf(e) < dl) ? e : dl * ((e > 0.f) - (e < 0.f)));
+        }
+        if (a.tg.term_mask && a.tg.term_mask[ray]) dT = k_term * (term - a.tg.term_probs[ray]);
+      } else {
+        const float4 d = reinterpret_cast<const float4*>(a.d_rgbds)[ray];
+        dC0 = d.x; dC1 = d.y; dC2 = d.z; dD = d.w;
+        if (a.d_term) dT = a.d_term[ray];
+      }
+    }
+    const float depth = -(dzc * t);
+    float dodg = 0.f;
+    const float occ = valid ? occ_pointwise(mode, gamma, geom, &dodg) : 0.f;
+    const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * depth + dT;
+    float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
+    seg_rscan_affine(A, B, kr, lane);
+    const bool extends = valid && (kr > 63 - lane);
+    const float Qend = extends ? carryQ : 0.f;
+    const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);
+    const float Qk = (kr >= 1 && lane < 63) ? fmaf(nB, Qend, nA) : Qend;
+    const float Qbefore = fmaf(B, Qend, A);
+    carryQ = __shfl(Qbefore, 0, 64);
+    if (valid) {
+      const float w = occ * T;
+      float dg = T * (ak - Qk) * dodg;
+      if (a.seed_mode == 0) {
+        const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);
+        if (t < thr) dg += k_fs * (geom * tau - tau) * tau;
+        const float dl = gt - t;
+        if (fabsf(dl) < tau && gt != 0.0f) dg += k_ts * (geom * tau - dl) * tau;
+      } else if (a.d_geom_samples) {
+        dg += a.d_geom_samples[g];
+      }
+      a.stashA[g] = make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg);
+    }
+  }
+}
+
+int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
+  if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
+  int rpw;
+  const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);
+  hipLaunchKernelGGL(k_stash_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  return 0;
+}
+
+// ================================================================================================
+// loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination,
+// photometric, depth, freespace, tsdf.  Empty selections contribute 0 (the reference yields NaN).
+// ================================================================================================
+__global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
+              n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
+  const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
+  const float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
+  const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : 0.f;
+  const float lf = n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : 0.f;
+  const float ls = n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : 0.f;
+  out[1] = lt; out[2] = lp; out[3] = ld; out[4] = lf; out[5] = ls;
+  out[0] = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld + rc.w_freespace * lf + rc.w_tsdf * ls;
+  out[6] = 0.f; out[7] = 0.f;
+}
+int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_loss_values, dim3(1), dim3(64), 0, st, *rc, sums, out);
+  return 0;
+}
+
+// sum of per-workgroup loss partials (fixed order)
+__global__ void k_loss_reduce(const float* partials, int nblocks, float* sums) {
+  const int i = threadIdx.x;
+  if (i >= NGM_NUM_LOSS_SUMS) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * NGM_NUM_LOSS_SUMS + i];
+  sums[i] = s;
+}
+int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, partials, nblocks, sums);
+  return 0;
+}
+
+// copy geometry / distance planes out of the stash (Prediction.freespace_geometry / tsdf_residuals)
+__global__ void k_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (geoms) geoms[i] = sa[i].w;
+    if (dists) dists[i] = sb[i].x;
+  }
+}
+int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_read_stash, dim3(std::max(blocks, 1)), dim3(256), 0, st, sa, sb, n, geoms, dists);
+  return 0;
+}
+
+// ================================================================================================
+// sparse per-field Adam (torch.optim.Adam, L2-coupled weight decay, shared step; rm.py:357-362)
+// ================================================================================================
+__global__ void k_adam_sparse(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
+                              const int64_t* field_index, int F, int64_t numel, float lr_bc1, float inv_sqrt_bc2,
+                              float beta1, float beta2, float eps, float wd) {
+  const int f = blockIdx.y;
+  const int64_t row = field_index ? field_index[f] : f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = row * stride + i;
+    const float p = param[o];
+    const float g = grad[(int64_t)f * gstride + i] + wd * p;
+    const float mn = beta1 * m[o] + (1.0f - beta1) * g;
+    const float vn = beta2 * v[o] + (1.0f - beta2) * g * g;
+    m[o] = mn; v[o] = vn;
+    const float denom = sqrtf(vn) * inv_sqrt_bc2 + eps;
+    param[o] = p - lr_bc1 * (mn / denom);
+  }
+}
+int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
+                    const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
+                    float eps, float wd, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float lr_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel + 255) / 256, 64)), (unsigned)F);
+  hipLaunchKernelGGL(k_adam_sparse, grid, dim3(256), 0, st, param, m, v, stride, grad, gstride, field_index, F, numel,
+                     lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd);
+  return 0;
+}

@@ -1,0 +1,255 @@
+// Device-side building blocks shared by all gfx950 kernels of the render/train hot path.
+// wave = 64 lanes everywhere (CDNA4); MFMA = v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain numerics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngm_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef NGM_BLOCK
+#define NGM_WAVE 64
+#define NGM_BLOCK 256
+#define NGM_WAVES_PER_BLOCK 4
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// MFMA 32x32x2 f32 fragment maps (cdna_hip_programming.md section 3):
+//   A: lane l holds A[i = l&31][k = l>>5]       B: lane l holds B[k = l>>5][j = l&31]
+//   C/D: lane l, reg r holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// We always put FEATURES on M (rows) and SAMPLES on N (cols = lane&31).  A layer's output
+// registers (C layout) are then directly the B operands of the next layer: k-step r of input tile
+// mi consumes register r, i.e. feature 32*mi + frow(r, hi) -- the weights (A operand) are stored in
+// LDS in exactly that permuted k order, so activations never move between lanes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int frow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// weight fragment storage in LDS: element W[32*mo + io][32*mi + frow(r,hi)] lives at
+//   ((((mo*MIN + mi)*16 + r)*2 + hi) * WGS + io);  WGS = 33 keeps both the forward read
+// (lanes vary io) and the transposed dgrad read (lanes vary (r,hi)) bank-conflict free.
+#define NGM_WGS 33
+__device__ __forceinline__ constexpr int wfrag_size(int mout, int min_) { return mout * min_ * 16 * 2 * NGM_WGS; }
+// (r', hi') such that frow(r', hi') == c for c in [0,32)
+__device__ __forceinline__ constexpr int col_r(int c) { return (c & 3) + 4 * (c >> 3); }
+__device__ __forceinline__ constexpr int col_hi(int c) { return (c >> 2) & 1; }
+
+// ------------------------------------------------------------------------------------------------
+// fast accurate sin/cos: Cody-Waite 3-term reduction by pi/2 + minimax polynomials on [-pi/4,pi/4].
+// |x| < 1e5: <= ~1.5 ulp.  Larger arguments fall back to the (slow, exact) library path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ngm_sincosf(float x, float* s_out, float* c_out) {
+  if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) {
+    *s_out = sinf(x);
+    *c_out = cosf(x);
+    return;
+  }
+  const float n = rintf(x * 0.63661977236758134f);
+  float r = fmaf(n, -1.57079601287841796875f, x);       // pi/2 hi
+  r = fmaf(n, -3.1391647326017846353e-7f, r);           // pi/2 mid
+  r = fmaf(n, -5.3903025299577648e-15f, r);             // pi/2 lo
+  const float z = r * r;
+  // cephes single-precision kernels on [-pi/4, pi/4]
+  float ps = -1.9515295891e-4f;
+  ps = fmaf(ps, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float sr = fmaf(r * z, ps, r);
+  float pc = 2.443315711809948e-5f;
+  pc = fmaf(pc, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float cr = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)n;
+  const float s1 = (q & 1) ? cr : sr;
+  const float c1 = (q & 1) ? sr : cr;
+  *s_out = (q & 2) ? -s1 : s1;
+  *c_out = ((q + 1) & 2) ? -c1 : c1;
+}
+
+__device__ __forceinline__ float ngm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (used when the caller passes no explicit torch.rand draws)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t stream_id) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = (uint32_t)offset;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0,1)
+}
+
+// ------------------------------------------------------------------------------------------------
+// quaternion / pose helpers (models.py:329-339 with pytorch3d's Hamilton convention, real first)
+// ------------------------------------------------------------------------------------------------
+struct Vec3 { float x, y, z; };
+__device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
+  return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// rotate v by the INVERSE of unit quaternion (w, u): v' = v + 2w(v x u)... written for q^-1 = (w,-u)
+__device__ __forceinline__ Vec3 quat_rotate_inv(float w, float ux, float uy, float uz, Vec3 v) {
+  const Vec3 u{-ux, -uy, -uz};
+  Vec3 t = cross3(u, v);
+  t.x *= 2.0f; t.y *= 2.0f; t.z *= 2.0f;
+  const Vec3 c = cross3(u, t);
+  return Vec3{v.x + w * t.x + c.x, v.y + w * t.y + c.y, v.z + w * t.z + c.z};
+}
+__device__ __forceinline__ void scale_consts(int scale_mode, float radius, float* div, float* off) {
+  if (scale_mode == NGM_SCALE_UNIT_CUBE) { *div = 2.0f * radius; *off = 0.5f; }
+  else if (scale_mode == NGM_SCALE_UNIT_BALL) { *div = radius; *off = 0.0f; }
+  else { *div = 1.0f; *off = 0.0f; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray sampler arithmetic (camera.py:186-203, 269-276; rm.py:521-545).  Separate roundings (no FMA
+// contraction) so that distances reproduce the reference's op sequence bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct RayGeom {
+  float dx, dy, dz;        // unit direction, camera frame (OpenGL: -z forward)
+  float near, far;         // coarse stratum
+  float gnear, gfar;       // depth-guided stratum (falls back to near/far, rm.py:522-530)
+  float gt;
+};
+
+__device__ __forceinline__ float strat_lin(const float* lin_tab, int n, int i) {
+  if (lin_tab) return lin_tab[i];
+  // torch.linspace(0,1,n+1) scalar formula (RangeFactories): symmetric about the middle
+  const float step = __fdiv_rn(1.0f, (float)n);
+  const int steps = n + 1, half = steps / 2;
+  return (i < half) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(steps - i - 1)));
+}
+// t_i = (delta*u + lin_i*(far-near)) + near
+__device__ __forceinline__ float strat_t(float near, float far, int n, int i, float u, const float* lin_tab) {
+  const float span = __fsub_rn(far, near);
+  const float delta = __fdiv_rn(span, (float)n);
+  const float b = __fmul_rn(strat_lin(lin_tab, n, i), span);
+  return __fadd_rn(__fadd_rn(__fmul_rn(delta, u), b), near);
+}
+
+__device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm_rays& rays, int64_t ray, bool guided) {
+  RayGeom g;
+  const int64_t i = rays.ijs[2 * ray], j = rays.ijs[2 * ray + 1];
+  const float vx = __fdiv_rn(__fsub_rn((float)j, cfg.cx), cfg.fx);
+  const float vy = -__fdiv_rn(__fsub_rn((float)i, cfg.cy), cfg.fy);
+  const float vz = -1.0f;
+  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+  const float den = fmaxf(nrm, 1e-12f);
+  g.dx = __fdiv_rn(vx, den); g.dy = __fdiv_rn(vy, den); g.dz = __fdiv_rn(vz, den);
+  g.near = rays.near ? rays.near[ray] : rays.near_const;
+  g.far = rays.far ? rays.far[ray] : rays.far_const;
+  g.gt = (guided && rays.gt) ? rays.gt[ray] : 0.0f;
+  g.gnear = g.near; g.gfar = g.far;
+  if (guided) {
+    const bool invalid = (g.gt == 0.0f) || (g.near > g.gt) || (g.far < g.gt);
+    if (!invalid) { g.gnear = __fsub_rn(g.gt, cfg.range_depth_guided); g.gfar = __fadd_rn(g.gt, cfg.range_depth_guided); }
+  }
+  return g;
+}
+
+// jitter draw for source element (stratum `which`, index i) of global ray `ray`
+__device__ __forceinline__ float jitter(const ngm_rays& rays, int which, int64_t ray, int n, int i) {
+  const float* u = which ? rays.u_guided : rays.u_coarse;
+  if (u) return u[ray * n + i];
+  return philox_uniform(rays.philox_seed, rays.philox_offset, (uint64_t)(ray * n + i), (uint32_t)which);
+}
+
+// number of elements of stratum (near,far,n) that are < x (strict=1) or <= x (strict=0).
+// Closed form from the stratified structure (element j lies in [near+j*d, near+(j+1)*d)), with the
+// three candidates around the boundary compared explicitly so fp32 rounding cannot mis-rank.
+__device__ __forceinline__ int strat_count_below(const ngm_rays& rays, int which, int64_t ray, float near, float far,
+                                                 int n, const float* lin_tab, float x, bool strict) {
+  const float span = far - near;
+  int q;
+  if (!(span > 0.0f)) q = 0;
+  else {
+    float qf = floorf((x - near) / (span / (float)n));
+    qf = fminf(fmaxf(qf, -2.0f), (float)n + 2.0f);
+    q = (int)qf;
+  }
+  int cnt = min(max(q - 1, 0), n);
+  if (!(span > 0.0f)) cnt = 0;
+  const int lo = (span > 0.0f) ? max(q - 1, 0) : 0;
+  const int hi = (span > 0.0f) ? min(q + 1, n - 1) : n - 1;
+  for (int j = lo; j <= hi; ++j) {
+    const float tj = strat_t(near, far, n, j, jitter(rays, which, ray, n, j), lin_tab);
+    cnt += strict ? (tj < x) : (tj <= x);
+  }
+  return min(cnt, n);
+}
+
+// sorted distance + rank of source element e (0..S_c-1 coarse, S_c.. guided) of a ray
+__device__ __forceinline__ void sample_rank(const ngm_render_cfg& cfg, const ngm_rays& rays, const RayGeom& g,
+                                            int64_t ray, int e, int S_c, int S_g, float* t_out, int* rank_out) {
+  if (e < S_c) {
+    const float t = strat_t(g.near, g.far, S_c, e, jitter(rays, 0, ray, S_c, e), rays.lin_coarse);
+    int rank = e;
+    if (S_g > 0) rank += strat_count_below(rays, 1, ray, g.gnear, g.gfar, S_g, rays.lin_guided, t, true);
+    *t_out = t; *rank_out = rank;
+  } else {
+    const int j = e - S_c;
+    const float t = strat_t(g.gnear, g.gfar, S_g, j, jitter(rays, 1, ray, S_g, j), rays.lin_guided);
+    const int rank = j + strat_count_below(rays, 0, ray, g.near, g.far, S_c, rays.lin_coarse, t, false);
+    *t_out = t; *rank_out = rank;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-level segmented scans over 64 lanes = 64 consecutive flat samples.  A segment = one ray;
+// k = sample index inside the ray, so lane-d belongs to the same segment iff k >= d (&& lane >= d).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float seg_scan_add(float v, int k, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d && k >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float seg_scan_mul(float v, int k, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d && k >= d) v *= o;
+  }
+  return v;
+}
+// reverse affine scan: composes x -> A + B*x from the segment END towards lower lanes.
+// kr = number of samples after this one inside the ray (S-1-k); result maps Q_end to Q_before(lane).
+__device__ __forceinline__ void seg_rscan_affine(float& A, float& B, int kr, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float oA = __shfl_down(A, d, 64);
+    const float oB = __shfl_down(B, d, 64);
+    if (lane + d < 64 && kr >= d) { A = fmaf(B, oA, A); B = B * oB; }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// occupancy probability of one sample (rm.py:746-762) and its derivative w.r.t. the geometry value.
+// density/neus need the neighbouring sample and are handled by the callers.
+__device__ __forceinline__ float occ_pointwise(int mode, float gamma, float g, float* docc_dg) {
+  const float x = gamma * g;
+  if (mode == NGM_GEO_NRGBD) {
+    const float s = ngm_sigmoid(x), sm = ngm_sigmoid(-x);
+    const float o = 4.0f * s * sm;
+    if (docc_dg) *docc_dg = gamma * o * (sm - s);
+    return o;
+  }
+  const float s = ngm_sigmoid(x);  // occupancy
+  if (docc_dg) *docc_dg = gamma * s * (1.0f - s);
+  return s;
+}

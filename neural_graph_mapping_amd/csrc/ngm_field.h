@@ -1,0 +1,212 @@
+// Per-field tiny-MLP machinery shared by the forward and backward kernels:
+//   * LDS-resident weights of ONE field per workgroup, stored as MFMA A-fragments,
+//   * positional encoding evaluated straight into MFMA B-operand registers,
+//   * layer chaining on v_mfma_f32_32x32x2_f32 with activations kept in registers.
+// Template parameters: MI = ceil(D/32) encoding tiles, MH = ceil(H/32) hidden tiles, L = hidden layers.
+#pragma once
+#include "ngm_device.h"
+
+// encoding feature descriptor kinds (LDS table encW[f] = {wx, wy, wz, kind})
+#define NGM_FK_ZERO 0.0f
+#define NGM_FK_RAW 1.0f   // value = w . x       (raw coordinates: unit weight vector)
+#define NGM_FK_SIN 2.0f   // value = sin(w . x)
+#define NGM_FK_COS 3.0f   // value = cos(w . x)
+
+template <int MI, int MH, int L>
+struct FieldLds {
+  static constexpr int ENCW = 0;                             // float4[MI*32]
+  static constexpr int ENCW_SIZE = MI * 32 * 4;
+  static constexpr int w_off(int l) {                        // hidden layer l weights
+    int o = ENCW + ENCW_SIZE;
+    for (int i = 0; i < l; ++i) o += wfrag_size(MH, i == 0 ? MI : MH) + MH * 32;
+    return o;
+  }
+  static constexpr int b_off(int l) { return w_off(l) + wfrag_size(MH, l == 0 ? MI : MH); }
+  static constexpr int WOUT = b_off(L - 1) + MH * 32;         // float4[MH*32]: the 4 output weights per feature
+  static constexpr int BOUT = WOUT + MH * 32 * 4;             // float[4]
+  static constexpr int TOTAL = (BOUT + 4 + 3) & ~3;           // floats, 16-byte multiple
+};
+
+struct FieldDims {
+  int D, H, L, n_raw, n_feat;  // logical sizes; Fourier: n_raw = 3 if raw_coords, n_feat rows of enc_w
+};
+
+// Build the per-feature encoding table and copy + permute one field's weights into LDS.
+// All 256 threads of the workgroup participate; caller must __syncthreads() afterwards.
+template <int MI, int MH, int L>
+__device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
+  using LY = FieldLds<MI, MH, L>;
+  const int tid = threadIdx.x;
+  const int D = fc.dim_enc, H = fc.dim_hidden;
+  // ---- encoding table
+  for (int f = tid; f < MI * 32; f += NGM_BLOCK) {
+    float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
+    if (f < D) {
+      if (fc.encoding == NGM_ENC_FOURIER) {
+        const int n_raw = fc.raw_coords ? 3 : 0;
+        if (f < n_raw) {
+          e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+        } else {
+          const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
+          e = make_float4(w[0], w[1], w[2], NGM_FK_SIN);
+        }
+      } else if (fc.encoding == NGM_ENC_NERF) {
+        // layout: sines (dim-major, octave-minor) then cosines (positional_encodings.py:268-271)
+        const int half = 3 * fc.num_octaves;
+        const int g = (f < half) ? f : f - half;
+        const int d = g / fc.num_octaves, o = g % fc.num_octaves;
+        const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
+        e = make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
+      } else {  // NGM_ENC_NONE: raw coordinates
+        e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+      }
+    }
+    reinterpret_cast<float4*>(sm + LY::ENCW)[f] = e;
+  }
+  // ---- hidden layers: W_l (H x Din) row-major in HBM -> A-fragment order
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int MIN = (l == 0) ? MI : MH;
+    const int Din = (l == 0) ? D : H;
+    const float* W = pr.w[l] + row * pr.w_stride[l];
+    const float* B = pr.b[l] + row * pr.b_stride[l];
+    float* dst = sm + LY::w_off(l);
+    const int ncol = MIN * 32, total = MH * 32 * ncol;
+    for (int e = tid; e < total; e += NGM_BLOCK) {
+      const int o = e / ncol, c = e - o * ncol;
+      const float v = (o < H && c < Din) ? W[(int64_t)o * Din + c] : 0.f;
+      const int mo = o >> 5, io = o & 31, mi = c >> 5, ic = c & 31;
+      dst[((((mo * MIN + mi) * 16 + col_r(ic)) * 2 + col_hi(ic)) * NGM_WGS) + io] = v;
+    }
+    for (int o = tid; o < MH * 32; o += NGM_BLOCK) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
+  }
+  // ---- output layer (4 x H) -> float4 per hidden feature
+  {
+    const float* W = pr.w[L] + row * pr.w_stride[L];
+    const float* B = pr.b[L] + row * pr.b_stride[L];
+    for (int f = tid; f < MH * 32; f += NGM_BLOCK) {
+      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < H) w4 = make_float4(W[f], W[H + f], W[2 * H + f], W[3 * H + f]);
+      reinterpret_cast<float4*>(sm + LY::WOUT)[f] = w4;
+    }
+    if (tid < 4) sm[LY::BOUT + tid] = B[tid];
+  }
+}
+
+// Encoding of one sample position into the lane's B-operand registers.
+// Lane (j = lane&31, hi = lane>>5) holds features 32*mi + frow(r,hi) of sample j.
+// WITH_DERIV additionally returns d(value)/d(arg) (cos for sin-features, -sin for cos-features,
+// 0 for raw/padding) -- used by the backward kernel for the learnable Fourier matrix.
+template <int MI, bool NEED_COS, bool WITH_DERIV>
+__device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, float x, float y, float z,
+                                              f32x16 (&E)[MI], f32x16 (&dE)[MI]) {
+  const float4* tab = reinterpret_cast<const float4*>(sm_encw);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w = tab[32 * mi + frow(r, 0) + 4 * hi];
+      const float arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
+      float s, c;
+      ngm_sincosf(arg, &s, &c);
+      float v = (w.w == NGM_FK_RAW) ? arg : ((w.w == NGM_FK_SIN) ? s : 0.f);
+      if (NEED_COS) v = (w.w == NGM_FK_COS) ? c : v;
+      E[mi][r] = v;
+      if (WITH_DERIV) {
+        float d = (w.w == NGM_FK_SIN) ? c : 0.f;
+        if (NEED_COS) d = (w.w == NGM_FK_COS) ? -s : d;
+        dE[mi][r] = d;
+      }
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// One hidden layer on the matrix cores: Y = relu(W X + b), X/Y in C-layout registers, NT sample tiles.
+template <int MIN, int MOUT, int NT>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const float* __restrict__ B, int lane,
+                                          const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT]) {
+  const int io = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mo = 0; mo < MOUT; ++mo) {
+    f32x16 bias;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
+      bias[4 * q + 0] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = bias;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MIN; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < MOUT; ++mo) {
+        const float a = W[((((mo * MIN + mi) * 16 + r) * 2 + hi) * NGM_WGS) + io];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma32(a, X[nt][mi][r], Y[nt][mo]);
+      }
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = fmaxf(Y[nt][mo][r], 0.f);
+}
+
+// Output layer (4 x H) on the VALU: each lane reduces over ITS 16*MH features; the two lane halves
+// of a sample hold disjoint feature sets and are combined by the caller.
+template <int MH, int NT>
+__device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, const f32x16 (&Hh)[NT][MH],
+                                                  float (&part)[NT][4]) {
+  const float4* w4 = reinterpret_cast<const float4*>(sm_wout);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { part[nt][0] = part[nt][1] = part[nt][2] = part[nt][3] = 0.f; }
+#pragma unroll
+  for (int mi = 0; mi < MH; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w = w4[32 * mi + frow(r, 0) + 4 * hi];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float h = Hh[nt][mi][r];
+        part[nt][0] = fmaf(w.x, h, part[nt][0]);
+        part[nt][1] = fmaf(w.y, h, part[nt][1]);
+        part[nt][2] = fmaf(w.z, h, part[nt][2]);
+        part[nt][3] = fmaf(w.w, h, part[nt][3]);
+      }
+    }
+  }
+}
+
+// Full forward MLP for NT tiles: E (encoding, C layout) -> partial outputs.  Keeps the last hidden
+// activations in Hlast (needed by the backward kernel for the ReLU mask / output-layer gradient).
+template <int MI, int MH, int L, int NT>
+__device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH]) {
+  using LY = FieldLds<MI, MH, L>;
+  layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
+#pragma unroll
+  for (int l = 1; l < L; ++l) {
+    f32x16 T[NT][MH];
+    layer_fwd<MH, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hlast, T);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
+  }
+}
+
+// dispatch helper: logical (D,H,L) -> compiled (MI,MH,L) instantiation
+struct FieldShape { int MI, MH, L; };
+static inline FieldShape field_shape(const ngm_field_cfg* fc) {
+  FieldShape s;
+  s.MI = (fc->dim_enc + 31) / 32;
+  s.MH = (fc->dim_hidden + 31) / 32;
+  s.L = fc->num_layers;
+  return s;
+}

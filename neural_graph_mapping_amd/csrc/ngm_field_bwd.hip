@@ -1,0 +1,422 @@
+// Backward of the per-field MLP + encoding on the matrix cores (gfx950).
+//
+// Input per sample: position (explicit points, or ray table + saved distance) and dL/d(raw outputs).
+// Per 32-sample tile a wave (a) recomputes the forward activations (nothing but 24 B/sample was saved
+// by the forward), (b) back-propagates through the layers with dgrad MFMAs whose B operands are the
+// C-layout registers of the previous step, and (c) accumulates the weight gradients with wgrad MFMAs
+// whose operands are the activations / pre-activation gradients transposed through a small per-wave
+// LDS staging buffer (samples become the contraction index).  Weight-gradient accumulators stay in
+// registers for the whole kernel; every workgroup writes ONE partial gradient vector, reduced (in a
+// fixed order -> deterministic) by k_grad_reduce.
+#include "ngm_field.h"
+#include "ngm_launch.h"
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+template <int MI, int MH, int L>
+struct BwdLds {
+  using LY = FieldLds<MI, MH, L>;
+  static constexpr int STR_E = 32 * MI + 4;
+  static constexpr int STR_H = 32 * MH + 4;
+  static constexpr int STR_D = (STR_E > STR_H) ? STR_E : STR_H;
+  static constexpr int X0 = 0;                                    // E       [32][STR_E]
+  static constexpr int x_off(int l) { return l == 0 ? 0 : 32 * STR_E + (l - 1) * 32 * STR_H; }  // X_l
+  static constexpr int DBUF = 32 * STR_E + (L - 1) * 32 * STR_H;   // [32][STR_D]
+  static constexpr int PBUF = DBUF + 32 * STR_D;                   // [32][4] positions
+  static constexpr int OBUF = PBUF + 128;                          // [32][4] dL/dout
+  static constexpr int WAVE_TOTAL = OBUF + 128;
+  static constexpr int TOTAL = LY::TOTAL + NGM_WAVES_PER_BLOCK * WAVE_TOTAL;
+};
+
+// C-layout registers -> staging buffer [sample][feature]; one 16-byte store per 4 registers
+template <int M>
+__device__ __forceinline__ void store_tile(float* buf, int stride, int lane, const f32x16 (&V)[M]) {
+  const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(buf + j * stride + 32 * m + 8 * q + 4 * hi) =
+          make_float4(V[m][4 * q], V[m][4 * q + 1], V[m][4 * q + 2], V[m][4 * q + 3]);
+}
+template <int M>
+__device__ __forceinline__ void load_tile(const float* buf, int stride, int lane, f32x16 (&V)[M]) {
+  const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(buf + j * stride + 32 * m + 8 * q + 4 * hi);
+      V[m][4 * q] = v.x; V[m][4 * q + 1] = v.y; V[m][4 * q + 2] = v.z; V[m][4 * q + 3] = v.w;
+    }
+}
+
+// dX = W^T dY  (dgrad): M = input features (MIN tiles), K = output features (MOUT tiles).
+template <int MIN, int MOUT>
+__device__ __forceinline__ void layer_dgrad(const float* __restrict__ W, int lane, const f32x16 (&dY)[MOUT],
+                                            f32x16 (&dX)[MIN]) {
+  const int i = lane & 31, hi = lane >> 5;
+  const int lane_off = (col_r(i) * 2 + col_hi(i)) * NGM_WGS + 4 * hi;
+#pragma unroll
+  for (int mi = 0; mi < MIN; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dX[mi][r] = 0.f;
+#pragma unroll
+  for (int mo = 0; mo < MOUT; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int mi = 0; mi < MIN; ++mi) {
+        const float a = W[(mo * MIN + mi) * 16 * 2 * NGM_WGS + lane_off + frow(r, 0)];
+        dX[mi] = mfma32(a, dY[mo][r], dX[mi]);
+      }
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// dW += dY^T (x) X^T  (wgrad): contraction over the 32 samples of the tile, operands from staging LDS.
+template <int MOUT, int MIN>
+__device__ __forceinline__ void layer_wgrad(const float* __restrict__ dbuf, int dstr, const float* __restrict__ xbuf,
+                                            int xstr, int lane, f32x16 (&acc)[MOUT][MIN]) {
+  const int i = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int s = t + 16 * hi;
+    float av[MOUT], bv[MIN];
+#pragma unroll
+    for (int mo = 0; mo < MOUT; ++mo) av[mo] = dbuf[s * dstr + 32 * mo + i];
+#pragma unroll
+    for (int mi = 0; mi < MIN; ++mi) bv[mi] = xbuf[s * xstr + 32 * mi + i];
+#pragma unroll
+    for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < MIN; ++mi) acc[mo][mi] = mfma32(av[mo], bv[mi], acc[mo][mi]);
+    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// column sums over the tile's samples with lane = feature (M*32 features; M==1 splits samples 2-way)
+template <int M>
+__device__ __forceinline__ float colsum(const float* buf, int stride, int lane) {
+  constexpr int NF = 32 * M, PARTS = 64 / NF, PER = 32 / PARTS;
+  const int fl = lane % NF, sp = lane / NF;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < PER; ++k) s += buf[(sp * PER + k) * stride + fl];
+  return s;
+}
+
+template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD>
+__global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  using LY = FieldLds<MI, MH, L>;
+  using BL = BwdLds<MI, MH, L>;
+  const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  float* wl = sm + LY::TOTAL + wave * BL::WAVE_TOTAL;
+  float* bufD = wl + BL::DBUF;
+  float* pbuf = wl + BL::PBUF;
+  float* obuf = wl + BL::OBUF;
+
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const bool ray_mode = a.points == nullptr;
+  const bool posed = a.pos != nullptr;
+  float px = 0, py = 0, pz = 0, qw = 1, qx = 0, qy = 0, qz = 0;
+  if (!ray_mode && posed) {
+    px = a.pos[3 * f]; py = a.pos[3 * f + 1]; pz = a.pos[3 * f + 2];
+    qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
+  }
+
+  // ---- register-resident gradient accumulators
+  f32x16 acc0[MH][MI];
+  f32x16 accH[(L > 1) ? (L - 1) : 1][MH][MH];
+#pragma unroll
+  for (int mo = 0; mo < MH; ++mo) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[mo][mi][r] = 0.f;
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+      for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accH[l][mo][mi][r] = 0.f;
+  }
+  float dbh[L];            // lane = hidden feature
+  float dwo[4], dbo[4];    // output layer: dwo lane = hidden feature; dbo per sample lane
+  float dwf[3];            // lane = encoding feature
+#pragma unroll
+  for (int l = 0; l < L; ++l) dbh[l] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dwo[c] = 0.f; dbo[c] = 0.f; }
+  dwf[0] = dwf[1] = dwf[2] = 0.f;
+
+  const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
+  for (int64_t base = beg + wave * 32; base < end; base += 32 * NGM_WAVES_PER_BLOCK) {
+    const int64_t n = base + j;
+    const bool valid = n < end;
+    // ---- sample position (scaled field-local) and incoming gradient
+    float x = 0, y = 0, z = 0;
+    float4 dout = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      const int64_t g = (int64_t)f * a.P + n;
+      if (ray_mode) {
+        const int64_t ray = g / a.S;
+        const float4 r0 = reinterpret_cast<const float4*>(a.raytab)[2 * ray];
+        const float4 r1 = reinterpret_cast<const float4*>(a.raytab)[2 * ray + 1];
+        const float t = a.stashB[g].x;
+        x = fmaf(t, r0.w, r0.x); y = fmaf(t, r1.x, r0.y); z = fmaf(t, r1.y, r0.z);
+      } else {
+        const float* p = a.points + g * 3;
+        Vec3 v{p[0], p[1], p[2]};
+        if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
+        x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
+      }
+      dout = a.d_out[g];
+    }
+    // ---- forward recompute, staging every layer input
+    f32x16 E[1][MI], dEa[MI];
+    encode_sample<MI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, hi, x, y, z, E[0], dEa);
+    WAVE_SYNC();   // previous tile's readers of the staging buffers are done (in-order LDS) - compiler fence
+    store_tile<MI>(wl + BL::x_off(0), BL::STR_E, lane, E[0]);
+    if (hi == 0) {
+      *reinterpret_cast<float4*>(pbuf + 4 * j) = make_float4(x, y, z, 0.f);
+      *reinterpret_cast<float4*>(obuf + 4 * j) = dout;
+    }
+    f32x16 Hc[1][MH];
+    layer_fwd<MI, MH, 1>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hc);
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+      store_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Hc[0]);
+      f32x16 Hn[1][MH];
+      layer_fwd<MH, MH, 1>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hc, Hn);
+#pragma unroll
+      for (int m = 0; m < MH; ++m) Hc[0][m] = Hn[0][m];
+    }
+    // ---- output layer gradients (VALU, lane = hidden feature)
+    store_tile<MH>(bufD, BL::STR_D, lane, Hc[0]);
+    WAVE_SYNC();
+    {
+      constexpr int NF = 32 * MH, PARTS = 64 / NF, PER = 32 / PARTS;
+      const int fl = lane % NF, sp = lane / NF;
+#pragma unroll 4
+      for (int k = 0; k < PER; ++k) {
+        const int s = sp * PER + k;
+        const float h = bufD[s * BL::STR_D + fl];
+        const float4 d = *reinterpret_cast<const float4*>(obuf + 4 * s);
+        dwo[0] = fmaf(d.x, h, dwo[0]); dwo[1] = fmaf(d.y, h, dwo[1]);
+        dwo[2] = fmaf(d.z, h, dwo[2]); dwo[3] = fmaf(d.w, h, dwo[3]);
+      }
+      if (hi == 0) { dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w; }
+    }
+    // dH_L = W_out^T dout, masked by the ReLU of the last hidden layer
+    f32x16 dY[MH];
+    {
+      const float4* w4 = reinterpret_cast<const float4*>(sm + LY::WOUT);
+#pragma unroll
+      for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float4 w = w4[32 * mi + frow(r, 0) + 4 * hi];
+          const float dh = fmaf(w.w, dout.w, fmaf(w.z, dout.z, fmaf(w.y, dout.y, w.x * dout.x)));
+          dY[mi][r] = (Hc[0][mi][r] > 0.f) ? dh : 0.f;
+        }
+    }
+    // ---- hidden layers, last to first
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      WAVE_SYNC();
+      store_tile<MH>(bufD, BL::STR_D, lane, dY);
+      WAVE_SYNC();
+      dbh[l] += colsum<MH>(bufD, BL::STR_D, lane);
+      if (l == 0) {
+        layer_wgrad<MH, MI>(bufD, BL::STR_D, wl + BL::x_off(0), BL::STR_E, lane, acc0);
+        if (ENC_GRAD) {
+          f32x16 dE[MI];
+          layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dE[mi][r] *= dEa[mi][r];
+          WAVE_SYNC();
+          store_tile<MI>(bufD, BL::STR_D, lane, dE);
+          WAVE_SYNC();
+          constexpr int NF = 32 * MI, PARTS = 64 / NF, PER = 32 / PARTS;
+          const int fl = lane % NF, sp = lane / NF;
+#pragma unroll 4
+          for (int k = 0; k < PER; ++k) {
+            const int s = sp * PER + k;
+            const float d = bufD[s * BL::STR_D + fl];
+            const float4 p = *reinterpret_cast<const float4*>(pbuf + 4 * s);
+            dwf[0] = fmaf(d, p.x, dwf[0]); dwf[1] = fmaf(d, p.y, dwf[1]); dwf[2] = fmaf(d, p.z, dwf[2]);
+          }
+        }
+      } else {
+        layer_wgrad<MH, MH>(bufD, BL::STR_D, wl + BL::x_off(l), BL::STR_H, lane, accH[l - 1]);
+        f32x16 dX[MH], Xl[MH];
+        layer_dgrad<MH, MH>(sm + LY::w_off(l), lane, dY, dX);
+        load_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Xl);
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dY[mi][r] = (Xl[mi][r] > 0.f) ? dX[mi][r] : 0.f;
+      }
+    }
+  }
+
+  // ---- epilogue: reduce the 4 waves' accumulators in LDS (fixed order), write one partial vector
+  __syncthreads();
+  float* red = sm + LY::TOTAL;
+  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
+  const int64_t ptot = ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
+  for (int64_t p = threadIdx.x; p < ptot; p += NGM_BLOCK) red[p] = 0.f;
+  __syncthreads();
+  const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
+  // wave-level finalisation of the lane=feature accumulators
+  if (MH == 1) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) dbh[l] += __shfl_down(dbh[l], 32, 64);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dwo[c] += __shfl_down(dwo[c], 32, 64);
+  }
+  if (MI == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dwf[c] += __shfl_down(dwf[c], 32, 64);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dbo[c] = wave_sum(dbo[c]);
+  for (int w = 0; w < NGM_WAVES_PER_BLOCK; ++w) {
+    if (wave == w) {
+      // hidden weight matrices
+#pragma unroll
+      for (int mo = 0; mo < MH; ++mo) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * mo + frow(r, hi);
+          if (o < H) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const int i = 32 * mi + j;
+              if (i < D) red[w_off[0] + (int64_t)o * D + i] += acc0[mo][mi][r];
+            }
+#pragma unroll
+            for (int l = 1; l < L; ++l)
+#pragma unroll
+              for (int mi = 0; mi < MH; ++mi) {
+                const int i = 32 * mi + j;
+                if (i < H) red[w_off[l] + (int64_t)o * H + i] += accH[l - 1][mo][mi][r];
+              }
+          }
+        }
+      }
+      // lane = feature quantities
+      if (lane < 32 * MH && lane < H) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) red[b_off[l] + lane] += dbh[l];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[w_off[L] + (int64_t)c * H + lane] += dwo[c];
+      }
+      if (lane < 4) red[b_off[L] + lane] += (lane == 0 ? dbo[0] : lane == 1 ? dbo[1] : lane == 2 ? dbo[2] : dbo[3]);
+      if (ENC_GRAD && a.fc.encoding == NGM_ENC_FOURIER) {
+        const int n_raw = a.fc.raw_coords ? 3 : 0;
+        if (lane < 32 * MI && lane < D && lane >= n_raw) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) red[enc_off + (int64_t)(lane - n_raw) * 3 + c] += dwf[c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
+  for (int64_t p = threadIdx.x; p < ptot; p += NGM_BLOCK) dst[p] = red[p];
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic reduction of the per-workgroup partial gradient vectors into the caller's tensors
+// ------------------------------------------------------------------------------------------------
+struct GradSeg { int64_t off, size; float* dst; int64_t stride; };
+struct GradReduceK {
+  int F, blocks_per_field, nseg;
+  const float* partials;
+  int64_t p_pad, ptot;
+  GradSeg seg[2 * (NGM_MAX_LAYERS + 1) + 1];
+};
+
+__global__ void k_grad_reduce(GradReduceK a) {
+  const int f = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.ptot) return;
+  float s = 0.f;
+  // workgroup b of the backward kernel handled field b % F
+  for (int c = 0; c < a.blocks_per_field; ++c) s += a.partials[((int64_t)c * a.F + f) * a.p_pad + p];
+  for (int k = 0; k < a.nseg; ++k) {
+    if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) {
+      if (a.seg[k].dst) a.seg[k].dst[(int64_t)f * a.seg[k].stride + (p - a.seg[k].off)] = s;
+      break;
+    }
+  }
+}
+
+int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
+  GradReduceK k;
+  k.F = g.F; k.blocks_per_field = g.blocks_per_field; k.partials = g.partials; k.p_pad = g.p_pad;
+  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
+  k.ptot = ngm_param_offsets(&g.fc, &enc_off, w_off, b_off);
+  int n = 0;
+  if (g.fc.encoding == NGM_ENC_FOURIER) {
+    const int64_t sz = (int64_t)(g.fc.raw_coords ? g.fc.dim_enc - 3 : g.fc.dim_enc) * 3;
+    k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride};
+  }
+  for (int l = 0; l <= g.fc.num_layers; ++l) {
+    const int din = (l == 0) ? g.fc.dim_enc : g.fc.dim_hidden;
+    const int dout = (l == g.fc.num_layers) ? g.fc.dim_out : g.fc.dim_hidden;
+    k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l]};
+    k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l]};
+  }
+  k.nseg = n;
+  dim3 grid((unsigned)((k.ptot + 255) / 256), (unsigned)g.F);
+  hipLaunchKernelGGL(k_grad_reduce, grid, dim3(256), 0, st, k);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MI, int MH, int L>
+static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = BwdLds<MI, MH, L>::TOTAL * sizeof(float);
+  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
+  const bool enc_grad = a.fc.encoding == NGM_ENC_FOURIER;
+#define NGM_LB(NC, EG)                                                                                             \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)k_field_bwd<MI, MH, L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                           \
+    hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);               \
+  } while (0)
+  if (enc_grad) NGM_LB(false, true);
+  else if (need_cos) NGM_LB(true, false);
+  else NGM_LB(false, false);
+#undef NGM_LB
+  return 0;
+}
+
+int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const FieldShape s = field_shape(&a.fc);
+  if (s.MI == 2 && s.MH == 2 && s.L == 2) return launch_bwd<2, 2, 2>(a, blocks, st);
+#ifndef NGM_FAST_BUILD
+  if (s.MI == 2 && s.MH == 2 && s.L == 1) return launch_bwd<2, 2, 1>(a, blocks, st);
+  if (s.MI == 1 && s.MH == 1 && s.L == 1) return launch_bwd<1, 1, 1>(a, blocks, st);
+  if (s.MI == 1 && s.MH == 1 && s.L == 2) return launch_bwd<1, 1, 2>(a, blocks, st);
+#endif
+  return NGM_E_UNSUPPORTED;
+}

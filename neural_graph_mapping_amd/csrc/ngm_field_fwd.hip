@@ -1,0 +1,347 @@
+// Forward kernels of the per-field NeRF hot path (gfx950).
+//   k_field_points_fwd : NeuralFieldSet.forward(use_vmap=True)  (models.py:329-345)
+//   k_render_fwd       : NeuralGraphMap._render_ijs(use_vmap=True) fused in ONE pass
+//                        (rm.py:439-666): ray setup -> stratified + depth-guided samples (rank
+//                        merge, no sort) -> world->field-local -> encoding -> MLP on MFMA ->
+//                        alpha compositing (wave segmented prefix-product scan) -> loss partial sums.
+// One workgroup = 4 waves = one field (weights resident in LDS); each wave pushes 64 samples per
+// step through the MLP as two 32-column MFMA tiles and owns one sample per lane for all per-sample
+// scalar work.
+#include "ngm_field.h"
+#include "ngm_launch.h"
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
+// (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
+template <int MI, int MH, int L, bool NEED_COS>
+__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z) {
+  using LY = FieldLds<MI, MH, L>;
+  const int hi = lane >> 5;
+  // partner lane (same column j, other half) owns the sample of the other tile
+  const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
+  f32x16 E[2][MI], dummy[MI];
+  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
+  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+  f32x16 Hl[2][MH];
+  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl);
+  float part[2][4];
+  out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float send = hi ? part[0][c] : part[1][c];
+    const float recv = __shfl_xor(send, 32, 64);
+    const float own = hi ? part[1][c] : part[0][c];
+    // fixed summation order: low-feature half first
+    o[c] = (hi ? (recv + own) : (own + recv)) + sm[LY::BOUT + c];
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MI, int MH, int L, bool NEED_COS>
+__global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const bool posed = a.pos != nullptr;
+  float px = 0, py = 0, pz = 0, qw = 1, qx = 0, qy = 0, qz = 0;
+  if (posed) {
+    px = a.pos[3 * f]; py = a.pos[3 * f + 1]; pz = a.pos[3 * f + 2];
+    qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
+  }
+  const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
+  for (int64_t base = beg + wave * 64; base < end; base += NGM_BLOCK) {
+    const int64_t idx = base + lane;
+    const bool valid = idx < end;
+    float x = 0, y = 0, z = 0;
+    if (valid) {
+      const float* p = a.points + ((int64_t)f * a.P + idx) * 3;
+      Vec3 v{p[0], p[1], p[2]};
+      if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
+      x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
+    }
+    const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+    if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused render forward
+// ------------------------------------------------------------------------------------------------
+#define RF_BRMAX 32     // rays per wave batch
+#define RF_MAXS 1024    // samples per wave batch
+#define RF_RT 16        // floats per ray-table row
+#define RF_RA 12        // floats per ray-accumulator row
+
+struct RenderWaveLds {
+  float rt[RF_BRMAX][RF_RT];   // ox,oy,oz, dx,dy,dz (field-local, scaled), dzcam, near,far,gnear,gfar, gt
+  float ra[RF_BRMAX][RF_RA];   // C(3), D, W, Cv(3), Dv
+  float tbuf[RF_MAXS];
+  float wbuf[RF_MAXS];
+  float cbuf[3][RF_MAXS];
+};
+
+__device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
+  int q = (int)(((float)idx + 0.5f) * inv_s);
+  // guard the reciprocal rounding at segment borders
+  if (q * S > idx) --q;
+  if ((q + 1) * S <= idx) ++q;
+  return q;
+}
+
+template <int MI, int MH, int L, bool NEED_COS>
+__global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  using LY = FieldLds<MI, MH, L>;
+  const int F = a.rays.F, R = a.rays.R;
+  const int f = blockIdx.x % F, chunk = blockIdx.x / F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RenderWaveLds& wl = reinterpret_cast<RenderWaveLds*>(sm + LY::TOTAL)[wave];
+
+  const int S = a.S, S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
+  const float inv_s = 1.0f / (float)S;
+  const bool guided = S_g > 0;
+  const float tau = a.rc.truncation_distance;
+  const float gamma = a.rc.geometry_factor, cf = a.rc.color_factor;
+  const int mode = a.rc.geometry_mode;
+
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const float px = a.rays.field_pos[3 * f], py = a.rays.field_pos[3 * f + 1], pz = a.rays.field_pos[3 * f + 2];
+  const float qw = a.rays.field_quat[4 * f], qx = a.rays.field_quat[4 * f + 1], qy = a.rays.field_quat[4 * f + 2],
+              qz = a.rays.field_quat[4 * f + 3];
+
+  // this wave's rays [r_beg, r_end) inside field f
+  const int blk_beg = chunk * a.rays_per_block, blk_end = min(R, blk_beg + a.rays_per_block);
+  const int per_wave = (blk_end - blk_beg + NGM_WAVES_PER_BLOCK - 1) / NGM_WAVES_PER_BLOCK;
+  const int r_beg = min(blk_end, blk_beg + wave * per_wave), r_end = min(blk_end, r_beg + per_wave);
+  const int BR = max(1, min(RF_BRMAX, RF_MAXS / S));
+
+  float ls[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) ls[i] = 0.f;
+
+  for (int rb = r_beg; rb < r_end; rb += BR) {
+    const int nb = min(BR, r_end - rb);
+    const int nsamp = nb * S;
+    // ---- (1) ray setup: one lane per ray
+    if (lane < nb) {
+      const int64_t ray = (int64_t)f * R + rb + lane;
+      const RayGeom g = ray_geom(a.rc, a.rays, ray, guided);
+      const float* T = a.rays.c2w_per_ray ? a.rays.c2ws + ray * 16 : a.rays.c2ws;
+      Vec3 dw{T[0] * g.dx + T[1] * g.dy + T[2] * g.dz, T[4] * g.dx + T[5] * g.dy + T[6] * g.dz,
+              T[8] * g.dx + T[9] * g.dy + T[10] * g.dz};
+      Vec3 ow{T[3] - px, T[7] - py, T[11] - pz};
+      dw = quat_rotate_inv(qw, qx, qy, qz, dw);
+      ow = quat_rotate_inv(qw, qx, qy, qz, ow);
+      float* rt = wl.rt[lane];
+      rt[0] = ow.x / div + off; rt[1] = ow.y / div + off; rt[2] = ow.z / div + off;
+      rt[3] = dw.x / div; rt[4] = dw.y / div; rt[5] = dw.z / div;
+      rt[6] = g.dz; rt[7] = g.near; rt[8] = g.far; rt[9] = g.gnear; rt[10] = g.gfar; rt[11] = g.gt;
+      if (a.raytab) {
+        float4* o = reinterpret_cast<float4*>(a.raytab + ray * 8);
+        o[0] = make_float4(rt[0], rt[1], rt[2], rt[3]);
+        o[1] = make_float4(rt[4], rt[5], rt[6], g.gt);
+      }
+#pragma unroll
+      for (int c = 0; c < RF_RA; ++c) wl.ra[lane][c] = 0.f;
+    }
+    WAVE_SYNC();
+    // ---- (2) sorted sample distances: closed-form rank of every source element (no sort)
+    for (int idx = lane; idx < nsamp; idx += 64) {
+      const int rl = fdiv_idx(idx, inv_s, S), e = idx - rl * S;
+      const int64_t ray = (int64_t)f * R + rb + rl;
+      RayGeom g;
+      g.near = wl.rt[rl][7]; g.far = wl.rt[rl][8]; g.gnear = wl.rt[rl][9]; g.gfar = wl.rt[rl][10];
+      float t; int rank;
+      sample_rank(a.rc, a.rays, g, ray, e, S_c, S_g, &t, &rank);
+      wl.tbuf[rl * S + rank] = t;
+    }
+    WAVE_SYNC();
+    // ---- (3) MLP + compositing pass, 64 consecutive flat samples per step
+    float carry = 1.0f;
+    for (int base = 0; base < nsamp; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      const float* rt = wl.rt[rl];
+      const float t = valid ? wl.tbuf[idx] : 0.f;
+      float x = 0, y = 0, z = 0;
+      if (valid) { x = fmaf(t, rt[3], rt[0]); y = fmaf(t, rt[4], rt[1]); z = fmaf(t, rt[5], rt[2]); }
+      const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+      const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z, geom = o.w;
+      const float depth = -(rt[6] * t);
+      const float occ = valid ? occ_pointwise(mode, gamma, geom, nullptr) : 0.f;
+      // transmittance: segmented inclusive product of (1-occ), carried across steps
+      float q = seg_scan_mul(1.0f - occ, k, lane);
+      if (k > lane) q *= carry;
+      const float up = __shfl_up(q, 1, 64);
+      const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
+      carry = __shfl(q, 63, 64);
+      const float w = valid ? occ * T_excl : 0.f;
+      if (valid) {
+        wl.wbuf[idx] = w; wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2;
+        if (a.stashA) {
+          const int64_t gs = ((int64_t)f * R + rb) * S + idx;
+          a.stashA[gs] = make_float4(c0, c1, c2, geom);
+          a.stashB[gs] = make_float2(t, T_excl);
+        }
+      }
+      const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
+                  s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * depth, k, lane),
+                  s4 = seg_scan_add(w, k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+      if (tail) {
+        float* ra = wl.ra[rl];
+        ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4;
+      }
+      if (a.has_targets && valid) {
+        const float gt = rt[11];
+        const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);       // rm.py:625-627
+        if (t < thr) { const float e = geom * tau - tau; ls[NGM_LS_FS_SUM] += e * e; ls[NGM_LS_FS_CNT] += 1.f; }
+        const float dl = gt - t;
+        if (fabsf(dl) < tau && gt != 0.0f) {                              // rm.py:633-637
+          const float e = geom * tau - dl; ls[NGM_LS_TSDF_SUM] += e * e; ls[NGM_LS_TSDF_CNT] += 1.f;
+        }
+      }
+      WAVE_SYNC();
+    }
+    // ---- (4) variance pass around the finished means (rm.py:781-790)
+    for (int base = 0; base < nsamp; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < nsamp;
+      const int rl = valid ? fdiv_idx(idx, inv_s, S) : 0;
+      const int k = valid ? idx - rl * S : 0;
+      const float* ra = wl.ra[rl];
+      const float w = valid ? wl.wbuf[idx] : 0.f;
+      const float t = valid ? wl.tbuf[idx] : 0.f;
+      const float depth = -(wl.rt[rl][6] * t);
+      float e0 = ra[0] - (valid ? wl.cbuf[0][idx] : 0.f), e1 = ra[1] - (valid ? wl.cbuf[1][idx] : 0.f),
+            e2 = ra[2] - (valid ? wl.cbuf[2][idx] : 0.f), e3 = ra[3] - depth;
+      const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
+                  v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+      WAVE_SYNC();   // all lanes have read ra[] means before tails update the variance slots
+      if (tail) {
+        float* rw = wl.ra[rl];
+        rw[5] += v0; rw[6] += v1; rw[7] += v2; rw[8] += v3;
+      }
+      WAVE_SYNC();
+    }
+    // ---- (5) per-ray outputs + loss partial sums
+    if (lane < nb) {
+      const int64_t ray = (int64_t)f * R + rb + lane;
+      const float* ra = wl.ra[lane];
+      const float term = 1.0f - (1.0f - ra[4]);                           // rm.py:774,796
+      if (a.pred.rgbds) reinterpret_cast<float4*>(a.pred.rgbds)[ray] = make_float4(ra[0], ra[1], ra[2], ra[3]);
+      if (a.pred.color_vars) { float* cv = a.pred.color_vars + ray * 3; cv[0] = ra[5]; cv[1] = ra[6]; cv[2] = ra[7]; }
+      if (a.pred.depth_vars) a.pred.depth_vars[ray] = ra[8];
+      if (a.pred.term_probs) a.pred.term_probs[ray] = term;
+      if (a.has_targets) {
+        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
+        const bool m = a.tg.depth_mask[ray] && (term > a.rc.term_threshold);  // rm.py:1787
+        if (m) {
+          ls[NGM_LS_PHOTO_SUM] += fabsf(tg.x - ra[0]) + fabsf(tg.y - ra[1]) + fabsf(tg.z - ra[2]);
+          ls[NGM_LS_PHOTO_CNT] += 1.f;
+          const float e = ra[3] - tg.w, ae = fabsf(e), dlt = a.rc.huber_delta;
+          ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);
+          ls[NGM_LS_DEPTH_CNT] += 1.f;
+        }
+        if (a.tg.term_mask && a.tg.term_mask[ray]) {
+          const float e = term - a.tg.term_probs[ray];
+          ls[NGM_LS_TERM_SUM] += e * e; ls[NGM_LS_TERM_CNT] += 1.f;
+        }
+      }
+    }
+    WAVE_SYNC();
+  }
+  // ---- block reduction of the loss partial sums (deterministic order)
+  if (a.has_targets && a.loss_partials) {
+    __syncthreads();
+    float* red = sm + LY::TOTAL;  // reuse wave 0's scratch
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const float v = wave_sum(ls[i]);
+      if (lane == 0) red[wave * 16 + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
+      float v = 0.f;
+      if (threadIdx.x < 10) v = ((red[threadIdx.x] + red[16 + threadIdx.x]) + red[32 + threadIdx.x]) + red[48 + threadIdx.x];
+      a.loss_partials[(int64_t)blockIdx.x * NGM_NUM_LOSS_SUMS + threadIdx.x] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+template <int MI, int MH, int L>
+static int launch_points(const PointsFwdArgs& a, int blocks, bool need_cos, hipStream_t st) {
+  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
+  if (need_cos) {
+    (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, true>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+  }
+  return 0;
+}
+template <int MI, int MH, int L>
+static int launch_render(const RenderFwdArgs& a, int blocks, bool need_cos, hipStream_t st) {
+  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + NGM_WAVES_PER_BLOCK * sizeof(RenderWaveLds);
+  if (need_cos) {
+    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, true>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+  }
+  return 0;
+}
+
+#ifdef NGM_FAST_BUILD
+#define NGM_SHAPE_DISPATCH(FN, ...)                                             \
+  do {                                                                          \
+    const FieldShape s_ = field_shape(&a.fc);                                   \
+    if (s_.MI == 2 && s_.MH == 2 && s_.L == 2) return FN<2, 2, 2>(__VA_ARGS__); \
+    return NGM_E_UNSUPPORTED;                                                   \
+  } while (0)
+#else
+#define NGM_SHAPE_DISPATCH(FN, ...)                                             \
+  do {                                                                          \
+    const FieldShape s_ = field_shape(&a.fc);                                   \
+    if (s_.MI == 2 && s_.MH == 2 && s_.L == 2) return FN<2, 2, 2>(__VA_ARGS__); \
+    if (s_.MI == 2 && s_.MH == 2 && s_.L == 1) return FN<2, 2, 1>(__VA_ARGS__); \
+    if (s_.MI == 1 && s_.MH == 1 && s_.L == 1) return FN<1, 1, 1>(__VA_ARGS__); \
+    if (s_.MI == 1 && s_.MH == 1 && s_.L == 2) return FN<1, 1, 2>(__VA_ARGS__); \
+    if (s_.MI == 2 && s_.MH == 2 && s_.L == 3) return FN<2, 2, 3>(__VA_ARGS__); \
+    return NGM_E_UNSUPPORTED;                                                   \
+  } while (0)
+#endif
+
+int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st) {
+  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
+  NGM_SHAPE_DISPATCH(launch_points, a, blocks, need_cos, st);
+}
+int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st) {
+  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
+  NGM_SHAPE_DISPATCH(launch_render, a, blocks, need_cos, st);
+}

@@ -1,0 +1,122 @@
+// Kernel argument records + host launcher prototypes (internal; the public surface is include/ngm_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ngm_hip.h"
+
+#ifndef NGM_BLOCK
+#define NGM_WAVE 64
+#define NGM_BLOCK 256
+#define NGM_WAVES_PER_BLOCK 4
+#endif
+
+struct PointsFwdArgs {
+  ngm_field_cfg fc;
+  ngm_params pr;
+  int F;
+  int64_t P;
+  int64_t per_block;      // samples per workgroup (multiple of 256)
+  const float* points;    // (F,P,3)
+  const float* pos;       // (F,3) or NULL
+  const float* quat;      // (F,4) or NULL
+  float* out;             // (F,P,4)
+};
+
+struct RenderFwdArgs {
+  ngm_field_cfg fc;
+  ngm_params pr;
+  ngm_render_cfg rc;
+  ngm_rays rays;
+  ngm_targets tg;
+  ngm_prediction pred;
+  int has_targets;
+  int S;                  // samples per ray actually drawn (S_c + S_g when gt given)
+  int rays_per_block;
+  float* raytab;          // (F*R, 8): o_local(3), d_local(3), dz_cam, gt     (train) or NULL
+  float4* stashA;         // (F*R*S): colour(3), geometry                      (train) or NULL
+  float2* stashB;         // (F*R*S): t, T_exclusive
+  float* loss_partials;   // (blocks, 16)
+};
+
+// backward of the field MLP for flat samples of each field
+struct FieldBwdArgs {
+  ngm_field_cfg fc;
+  ngm_params pr;
+  int F;
+  int64_t P;              // samples per field
+  int64_t per_block;      // samples per workgroup (multiple of 128)
+  int blocks_per_field;
+  // sample source: explicit points (points != NULL) or rays (raytab + stashB.t)
+  const float* points;    // (F,P,3) world/local
+  const float* pos;
+  const float* quat;
+  const float* raytab;    // (F*R, 8)
+  const float2* stashB;   // (F*R*S)
+  int S;                  // samples per ray (ray mode)
+  const float4* d_out;    // (F,P) float4: dL/d(r,g,b,geometry) raw MLP outputs
+  float* partials;        // (F*blocks_per_field, P_pad) per-workgroup gradient partial sums
+  int64_t p_pad;          // padded parameter count per field (floats)
+};
+
+struct GradReduceArgs {
+  ngm_field_cfg fc;
+  ngm_grads gr;
+  int F;
+  int blocks_per_field;
+  const float* partials;
+  int64_t p_pad;
+};
+
+// composite (quadrature) standalone + stash variants
+struct CompositeArgs {
+  ngm_render_cfg rc;
+  int64_t N;              // rays
+  int S;
+  // separate-tensor source (standalone API)
+  const float* colors; const float* geoms; const float* dists; const float* depths; const float* isds;
+  // outputs fwd
+  float* C; float* D; float* Cv; float* Dv; float* term; float* weights;
+  // bwd seeds / outputs
+  const float* dC; const float* dD; const float* dterm;
+  float* d_colors; float* d_geoms;
+};
+
+// backward of compositing on the saved per-sample stash of the fused forward; overwrites stashA with
+// dL/d(raw MLP outputs)
+struct StashBwdArgs {
+  ngm_render_cfg rc;
+  int F, R, S;
+  float4* stashA;
+  const float2* stashB;
+  const float* raytab;
+  // seed mode 0: losses (targets + global sums), 1: explicit seeds
+  int seed_mode;
+  ngm_targets tg;
+  ngm_prediction pred;
+  const float* loss_sums;     // global (all-reduced) sums
+  const float* d_rgbds;       // (F,R,4)
+  const float* d_term;        // (F,R)
+  const float* d_geom_samples;// (F,R,S) or NULL
+};
+
+int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
+int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
+int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
+int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st);
+
+// flat parameter vector layout of one field: [enc_w][w0][b0]...[wL][bL]
+__host__ __device__ static inline int64_t ngm_param_offsets(const ngm_field_cfg* fc, int64_t* enc_off, int64_t* w_off, int64_t* b_off) {
+  int64_t o = 0;
+  *enc_off = 0;
+  if (fc->encoding == NGM_ENC_FOURIER) o += (int64_t)(fc->raw_coords ? fc->dim_enc - 3 : fc->dim_enc) * 3;
+  for (int l = 0; l <= fc->num_layers; ++l) {
+    const int din = (l == 0) ? fc->dim_enc : fc->dim_hidden;
+    const int dout = (l == fc->num_layers) ? fc->dim_out : fc->dim_hidden;
+    w_off[l] = o; o += (int64_t)din * dout;
+    b_off[l] = o; o += dout;
+  }
+  return o;
+}

@@ -1,0 +1,216 @@
+"""Headline benchmark: ray-samples/s of the per-field NeRF train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, SURVEY 8d "M1"): synthetic 4096-ray x 128-sample batch per GPU --
+F = 8 fields x R = 512 rays, S = 64 coarse + 64 depth-guided samples, Fourier(64, raw) + 2x64 MLP,
+nrgbd compositing, default loss weights, NRGBD intrinsics, 10 % missing depth.  One "step" = one
+pass of the hot path over one batch: fused forward + losses, loss all-reduce (N > 1), fused backward
+w.r.t. every field parameter, sparse per-field Adam.  Jitter is drawn in-kernel (Philox), inputs are
+resident in HBM before the timed region.  Weak scaling: every rank owns its own 8 fields (field-per-
+GPU sharding); the only collective is the 64-byte loss-sum all-reduce (RCCL over xGMI).
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (MFMA backward) : algorithmic flops / HIP-event time on the launch stream
+  cpu_baseline -- the CPU oracle (oracle/ngm_oracle.py, a restatement pinned to the reference) timed on
+                  this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_PER_GPU, R, S_C, S_G = 8, 512, 64, 64
+D_ENC, N_LAYERS = 64, 2
+FLOP_FWD = 2 * (64 * 64 + 64 * 64 + 64 * 4)      # 16 896 flop / sample
+FLOP_BWD = 2 * FLOP_FWD                          # wgrad + dgrad: 33 792 flop / sample
+PEAK_F32_MFMA_TF = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def synth_target(F, Rn, seed, field_offset=0):
+    """Synthetic Target in the spirit of _sample_target_mv (rm.py:1383-1459); CPU tensors."""
+    from neural_graph_mapping_amd.renderer import Target
+    g = torch.Generator().manual_seed(seed)
+    pos = 0.5 * torch.randn(F, 3, generator=g)
+    quat = torch.nn.functional.normalize(torch.randn(F, 4, generator=g), dim=-1)
+    ijs = torch.stack([torch.randint(0, 480, (F, Rn), generator=g), torch.randint(0, 640, (F, Rn), generator=g)], -1)
+    eye = pos[:, None] + torch.nn.functional.normalize(torch.randn(F, Rn, 3, generator=g), dim=-1) * (
+        2 + torch.rand(F, Rn, 1, generator=g))
+    fwd = torch.nn.functional.normalize(pos[:, None] + 0.3 * torch.randn(F, Rn, 3, generator=g) - eye, dim=-1)
+    right = torch.nn.functional.normalize(torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]).expand_as(fwd)), dim=-1)
+    c2w = torch.eye(4).repeat(F, Rn, 1, 1)
+    c2w[..., :3, 0], c2w[..., :3, 1], c2w[..., :3, 2], c2w[..., :3, 3] = right, torch.linalg.cross(right, fwd), -fwd, eye
+    dx = (ijs[..., 1] - 319.5) / 554.2562584220408
+    dy = -(ijs[..., 0] - 239.5) / 554.2562584220408
+    d = torch.nn.functional.normalize(torch.stack([dx, dy, -torch.ones_like(dx)], -1), dim=-1)
+    pos_c = torch.einsum("...kd,...k->...d", c2w[..., :3, :3], pos[:, None] - c2w[..., :3, 3])
+    center = (pos_c * d).sum(-1)
+    near, far = (center - 1).clamp_min(0), (center + 1).clamp_min(0)
+    gt = near + (far - near) * (0.1 + 0.8 * torch.rand(F, Rn, generator=g))
+    gt[torch.rand(F, Rn, generator=g) < 0.1] = 0.0
+    rgbds = torch.cat([torch.rand(F, Rn, 3, generator=g), (gt * d[..., 2].abs())[..., None]], -1)
+    dm = (gt > near) & (gt < far) & (gt != 0)
+    tgt = Target(ijs=ijs, c2ws=c2w, near_distances=near, far_distances=far, gt_distances=gt,
+                 field_ids=torch.arange(F) + field_offset, rgbds=rgbds, rgb_mask=dm, depth_mask=dm,
+                 term_probs=(gt < far).float(), term_mask=(gt > near) & (gt != 0))
+    return pos, quat, tgt
+
+
+def build_renderer(device, num_fields):
+    from neural_graph_mapping_amd import models as M
+    from neural_graph_mapping_amd import renderer as Rr
+    torch.manual_seed(0)
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=D_ENC, mu=0.0, sigma=4.0, raw_coords=True), num_layers=N_LAYERS, dim_out=4,
+        dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0), num_knn=2,
+        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(device)
+    cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
+               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
+               learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0,
+               num_samples_coarse=S_C, num_samples_depth_guided=S_G)
+    cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, cfg, device=device)
+    r.add_fields(num_fields)
+    with torch.no_grad():          # de-correlate the cloned prototype so fields differ (random-init weights)
+        for v in model.all_fields_params.values():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn_like(v))
+    return r
+
+
+def cpu_baseline(budget_s=15.0):
+    """Oracle (CPU restatement of the reference path) on a bounded sample: 1 field x 512 rays x 128 samples."""
+    from oracle import ngm_oracle as O
+    F = 1
+    fs = O.FieldSpec(encoding="fourier", dim_enc=D_ENC, num_layers=N_LAYERS)
+    rs = O.RenderSpec(num_samples_coarse=S_C, num_samples_depth_guided=S_G, geometry_factor=20.0)
+    cam = O.CameraSpec(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5)
+    pos, quat, t = synth_target(F, R, seed=123)
+    params = {k: v.requires_grad_() for k, v in O.init_params(fs, F, seed=1).items()}
+    g = torch.Generator().manual_seed(5)
+
+    def step():
+        u_c, u_g = torch.rand(F, R, S_C, generator=g), torch.rand(F, R, S_G, generator=g)
+        pred = O.render_ijs(t.ijs, t.c2ws, cam, pos, quat, params, fs, rs, t.near_distances, t.far_distances,
+                            t.gt_distances, u_c, u_g)
+        loss = O.compute_losses(pred, t.rgbds, t.depth_mask, t.term_mask, t.term_probs, rs)
+        for p in params.values():
+            p.grad = None
+        loss["combined"].backward()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    n = max(3, min(200, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=F * R * (S_C + S_G) * n / dt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps (fwd+loss+bwd) of 1 field x {R} rays x {S_C + S_G} samples, "
+                       f"oracle/ngm_oracle.py on torch CPU fp32, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from neural_graph_mapping_amd import _capi as K
+    from neural_graph_mapping_amd import distributed as D
+    rank, local, world = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L = K.lib()
+
+    # field-per-GPU sharding: rank r owns global fields r, r+world, ... ; local slot = id // world
+    nf_global = F_PER_GPU * world
+    r = build_renderer(dev, F_PER_GPU)
+    pos, quat, tgt_cpu = synth_target(F_PER_GPU, R, seed=1000 + rank)
+    r.set_field_poses(pos.to(dev), quat.to(dev))
+    tgt = type(tgt_cpu)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tgt_cpu])
+    tgt = tgt._replace(field_ids=torch.arange(F_PER_GPU, device=dev))      # local slots of this rank's fields
+    if world > 1:
+        r.process_group = torch.distributed.group.WORLD
+
+    def step(i):
+        return r.optimization_iteration(tgt, seed=i, update=True)
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    L.ngm_profile_reset()
+    L.ngm_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.ngm_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out["combined"])
+
+    kern = {}
+    for name, kid in K.KERNEL_IDS.items():
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.ngm_profile_read(kid, C.byref(ms), C.byref(n))
+        if n.value:
+            kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
+
+    if rank == 0:
+        n_local = F_PER_GPU * R * (S_C + S_G)
+        value = world * n_local * args.steps / dt
+        res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
+                   value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32", data="synthetic",
+                   config=dict(workload="M1: 8 fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
+                                        "Fourier(64,raw)+2x64 MLP, nrgbd compositing, NRGBD intrinsics",
+                               fields_per_gpu=F_PER_GPU, rays_per_field=R, samples_per_ray=S_C + S_G,
+                               sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox", final_loss=loss))
+        fb = kern.get("field_bwd")
+        if fb:
+            achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_field_bwd.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            res["roofline"] = dict(bound="mfma", kernel="k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=achieved,
+                                   peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
+                                   traffic=traffic, avg_launch_us=fb["avg_us"],
+                                   algorithmic_flop_per_launch=FLOP_BWD * n_local)
+        res["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in kern.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -239,6 +239,24 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
                        const float* field_quat, int32_t num_knn, float distance_factor,
                        float outside_value, float* out, void* stream);
 
+/* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------
+ * When enabled, every launch of the listed kernels is bracketed by hipEvents recorded on the launch
+ * stream; ngm_profile_read() synchronises them and returns the accumulated device time. */
+enum ngm_kernel_id {
+  NGM_K_RENDER_FWD = 0, /* fused forward (sampler+encode+MLP+composite)                 */
+  NGM_K_STASH_BWD = 1,  /* compositing + loss backward on the stash                      */
+  NGM_K_FIELD_BWD = 2,  /* MFMA backward of encoding + MLP (dominant kernel)             */
+  NGM_K_GRAD_REDUCE = 3,
+  NGM_K_ADAM = 4,
+  NGM_K_POINTS_FWD = 5,
+  NGM_K_COMPOSITE_FWD = 6,
+  NGM_K_COMPOSITE_BWD = 7,
+  NGM_K_COUNT = 8
+};
+int ngm_profile_enable(int32_t on);
+int ngm_profile_reset(void);
+int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,10 @@ def lib():
     L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
     L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp]
+    L.ngm_profile_enable.argtypes = [i32]
+    L.ngm_profile_read.argtypes = [i32, P(C.c_double), P(i64)]
+    for name in ("ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"):
+        getattr(L, name).restype = C.c_int
     for name in ("ngm_sample_rays", "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_composite_fwd",
                  "ngm_composite_bwd", "ngm_render_fwd", "ngm_render_bwd", "ngm_render_bwd_seeded",
                  "ngm_render_read_samples", "ngm_adam_sparse", "ngm_field_eval_knn", "ngm_device_info"):
@@ -118,7 +122,10 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_
             "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
-            "ngm_field_eval_knn"]
+            "ngm_field_eval_knn", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
+
+KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
+                  composite_bwd=7)
 
 
 class NgmError(RuntimeError):

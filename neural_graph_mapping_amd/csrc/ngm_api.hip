@@ -19,7 +19,56 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
                    hipStream_t st);
 
+#include <mutex>
+#include <vector>
+
 static thread_local char g_err[512] = "";
+
+// ---- profiling hooks ----------------------------------------------------------------------------
+namespace {
+struct EvPair { hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<EvPair> g_prof_pending[NGM_K_COUNT];
+std::vector<EvPair> g_prof_free;
+double g_prof_ms[NGM_K_COUNT] = {0};
+int64_t g_prof_n[NGM_K_COUNT] = {0};
+thread_local EvPair g_cur;
+}  // namespace
+
+NgmProfScope::NgmProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), st(stream), on(false) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return;
+  on = true;
+  if (g_prof_free.empty()) {
+    EvPair p;
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    g_cur = p;
+  } else {
+    g_cur = g_prof_free.back();
+    g_prof_free.pop_back();
+  }
+  (void)hipEventRecord(g_cur.a, st);
+}
+NgmProfScope::~NgmProfScope() {
+  if (!on) return;
+  (void)hipEventRecord(g_cur.b, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_pending[id].push_back(g_cur);
+}
+static void prof_drain() {
+  for (int k = 0; k < NGM_K_COUNT; ++k) {
+    for (auto& p : g_prof_pending[k]) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(p.b);
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_prof_ms[k] += ms; g_prof_n[k] += 1; }
+      g_prof_free.push_back(p);
+    }
+    g_prof_pending[k].clear();
+  }
+}
+
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
@@ -71,6 +120,26 @@ extern "C" {
 
 int ngm_abi_version(void) { return NGM_ABI_VERSION; }
 const char* ngm_last_error(void) { return g_err; }
+
+int ngm_profile_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return NGM_OK;
+}
+int ngm_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_drain();
+  for (int k = 0; k < NGM_K_COUNT; ++k) { g_prof_ms[k] = 0; g_prof_n[k] = 0; }
+  return NGM_OK;
+}
+int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches) {
+  if (kernel_id < 0 || kernel_id >= NGM_K_COUNT) return fail(NGM_E_INVALID, "bad kernel id");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_drain();
+  if (total_ms) *total_ms = g_prof_ms[kernel_id];
+  if (launches) *launches = g_prof_n[kernel_id];
+  return NGM_OK;
+}
 
 int ngm_device_info(int* ncu, char* name, int name_len) {
   int dev = 0;
@@ -256,20 +325,22 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   int e = check_render(fcfg, rcfg, params, rays);
   if (e) return e;
   if (!pred) return fail(NGM_E_INVALID, "render_fwd: pred is NULL");
-  const bool train = targets != nullptr;
-  if (train && (!targets->rgbds || !targets->depth_mask || !loss_sums)) return fail(NGM_E_INVALID, "render_fwd: incomplete targets");
-  if (train && targets->term_mask && !targets->term_probs) return fail(NGM_E_INVALID, "render_fwd: term_mask without term_probs");
-  if (train && (!pred->rgbds || !pred->term_probs)) return fail(NGM_E_INVALID, "render_fwd(train): pred.rgbds/term_probs required");
-  const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, train);
-  if (train && (!workspace || workspace_bytes < p.total)) return fail(NGM_E_WORKSPACE, "render_fwd: workspace too small");
+  const bool has_tg = targets != nullptr;
+  const bool save = workspace != nullptr;   // keep the per-sample stash for a later backward
+  if (has_tg && (!targets->rgbds || !targets->depth_mask || !loss_sums)) return fail(NGM_E_INVALID, "render_fwd: incomplete targets");
+  if (has_tg && targets->term_mask && !targets->term_probs) return fail(NGM_E_INVALID, "render_fwd: term_mask without term_probs");
+  if (has_tg && !save) return fail(NGM_E_WORKSPACE, "render_fwd: targets need a workspace");
+  if (save && (!pred->rgbds || !pred->term_probs)) return fail(NGM_E_INVALID, "render_fwd(save): pred.rgbds/term_probs required");
+  const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, save);
+  if (save && workspace_bytes < p.total) return fail(NGM_E_WORKSPACE, "render_fwd: workspace too small");
   char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
   RenderFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.rc = *rcfg; a.rays = *rays; a.pred = *pred;
-  a.has_targets = train ? 1 : 0;
-  if (train) a.tg = *targets;
+  a.has_targets = has_tg ? 1 : 0;
+  if (has_tg) a.tg = *targets;
   a.S = p.S; a.rays_per_block = p.rays_per_block;
-  if (train) {
+  if (save) {
     a.raytab = reinterpret_cast<float*>(ws + p.off_raytab);
     a.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
     a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
@@ -279,7 +350,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_render_fwd");
   if (e) return e;
-  if (train) {
+  if (has_tg) {
     ngm_launch_loss_reduce(a.loss_partials, p.blocks_fwd, loss_sums, (hipStream_t)stream);
     e = check_launch("ngm_loss_reduce");
   }

@@ -173,6 +173,7 @@ static int comp_grid(int64_t N, int S, int* rays_per_wave) {
 }
 
 int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_COMPOSITE_FWD, st);
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
 }
 
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_COMPOSITE_BWD, st);
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
   int rpw;
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
 }
 
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_STASH_BWD, st);
   if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);
@@ -387,16 +390,23 @@ int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* o
   return 0;
 }
 
-// sum of per-workgroup loss partials (fixed order)
+// sum of per-workgroup loss partials: 16 slots x 16 strided lanes, then a fixed-order tree
 __global__ void k_loss_reduce(const float* partials, int nblocks, float* sums) {
-  const int i = threadIdx.x;
-  if (i >= NGM_NUM_LOSS_SUMS) return;
+  __shared__ float red[16][17];
+  const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;   // 256 threads
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * NGM_NUM_LOSS_SUMS + i];
-  sums[i] = s;
+  for (int b = part; b < nblocks; b += 16) s += partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
+  red[part][slot] = s;
+  __syncthreads();
+  if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+    sums[threadIdx.x] = t;
+  }
 }
 int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st) {
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, partials, nblocks, sums);
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, partials, nblocks, sums);
   return 0;
 }
 
@@ -435,6 +445,7 @@ __global__ void k_adam_sparse(float* param, float* m, float* v, int64_t stride, 
 int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
                     const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
                     float eps, float wd, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_ADAM, st);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float lr_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel + 255) / 256, 64)), (unsigned)F);

@@ -146,7 +146,7 @@ __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm
   g.dx = __fdiv_rn(vx, den); g.dy = __fdiv_rn(vy, den); g.dz = __fdiv_rn(vz, den);
   g.near = rays.near ? rays.near[ray] : rays.near_const;
   g.far = rays.far ? rays.far[ray] : rays.far_const;
-  g.gt = (guided && rays.gt) ? rays.gt[ray] : 0.0f;
+  g.gt = rays.gt ? rays.gt[ray] : 0.0f;
   g.gnear = g.near; g.gfar = g.far;
   if (guided) {
     const bool invalid = (g.gt == 0.0f) || (g.near > g.gt) || (g.far < g.gt);

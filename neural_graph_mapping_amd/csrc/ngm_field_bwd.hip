@@ -370,6 +370,7 @@ __global__ void k_grad_reduce(GradReduceK a) {
 }
 
 int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_GRAD_REDUCE, st);
   GradReduceK k;
   k.F = g.F; k.blocks_per_field = g.blocks_per_field; k.partials = g.partials; k.p_pad = g.p_pad;
   int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
@@ -411,6 +412,7 @@ static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 }
 
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   const FieldShape s = field_shape(&a.fc);
   if (s.MI == 2 && s.MH == 2 && s.L == 2) return launch_bwd<2, 2, 2>(a, blocks, st);
 #ifndef NGM_FAST_BUILD

@@ -338,10 +338,12 @@ static int launch_render(const RenderFwdArgs& a, int blocks, bool need_cos, hipS
 #endif
 
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_POINTS_FWD, st);
   const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
   NGM_SHAPE_DISPATCH(launch_points, a, blocks, need_cos, st);
 }
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_RENDER_FWD, st);
   const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
   NGM_SHAPE_DISPATCH(launch_render, a, blocks, need_cos, st);
 }

@@ -120,3 +120,10 @@ __host__ __device__ static inline int64_t ngm_param_offsets(const ngm_field_cfg*
   }
   return o;
 }
+
+// ---- measurement hooks: HIP events on the launch stream around selected kernels ----------------
+struct NgmProfScope {
+  int id; hipStream_t st; bool on;
+  NgmProfScope(int kernel_id, hipStream_t stream);
+  ~NgmProfScope();
+};

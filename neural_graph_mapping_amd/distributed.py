@@ -1,0 +1,79 @@
+"""Field-per-GPU sharding of the train step.
+
+Each field's rays touch only that field's parameters (the vmap axis of models.py:342-344) and loop
+closure moves only poses (rm.py:936-952), so fields are partitioned by ``owner = field_id % world``.
+Every rank runs the (cheap, seeded) target sampler identically and keeps the slice of the Target it
+owns; the ONLY data-path collective is a sum all-reduce of the 16-float loss sum/count vector
+between the fused forward and the fused backward (RCCL over xGMI: backend "nccl" on ROCm; "gloo" in
+the CPU tests).  No ray or activation ever crosses GPUs.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def field_owner(field_ids: torch.Tensor, world_size: int) -> torch.Tensor:
+    """Rank that owns each field (fields are appended monotonically, rm.py:327-336)."""
+    return field_ids % world_size
+
+
+def owned_mask(field_ids: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+    return field_owner(field_ids, world_size) == rank
+
+
+def shard_target(target, rank: int, world_size: int):
+    """Keep the rows (fields) of a Target namedtuple owned by `rank`.  May return F == 0."""
+    keep = owned_mask(target.field_ids, rank, world_size)
+    vals = []
+    for name, v in zip(target._fields, target):
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == target.field_ids.shape[0]:
+            vals.append(v[keep])
+        else:
+            vals.append(v)
+    return type(target)(*vals)
+
+
+def local_field_slots(num_fields: int, rank: int, world_size: int) -> torch.Tensor:
+    """Global ids of the fields stored on this rank, in local slot order (slot = id // world)."""
+    return torch.arange(rank, num_fields, world_size)
+
+
+def global_to_local(field_ids: torch.Tensor, world_size: int) -> torch.Tensor:
+    return field_ids // world_size
+
+
+def allreduce_loss_sums(loss_sums: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum the per-rank loss sums / counts in place.  Ranks without active fields pass zeros but
+    MUST still call this."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(loss_sums, op=dist.ReduceOp.SUM, group=group)
+    return loss_sums
+
+
+def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsdf) -> dict:
+    """rm.py:1803-1871 from the global sums (slot layout: include/ngm_hip.h ngm_loss_slot)."""
+    def mean(num, den, scale=1.0):
+        return torch.where(den > 0, num / (scale * den.clamp_min(1.0)), torch.zeros_like(num))
+    out = dict(photometric_l1=mean(s[0], s[1], 3.0), depth_huber=mean(s[2], s[3]), freespace=mean(s[4], s[5]),
+               tsdf=mean(s[6], s[7]), termination=mean(s[8], s[9]))
+    out["combined"] = (w_term * out["termination"] + w_photo * out["photometric_l1"] + w_depth * out["depth_huber"]
+                       + w_fs * out["freespace"] + w_tsdf * out["tsdf"])
+    return out
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); returns (rank, local, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -1,0 +1,205 @@
+"""Drop-in counterparts of the reference's field model classes, backed by the gfx950 kernels.
+
+Mirrors ``neural_graph_mapping/models.py`` (NeuralField :66-182, NeuralFieldSet :185-411) and
+``positional_encodings.py`` (:164-276): same constructor kwargs, same parameter names
+("_encoding._linear.weight", "_linears.{i}.weight/bias", "_neus_sd"), same stacked
+``all_fields_params`` / ``vmap_fields_params`` dictionaries, same forward signature.  The arithmetic
+is NOT torch.vmap over nn.Modules: ``forward`` launches the hand-written HIP kernels through
+``ops`` (no CPU fallback).
+"""
+import math
+from pydoc import locate
+from typing import Dict, Literal, Optional
+
+import torch
+
+from . import _capi as K
+from . import ops
+
+_ALIASES = {"neural_graph_mapping.": "neural_graph_mapping_amd."}
+
+
+def str_to_object(name):
+    """Resolve a class given by (reference or local) dotted name (utils.py:114-138 semantics)."""
+    if not isinstance(name, str):
+        return name
+    for old, new in _ALIASES.items():
+        if name.startswith(old):
+            name = new + name[len(old):]
+    obj = globals().get(name.rsplit(".", 1)[-1]) if name.startswith("neural_graph_mapping_amd.") else None
+    return obj or locate(name)
+
+
+# ------------------------------------------------------------------------------------------------
+# encodings (descriptors + parameters; evaluated inside the fused kernels)
+# ------------------------------------------------------------------------------------------------
+class PositionalEncoding(torch.nn.Module):
+    def get_out_dim(self) -> int:
+        raise NotImplementedError()
+
+    def spec(self) -> dict:
+        raise NotImplementedError()
+
+    def forward(self, points):
+        raise NotImplementedError("encodings are evaluated inside the fused field kernels; call the "
+                                  "owning NeuralField / NeuralFieldSet")
+
+
+class PositionalEncodingFourier(PositionalEncoding):
+    """cat(x, sin(W x)) with learnable W (positional_encodings.py:164-216)."""
+
+    def __init__(self, dim_in: int, dim_out: int, mu: float, sigma: float, raw_coords: bool) -> None:
+        super().__init__()
+        if dim_in != 3:
+            raise NotImplementedError("only 3D fields are supported")
+        self._linear = torch.nn.Linear(dim_in, dim_out - dim_in if raw_coords else dim_out, False)
+        self._dim_out = dim_out
+        self._raw_coords = raw_coords
+        torch.nn.init.normal_(self._linear.weight, mu, sigma)
+
+    def get_out_dim(self) -> int:
+        return self._dim_out
+
+    def spec(self):
+        return dict(encoding="fourier", dim_enc=self._dim_out, raw_coords=self._raw_coords)
+
+
+class PositionalEncodingNeRF(PositionalEncoding):
+    """sin / cos(2^i pi x) octaves, sines first (positional_encodings.py:219-276)."""
+
+    def __init__(self, dim_in: int, num_octaves: int = 8, start_octave: int = 0) -> None:
+        super().__init__()
+        if dim_in != 3:
+            raise NotImplementedError("only 3D fields are supported")
+        self.num_octaves, self.start_octave, self.dim_in = num_octaves, start_octave, dim_in
+
+    def get_out_dim(self) -> int:
+        return self.dim_in * self.num_octaves * 2
+
+    def spec(self):
+        return dict(encoding="nerf", num_octaves=self.num_octaves, start_octave=self.start_octave)
+
+
+class PermutohedralEncoding(PositionalEncoding):
+    """Multi-resolution permutohedral-lattice hash encoding (positional_encodings.py:19-66).
+
+    The reference delegates to an un-vendored CUDA package; parity is unpinned.  The HIP
+    kernel for it is not built yet: constructing the descriptor works (config compatibility), using
+    it raises."""
+
+    def __init__(self, pos_dim, log2_hashmap_size, nr_levels, nr_feat_per_level, coarsest_scale, finest_scale,
+                 appply_random_shift_per_level=True, concat_points=False, concat_points_scaling=1.0,
+                 init_scale=1e-5) -> None:
+        super().__init__()
+        self.kw = dict(pos_dim=pos_dim, log2_hashmap_size=log2_hashmap_size, nr_levels=nr_levels,
+                       nr_feat_per_level=nr_feat_per_level, coarsest_scale=coarsest_scale,
+                       finest_scale=finest_scale, concat_points=concat_points)
+        self._out = nr_levels * nr_feat_per_level + (pos_dim if concat_points else 0)
+
+    def get_out_dim(self) -> int:
+        return self._out
+
+    def spec(self):
+        raise NotImplementedError("permutohedral hash encoding: HIP kernel not built yet (parity unpinned)")
+
+
+# ------------------------------------------------------------------------------------------------
+class NeuralField(torch.nn.Module):
+    """Positional encoding + MLP prototype (models.py:66-182); holds ONE field's parameters."""
+
+    def __init__(self, encoding_type, encoding_kwargs: dict, num_layers: int, dim_out: int,
+                 dim_mlp_out: Optional[int] = None, skip_mode: Literal["no", "add", "concat", "rezero"] = "no",
+                 initial_geometry_bias: float = 0.0, neus_initial_sd: Optional[float] = None) -> None:
+        super().__init__()
+        if skip_mode != "no":
+            raise NotImplementedError(f"skip_mode={skip_mode!r}: only 'no' has a kernel so far")
+        self._encoding = str_to_object(encoding_type)(**encoding_kwargs)
+        self._dim_encoding = self._encoding.get_out_dim()
+        self._dim_out = dim_out
+        self._dim_mlp_out = dim_mlp_out if dim_mlp_out is not None else self._dim_encoding
+        self._num_layers = num_layers
+        self._skip_mode = skip_mode
+        if neus_initial_sd is not None:
+            self._neus_sd = torch.nn.Parameter(torch.tensor(float(neus_initial_sd)))
+        dims_in = [self._dim_encoding] + [self._dim_mlp_out] * num_layers
+        dims_out = [self._dim_mlp_out] * num_layers + [dim_out]
+        self._linears = torch.nn.ModuleList(torch.nn.Linear(i, o) for i, o in zip(dims_in, dims_out))
+        with torch.no_grad():
+            self._linears[-1].bias[-1] += initial_geometry_bias
+
+    def field_cfg(self, scale_mode="no", field_radius=1.0) -> K.FieldCfg:
+        return K.field_cfg(num_layers=self._num_layers, dim_hidden=self._dim_mlp_out, dim_out=self._dim_out,
+                           scale_mode=scale_mode, field_radius=field_radius or 1.0, **self._encoding.spec())
+
+    def numel(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def forward(self, query_points: torch.Tensor) -> torch.Tensor:
+        """Single field, points already in the field frame: (...,3) -> (...,dim_out)."""
+        fc = self.field_cfg()
+        lead = query_points.shape[:-1]
+        params = {k: v.unsqueeze(0) for k, v in self.state_dict(keep_vars=True).items() if k != "_neus_sd"}
+        return ops.field_eval(fc, params, query_points.reshape(1, -1, 3)).view(*lead, self._dim_out)
+
+
+class NeuralFieldSet(torch.nn.Module):
+    """Set of posed neural fields (models.py:185-411) evaluated by the HIP kernels."""
+
+    def __init__(self, dim_points: int, field_type, field_kwargs: dict, num_knn: int, distance_factor: float,
+                 outside_value: float, field_radius: Optional[float] = None,
+                 scale_mode: Literal["no", "unit_ball", "unit_cube"] = "no") -> None:
+        super().__init__()
+        if scale_mode != "no" and field_radius is None:
+            raise ValueError(f"{scale_mode=} requires field_radius to be specified.")
+        if dim_points != 3:
+            raise NotImplementedError("Only 3D spaces are supported by the HIP path.")
+        if scale_mode not in K.SCALE:
+            raise NotImplementedError(f"{scale_mode=} is not available.")
+        self._scale_mode, self._field_radius, self._dim_points = scale_mode, field_radius, dim_points
+        self._num_knn, self._distance_factor, self._outside_value = num_knn, distance_factor, outside_value
+        self._prototype_field = str_to_object(field_type)(**field_kwargs)
+        self.all_fields_params: Optional[Dict[str, torch.Tensor]] = None
+        self.vmap_fields_params: Optional[Dict[str, torch.Tensor]] = None
+
+    # -- parameter store -----------------------------------------------------------------------
+    def field_cfg(self, field_radius=None) -> K.FieldCfg:
+        r = self._field_radius if field_radius is None else field_radius
+        return self._prototype_field.field_cfg(self._scale_mode, r)
+
+    def add_fields(self, num_fields: int) -> None:
+        """Append clones of the prototype's state (models.py:245-264)."""
+        new = {k: v.detach().unsqueeze(0).repeat(num_fields, *([1] * v.dim())).clone()
+               for k, v in self._prototype_field.state_dict().items()}
+        if self.all_fields_params is None:
+            self.all_fields_params = new
+        else:
+            self.all_fields_params = {k: torch.cat((v, new[k])) for k, v in self.all_fields_params.items()}
+
+    def set_vmap_fields(self, field_ids: Optional[torch.Tensor]) -> None:
+        if field_ids is None:
+            self.vmap_fields_params = self.all_fields_params
+        else:
+            self.vmap_fields_params = {k: v[field_ids] for k, v in self.all_fields_params.items()}
+
+    def _apply(self, fn, *a, **kw):
+        super()._apply(fn, *a, **kw)
+        if self.all_fields_params is not None:
+            self.all_fields_params = {k: fn(v) for k, v in self.all_fields_params.items()}
+        return self
+
+    def numel(self) -> int:
+        # reference quirk kept: multiplies by the number of parameter NAMES (models.py:407-411)
+        return self._prototype_field.numel() * len(self.all_fields_params)
+
+    # -- evaluation ----------------------------------------------------------------------------
+    def forward(self, query_points, field_positions=None, field_orientations=None, field_ids=None,
+                use_vmap: bool = True, field_radius: Optional[float] = None) -> torch.Tensor:
+        fc = self.field_cfg(field_radius)
+        if use_vmap:
+            params = {k: v for k, v in self.vmap_fields_params.items() if k != "_neus_sd"}
+            return ops.field_eval(fc, params, query_points, field_positions, field_orientations)
+        lead = query_points.shape[:-1]
+        params = {k: v for k, v in self.all_fields_params.items() if k != "_neus_sd"}
+        out = ops.field_eval_knn(fc, params, query_points.reshape(-1, 3), field_positions, field_orientations,
+                                 self._num_knn, self._distance_factor, self._outside_value, field_ids)
+        return out.reshape(*lead, -1)

@@ -1,0 +1,271 @@
+"""Render / train step of Neural Graph Mapping on the gfx950 kernels.
+
+Host-side mirror of the renderer half of ``NeuralGraphMap`` (run_mapping.py): ``Target`` /
+``Prediction`` records (:43-69), ``render_ijs`` (:439-666), ``quadrature`` (:709-799),
+``compute_losses`` (:1769-1872) and the sparse-Adam plumbing (:347-389, :668-707, :1183-1221), plus
+the fused fast path ``optimization_iteration`` that the mapping loop calls once per iteration
+(:1123-1181).  The SLAM / pose-graph loop itself stays in the caller.
+"""
+import ctypes as C
+from collections import namedtuple
+from typing import Dict, Optional
+
+import torch
+
+from . import _capi as K
+from . import ops
+from .models import NeuralFieldSet
+
+Target = namedtuple("Target", ["ijs", "c2ws", "near_distances", "far_distances", "gt_distances", "field_ids", "rgbds",
+                               "rgb_mask", "depth_mask", "term_probs", "term_mask"])
+Prediction = namedtuple("Prediction", ["rgbds", "color_vars", "depth_vars", "term_probs", "freespace_geometry",
+                                       "tsdf_residuals"])
+
+
+class Camera:
+    """Pinhole intrinsics with the reference's pixel-centre convention (camera.py:15-116)."""
+
+    def __init__(self, width, height, fx, fy, cx, cy, s=0.0, pixel_center=0.0):
+        if s != 0:
+            raise NotImplementedError("Skew != 0 not supported.")
+        self.fx, self.fy = fx, fy
+        self.cx = cx - pixel_center + 0.5
+        self.cy = cy - pixel_center + 0.5
+        self.s, self.width, self.height = s, width, height
+
+    def get_pinhole_camera_parameters(self, pixel_center: float):
+        return self.fx, self.fy, self.cx - 0.5 + pixel_center, self.cy - 0.5 + pixel_center, self.s
+
+
+class LossConfig:
+    """Loss weights of rm.py:129-135 (defaults of config/neural_graph_map.yaml:31-37)."""
+
+    def __init__(self, termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0,
+                 tsdf_weight=50.0):
+        self.termination_weight, self.photometric_weight = termination_weight, photometric_weight
+        self.depth_weight, self.freespace_weight, self.tsdf_weight = depth_weight, freespace_weight, tsdf_weight
+
+
+def make_render_cfg(camera: Camera, config: dict, guided: bool = True) -> K.RenderCfg:
+    """Reference config keys (rm.py:116-220) -> ngm_render_cfg."""
+    fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
+    tau = config.get("truncation_distance", 0.1)
+    rho = config.get("range_depth_guided") or tau
+    return K.render_cfg(
+        geometry_mode=config.get("geometry_mode", "nrgbd"), num_samples_coarse=config["num_samples_coarse"],
+        num_samples_guided=config.get("num_samples_depth_guided", 0) if guided else 0,
+        geometry_factor=config.get("geometry_factor", 1.0), color_factor=config.get("color_factor", 1.0),
+        truncation_distance=tau, range_depth_guided=rho, fx=fx, fy=fy, cx=cx, cy=cy,
+        w_termination=config.get("termination_weight", 0.0), w_photometric=config.get("photometric_weight", 1.0),
+        w_depth=config.get("depth_weight", 1.0), w_freespace=config.get("freespace_weight", 0.0),
+        w_tsdf=config.get("tsdf_weight", 0.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# generic (autograd) render: Prediction with the compacted free-space / TSDF vectors
+# ------------------------------------------------------------------------------------------------
+class _RenderIjs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fc, rc, names, rays_kw, *param_tensors):
+        params = dict(zip(names, param_tensors))
+        keep = []
+        rays = ops.make_rays(rc, keep=keep, **rays_kw)
+        F, R = rays.F, rays.R
+        dev = param_tensors[0].device
+        S = rc.num_samples_coarse + (rc.num_samples_guided if rays_kw.get("gt") is not None else 0)
+        pr = dict(rgbds=torch.empty(F, R, 4, device=dev), color_vars=torch.empty(F, R, 3, device=dev),
+                  depth_vars=torch.empty(F, R, device=dev), term_probs=torch.empty(F, R, device=dev))
+        pred = K.Prediction(*[t.data_ptr() for t in pr.values()])
+        L = K.lib()
+        ps = ops.params_struct(fc, params)
+        need_grad = any(t.requires_grad for t in param_tensors)
+        ws, wsb = None, 0
+        if need_grad or rays_kw.get("gt") is not None:
+            wsb = L.ngm_render_workspace(C.byref(fc), C.byref(rc), F, R, 1)
+            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), None, C.byref(pred), None,
+                                 ops._ptr(ws), wsb, ops._stream()), "ngm_render_fwd")
+        geoms = dists = None
+        if ws is not None:
+            geoms, dists = torch.empty(F, R, S, device=dev), torch.empty(F, R, S, device=dev)
+            K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, ws.data_ptr(), geoms.data_ptr(),
+                                              dists.data_ptr(), ops._stream()), "ngm_render_read_samples")
+        ctx.fc, ctx.rc, ctx.names, ctx.rays_kw, ctx.ws, ctx.wsb = fc, rc, names, rays_kw, ws, wsb
+        ctx.save_for_backward(*param_tensors)
+        ctx.mark_non_differentiable(pr["color_vars"], pr["depth_vars"])
+        if dists is not None:
+            ctx.mark_non_differentiable(dists)
+        return pr["rgbds"], pr["color_vars"], pr["depth_vars"], pr["term_probs"], geoms, dists
+
+    @staticmethod
+    def backward(ctx, d_rgbds, d_cv, d_dv, d_term, d_geoms, d_dists):
+        fc, rc, names = ctx.fc, ctx.rc, ctx.names
+        params = dict(zip(names, ctx.saved_tensors))
+        keep = []
+        rays = ops.make_rays(rc, keep=keep, **ctx.rays_kw)
+        dev = ctx.saved_tensors[0].device
+        F, R = rays.F, rays.R
+        d_rgbds = torch.zeros(F, R, 4, device=dev) if d_rgbds is None else ops._f32c(d_rgbds)
+        d_term = None if d_term is None else ops._f32c(d_term)
+        d_geoms = None if d_geoms is None else ops._f32c(d_geoms)
+        grads, gs, _ = ops.alloc_grads(fc, F, dev)
+        ps = ops.params_struct(fc, params)
+        K.check(K.lib().ngm_render_bwd_seeded(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), ops._ptr(d_rgbds),
+                                              ops._ptr(d_term), ops._ptr(d_geoms), C.byref(gs), ctx.ws.data_ptr(),
+                                              ctx.wsb, ops._stream()), "ngm_render_bwd_seeded")
+        return (None, None, None, None) + tuple(grads[n] for n in names)
+
+
+class NeuralGraphRenderer:
+    """Renderer + per-field optimiser state for a ``NeuralFieldSet`` (hot-path half of NeuralGraphMap)."""
+
+    def __init__(self, model: NeuralFieldSet, camera: Camera, config: dict, device="cuda"):
+        self._model, self._camera, self._config, self._device = model, camera, dict(config), device
+        self._field_radius = config.get("field_radius", model._field_radius)
+        self._fc = model.field_cfg(self._field_radius)
+        self._rc_train = make_render_cfg(camera, config, guided=True)
+        self._rc_plain = make_render_cfg(camera, config, guided=False)
+        self._global_map_dict = None       # supplied by the mapping loop: positions / orientations
+        self._learning_rate = config.get("learning_rate", 1e-3)
+        self._adam_eps = config.get("adam_eps", 1e-15)
+        self._adam_weight_decay = config.get("adam_weight_decay", 0.0)
+        self._optim_state: Optional[Dict[str, Dict[str, torch.Tensor]]] = None
+        self._step = 0
+        self._ws_cache = {}
+        self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
+
+    # -- map bookkeeping supplied by the caller ------------------------------------------------
+    def set_field_poses(self, positions: torch.Tensor, orientations: torch.Tensor):
+        self._global_map_dict = {"positions": positions, "orientations": orientations, "num": positions.shape[0]}
+
+    def add_fields(self, num_new: int):
+        """NeuralGraphMap._add_fields (rm.py:364-389): grow params + zero moments, keep the shared step."""
+        self._model.add_fields(num_new)
+        allp = self._model.all_fields_params
+        new_state = {}
+        for k, v in allp.items():
+            m, s = torch.zeros_like(v), torch.zeros_like(v)
+            if self._optim_state is not None:
+                m[:-num_new] = self._optim_state[k]["exp_avg"]
+                s[:-num_new] = self._optim_state[k]["exp_avg_sq"]
+            new_state[k] = {"exp_avg": m, "exp_avg_sq": s}
+        self._optim_state = new_state
+
+    # -- reference-compatible API --------------------------------------------------------------
+    def quadrature(self, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):
+        return ops.quadrature(self._rc_train, sample_colors, sample_geometries, sample_distances, sample_depths,
+                              neus_isds)
+
+    def render_ijs(self, ijs, c2ws, camera=None, field_ids=None, use_vmap=True, near_distances=None,
+                   far_distances=None, gt_distances=None, overwrite_samples_behind_camera=True, u_coarse=None,
+                   u_guided=None, seed=0) -> Prediction:
+        """_render_ijs(use_vmap=True) (rm.py:439-666); differentiable w.r.t. vmap_fields_params."""
+        if not use_vmap or field_ids is None:
+            raise NotImplementedError("render_ijs: only the training path (use_vmap=True, field_ids given) is fused; "
+                                      "use render_image for the kNN evaluation path")
+        if near_distances is not None and not bool((near_distances >= 0).all()):
+            raise NotImplementedError("negative near distances (samples behind the camera) are not supported")
+        self._model.set_vmap_fields(field_ids)
+        for v in self._model.vmap_fields_params.values():
+            v.requires_grad_()
+        guided = gt_distances is not None and self._rc_train.num_samples_guided > 0
+        rc = self._rc_train if guided else self._rc_plain
+        pos = self._global_map_dict["positions"][field_ids]
+        quat = self._global_map_dict["orientations"][field_ids]
+        names = tuple(K.param_names(self._fc))
+        rays_kw = dict(ijs=ijs, c2ws=c2ws, near=near_distances, far=far_distances, gt=gt_distances if guided else None,
+                       pos=pos, quat=quat, u_coarse=u_coarse, u_guided=u_guided if guided else None, seed=seed,
+                       near_const=self._config.get("near_distance", 0.0), far_const=self._config.get("far_distance", 8.0))
+        params = self._model.vmap_fields_params
+        rgbds, cvars, dvars, term, geoms, dists = _RenderIjs.apply(self._fc, rc, names, rays_kw,
+                                                                   *[params[n] for n in names])
+        fs = ts = None
+        tau = rc.truncation_distance
+        if gt_distances is not None and geoms is not None:
+            gt = gt_distances[..., None]
+            if rc.w_freespace != 0.0:
+                fs = geoms[dists < (gt - tau) * (gt != 0.0)] * tau                      # rm.py:624-630
+            if rc.w_tsdf != 0.0:
+                deltas = gt - dists
+                m = (deltas.abs() < tau) & (gt != 0.0)
+                ts = geoms[m] * tau - deltas[m]                                         # rm.py:632-639
+        return Prediction(rgbds, cvars, dvars, term, fs, ts)
+
+    def compute_losses(self, target: Target, prediction: Prediction) -> dict:
+        """_compute_losses (rm.py:1769-1872) on torch tensors (l1 photometric, huber depth)."""
+        rc = self._rc_train
+        m = target.depth_mask & (prediction.term_probs > rc.term_threshold)
+        loss = {}
+        tm = target.term_mask
+        loss["termination"] = ((prediction.term_probs[tm] - target.term_probs[tm]) ** 2).mean()
+        loss["photometric_l1"] = (target.rgbds[m][:, :3] - prediction.rgbds[m][:, :3]).abs().mean()
+        loss["depth_huber"] = torch.nn.functional.huber_loss(prediction.rgbds[m][:, 3], target.rgbds[m][:, 3],
+                                                             delta=rc.huber_delta)
+        total = (rc.w_termination * loss["termination"] + rc.w_photometric * loss["photometric_l1"]
+                 + rc.w_depth * loss["depth_huber"])
+        if prediction.freespace_geometry is not None:
+            loss["freespace"] = ((prediction.freespace_geometry - rc.truncation_distance) ** 2).mean()
+            total = total + rc.w_freespace * loss["freespace"]
+        if prediction.tsdf_residuals is not None:
+            loss["tsdf"] = (prediction.tsdf_residuals ** 2).mean()
+            total = total + rc.w_tsdf * loss["tsdf"]
+        loss["combined"] = total
+        return loss
+
+    # -- fused fast path -----------------------------------------------------------------------
+    def _workspace(self, F, R):
+        key = (F, R)
+        if key not in self._ws_cache:
+            wsb = K.lib().ngm_render_workspace(C.byref(self._fc), C.byref(self._rc_train), F, R, 1)
+            dev = self._device
+            self._ws_cache[key] = dict(
+                ws=torch.empty(wsb, device=dev, dtype=torch.uint8), wsb=wsb,
+                rgbds=torch.empty(F, R, 4, device=dev), color_vars=torch.empty(F, R, 3, device=dev),
+                depth_vars=torch.empty(F, R, device=dev), term_probs=torch.empty(F, R, device=dev),
+                sums=torch.zeros(K.NGM_NUM_LOSS_SUMS, device=dev), loss=torch.zeros(8, device=dev))
+        return self._ws_cache[key]
+
+    def optimization_iteration(self, target: Target, u_coarse=None, u_guided=None, seed=0, update=True) -> dict:
+        """One training iteration (rm.py:1123-1221): fused forward + losses, (all-reduce), fused backward,
+        sparse Adam on the touched fields.  Returns the loss dict (device scalars) and, with
+        update=False, also the gradients."""
+        L = K.lib()
+        fc, rc = self._fc, self._rc_train
+        fids = target.field_ids
+        F, R = target.ijs.shape[0], target.ijs.shape[1]
+        names = K.param_names(fc)
+        allp = {n: self._model.all_fields_params[n] for n in names}
+        ps = ops.params_struct(fc, allp, fids)           # kernels read rows field_ids[f] in place: no gather
+        keep = []
+        rays = ops.make_rays(rc, target.ijs, target.c2ws, target.near_distances, target.far_distances,
+                             target.gt_distances, self._global_map_dict["positions"][fids],
+                             self._global_map_dict["orientations"][fids], u_coarse, u_guided, seed, keep=keep)
+        w = self._workspace(F, R)
+        dm = target.depth_mask.to(torch.uint8)
+        tm = target.term_mask.to(torch.uint8) if target.term_mask is not None else None
+        tg = K.Targets(ops._ptr(ops._f32c(target.rgbds)), dm.data_ptr(), ops._ptr(tm), ops._ptr(target.term_probs))
+        pred = K.Prediction(w["rgbds"].data_ptr(), w["color_vars"].data_ptr(), w["depth_vars"].data_ptr(),
+                            w["term_probs"].data_ptr())
+        st = ops._stream()
+        K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
+                                 w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
+        if self.process_group is not None:
+            # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
+            torch.distributed.all_reduce(w["sums"], group=self.process_group)
+        grads, gs, gflat = ops.alloc_grads(fc, F, self._device)
+        K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
+                                 w["sums"].data_ptr(), C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
+                                 st), "ngm_render_bwd")
+        lv = w["loss"]
+        loss = {"combined": lv[0], "termination": lv[1], "photometric_l1": lv[2], "depth_huber": lv[3],
+                "freespace": lv[4], "tsdf": lv[5]}
+        if update:
+            self._step += 1                                  # one counter for all fields (rm.py:380-385)
+            for n in names:
+                stt = self._optim_state[n]
+                ops.adam_sparse_(allp[n], stt["exp_avg"], stt["exp_avg_sq"], grads[n], fids, self._step,
+                                 lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
+        else:
+            loss["grads"] = grads
+        loss["prediction"] = Prediction(w["rgbds"], w["color_vars"], w["depth_vars"], w["term_probs"], None, None)
+        return loss

@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads, exports every symbol
+include/ngm_hip.h declares, struct layouts agree, and the product path refuses to run without a GPU
+(no silent CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ngm_hip.h")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from neural_graph_mapping_amd import _capi, build
+    if not os.path.exists(_capi.LIB_PATH):
+        build.build(verbose=False)
+    return _capi
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ngm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    L = capi.lib()
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ngm_hip.h but not exported"
+    assert sorted(capi.EXPORTED) == names
+    assert L.ngm_abi_version() == 1
+
+
+def test_struct_layouts_match_header(capi, tmp_path):
+    """Compile a tiny C program against the header and compare sizeof() with the ctypes mirrors."""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "ngm_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(ngm_field_cfg),sizeof(ngm_params),sizeof(ngm_grads),sizeof(ngm_render_cfg),"
+                   "sizeof(ngm_rays),sizeof(ngm_targets),sizeof(ngm_prediction));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [capi.FieldCfg, capi.Params, capi.Grads, capi.RenderCfg, capi.Rays, capi.Targets, capi.Prediction]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_workspace_sizing_and_validation_without_gpu(capi):
+    L = capi.lib()
+    fc = capi.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    rc = capi.render_cfg(num_samples_coarse=64, num_samples_guided=64)
+    ws = L.ngm_render_workspace(C.byref(fc), C.byref(rc), 8, 512, 1)
+    # stash: 24 B / sample + ray table + partial gradient vectors
+    assert ws > 8 * 512 * 128 * 24
+    assert L.ngm_render_workspace(C.byref(fc), C.byref(rc), 8, 512, 0) < 4096
+    bad = capi.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, dim_out=3)
+    assert L.ngm_render_workspace(C.byref(bad), C.byref(rc), 8, 512, 1) < 0
+    assert b"dim_out" in L.ngm_last_error()
+    # argument validation happens before any launch
+    assert L.ngm_field_eval_fwd(C.byref(fc), None, 1, 10, None, None, None, None, None) == -1
+
+
+def test_param_names_and_shapes_follow_reference(capi):
+    fc = capi.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    shapes = capi.param_shapes(fc)
+    assert shapes == {"_encoding._linear.weight": (61, 3), "_linears.0.weight": (64, 64), "_linears.0.bias": (64,),
+                      "_linears.1.weight": (64, 64), "_linears.1.bias": (64,), "_linears.2.weight": (4, 64),
+                      "_linears.2.bias": (4,)}          # SURVEY 8b, observed on the reference
+    from oracle import ngm_oracle as O
+    assert O.FieldSpec(encoding="fourier", dim_enc=64, num_layers=2).param_shapes() == shapes
+    fcn = capi.field_cfg(encoding="nerf", num_octaves=8, num_layers=1)
+    assert fcn.dim_enc == 48 and capi.param_shapes(fcn)["_linears.0.weight"] == (48, 48)
+
+
+def test_ops_refuse_cpu_tensors(capi):
+    from neural_graph_mapping_amd import ops
+    fc = capi.field_cfg()
+    params = {n: torch.zeros(1, *s) for n, s in capi.param_shapes(fc).items()}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.field_eval(fc, params, torch.zeros(1, 8, 3))
+    rc = capi.render_cfg()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.quadrature(rc, torch.zeros(2, 4, 3), torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+def test_missing_library_fails_loudly(capi, monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libngm_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.lib()

@@ -1,0 +1,400 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (a) the golden fixtures generated from the real reference,
+  (b) the CPU oracle on seeded random inputs (small sizes),
+  (c) size-independent properties at the full benchmark size (4096 rays x 128 samples).
+Tolerances (fp32): forward 2e-4 rel / 2e-5 abs; gradients 2e-3 of the tensor's max |grad|
+(same bars the oracle meets against the reference in test_oracle_golden.py); sample distances are
+bit-exact."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import load_golden, split_prefix
+
+pytestmark = pytest.mark.gpu
+
+from neural_graph_mapping_amd import _capi as K  # noqa: E402
+from neural_graph_mapping_amd import models as M  # noqa: E402
+from neural_graph_mapping_amd import ops  # noqa: E402
+from neural_graph_mapping_amd import renderer as Rr  # noqa: E402
+from oracle import ngm_oracle as O  # noqa: E402
+
+DEV = "cuda"
+NRGBD_KW = dict(fx=554.2562584220408, fy=554.2562584220408, cx=319.5, cy=239.5)
+NRGBD = O.CameraSpec(640, 480, **NRGBD_KW)
+
+
+def cu(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+def close(a, b, rtol=2e-4, atol=2e-5):
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol)
+
+
+def grad_close(a, b, tol=2e-3, name=""):
+    scale = b.abs().max().clamp_min(1e-12)
+    err = float((a.cpu() - b.cpu()).abs().max() / scale)
+    assert err < tol, (name, err)
+
+
+def test_device_is_gfx950_and_library_loaded():
+    n = C.c_int(0)
+    name = C.create_string_buffer(128)
+    assert K.lib().ngm_device_info(C.byref(n), name, 128) == 0
+    assert n.value >= 64
+    assert b"gfx9" in name.value
+
+
+# ---------------------------------------------------------------------------------- sampler (G1-G3)
+def test_sampler_golden_bit_exact():
+    g = load_golden("g3_sample_merged")
+    rc = K.render_cfg(num_samples_coarse=g["u_coarse"].shape[-1], num_samples_guided=g["u_guided"].shape[-1],
+                      truncation_distance=float(g["rho"]), **NRGBD_KW)
+    d = cu({k: g[k] for k in ("ijs", "near", "far", "gt", "u_coarse", "u_guided")})
+    pts, t, _ = ops.sample_rays(rc, d["ijs"], d["near"], d["far"], d["gt"], d["u_coarse"], d["u_guided"])
+    assert torch.equal(t.cpu(), g["distances"])          # rank merge == torch.sort, fp32 op order identical
+    close(pts, g["points"], rtol=1e-6, atol=1e-6)
+    g2 = load_golden("g2_sample_uniform")
+    rc2 = K.render_cfg(num_samples_coarse=g2["u"].shape[-1], num_samples_guided=0, **NRGBD_KW)
+    d2 = cu({k: g2[k] for k in ("ijs", "near", "far", "u")})
+    pts2, t2, _ = ops.sample_rays(rc2, d2["ijs"], d2["near"], d2["far"], None, d2["u"])
+    assert torch.equal(t2.cpu(), g2["distances"])
+    g1 = load_golden("g1_directions")
+    ij = g1["ijs"][None].to(DEV)
+    rc1 = K.render_cfg(num_samples_coarse=1, num_samples_guided=0, **NRGBD_KW)
+    z = torch.zeros(1, ij.shape[1], device=DEV)
+    _, _, dirs = ops.sample_rays(rc1, ij, z, z + 1, None, torch.zeros(1, ij.shape[1], 1, device=DEV))
+    close(dirs[0], g1["dirs"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_c,n_g", [(24, 0), (7, 5), (64, 64), (1, 1)])
+def test_sampler_vs_oracle_random(n_c, n_g):
+    torch.manual_seed(n_c * 100 + n_g)
+    F, R = 3, 37
+    ijs = torch.stack([torch.randint(0, 480, (F, R)), torch.randint(0, 640, (F, R))], -1)
+    near = torch.rand(F, R) * 2
+    far = near + 0.5 + torch.rand(F, R) * 3
+    far[0, 0] = near[0, 0]                                # degenerate segment (near == far)
+    gt = near + (far - near) * torch.rand(F, R)
+    gt[0, 1] = 0.0; gt[1, 2] = far[1, 2] + 1.0; gt[2, 3] = near[2, 3] * 0.5
+    u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
+    pts_o, t_o, _ = O.sample_rays(ijs, NRGBD, near, far, gt if n_g else None, rs, u_c, u_g)
+    rc = K.render_cfg(num_samples_coarse=n_c, num_samples_guided=n_g, **NRGBD_KW)
+    pts, t, _ = ops.sample_rays(rc, ijs.to(DEV), near.to(DEV), far.to(DEV), gt.to(DEV) if n_g else None, u_c.to(DEV),
+                                u_g.to(DEV) if n_g else None)
+    assert torch.equal(t.cpu(), t_o)
+    assert (t[..., 1:] >= t[..., :-1]).all()
+
+
+def test_sampler_philox_statistics_and_reproducibility():
+    F, R, n = 4, 256, 64
+    rc = K.render_cfg(num_samples_coarse=n, num_samples_guided=0, **NRGBD_KW)
+    ijs = torch.zeros(F, R, 2, dtype=torch.long, device=DEV)
+    near, far = torch.zeros(F, R, device=DEV), torch.full((F, R), float(n), device=DEV)
+    _, t1, _ = ops.sample_rays(rc, ijs, near, far, seed=7)
+    _, t2, _ = ops.sample_rays(rc, ijs, near, far, seed=7)
+    _, t3, _ = ops.sample_rays(rc, ijs, near, far, seed=8)
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3)
+    u = t1 - torch.arange(n, device=DEV)                  # delta = 1 -> jitter in [0,1)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 + 1e-5
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1 / 12) < 0.005
+
+
+# ------------------------------------------------------------------------- field evaluation (G4)
+@pytest.mark.parametrize("enc", ["fourier", "nerf"])
+def test_field_forward_golden(enc):
+    g = load_golden(f"g4_field_forward_{enc}")
+    fc = K.field_cfg(encoding=enc, dim_enc=64, num_layers=2, num_octaves=8)
+    params = cu({k: v for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"})
+    out = ops.field_eval(fc, params, g["query"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV))
+    close(out, g["out"], rtol=2e-4, atol=3e-5)
+
+
+FIELD_CASES = [dict(encoding="fourier", dim_enc=64, num_layers=2), dict(encoding="fourier", dim_enc=32, num_layers=2),
+               dict(encoding="fourier", dim_enc=32, num_layers=1), dict(encoding="nerf", num_octaves=8, num_layers=1),
+               dict(encoding="fourier", dim_enc=64, num_layers=1, raw_coords=False),
+               dict(encoding="nerf", num_octaves=4, num_layers=2)]
+
+
+@pytest.mark.parametrize("kw", FIELD_CASES)
+@pytest.mark.parametrize("P", [1, 257])
+def test_field_eval_forward_backward_vs_oracle(kw, P):
+    torch.manual_seed(3)
+    F = 3
+    fs = O.FieldSpec(**kw)
+    fc = K.field_cfg(**kw)
+    params = O.init_params(fs, F, seed=5, sigma=3.0)
+    pos, quat = torch.randn(F, 3), torch.nn.functional.normalize(torch.randn(F, 4), dim=-1)
+    q = pos[:, None] + 0.5 * torch.randn(F, P, 3)
+    d_out = torch.randn(F, P, 4)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    out_o = O.field_set_forward_vmap(q, pos, quat, po, fs)
+    (out_o * d_out).sum().backward()
+    pg = {k: v.to(DEV).requires_grad_() for k, v in params.items()}
+    out = ops.field_eval(fc, pg, q.to(DEV), pos.to(DEV), quat.to(DEV))
+    tol = 2e-4 if kw["encoding"] == "fourier" else 2e-3        # octave encoding amplifies fp32 argument error
+    close(out, out_o.detach(), rtol=tol, atol=tol * 0.2)
+    (out * d_out.to(DEV)).sum().backward()
+    for k in po:
+        grad_close(pg[k].grad, po[k].grad, 2e-3 if kw["encoding"] == "fourier" else 1e-2, k)
+
+
+def test_neural_field_set_module_matches_oracle():
+    torch.manual_seed(0)
+    fs = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
+        num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
+    fs.add_fields(4)
+    ids = torch.tensor([3, 1], device=DEV)
+    fs.set_vmap_fields(ids)
+    pos, quat = torch.randn(2, 3), torch.nn.functional.normalize(torch.randn(2, 4), dim=-1)
+    q = pos[:, None] + 0.4 * torch.randn(2, 50, 3)
+    out = fs(q.to(DEV), pos.to(DEV), quat.to(DEV), ids, True)
+    ospec = O.FieldSpec(encoding="fourier", dim_enc=64, num_layers=2)
+    pcpu = {k: v.cpu() for k, v in fs.vmap_fields_params.items() if k != "_neus_sd"}
+    close(out, O.field_set_forward_vmap(q, pos, quat, pcpu, ospec))
+
+
+# ------------------------------------------------------------------------------ quadrature (G5)
+@pytest.mark.parametrize("mode", ["nrgbd", "occupancy", "density", "neus"])
+@pytest.mark.parametrize("S", [2, 24, 128])
+def test_quadrature_golden(mode, S):
+    g = load_golden(f"g5_quadrature_{mode}_S{S}")
+    rc = K.render_cfg(geometry_mode=mode, geometry_factor=float(g["geometry_factor"]))
+    isds = g["isds"].to(DEV) if "isds" in g else None
+    C_, D, Cv, Dv, term, w = ops.quadrature(rc, g["colors"].to(DEV), g["geoms"].to(DEV), g["dists"].to(DEV),
+                                            g["depths"].to(DEV), isds)
+    for a, b in ((C_, "C"), (D, "D"), (Cv, "Cv"), (Dv, "Dv"), (term, "term"), (w, "w")):
+        close(a, g[b], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["nrgbd", "occupancy"])
+@pytest.mark.parametrize("lead,S", [((3, 5), 24), ((7,), 128), ((2, 3), 1), ((1,), 200), ((40,), 7)])
+def test_quadrature_backward_vs_oracle(mode, lead, S):
+    torch.manual_seed(S)
+    colors = torch.rand(*lead, S, 3)
+    geoms = 0.1 * torch.randn(*lead, S)
+    geoms.view(-1)[0] = 0.0                          # occ == 1 exactly: division-free recursion must be exact
+    if S > 3:
+        geoms.view(-1, S)[0, 3] = 0.0
+    dists = torch.sort(torch.rand(*lead, S) * 3 + 0.5, -1)[0]
+    depths = dists * 0.9
+    dC, dD, dT = torch.randn(*lead, 3), torch.randn(*lead), torch.randn(*lead)
+    co, go = colors.clone().requires_grad_(), geoms.clone().requires_grad_()
+    Co, Do, _, _, To, _ = O.quadrature(mode, co, go, dists, depths, 20.0)
+    ((Co * dC).sum() + (Do * dD).sum() + (To * dT).sum()).backward()
+    rc = K.render_cfg(geometry_mode=mode, geometry_factor=20.0)
+    cg, gg = colors.to(DEV).requires_grad_(), geoms.to(DEV).requires_grad_()
+    Cg, Dg, _, _, Tg, _ = ops.quadrature(rc, cg, gg, dists.to(DEV), depths.to(DEV))
+    close(Cg, Co.detach(), 1e-5, 2e-6)
+    ((Cg * dC.to(DEV)).sum() + (Dg * dD.to(DEV)).sum() + (Tg * dT.to(DEV)).sum()).backward()
+    grad_close(cg.grad, co.grad, 1e-5, "d_colors")
+    grad_close(gg.grad, go.grad, 2e-5, "d_geoms")
+
+
+# ------------------------------------------------------------------------- train step (G6, G7)
+CASES = {
+    "g6_train_cfg0": (dict(encoding="fourier", dim_enc=64, num_layers=2), dict(num_samples_coarse=16, num_samples_depth_guided=16)),
+    "g6_train_3field": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                        dict(num_samples_coarse=8, num_samples_depth_guided=16, termination_weight=0.5)),
+    "g6_train_nerf_l1": (dict(encoding="nerf", num_octaves=8, num_layers=1), dict(num_samples_coarse=8, num_samples_depth_guided=8)),
+}
+
+
+def make_renderer(fkw, ckw, num_fields, params=None):
+    if fkw["encoding"] == "fourier":
+        et = "neural_graph_mapping.positional_encodings.PositionalEncodingFourier"
+        ek = dict(dim_in=3, dim_out=fkw["dim_enc"], mu=0.0, sigma=4.0, raw_coords=True)
+    else:
+        et = "neural_graph_mapping.positional_encodings.PositionalEncodingNeRF"
+        ek = dict(dim_in=3, num_octaves=fkw["num_octaves"], start_octave=0)
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0), num_knn=2,
+        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
+    cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
+               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
+               learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0)
+    cfg.update(ckw)
+    cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, cfg, device=DEV)
+    r.add_fields(num_fields)
+    if params is not None:
+        for k, v in params.items():
+            model.all_fields_params[k].copy_(v.to(DEV))
+    return r
+
+
+def make_target(t, ids):
+    t = cu(t)
+    return Rr.Target(ijs=t["ijs"], c2ws=t["c2ws"], near_distances=t["near"], far_distances=t["far"], gt_distances=t["gt"],
+                     field_ids=ids.to(DEV), rgbds=t["rgbds"], rgb_mask=t["depth_mask"], depth_mask=t["depth_mask"],
+                     term_probs=t["term_probs"], term_mask=t["term_mask"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_train_step_golden(name):
+    g = load_golden(name)
+    fkw, ckw = CASES[name]
+    F = g["pos"].shape[0]
+    r = make_renderer(fkw, ckw, F, split_prefix(g, "p::"))
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    tgt = make_target(split_prefix(g, "t::"), torch.arange(F))
+    res = r.optimization_iteration(tgt, g["u_coarse"].to(DEV), g["u_guided"].to(DEV), update=False)
+    nerf = fkw["encoding"] == "nerf"
+    ft = dict(rtol=2e-3, atol=3e-4) if nerf else dict(rtol=2e-4, atol=2e-5)
+    p = res["prediction"]
+    close(p.rgbds, g["pred_rgbds"], **ft)
+    close(p.color_vars, g["pred_color_vars"], **ft)
+    close(p.depth_vars, g["pred_depth_vars"], **ft)
+    close(p.term_probs, g["pred_term_probs"], **ft)
+    ref_loss = split_prefix(g, "loss::")
+    for k, v in ref_loss.items():
+        close(res[k], v, rtol=1e-3 if nerf else 2e-4, atol=1e-5)
+    for k, v in split_prefix(g, "g::").items():
+        grad_close(res["grads"][k], v, 1e-2 if nerf else 2e-3, k)
+
+
+@pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field"])
+def test_render_ijs_autograd_path_golden(name):
+    """reference-style call sequence: render_ijs -> compute_losses -> backward (rm.py:1164-1186)."""
+    g = load_golden(name)
+    fkw, ckw = CASES[name]
+    F = g["pos"].shape[0]
+    r = make_renderer(fkw, ckw, F, split_prefix(g, "p::"))
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    ids = torch.arange(F, device=DEV)
+    tgt = make_target(split_prefix(g, "t::"), ids)
+    pred = r.render_ijs(tgt.ijs, tgt.c2ws, None, field_ids=ids, use_vmap=True, near_distances=tgt.near_distances,
+                        far_distances=tgt.far_distances, gt_distances=tgt.gt_distances,
+                        u_coarse=g["u_coarse"].to(DEV), u_guided=g["u_guided"].to(DEV))
+    close(pred.rgbds, g["pred_rgbds"])
+    assert pred.freespace_geometry.shape == g["pred_freespace"].shape
+    assert pred.tsdf_residuals.shape == g["pred_tsdf"].shape
+    close(pred.freespace_geometry, g["pred_freespace"])
+    close(pred.tsdf_residuals, g["pred_tsdf"])
+    loss = r.compute_losses(tgt, pred)
+    close(loss["combined"], split_prefix(g, "loss::")["combined"], rtol=2e-4, atol=1e-6)
+    loss["combined"].backward()
+    vp = r._model.vmap_fields_params
+    for k, v in split_prefix(g, "g::").items():
+        grad_close(vp[k].grad, v, 2e-3, k)
+
+
+def test_sparse_adam_ten_iterations_golden():
+    """G7: trained parameters after 10 iterations with changing active sets and the shared step."""
+    g = load_golden("g7_adam")
+    fkw = dict(encoding="fourier", dim_enc=32, num_layers=2)
+    ckw = dict(num_samples_coarse=4, num_samples_depth_guided=8)
+    NF = g["pos"].shape[0]
+    r = make_renderer(fkw, ckw, NF, {k: v for k, v in split_prefix(g, "p0::").items()})
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    for it in range(int(g["num_iters"])):
+        t = split_prefix(g, f"it{it}::")
+        ids = t.pop("field_ids")
+        uc, ug, ref = t.pop("u_coarse"), t.pop("u_guided"), t.pop("loss")
+        res = r.optimization_iteration(make_target(t, ids), uc.to(DEV), ug.to(DEV), update=True)
+        close(res["combined"], ref, rtol=2e-3, atol=1e-5)
+    for k, v in split_prefix(g, "p1::").items():
+        if k == "_neus_sd":
+            continue
+        close(r._model.all_fields_params[k], v, rtol=2e-3, atol=5e-5)
+        close(r._optim_state[k]["exp_avg"], g["m1::" + k], rtol=5e-3, atol=1e-6)
+
+
+# ---------------------------------------------------------------- full-size properties (M1 shape)
+def synth_target(F, R, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    pos = 0.5 * torch.randn(F, 3, generator=gen)
+    quat = torch.nn.functional.normalize(torch.randn(F, 4, generator=gen), dim=-1)
+    ijs = torch.stack([torch.randint(0, 480, (F, R), generator=gen), torch.randint(0, 640, (F, R), generator=gen)], -1)
+    eye = pos[:, None] + torch.nn.functional.normalize(torch.randn(F, R, 3, generator=gen), dim=-1) * (2 + torch.rand(F, R, 1, generator=gen))
+    fwd = torch.nn.functional.normalize(pos[:, None] + 0.3 * torch.randn(F, R, 3, generator=gen) - eye, dim=-1)
+    right = torch.nn.functional.normalize(torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]).expand_as(fwd)), dim=-1)
+    c2w = torch.eye(4).repeat(F, R, 1, 1)
+    c2w[..., :3, 0], c2w[..., :3, 1], c2w[..., :3, 2], c2w[..., :3, 3] = right, torch.linalg.cross(right, fwd), -fwd, eye
+    d = O.ijs_to_directions(ijs, NRGBD)
+    pos_c = torch.einsum("...kd,...k->...d", c2w[..., :3, :3], pos[:, None] - c2w[..., :3, 3])
+    center = (pos_c * d).sum(-1)
+    near, far = (center - 1).clamp_min(0), (center + 1).clamp_min(0)
+    gt = near + (far - near) * (0.1 + 0.8 * torch.rand(F, R, generator=gen))
+    gt[torch.rand(F, R, generator=gen) < 0.1] = 0.0
+    rgbds = torch.cat([torch.rand(F, R, 3, generator=gen), (gt * d[..., 2].abs())[..., None]], -1)
+    dm = (gt > near) & (gt < far) & (gt != 0)
+    return pos, quat, dict(ijs=ijs, c2ws=c2w, near=near, far=far, gt=gt, rgbds=rgbds, depth_mask=dm,
+                           term_probs=(gt < far).float(), term_mask=(gt > near) & (gt != 0))
+
+
+def test_full_size_properties_m1():
+    F, R = 8, 512
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=64, num_samples_depth_guided=64)
+    pos, quat, t = synth_target(F, R)
+    r = make_renderer(fkw, ckw, F)
+    with torch.no_grad():
+        for k, v in r._model.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn_like(v))
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    a = r.optimization_iteration(tgt, seed=11, update=False)
+    pa = {k: v.clone() for k, v in a["grads"].items()}
+    pred_a = a["prediction"].rgbds.clone()
+    term = a["prediction"].term_probs
+    assert torch.isfinite(pred_a).all() and all(torch.isfinite(v).all() for v in pa.values())
+    assert float(term.min()) >= -1e-6 and float(term.max()) <= 1 + 1e-5          # sum w + bg = 1
+    assert (a["prediction"].color_vars >= -1e-7).all() and (a["prediction"].depth_vars >= -1e-7).all()
+    # determinism: same seed -> bitwise identical predictions and gradients (fixed reduction order)
+    b = r.optimization_iteration(tgt, seed=11, update=False)
+    assert torch.equal(b["prediction"].rgbds, pred_a)
+    for k in pa:
+        assert torch.equal(b["grads"][k], pa[k]), k
+    # field permutation equivariance (fields are independent; only the global loss counts couple them)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+    tp = {k: v[perm] for k, v in t.items()}
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    c = r.optimization_iteration(make_target(tp, perm), seed=11, update=False)
+    # Philox streams are keyed by batch position, so compare statistically-free quantities: loss counts
+    assert abs(float(c["combined"]) - float(a["combined"])) / float(a["combined"]) < 0.05
+    # linearity of the backward in the loss weights
+    r2 = make_renderer(fkw, {**ckw, "photometric_weight": 2.0, "depth_weight": 2.0, "freespace_weight": 80.0,
+                             "tsdf_weight": 100.0}, F, {k: v for k, v in r._model.all_fields_params.items()})
+    r2.set_field_poses(pos.to(DEV), quat.to(DEV))
+    d = r2.optimization_iteration(tgt, seed=11, update=False)
+    for k in pa:
+        grad_close(d["grads"][k], 2 * pa[k], 1e-5, k)
+
+
+@pytest.mark.parametrize("F,R,n_c,n_g", [(1, 5, 3, 0), (2, 33, 1, 1), (5, 7, 8, 16), (1, 1, 128, 0), (3, 130, 20, 4)])
+def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
+    torch.manual_seed(F * 1000 + R)
+    fkw = dict(encoding="fourier", dim_enc=32, num_layers=1)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos, quat, t = synth_target(F, R, seed=R)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params = O.init_params(fs, F, seed=R, sigma=3.0)
+    params["_linears.1.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV) if n_g else None,
+                                   update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    close(res["prediction"].term_probs, pred["term_probs"].detach())
+    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
+    n_fs, n_ts, n_t = pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())
+    if min(n_m, n_fs, n_ts, n_t) == 0:
+        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 3e-3, k)
+EOF
+echo ok

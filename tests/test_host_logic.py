@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference interface (models / renderer / distributed helpers) on CPU."""
+import torch
+
+from conftest import load_golden, split_prefix
+from neural_graph_mapping_amd import distributed as D
+from neural_graph_mapping_amd import models as M
+from neural_graph_mapping_amd import renderer as Rr
+from oracle import ngm_oracle as O
+
+FIELD_KW = dict(
+    encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+    encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True),
+    num_layers=2, dim_out=4, dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0)
+SET_KW = dict(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=FIELD_KW, num_knn=2,
+              distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube")
+
+
+def test_reference_class_names_resolve_to_local_counterparts():
+    assert M.str_to_object("neural_graph_mapping.models.NeuralField") is M.NeuralField
+    assert M.str_to_object("neural_graph_mapping.positional_encodings.PositionalEncodingNeRF") is M.PositionalEncodingNeRF
+    assert M.str_to_object("neural_graph_mapping.models.NeuralFieldSet") is M.NeuralFieldSet
+
+
+def test_field_set_parameter_store_matches_reference_layout():
+    fs = M.NeuralFieldSet(**SET_KW)
+    fs.add_fields(3)
+    fs.add_fields(2)
+    g = load_golden("g6_train_cfg0")
+    ref_shapes = {k: tuple(v.shape[1:]) for k, v in split_prefix(g, "p::").items()}
+    assert {k: tuple(v.shape[1:]) for k, v in fs.all_fields_params.items()} == ref_shapes
+    assert all(v.shape[0] == 5 for v in fs.all_fields_params.values())
+    # add_fields clones ONE prototype (models.py:254-257): all fields start identical
+    w = fs.all_fields_params["_linears.0.weight"]
+    assert torch.equal(w[0], w[4])
+    fs.set_vmap_fields(torch.tensor([4, 1]))
+    assert fs.vmap_fields_params["_linears.1.bias"].shape == (2, 64)
+    fs.set_vmap_fields(None)
+    assert fs.vmap_fields_params is fs.all_fields_params
+    assert fs.numel() == fs._prototype_field.numel() * len(fs.all_fields_params)   # reference quirk kept
+    fc = fs.field_cfg()
+    assert (fc.dim_enc, fc.dim_hidden, fc.num_layers, fc.scale_mode) == (64, 64, 2, 2)
+
+
+def test_unsupported_variants_raise():
+    import pytest
+    with pytest.raises(NotImplementedError):
+        M.NeuralField(**{**FIELD_KW, "skip_mode": "concat"})
+    with pytest.raises(ValueError):
+        M.NeuralFieldSet(**{**SET_KW, "field_radius": None})
+
+
+def test_camera_effective_principal_point():
+    cam = Rr.Camera(640, 480, 554.25, 554.25, 319.5, 239.5, pixel_center=0.0)
+    fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
+    assert (cx, cy) == (319.5, 239.5)
+    rc = Rr.make_render_cfg(cam, dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_factor=20.0,
+                                      truncation_distance=0.1, freespace_weight=40.0, tsdf_weight=50.0))
+    assert rc.num_samples_guided == 16 and abs(rc.range_depth_guided - 0.1) < 1e-7 and rc.w_tsdf == 50.0
+
+
+def test_field_sharding_partitions_targets():
+    ids = torch.tensor([0, 3, 4, 7, 9])
+    T = Rr.Target(ijs=torch.zeros(5, 6, 2, dtype=torch.long), c2ws=torch.zeros(5, 6, 4, 4), near_distances=torch.zeros(5, 6),
+                  far_distances=torch.ones(5, 6), gt_distances=torch.ones(5, 6), field_ids=ids, rgbds=torch.zeros(5, 6, 4),
+                  rgb_mask=torch.ones(5, 6, dtype=torch.bool), depth_mask=torch.ones(5, 6, dtype=torch.bool),
+                  term_probs=torch.ones(5, 6), term_mask=torch.ones(5, 6, dtype=torch.bool))
+    seen = []
+    for r in range(4):
+        sh = D.shard_target(T, r, 4)
+        assert (sh.field_ids % 4 == r).all() and sh.ijs.shape[0] == sh.field_ids.shape[0]
+        seen += sh.field_ids.tolist()
+    assert sorted(seen) == ids.tolist()
+    assert D.local_field_slots(10, 1, 4).tolist() == [1, 5, 9]
+    assert D.global_to_local(torch.tensor([1, 5, 9]), 4).tolist() == [0, 1, 2]
+
+
+def test_loss_values_from_global_sums_match_oracle():
+    g = load_golden("g6_train_3field")
+    fs = O.FieldSpec(encoding="fourier", dim_enc=64, num_layers=2)
+    rs = O.RenderSpec(num_samples_coarse=8, num_samples_depth_guided=16, termination_weight=0.5)
+    params = {k: v for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"}
+    t = split_prefix(g, "t::")
+    nrgbd = O.CameraSpec(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5)
+    pred = O.render_ijs(t["ijs"], t["c2ws"], nrgbd, g["pos"], g["quat"], params, fs, rs, t["near"], t["far"], t["gt"],
+                        g["u_coarse"], g["u_guided"])
+    m = t["depth_mask"] & (pred["term_probs"] > 0.8)
+    e = pred["rgbds"][m][:, 3] - t["rgbds"][m][:, 3]
+    hub = torch.where(e.abs() < 0.05, 0.5 * e * e, 0.05 * (e.abs() - 0.025))
+    tm = t["term_mask"]
+    s = torch.zeros(16)
+    s[0] = (t["rgbds"][m][:, :3] - pred["rgbds"][m][:, :3]).abs().sum(); s[1] = m.sum()
+    s[2] = hub.sum(); s[3] = m.sum()
+    s[4] = ((pred["freespace_geometry"] - 0.1) ** 2).sum(); s[5] = pred["freespace_geometry"].numel()
+    s[6] = (pred["tsdf_residuals"] ** 2).sum(); s[7] = pred["tsdf_residuals"].numel()
+    s[8] = ((pred["term_probs"][tm] - t["term_probs"][tm]) ** 2).sum(); s[9] = tm.sum()
+    vals = D.loss_values_from_sums(s, 0.5, 1.0, 1.0, 40.0, 50.0)
+    ref = split_prefix(g, "loss::")
+    for k in ref:
+        torch.testing.assert_close(vals[k], ref[k], rtol=2e-4, atol=1e-6)

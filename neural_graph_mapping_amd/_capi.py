@@ -4,6 +4,10 @@ Torch-free: every call takes raw device addresses (ints) and a stream handle, so
 the torch layer (``tensor.data_ptr()``) and the torch-free harness (``hiprt.DeviceArray.ptr``).
 The product path has NO CPU fallback: if the library is missing, importing this module's `lib()`
 raises.
+
+NOTE on HIP runtimes: PyTorch-ROCm bundles its own libamdhip64.  A process that uses torch must
+import torch BEFORE the first `lib()` call so that libngm_hip.so binds to the same runtime instance
+(`ops` does this by importing torch at module import); the torch-free harness uses the system ROCm.
 """
 import ctypes as C
 import os

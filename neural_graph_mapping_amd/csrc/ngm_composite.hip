@@ -30,6 +30,7 @@ struct SamplerArgs {
 };
 
 __global__ void k_sample_rays(SamplerArgs a) {
+#pragma clang fp contract(off)
   const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
   const int S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {

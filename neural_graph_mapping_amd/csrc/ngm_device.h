@@ -121,6 +121,7 @@ struct RayGeom {
 };
 
 __device__ __forceinline__ float strat_lin(const float* lin_tab, int n, int i) {
+#pragma clang fp contract(off)
   if (lin_tab) return lin_tab[i];
   // torch.linspace(0,1,n+1) scalar formula (RangeFactories): symmetric about the middle
   const float step = __fdiv_rn(1.0f, (float)n);
@@ -129,6 +130,7 @@ __device__ __forceinline__ float strat_lin(const float* lin_tab, int n, int i) {
 }
 // t_i = (delta*u + lin_i*(far-near)) + near
 __device__ __forceinline__ float strat_t(float near, float far, int n, int i, float u, const float* lin_tab) {
+#pragma clang fp contract(off)   // hipcc contracts a*b+c by default; the reference rounds each op
   const float span = __fsub_rn(far, near);
   const float delta = __fdiv_rn(span, (float)n);
   const float b = __fmul_rn(strat_lin(lin_tab, n, i), span);
@@ -136,6 +138,7 @@ __device__ __forceinline__ float strat_t(float near, float far, int n, int i, fl
 }
 
 __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm_rays& rays, int64_t ray, bool guided) {
+#pragma clang fp contract(off)
   RayGeom g;
   const int64_t i = rays.ijs[2 * ray], j = rays.ijs[2 * ray + 1];
   const float vx = __fdiv_rn(__fsub_rn((float)j, cfg.cx), cfg.fx);

@@ -133,9 +133,17 @@ def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.
 # ------------------------------------------------------------------------------------------------
 # K1: sampler
 # ------------------------------------------------------------------------------------------------
+_LIN_CACHE = {}
+
+
 def linspace_table(n: int, device):
-    """torch.linspace(0,1,n+1) exactly as camera.py:271 builds it (device-side table for the kernel)."""
-    return torch.linspace(0.0, 1.0, steps=n + 1, device=device, dtype=torch.float32)
+    """torch.linspace(0,1,n+1) of camera.py:271 as a device table for the kernels.  Computed by torch on
+    the host (bit-identical to the CPU reference / oracle; ROCm's device linspace may differ in the
+    last bit for non power-of-two n) and cached per (n, device)."""
+    key = (int(n), str(device))
+    if key not in _LIN_CACHE:
+        _LIN_CACHE[key] = torch.linspace(0.0, 1.0, steps=n + 1, dtype=torch.float32).to(device)
+    return _LIN_CACHE[key]
 
 
 def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=None, u_guided=None, seed=0, offset=0,

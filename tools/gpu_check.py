@@ -329,6 +329,45 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10):
            finite=bool(all(np.isfinite(v.numpy()).all() for v in gdev.values())))
 
 
+def check_sampler_random(n_c=7, n_g=5, F=3, R=37, seed=705):
+    """debug: GPU rank-merge vs numpy sort on random rays"""
+    f32 = np.float32
+    L = K.lib()
+    rng = np.random.default_rng(seed)
+    near = (rng.random((F, R)) * 2).astype(f32)
+    far = (near + 0.5 + rng.random((F, R)) * 3).astype(f32)
+    far[0, 0] = near[0, 0]
+    gt = (near + (far - near) * rng.random((F, R))).astype(f32)
+    gt[0, 1] = 0.0; gt[1, 2] = far[1, 2] + 1.0; gt[2, 3] = near[2, 3] * 0.5
+    u_c, u_g = rng.random((F, R, n_c)).astype(f32), rng.random((F, R, n_g)).astype(f32)
+    lc, lg = lin_table(n_c), lin_table(n_g)
+
+    def strat(ne, fa, n, u, lin):
+        span = (fa - ne).astype(f32)
+        delta = (span / f32(n)).astype(f32)
+        b = (lin[None, None, :-1] * span[..., None]).astype(f32)
+        return (((delta[..., None] * u).astype(f32) + b).astype(f32) + ne[..., None]).astype(f32)
+    inv = (gt == 0) | (near > gt) | (far < gt)
+    gn = np.where(inv, near, (gt - f32(0.1)).astype(f32)).astype(f32)
+    gf = np.where(inv, far, (gt + f32(0.1)).astype(f32)).astype(f32)
+    ref = np.sort(np.concatenate([strat(near, far, n_c, u_c, lc), strat(gn, gf, n_g, u_g, lg)], -1), -1)
+    rc = K.render_cfg(num_samples_coarse=n_c, num_samples_guided=n_g, **NRGBD)
+    ijs = H.to_dev(np.zeros((F, R, 2), np.int64))
+    keep = [H.to_dev(x) for x in (near, far, gt, u_c, u_g, lc, lg, np.eye(4, dtype=f32), np.zeros((F, 3), f32),
+                                  np.tile(np.array([1, 0, 0, 0], f32), (F, 1)))]
+    rays = K.Rays(F, R, ijs.ptr, keep[7].ptr, 0, 0, keep[0].ptr, keep[1].ptr, keep[2].ptr, 0.0, 8.0, keep[8].ptr,
+                  keep[9].ptr, keep[3].ptr, keep[4].ptr, keep[5].ptr, keep[6].ptr, 0, 0)
+    dist = H.DeviceArray((F, R, n_c + n_g))
+    dist.fill_bytes(0xFF)
+    K.check(L.ngm_sample_rays(C.byref(rc), C.byref(rays), None, dist.ptr, None, None), "sample_rays")
+    t = dist.numpy()
+    bad = np.argwhere((t != ref).any(-1))
+    record(f"sampler_random_{n_c}_{n_g}", mismatching_rays=len(bad), total=F * R)
+    for f, r in bad[:4]:
+        print(" ray", f, r, "near/far/gt", near[f, r], far[f, r], gt[f, r], "inv", inv[f, r])
+        print("  gpu", t[f, r]); print("  ref", ref[f, r])
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     out = "gpurun_out/check.json"
@@ -345,7 +384,8 @@ if __name__ == "__main__":
     for c in todo:
         try:
             {"sampler": check_sampler, "field": check_field, "quad": check_quad, "train": check_train,
-             "time": check_time}[c]()
+             "time": check_time, "sampler_random": lambda: (check_sampler_random(7, 5), check_sampler_random(64, 64),
+                                                             check_sampler_random(4, 4))}[c]()
         except Exception:
             traceback.print_exc()
             record(c, error=traceback.format_exc()[-800:])

@@ -42,8 +42,8 @@ __global__ void k_sample_rays(SamplerArgs a) {
     const int64_t o = ray * a.S + rank;
     if (a.distances) a.distances[o] = t;
     if (a.points_cam) {
-      a.points_cam[3 * o] = __fmul_rn(rg.dx, t); a.points_cam[3 * o + 1] = __fmul_rn(rg.dy, t);
-      a.points_cam[3 * o + 2] = __fmul_rn(rg.dz, t);
+      a.points_cam[3 * o] = rg.dx * t; a.points_cam[3 * o + 1] = rg.dy * t;
+      a.points_cam[3 * o + 2] = rg.dz * t;
     }
     if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
   }

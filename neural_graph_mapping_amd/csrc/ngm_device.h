@@ -120,40 +120,48 @@ struct RayGeom {
   float gt;
 };
 
+// NOTE: plain operators, not __fmul_rn/__fadd_rn: those header wrappers are compiled with the `contract`
+// fast-math flag and still fuse into FMAs after inlining; the pragma only governs operators written here.
 __device__ __forceinline__ float strat_lin(const float* lin_tab, int n, int i) {
 #pragma clang fp contract(off)
   if (lin_tab) return lin_tab[i];
   // torch.linspace(0,1,n+1) scalar formula (RangeFactories): symmetric about the middle
-  const float step = __fdiv_rn(1.0f, (float)n);
+  const float step = 1.0f / (float)n;
   const int steps = n + 1, half = steps / 2;
-  return (i < half) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(steps - i - 1)));
+  const float a = step * (float)i;
+  const float b = step * (float)(steps - i - 1);
+  return (i < half) ? a : (1.0f - b);
 }
-// t_i = (delta*u + lin_i*(far-near)) + near
+// t_i = (delta*u + lin_i*(far-near)) + near, every operation rounded separately (camera.py:269-276)
 __device__ __forceinline__ float strat_t(float near, float far, int n, int i, float u, const float* lin_tab) {
-#pragma clang fp contract(off)   // hipcc contracts a*b+c by default; the reference rounds each op
-  const float span = __fsub_rn(far, near);
-  const float delta = __fdiv_rn(span, (float)n);
-  const float b = __fmul_rn(strat_lin(lin_tab, n, i), span);
-  return __fadd_rn(__fadd_rn(__fmul_rn(delta, u), b), near);
+#pragma clang fp contract(off)
+  const float span = far - near;
+  const float delta = span / (float)n;
+  const float b = strat_lin(lin_tab, n, i) * span;
+  const float du = delta * u;
+  const float s = du + b;
+  return s + near;
 }
 
 __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm_rays& rays, int64_t ray, bool guided) {
 #pragma clang fp contract(off)
   RayGeom g;
   const int64_t i = rays.ijs[2 * ray], j = rays.ijs[2 * ray + 1];
-  const float vx = __fdiv_rn(__fsub_rn((float)j, cfg.cx), cfg.fx);
-  const float vy = -__fdiv_rn(__fsub_rn((float)i, cfg.cy), cfg.fy);
+  const float vx = ((float)j - cfg.cx) / cfg.fx;
+  const float vy = -(((float)i - cfg.cy) / cfg.fy);
   const float vz = -1.0f;
-  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+  const float xx = vx * vx, yy = vy * vy, zz = vz * vz;
+  const float sxy = xx + yy;
+  const float nrm = sqrtf(sxy + zz);
   const float den = fmaxf(nrm, 1e-12f);
-  g.dx = __fdiv_rn(vx, den); g.dy = __fdiv_rn(vy, den); g.dz = __fdiv_rn(vz, den);
+  g.dx = vx / den; g.dy = vy / den; g.dz = vz / den;
   g.near = rays.near ? rays.near[ray] : rays.near_const;
   g.far = rays.far ? rays.far[ray] : rays.far_const;
   g.gt = rays.gt ? rays.gt[ray] : 0.0f;
   g.gnear = g.near; g.gfar = g.far;
   if (guided) {
     const bool invalid = (g.gt == 0.0f) || (g.near > g.gt) || (g.far < g.gt);
-    if (!invalid) { g.gnear = __fsub_rn(g.gt, cfg.range_depth_guided); g.gfar = __fadd_rn(g.gt, cfg.range_depth_guided); }
+    if (!invalid) { g.gnear = g.gt - cfg.range_depth_guided; g.gfar = g.gt + cfg.range_depth_guided; }
   }
   return g;
 }

@@ -94,6 +94,13 @@ static int num_cus() {
   return cached;
 }
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+// floats of LDS taken by one field's weights (mirrors FieldLds<MI,MH,L>::TOTAL in ngm_field.h)
+static int64_t field_lds_floats(const ngm_field_cfg* fc) {
+  const int64_t MI = (fc->dim_enc + 31) / 32, MH = (fc->dim_hidden + 31) / 32;
+  int64_t t = MI * 32 * 4;
+  for (int l = 0; l < fc->num_layers; ++l) t += MH * (l == 0 ? MI : MH) * 16 * 2 * 33 + MH * 32;
+  return t + MH * 32 * 4 + 8;
+}
 
 static int check_field_cfg(const ngm_field_cfg* fc) {
   if (!fc) return fail(NGM_E_INVALID, "field cfg is NULL");
@@ -265,7 +272,7 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 // fused render / train step
 // ------------------------------------------------------------------------------------------------
 struct RenderPlan {
-  int S, rays_per_block, blocks_fwd;
+  int S, rays_per_block, blocks_fwd, waves_fwd, maxs;
   int64_t per_block_bwd; int blocks_per_field_bwd;
   int64_t p_pad;
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, total;
@@ -275,14 +282,26 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   memset(&p, 0, sizeof(p));
   p.S = rc->num_samples_coarse + (guided ? rc->num_samples_guided : 0);
   const int ncu = num_cus();
-  int ch = (ncu + F - 1) / F;
-  const int max_ch = (R + NGM_WAVES_PER_BLOCK - 1) / NGM_WAVES_PER_BLOCK;
-  if (ch > max_ch) ch = max_ch;
-  if (ch < 1) ch = 1;
-  int rpb = (R + ch - 1) / ch;
-  rpb = (int)align_up(rpb, NGM_WAVES_PER_BLOCK);
-  p.rays_per_block = rpb;
-  p.blocks_fwd = F * ((R + rpb - 1) / rpb);
+  // forward: one workgroup per CU-slot; 8 waves (2 per SIMD, VALU of one hides under the MFMAs of the
+  // other) unless the per-wave LDS sample planes would not fit in 160 KiB, then 4 waves
+  int waves = 8;
+  for (;;) {
+    int ch = (ncu + F - 1) / F;
+    const int max_ch = (R + waves - 1) / waves;
+    if (ch > max_ch) ch = max_ch;
+    if (ch < 1) ch = 1;
+    int rpb = (R + ch - 1) / ch;
+    rpb = (int)align_up(rpb, waves);
+    const int rpw = rpb / waves;
+    int64_t maxs = align_up((int64_t)(rpw < 32 ? rpw : 32) * p.S, 64);
+    if (maxs > 1024) maxs = 1024;
+    if (maxs < align_up(p.S, 64)) maxs = align_up(p.S, 64);
+    const int64_t lds = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs));
+    if (waves == 8 && (lds > 160 * 1024 || R < 8)) { waves = 4; continue; }
+    p.rays_per_block = rpb; p.waves_fwd = waves; p.maxs = (int)maxs;
+    p.blocks_fwd = F * ((R + rpb - 1) / rpb);
+    break;
+  }
   p.p_pad = param_pad(fc);
   int64_t o = 0;
   if (train) {
@@ -339,7 +358,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   a.fc = *fcfg; a.pr = *params; a.rc = *rcfg; a.rays = *rays; a.pred = *pred;
   a.has_targets = has_tg ? 1 : 0;
   if (has_tg) a.tg = *targets;
-  a.S = p.S; a.rays_per_block = p.rays_per_block;
+  a.S = p.S; a.rays_per_block = p.rays_per_block; a.waves_per_block = p.waves_fwd; a.maxs = p.maxs;
   if (save) {
     a.raytab = reinterpret_cast<float*>(ws + p.off_raytab);
     a.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);

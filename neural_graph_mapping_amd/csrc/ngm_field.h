@@ -32,14 +32,15 @@ struct FieldDims {
 };
 
 // Build the per-feature encoding table and copy + permute one field's weights into LDS.
-// All 256 threads of the workgroup participate; caller must __syncthreads() afterwards.
+// All threads of the workgroup participate; caller must __syncthreads() afterwards.
 template <int MI, int MH, int L>
 __device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
   using LY = FieldLds<MI, MH, L>;
   const int tid = threadIdx.x;
   const int D = fc.dim_enc, H = fc.dim_hidden;
   // ---- encoding table
-  for (int f = tid; f < MI * 32; f += NGM_BLOCK) {
+  const int nthr = blockDim.x;
+  for (int f = tid; f < MI * 32; f += nthr) {
     float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
     if (f < D) {
       if (fc.encoding == NGM_ENC_FOURIER) {
@@ -72,19 +73,19 @@ __device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg
     const float* B = pr.b[l] + row * pr.b_stride[l];
     float* dst = sm + LY::w_off(l);
     const int ncol = MIN * 32, total = MH * 32 * ncol;
-    for (int e = tid; e < total; e += NGM_BLOCK) {
+    for (int e = tid; e < total; e += nthr) {
       const int o = e / ncol, c = e - o * ncol;
       const float v = (o < H && c < Din) ? W[(int64_t)o * Din + c] : 0.f;
       const int mo = o >> 5, io = o & 31, mi = c >> 5, ic = c & 31;
       dst[((((mo * MIN + mi) * 16 + col_r(ic)) * 2 + col_hi(ic)) * NGM_WGS) + io] = v;
     }
-    for (int o = tid; o < MH * 32; o += NGM_BLOCK) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
+    for (int o = tid; o < MH * 32; o += nthr) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
   }
   // ---- output layer (4 x H) -> float4 per hidden feature
   {
     const float* W = pr.w[L] + row * pr.w_stride[L];
     const float* B = pr.b[L] + row * pr.b_stride[L];
-    for (int f = tid; f < MH * 32; f += NGM_BLOCK) {
+    for (int f = tid; f < MH * 32; f += nthr) {
       float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (f < H) w4 = make_float4(W[f], W[H + f], W[2 * H + f], W[3 * H + f]);
       reinterpret_cast<float4*>(sm + LY::WOUT)[f] = w4;
@@ -95,8 +96,10 @@ __device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg
 
 // Encoding of one sample position into the lane's B-operand registers.
 // Lane (j = lane&31, hi = lane>>5) holds features 32*mi + frow(r,hi) of sample j.
-// WITH_DERIV additionally returns d(value)/d(arg) (cos for sin-features, -sin for cos-features,
-// 0 for raw/padding) -- used by the backward kernel for the learnable Fourier matrix.
+// Feature kinds: RAW features can only sit in slots (mi = 0, r < 3, hi = 0) (features 0..2); every other
+// slot is sin(w.x) -- or cos(w.x) when NEED_COS (NeRF octaves).  Padded features (>= D) have zero table
+// rows and meet zero weight columns, so their value (sin 0 / cos 0) never reaches an output.
+// WITH_DERIV additionally returns d(value)/d(arg) for the learnable Fourier matrix.
 template <int MI, bool NEED_COS, bool WITH_DERIV>
 __device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, float x, float y, float z,
                                               f32x16 (&E)[MI], f32x16 (&dE)[MI]) {
@@ -109,14 +112,11 @@ __device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, floa
       const float arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
       float s, c;
       ngm_sincosf(arg, &s, &c);
-      float v = (w.w == NGM_FK_RAW) ? arg : ((w.w == NGM_FK_SIN) ? s : 0.f);
-      if (NEED_COS) v = (w.w == NGM_FK_COS) ? c : v;
+      float v = s, d = c;
+      if (NEED_COS) { const bool is_cos = (w.w == NGM_FK_COS); v = is_cos ? c : s; d = is_cos ? -s : c; }
+      if (mi == 0 && r < 3) { const bool raw = (w.w == NGM_FK_RAW); v = raw ? arg : v; d = raw ? 0.f : d; }
       E[mi][r] = v;
-      if (WITH_DERIV) {
-        float d = (w.w == NGM_FK_SIN) ? c : 0.f;
-        if (NEED_COS) d = (w.w == NGM_FK_COS) ? -s : d;
-        dE[mi][r] = d;
-      }
+      if (WITH_DERIV) dE[mi][r] = d;
       if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -138,18 +138,33 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const flo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = bias;
   }
+  // software-pipelined A-fragment fetch: the LDS reads of k-step group g+1 are issued before the MFMAs
+  // of group g (4 k-steps per group), so their latency hides under the matrix pipe.
+  constexpr int NG = MIN * 4;
+  float abuf[2][4][MOUT];
+  const float* Wl = W + hi * NGM_WGS + io;
 #pragma unroll
-  for (int mi = 0; mi < MIN; ++mi) {
+  for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int mo = 0; mo < MOUT; ++mo) abuf[0][rr][mo] = Wl[((mo * MIN + 0) * 16 + rr) * 2 * NGM_WGS];
 #pragma unroll
-      for (int mo = 0; mo < MOUT; ++mo) {
-        const float a = W[((((mo * MIN + mi) * 16 + r) * 2 + hi) * NGM_WGS) + io];
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+      const int mi1 = (4 * (g + 1)) / 16, r1 = (4 * (g + 1)) % 16;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma32(a, X[nt][mi][r], Y[nt][mo]);
-      }
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int mo = 0; mo < MOUT; ++mo)
+          abuf[(g + 1) & 1][rr][mo] = Wl[((mo * MIN + mi1) * 16 + r1 + rr) * 2 * NGM_WGS];
     }
+    const int mi = (4 * g) / 16, r0 = (4 * g) % 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma32(abuf[g & 1][rr][mo], X[nt][mi][r0 + rr], Y[nt][mo]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)

@@ -66,17 +66,29 @@ __device__ __forceinline__ void layer_dgrad(const float* __restrict__ W, int lan
   for (int mi = 0; mi < MIN; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dX[mi][r] = 0.f;
+  constexpr int NG = MOUT * 4;
+  float abuf[2][4][MIN];
+  const float* Wl = W + lane_off;
 #pragma unroll
-  for (int mo = 0; mo < MOUT; ++mo) {
+  for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int mi = 0; mi < MIN; ++mi) abuf[0][rr][mi] = Wl[(0 * MIN + mi) * 16 * 2 * NGM_WGS + frow(rr, 0)];
 #pragma unroll
-      for (int mi = 0; mi < MIN; ++mi) {
-        const float a = W[(mo * MIN + mi) * 16 * 2 * NGM_WGS + lane_off + frow(r, 0)];
-        dX[mi] = mfma32(a, dY[mo][r], dX[mi]);
-      }
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+      const int mo1 = (4 * (g + 1)) / 16, r1 = (4 * (g + 1)) % 16;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int mi = 0; mi < MIN; ++mi)
+          abuf[(g + 1) & 1][rr][mi] = Wl[(mo1 * MIN + mi) * 16 * 2 * NGM_WGS + frow(r1 + rr, 0)];
     }
+    const int mo = (4 * g) / 16, r0 = (4 * g) % 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int mi = 0; mi < MIN; ++mi) dX[mi] = mfma32(abuf[g & 1][rr][mi], dY[mo][r0 + rr], dX[mi]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -85,19 +97,35 @@ template <int MOUT, int MIN>
 __device__ __forceinline__ void layer_wgrad(const float* __restrict__ dbuf, int dstr, const float* __restrict__ xbuf,
                                             int xstr, int lane, f32x16 (&acc)[MOUT][MIN]) {
   const int i = lane & 31, hi = lane >> 5;
+  // operands of k-step group g+1 (4 sample pairs) are fetched while group g multiplies
+  float av[2][4][MOUT], bv[2][4][MIN];
+  const float* dl = dbuf + (16 * hi) * dstr + i;
+  const float* xl = xbuf + (16 * hi) * xstr + i;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int s = t + 16 * hi;
-    float av[MOUT], bv[MIN];
+  for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
-    for (int mo = 0; mo < MOUT; ++mo) av[mo] = dbuf[s * dstr + 32 * mo + i];
+    for (int mo = 0; mo < MOUT; ++mo) av[0][tt][mo] = dl[tt * dstr + 32 * mo];
 #pragma unroll
-    for (int mi = 0; mi < MIN; ++mi) bv[mi] = xbuf[s * xstr + 32 * mi + i];
+    for (int mi = 0; mi < MIN; ++mi) bv[0][tt][mi] = xl[tt * xstr + 32 * mi];
+  }
 #pragma unroll
-    for (int mo = 0; mo < MOUT; ++mo)
+  for (int g = 0; g < 4; ++g) {
+    if (g + 1 < 4) {
 #pragma unroll
-      for (int mi = 0; mi < MIN; ++mi) acc[mo][mi] = mfma32(av[mo], bv[mi], acc[mo][mi]);
-    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int mo = 0; mo < MOUT; ++mo) av[(g + 1) & 1][tt][mo] = dl[(4 * (g + 1) + tt) * dstr + 32 * mo];
+#pragma unroll
+        for (int mi = 0; mi < MIN; ++mi) bv[(g + 1) & 1][tt][mi] = xl[(4 * (g + 1) + tt) * xstr + 32 * mi];
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < MIN; ++mi) acc[mo][mi] = mfma32(av[g & 1][tt][mo], bv[g & 1][tt][mi], acc[mo][mi]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -106,10 +134,40 @@ template <int M>
 __device__ __forceinline__ float colsum(const float* buf, int stride, int lane) {
   constexpr int NF = 32 * M, PARTS = 64 / NF, PER = 32 / PARTS;
   const int fl = lane % NF, sp = lane / NF;
-  float s = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < PER; ++k) s += buf[(sp * PER + k) * stride + fl];
-  return s;
+  // all LDS reads first (one latency), then a pairwise tree
+  float v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) v[k] = buf[(sp * PER + k) * stride + fl];
+#pragma unroll
+  for (int w = PER / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) v[k] += v[k + w];
+  return v[0];
+}
+
+// acc[c] += sum_s col[s][fl] * row4[s][c]  (lane = feature): LDS reads batched 8 samples at a time
+template <int M, int NC>
+__device__ __forceinline__ void outer_accum(const float* colbuf, int stride, const float* row4, int lane, float (&acc)[NC]) {
+  constexpr int NF = 32 * M, PARTS = 64 / NF, PER = 32 / PARTS;
+  const int fl = lane % NF, sp = lane / NF;
+#pragma unroll
+  for (int k0 = 0; k0 < PER; k0 += 8) {
+    float h[8];
+    float4 d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int s = sp * PER + k0 + k;
+      h[k] = colbuf[s * stride + fl];
+      d[k] = *reinterpret_cast<const float4*>(row4 + 4 * s);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[0] = fmaf(d[k].x, h[k], acc[0]);
+      acc[1] = fmaf(d[k].y, h[k], acc[1]);
+      acc[2] = fmaf(d[k].z, h[k], acc[2]);
+      if (NC > 3) acc[3] = fmaf(d[k].w, h[k], acc[3]);
+    }
+  }
 }
 
 template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD>
@@ -208,19 +266,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     // ---- output layer gradients (VALU, lane = hidden feature)
     store_tile<MH>(bufD, BL::STR_D, lane, Hc[0]);
     WAVE_SYNC();
-    {
-      constexpr int NF = 32 * MH, PARTS = 64 / NF, PER = 32 / PARTS;
-      const int fl = lane % NF, sp = lane / NF;
-#pragma unroll 4
-      for (int k = 0; k < PER; ++k) {
-        const int s = sp * PER + k;
-        const float h = bufD[s * BL::STR_D + fl];
-        const float4 d = *reinterpret_cast<const float4*>(obuf + 4 * s);
-        dwo[0] = fmaf(d.x, h, dwo[0]); dwo[1] = fmaf(d.y, h, dwo[1]);
-        dwo[2] = fmaf(d.z, h, dwo[2]); dwo[3] = fmaf(d.w, h, dwo[3]);
-      }
-      if (hi == 0) { dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w; }
-    }
+    outer_accum<MH, 4>(bufD, BL::STR_D, obuf, lane, dwo);
+    if (hi == 0) { dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w; }
     // dH_L = W_out^T dout, masked by the ReLU of the last hidden layer
     f32x16 dY[MH];
     {
@@ -253,15 +300,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
           WAVE_SYNC();
           store_tile<MI>(bufD, BL::STR_D, lane, dE);
           WAVE_SYNC();
-          constexpr int NF = 32 * MI, PARTS = 64 / NF, PER = 32 / PARTS;
-          const int fl = lane % NF, sp = lane / NF;
-#pragma unroll 4
-          for (int k = 0; k < PER; ++k) {
-            const int s = sp * PER + k;
-            const float d = bufD[s * BL::STR_D + fl];
-            const float4 p = *reinterpret_cast<const float4*>(pbuf + 4 * s);
-            dwf[0] = fmaf(d, p.x, dwf[0]); dwf[1] = fmaf(d, p.y, dwf[1]); dwf[2] = fmaf(d, p.z, dwf[2]);
-          }
+          outer_accum<MI, 3>(bufD, BL::STR_D, pbuf, lane, dwf);
         }
       } else {
         layer_wgrad<MH, MH>(bufD, BL::STR_D, wl + BL::x_off(l), BL::STR_H, lane, accH[l - 1]);

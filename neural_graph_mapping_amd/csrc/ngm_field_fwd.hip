@@ -81,16 +81,22 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
 // fused render forward
 // ------------------------------------------------------------------------------------------------
 #define RF_BRMAX 32     // rays per wave batch
-#define RF_MAXS 1024    // samples per wave batch
+#define RF_MAXS_CAP 1024  // samples per wave batch (upper bound; actual size a.maxs is chosen by the host)
 #define RF_RT 16        // floats per ray-table row
 #define RF_RA 12        // floats per ray-accumulator row
 
+// per-wave LDS carve (floats): ray table, ray accumulators, then 5 sample planes of `maxs`
 struct RenderWaveLds {
-  float rt[RF_BRMAX][RF_RT];   // ox,oy,oz, dx,dy,dz (field-local, scaled), dzcam, near,far,gnear,gfar, gt
-  float ra[RF_BRMAX][RF_RA];   // C(3), D, W, Cv(3), Dv
-  float tbuf[RF_MAXS];
-  float wbuf[RF_MAXS];
-  float cbuf[3][RF_MAXS];
+  float (*rt)[RF_RT];     // ox,oy,oz, dx,dy,dz (field-local, scaled), dzcam, near,far,gnear,gfar, gt
+  float (*ra)[RF_RA];     // C(3), D, W, Cv(3), Dv
+  float* tbuf; float* wbuf; float* cbuf[3];
+  __device__ __forceinline__ RenderWaveLds(float* base, int maxs) {
+    rt = reinterpret_cast<float (*)[RF_RT]>(base);
+    ra = reinterpret_cast<float (*)[RF_RA]>(base + RF_BRMAX * RF_RT);
+    float* p = base + RF_BRMAX * (RF_RT + RF_RA);
+    tbuf = p; wbuf = p + maxs; cbuf[0] = p + 2 * maxs; cbuf[1] = p + 3 * maxs; cbuf[2] = p + 4 * maxs;
+  }
+  static __host__ __device__ int floats(int maxs) { return RF_BRMAX * (RF_RT + RF_RA) + 5 * maxs; }
 };
 
 __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
@@ -102,7 +108,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
 }
 
 template <int MI, int MH, int L, bool NEED_COS>
-__global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
+__global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L>;
   const int F = a.rays.F, R = a.rays.R;
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
   load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  RenderWaveLds& wl = reinterpret_cast<RenderWaveLds*>(sm + LY::TOTAL)[wave];
+  const int nwaves = blockDim.x >> 6;
+  RenderWaveLds wl(sm + LY::TOTAL + wave * RenderWaveLds::floats(a.maxs), a.maxs);
 
   const int S = a.S, S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
   const float inv_s = 1.0f / (float)S;
@@ -128,9 +135,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
 
   // this wave's rays [r_beg, r_end) inside field f
   const int blk_beg = chunk * a.rays_per_block, blk_end = min(R, blk_beg + a.rays_per_block);
-  const int per_wave = (blk_end - blk_beg + NGM_WAVES_PER_BLOCK - 1) / NGM_WAVES_PER_BLOCK;
+  const int per_wave = (blk_end - blk_beg + nwaves - 1) / nwaves;
   const int r_beg = min(blk_end, blk_beg + wave * per_wave), r_end = min(blk_end, r_beg + per_wave);
-  const int BR = max(1, min(RF_BRMAX, RF_MAXS / S));
+  const int BR = max(1, min(RF_BRMAX, a.maxs / S));
 
   float ls[10];
 #pragma unroll
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
   // ---- block reduction of the loss partial sums (deterministic order)
   if (a.has_targets && a.loss_partials) {
     __syncthreads();
-    float* red = sm + LY::TOTAL;  // reuse wave 0's scratch
+    float* red = sm + LY::TOTAL;  // reuse wave 0's scratch (>= 8*16 floats)
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const float v = wave_sum(ls[i]);
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_render_fwd(RenderFwdArgs a) {
     __syncthreads();
     if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
       float v = 0.f;
-      if (threadIdx.x < 10) v = ((red[threadIdx.x] + red[16 + threadIdx.x]) + red[32 + threadIdx.x]) + red[48 + threadIdx.x];
+      if (threadIdx.x < 10)
+        for (int w = 0; w < nwaves; ++w) v += red[w * 16 + threadIdx.x];
       a.loss_partials[(int64_t)blockIdx.x * NGM_NUM_LOSS_SUMS + threadIdx.x] = v;
     }
   }
@@ -306,13 +314,14 @@ static int launch_points(const PointsFwdArgs& a, int blocks, bool need_cos, hipS
 }
 template <int MI, int MH, int L>
 static int launch_render(const RenderFwdArgs& a, int blocks, bool need_cos, hipStream_t st) {
-  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + NGM_WAVES_PER_BLOCK * sizeof(RenderWaveLds);
+  const size_t lds = (FieldLds<MI, MH, L>::TOTAL + a.waves_per_block * RenderWaveLds::floats(a.maxs)) * sizeof(float);
+  const dim3 blk(64 * a.waves_per_block);
   if (need_cos) {
     (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, true>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, true>), dim3(blocks), blk, lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false>), dim3(blocks), blk, lds, st, a);
   }
   return 0;
 }

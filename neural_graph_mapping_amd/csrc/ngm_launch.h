@@ -32,6 +32,8 @@ struct RenderFwdArgs {
   int has_targets;
   int S;                  // samples per ray actually drawn (S_c + S_g when gt given)
   int rays_per_block;
+  int waves_per_block;    // 8 (two waves per SIMD) when the per-wave LDS planes fit, else 4
+  int maxs;               // samples per wave batch (size of the per-wave LDS sample planes)
   float* raytab;          // (F*R, 8): o_local(3), d_local(3), dz_cam, gt     (train) or NULL
   float4* stashA;         // (F*R*S): colour(3), geometry                      (train) or NULL
   float2* stashB;         // (F*R*S): t, T_exclusive

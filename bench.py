@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     from neural_graph_mapping_amd import _capi as K
@@ -149,8 +150,13 @@ def main():
     if world > 1:
         r.process_group = torch.distributed.group.WORLD
 
+    # single-GPU: the whole iteration (5 kernels + bookkeeping) is captured once into a hipGraph and replayed;
+    # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
+    use_graph = (world == 1) and not args.eager
+    replay = r.capture_iteration(tgt, seed=7) if use_graph else None
+
     def step(i):
-        return r.optimization_iteration(tgt, seed=i, update=True)
+        return replay() if use_graph else r.optimization_iteration(tgt, seed=7, update=True)
 
     for i in range(args.warmup):
         out = step(i)
@@ -192,7 +198,8 @@ def main():
                    config=dict(workload="M1: 8 fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         "Fourier(64,raw)+2x64 MLP, nrgbd compositing, NRGBD intrinsics",
                                fields_per_gpu=F_PER_GPU, rays_per_field=R, samples_per_ray=S_C + S_G,
-                               sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox", final_loss=loss))
+                               sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox",
+                               launch="hipGraph replay" if use_graph else "eager", final_loss=loss))
         fb = kern.get("field_bwd")
         if fb:
             achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12

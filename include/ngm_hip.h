@@ -127,6 +127,9 @@ typedef struct ngm_rays {
   const float* lin_guided; /* (S_g+1) or NULL                                                */
   uint64_t philox_seed;    /* used when u_* is NULL                                          */
   uint64_t philox_offset;
+  const int64_t* pose_index;          /* optional (F,): batch field f uses field_pos/field_quat row pose_index[f] */
+  const uint64_t* philox_offset_dev;  /* optional device counter added to philox_offset (hipGraph replay:  */
+                                      /* a captured step draws fresh jitter every replay)                   */
 } ngm_rays;
 
 /* Supervision of one batch (rm.py:43-58, 1769-1872); masks are uint8 0/1. */
@@ -230,6 +233,20 @@ int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t str
                     const float* grad, int64_t grad_stride, const int64_t* field_index, int32_t F,
                     int64_t numel_per_field, int64_t step, float lr, float beta1, float beta2,
                     float eps, float weight_decay, void* stream);
+
+/* All parameter tensors of a field set in ONE launch.  `step_dev` (optional device int64) overrides
+ * `step` so that a captured hipGraph advances the bias correction on every replay. */
+typedef struct ngm_adam_tensor {
+  float* param; float* exp_avg; float* exp_avg_sq; /* (N, numel) rows with `stride` elements between fields */
+  const float* grad;                               /* (F, numel) rows with `grad_stride`                    */
+  int64_t stride, grad_stride, numel;
+} ngm_adam_tensor;
+int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, const int64_t* field_index,
+                          int32_t F, int64_t step, const int64_t* step_dev, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, void* stream);
+/* ++*step_dev, ++*philox_offset_dev on the stream (either may be NULL): end-of-iteration bookkeeping
+ * for graph-captured training loops. */
+int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* stream);
 
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,

@@ -62,7 +62,12 @@ class Rays(C.Structure):
                 ("gt", f32p), ("near_const", C.c_float), ("far_const", C.c_float),
                 ("field_pos", f32p), ("field_quat", f32p), ("u_coarse", f32p), ("u_guided", f32p),
                 ("lin_coarse", f32p), ("lin_guided", f32p), ("philox_seed", C.c_uint64),
-                ("philox_offset", C.c_uint64)]
+                ("philox_offset", C.c_uint64), ("pose_index", C.c_void_p), ("philox_offset_dev", C.c_void_p)]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", f32p), ("exp_avg", f32p), ("exp_avg_sq", f32p), ("grad", f32p),
+                ("stride", C.c_int64), ("grad_stride", C.c_int64), ("numel", C.c_int64)]
 
 
 class Targets(C.Structure):
@@ -109,6 +114,10 @@ def lib():
                                         P(Grads), vp, i64, vp]
     L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
+    L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp]
+    L.ngm_step_advance.argtypes = [vp, vp, vp]
+    L.ngm_adam_sparse_multi.restype = C.c_int
+    L.ngm_step_advance.restype = C.c_int
     L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp]
     L.ngm_profile_enable.argtypes = [i32]
     L.ngm_profile_read.argtypes = [i32, P(C.c_double), P(i64)]
@@ -126,7 +135,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_
             "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
-            "ngm_field_eval_knn", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
+            "ngm_field_eval_knn", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
 
 KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
                   composite_bwd=7)

@@ -15,6 +15,9 @@ int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* 
 int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
                     const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
                     float eps, float wd, hipStream_t st);
+int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* field_index, int F, int64_t step,
+                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd, hipStream_t st);
+int ngm_launch_step_advance(int64_t* step_dev, uint64_t* off_dev, hipStream_t st);
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
                    hipStream_t st);
@@ -457,6 +460,24 @@ int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t str
   ngm_launch_adam(param, exp_avg, exp_avg_sq, stride, grad, grad_stride, field_index, F, numel_per_field, step, lr, beta1,
                   beta2, eps, weight_decay, (hipStream_t)stream);
   return check_launch("ngm_adam_sparse");
+}
+
+int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, const int64_t* field_index, int32_t F,
+                          int64_t step, const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, void* stream) {
+  if (!tensors || num_tensors < 1 || num_tensors > 2 * (NGM_MAX_LAYERS + 1) + 2 || F < 1 || (step < 1 && !step_dev))
+    return fail(NGM_E_INVALID, "ngm_adam_sparse_multi: bad argument");
+  for (int i = 0; i < num_tensors; ++i)
+    if (!tensors[i].param || !tensors[i].exp_avg || !tensors[i].exp_avg_sq || !tensors[i].grad || tensors[i].numel < 1)
+      return fail(NGM_E_INVALID, "ngm_adam_sparse_multi: NULL tensor");
+  ngm_launch_adam_multi(tensors, num_tensors, field_index, F, step, step_dev, lr, beta1, beta2, eps, weight_decay,
+                        (hipStream_t)stream);
+  return check_launch("ngm_adam_sparse_multi");
+}
+
+int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* stream) {
+  ngm_launch_step_advance(step_dev, philox_offset_dev, (hipStream_t)stream);
+  return check_launch("ngm_step_advance");
 }
 
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields, int64_t P,

@@ -454,3 +454,52 @@ int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const floa
                      lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd);
   return 0;
 }
+
+// all tensors of the field set in one launch: blockIdx.y = field, blockIdx.z = tensor
+struct AdamMultiK {
+  ngm_adam_tensor t[2 * (NGM_MAX_LAYERS + 1) + 2];
+  int n;
+  const int64_t* field_index;
+  const int64_t* step_dev;
+  int64_t step;
+  float lr, beta1, beta2, eps, wd;
+};
+__global__ void k_adam_multi(AdamMultiK a) {
+  const ngm_adam_tensor& t = a.t[blockIdx.z];
+  const int f = blockIdx.y;
+  const int64_t row = a.field_index ? a.field_index[f] : f;
+  const double step = (double)(a.step_dev ? *a.step_dev : a.step);
+  const float lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = row * t.stride + i;
+    const float p = t.param[o];
+    const float g = t.grad[(int64_t)f * t.grad_stride + i] + a.wd * p;
+    const float mn = a.beta1 * t.exp_avg[o] + (1.0f - a.beta1) * g;
+    const float vn = a.beta2 * t.exp_avg_sq[o] + (1.0f - a.beta2) * g * g;
+    t.exp_avg[o] = mn; t.exp_avg_sq[o] = vn;
+    t.param[o] = p - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+  }
+}
+int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* field_index, int F, int64_t step,
+                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_ADAM, st);
+  AdamMultiK a;
+  int64_t mx = 1;
+  for (int i = 0; i < n; ++i) { a.t[i] = tensors[i]; mx = std::max<int64_t>(mx, tensors[i].numel); }
+  a.n = n; a.field_index = field_index; a.step_dev = step_dev; a.step = step;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
+  dim3 grid((unsigned)std::min<int64_t>((mx + 255) / 256, 16), (unsigned)F, (unsigned)n);
+  hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, st, a);
+  return 0;
+}
+__global__ void k_step_advance(int64_t* step_dev, uint64_t* off_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (step_dev) *step_dev += 1;
+    if (off_dev) *off_dev += 1;
+  }
+}
+int ngm_launch_step_advance(int64_t* step_dev, uint64_t* off_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, st, step_dev, off_dev);
+  return 0;
+}

@@ -167,7 +167,8 @@ __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm
 __device__ __forceinline__ float jitter(const ngm_rays& rays, int which, int64_t ray, int n, int i) {
   const float* u = which ? rays.u_guided : rays.u_coarse;
   if (u) return u[ray * n + i];
-  return philox_uniform(rays.philox_seed, rays.philox_offset, (uint64_t)(ray * n + i), (uint32_t)which);
+  const uint64_t off = rays.philox_offset + (rays.philox_offset_dev ? *rays.philox_offset_dev : 0ull);
+  return philox_uniform(rays.philox_seed, off, (uint64_t)(ray * n + i), (uint32_t)which);
 }
 
 // number of elements of stratum (near,far,n) that are < x (strict=1) or <= x (strict=0).

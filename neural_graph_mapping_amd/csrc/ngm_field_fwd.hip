@@ -129,9 +129,10 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 
   float div, off;
   scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
-  const float px = a.rays.field_pos[3 * f], py = a.rays.field_pos[3 * f + 1], pz = a.rays.field_pos[3 * f + 2];
-  const float qw = a.rays.field_quat[4 * f], qx = a.rays.field_quat[4 * f + 1], qy = a.rays.field_quat[4 * f + 2],
-              qz = a.rays.field_quat[4 * f + 3];
+  const int64_t pf = a.rays.pose_index ? a.rays.pose_index[f] : f;
+  const float px = a.rays.field_pos[3 * pf], py = a.rays.field_pos[3 * pf + 1], pz = a.rays.field_pos[3 * pf + 2];
+  const float qw = a.rays.field_quat[4 * pf], qx = a.rays.field_quat[4 * pf + 1], qy = a.rays.field_quat[4 * pf + 2],
+              qz = a.rays.field_quat[4 * pf + 3];
 
   // this wave's rays [r_beg, r_end) inside field f
   const int blk_beg = chunk * a.rays_per_block, blk_end = min(R, blk_beg + a.rays_per_block);

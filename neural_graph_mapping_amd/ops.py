@@ -147,7 +147,7 @@ def linspace_table(n: int, device):
 
 
 def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=None, u_guided=None, seed=0, offset=0,
-              near_const=0.0, far_const=8.0, keep=None):
+              near_const=0.0, far_const=8.0, keep=None, pose_index=None, philox_offset_dev=None):
     """Build an ngm_rays record; `keep` (list) receives every temporary that must outlive the launch."""
     keep = keep if keep is not None else []
     _require_gpu(ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided)
@@ -164,10 +164,13 @@ def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=Non
     lin_g = linspace_table(rc.num_samples_guided, dev) if rc.num_samples_guided > 0 else None
     ts = [ijs, c2ws, _f32c(near), _f32c(far), _f32c(gt), _f32c(pos), _f32c(quat), _f32c(u_coarse), _f32c(u_guided),
           lin_c, lin_g]
-    keep.extend(ts)
+    if pose_index is not None:
+        pose_index = pose_index.contiguous()
+        _require_gpu(pose_index)
+    keep.extend(ts + [pose_index, philox_offset_dev])
     return K.Rays(F, R, _ptr(ts[0]), _ptr(ts[1]), per_ray, 0, _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]),
                   float(near_const), float(far_const), _ptr(ts[5]), _ptr(ts[6]), _ptr(ts[7]), _ptr(ts[8]),
-                  _ptr(ts[9]), _ptr(ts[10]), int(seed), int(offset))
+                  _ptr(ts[9]), _ptr(ts[10]), int(seed), int(offset), _ptr(pose_index), _ptr(philox_offset_dev))
 
 
 def sample_rays(rc: K.RenderCfg, ijs, near, far, gt=None, u_coarse=None, u_guided=None, seed=0):
@@ -246,3 +249,17 @@ def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, b
     K.check(K.lib().ngm_adam_sparse(_ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), param.stride(0), _ptr(grad),
                                     grad.stride(0), _ptr(field_index), F, numel, int(step), lr, betas[0], betas[1], eps,
                                     weight_decay, _stream()), "ngm_adam_sparse")
+
+
+def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=None, lr=1e-3, betas=(0.9, 0.999),
+                       eps=1e-15, weight_decay=1e-5):
+    """One launch for every parameter tensor of the field set (rows `field_index` updated in place)."""
+    names = K.param_names(fc)
+    arr = (K.AdamTensor * len(names))()
+    for i, n in enumerate(names):
+        p, g = params[n], grads[n]
+        arr[i] = K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
+                              g.data_ptr(), p.stride(0), g.stride(0), g[0].numel())
+    K.check(K.lib().ngm_adam_sparse_multi(arr, len(names), _ptr(field_index), grads[names[0]].shape[0], int(step),
+                                          _ptr(step_dev), lr, betas[0], betas[1], eps, weight_decay, _stream()),
+            "ngm_adam_sparse_multi")

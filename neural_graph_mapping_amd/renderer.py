@@ -131,6 +131,7 @@ class NeuralGraphRenderer:
         self._adam_weight_decay = config.get("adam_weight_decay", 0.0)
         self._optim_state: Optional[Dict[str, Dict[str, torch.Tensor]]] = None
         self._step = 0
+        self._step_dev = None
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
 
@@ -222,13 +223,16 @@ class NeuralGraphRenderer:
                 ws=torch.empty(wsb, device=dev, dtype=torch.uint8), wsb=wsb,
                 rgbds=torch.empty(F, R, 4, device=dev), color_vars=torch.empty(F, R, 3, device=dev),
                 depth_vars=torch.empty(F, R, device=dev), term_probs=torch.empty(F, R, device=dev),
-                sums=torch.zeros(K.NGM_NUM_LOSS_SUMS, device=dev), loss=torch.zeros(8, device=dev))
+                sums=torch.zeros(K.NGM_NUM_LOSS_SUMS, device=dev), loss=torch.zeros(8, device=dev),
+                philox=torch.zeros(1, device=dev, dtype=torch.int64))
         return self._ws_cache[key]
 
     def optimization_iteration(self, target: Target, u_coarse=None, u_guided=None, seed=0, update=True) -> dict:
         """One training iteration (rm.py:1123-1221): fused forward + losses, (all-reduce), fused backward,
         sparse Adam on the touched fields.  Returns the loss dict (device scalars) and, with
-        update=False, also the gradients."""
+        update=False, also the gradients.  Every launch is asynchronous on the current stream and the
+        sequence is hipGraph-capturable (device-side step / jitter counters, no allocation after the
+        first call with a given batch shape)."""
         L = K.lib()
         fc, rc = self._fc, self._rc_train
         fids = target.field_ids
@@ -236,13 +240,16 @@ class NeuralGraphRenderer:
         names = K.param_names(fc)
         allp = {n: self._model.all_fields_params[n] for n in names}
         ps = ops.params_struct(fc, allp, fids)           # kernels read rows field_ids[f] in place: no gather
+        w = self._workspace(F, R)
         keep = []
         rays = ops.make_rays(rc, target.ijs, target.c2ws, target.near_distances, target.far_distances,
-                             target.gt_distances, self._global_map_dict["positions"][fids],
-                             self._global_map_dict["orientations"][fids], u_coarse, u_guided, seed, keep=keep)
-        w = self._workspace(F, R)
-        dm = target.depth_mask.to(torch.uint8)
-        tm = target.term_mask.to(torch.uint8) if target.term_mask is not None else None
+                             target.gt_distances, self._global_map_dict["positions"],
+                             self._global_map_dict["orientations"], u_coarse, u_guided, seed, keep=keep,
+                             pose_index=fids, philox_offset_dev=w["philox"])
+        dm = target.depth_mask.view(torch.uint8) if target.depth_mask.dtype == torch.bool else target.depth_mask
+        tm = target.term_mask
+        if tm is not None and tm.dtype == torch.bool:
+            tm = tm.view(torch.uint8)
         tg = K.Targets(ops._ptr(ops._f32c(target.rgbds)), dm.data_ptr(), ops._ptr(tm), ops._ptr(target.term_probs))
         pred = K.Prediction(w["rgbds"].data_ptr(), w["color_vars"].data_ptr(), w["depth_vars"].data_ptr(),
                             w["term_probs"].data_ptr())
@@ -252,7 +259,9 @@ class NeuralGraphRenderer:
         if self.process_group is not None:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
             torch.distributed.all_reduce(w["sums"], group=self.process_group)
-        grads, gs, gflat = ops.alloc_grads(fc, F, self._device)
+        if "grads" not in w:
+            w["grads"], w["gs"], w["gflat"] = ops.alloc_grads(fc, F, self._device)
+        grads, gs = w["grads"], w["gs"]
         K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                  w["sums"].data_ptr(), C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
                                  st), "ngm_render_bwd")
@@ -261,11 +270,34 @@ class NeuralGraphRenderer:
                 "freespace": lv[4], "tsdf": lv[5]}
         if update:
             self._step += 1                                  # one counter for all fields (rm.py:380-385)
-            for n in names:
-                stt = self._optim_state[n]
-                ops.adam_sparse_(allp[n], stt["exp_avg"], stt["exp_avg_sq"], grads[n], fids, self._step,
-                                 lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
+            if self._step_dev is None:
+                self._step_dev = torch.full((1,), self._step, device=self._device, dtype=torch.int64)
+            ops.adam_sparse_multi_(fc, allp, self._optim_state, grads, fids, self._step, self._step_dev,
+                                   lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
+            K.check(L.ngm_step_advance(self._step_dev.data_ptr(), w["philox"].data_ptr(), st), "ngm_step_advance")
         else:
             loss["grads"] = grads
         loss["prediction"] = Prediction(w["rgbds"], w["color_vars"], w["depth_vars"], w["term_probs"], None, None)
         return loss
+
+    def capture_iteration(self, target: Target, seed=0):
+        """Capture optimization_iteration(target) into a hipGraph (torch.cuda.CUDAGraph); the returned
+        callable replays it.  Tensors of `target` are read in place at every replay; the Adam step counter
+        and the Philox jitter offset live on the device and advance inside the graph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                                # warm-up on a side stream (allocations, lazy init)
+                out = self.optimization_iteration(target, seed=seed)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.optimization_iteration(target, seed=seed)
+        self._step -= 1                                       # the capture pass records, it does not execute
+
+        def replay():
+            graph.replay()
+            self._step += 1
+            return out
+        replay.graph = graph
+        return replay

@@ -160,6 +160,10 @@ int ngm_device_info(int* num_cus, char* name, int name_len);
  * frame: points_cam (F,R,S,3), distances (F,R,S), dirs (F,R,3) (any may be NULL). */
 int ngm_sample_rays(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam,
                     float* distances, float* dirs, void* stream);
+/* same, additionally the samples in the WORLD frame (utils.transform_points, utils.py:276-286 via
+ * rm.py:547): points_world (F,R,S,3) = R(c2w) p_cam + t(c2w). */
+int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam,
+                          float* points_world, float* distances, float* dirs, void* stream);
 
 /* ---- K2+K3: NeuralFieldSet.forward(use_vmap=True) -----------------------------------------
  * models.py:329-345: world -> field-local transform, scaling, encoding, MLP; points (F,P,3)
@@ -183,6 +187,12 @@ int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
                       const float* geoms, const float* dists, const float* depths,
                       const float* neus_isds, float* C, float* D, float* Cvar, float* Dvar,
                       float* term, float* weights, void* stream);
+/* Same quadrature fed directly by the (N,S,4) field outputs [r,g,b,geometry] (colour scaled by
+ * cfg->color_factor, rm.py:610-612) and the camera-frame sample points (depth = -z): the eval path
+ * render_image -> _render_ijs(use_vmap=False) -> _quadrature (rm.py:402-437, 586-595, 650-656). */
+int ngm_composite_fwd_packed(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* field_out4,
+                             const float* dists, const float* points_cam, float* rgbd, float* Cvar,
+                             float* Dvar, float* term, void* stream);
 /* Backward of C, D, term (and optionally a direct per-sample seed) w.r.t. colors and geoms. */
 int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors,
                       const float* geoms, const float* dists, const float* depths,
@@ -251,10 +261,12 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
  * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4. */
+int64_t ngm_field_eval_knn_workspace(int32_t num_fields, int64_t P, int32_t num_knn);
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields,
                        int64_t P, const float* points, const float* field_pos,
                        const float* field_quat, int32_t num_knn, float distance_factor,
-                       float outside_value, float* out, void* stream);
+                       float outside_value, float* out, void* workspace, int64_t workspace_bytes,
+                       void* stream);
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------
  * When enabled, every launch of the listed kernels is bracketed by hipEvents recorded on the launch

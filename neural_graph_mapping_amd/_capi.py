@@ -98,6 +98,10 @@ def lib():
     L.ngm_last_error.restype = C.c_char_p
     L.ngm_device_info.argtypes = [P(C.c_int), C.c_char_p, C.c_int]
     L.ngm_sample_rays.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp]
+    L.ngm_sample_rays_world.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp, vp]
+    L.ngm_composite_fwd_packed.argtypes = [P(RenderCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ngm_sample_rays_world.restype = C.c_int
+    L.ngm_composite_fwd_packed.restype = C.c_int
     L.ngm_field_eval_fwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, vp]
     L.ngm_field_eval_bwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp]
     L.ngm_field_eval_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
@@ -118,7 +122,9 @@ def lib():
     L.ngm_step_advance.argtypes = [vp, vp, vp]
     L.ngm_adam_sparse_multi.restype = C.c_int
     L.ngm_step_advance.restype = C.c_int
-    L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp]
+    L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp, i64, vp]
+    L.ngm_field_eval_knn_workspace.argtypes = [i32, i64, i32]
+    L.ngm_field_eval_knn_workspace.restype = i64
     L.ngm_profile_enable.argtypes = [i32]
     L.ngm_profile_read.argtypes = [i32, P(C.c_double), P(i64)]
     for name in ("ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"):
@@ -131,11 +137,12 @@ def lib():
     return L
 
 
-EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_rays",
+EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_rays", "ngm_sample_rays_world",
+            "ngm_composite_fwd_packed",
             "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
-            "ngm_field_eval_knn", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
+            "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
 
 KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
                   composite_bwd=7)

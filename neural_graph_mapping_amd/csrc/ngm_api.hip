@@ -8,7 +8,7 @@
 #include "ngm_launch.h"
 
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
-                       float* dirs, hipStream_t st);
+                       float* dirs, float* points_world, hipStream_t st);
 int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st);
 int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st);
 int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists, hipStream_t st);
@@ -20,7 +20,8 @@ int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* 
 int ngm_launch_step_advance(int64_t* step_dev, uint64_t* off_dev, hipStream_t st);
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
-                   hipStream_t st);
+                   void* workspace, int64_t workspace_bytes, hipStream_t st);
+int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K);
 
 #include <mutex>
 #include <vector>
@@ -169,8 +170,18 @@ int ngm_sample_rays(const ngm_render_cfg* cfg, const ngm_rays* rays, float* poin
   if (!cfg || !rays || !rays->ijs) return fail(NGM_E_INVALID, "ngm_sample_rays: NULL argument");
   const int S = cfg->num_samples_coarse + (rays->gt ? cfg->num_samples_guided : 0);
   if (S < 1) return fail(NGM_E_INVALID, "no samples");
-  ngm_launch_sampler(cfg, rays, S, points_cam, distances, dirs, (hipStream_t)stream);
+  ngm_launch_sampler(cfg, rays, S, points_cam, distances, dirs, nullptr, (hipStream_t)stream);
   return check_launch("ngm_sample_rays");
+}
+
+int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam, float* points_world,
+                          float* distances, float* dirs, void* stream) {
+  if (!cfg || !rays || !rays->ijs) return fail(NGM_E_INVALID, "ngm_sample_rays_world: NULL argument");
+  if (points_world && !rays->c2ws) return fail(NGM_E_INVALID, "ngm_sample_rays_world: c2ws required");
+  const int S = cfg->num_samples_coarse + (rays->gt ? cfg->num_samples_guided : 0);
+  if (S < 1) return fail(NGM_E_INVALID, "no samples");
+  ngm_launch_sampler(cfg, rays, S, points_cam, distances, dirs, points_world, (hipStream_t)stream);
+  return check_launch("ngm_sample_rays_world");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +266,19 @@ int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
   const int rc = ngm_launch_composite_fwd(a, (hipStream_t)stream);
   if (rc) return fail(rc, "ngm_composite_fwd: unsupported S (max 1024)");
   return check_launch("ngm_composite_fwd");
+}
+
+int ngm_composite_fwd_packed(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* field_out4, const float* dists,
+                             const float* points_cam, float* rgbd, float* Cvar, float* Dvar, float* term, void* stream) {
+  if (!cfg || !field_out4 || !dists || !points_cam || N < 0) return fail(NGM_E_INVALID, "ngm_composite_fwd_packed: bad argument");
+  if (N == 0) return NGM_OK;
+  CompositeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rc = *cfg; a.N = N; a.S = S; a.out4 = reinterpret_cast<const float4*>(field_out4); a.pcam = points_cam; a.dists = dists;
+  a.rgbd = rgbd; a.Cv = Cvar; a.Dv = Dvar; a.term = term;
+  const int rc = ngm_launch_composite_fwd(a, (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_composite_fwd_packed: unsupported S (max 1024)");
+  return check_launch("ngm_composite_fwd_packed");
 }
 
 int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors, const float* geoms,
@@ -480,9 +504,16 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
   return check_launch("ngm_step_advance");
 }
 
+int64_t ngm_field_eval_knn_workspace(int32_t num_fields, int64_t P, int32_t num_knn) {
+  const int K = num_knn < num_fields ? num_knn : num_fields;
+  if (num_fields < 1 || P < 0 || K < 1) return NGM_E_INVALID;
+  return ngm_knn_workspace_bytes(num_fields, P, K);
+}
+
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields, int64_t P,
                        const float* points, const float* field_pos, const float* field_quat, int32_t num_knn,
-                       float distance_factor, float outside_value, float* out, void* stream) {
+                       float distance_factor, float outside_value, float* out, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
   int e = check_field_cfg(fcfg);
   if (e) return e;
   e = check_params(fcfg, params);
@@ -492,7 +523,8 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   const int K = num_knn < num_fields ? num_knn : num_fields;
   if (K < 1 || K > 4) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_knn: K must be in [1,4]");
   e = ngm_launch_knn(fcfg, params, num_fields, P, points, field_pos, field_quat, K, distance_factor, outside_value, out,
-                     (hipStream_t)stream);
+                     workspace, workspace_bytes, (hipStream_t)stream);
+  if (e == NGM_E_WORKSPACE) return fail(e, "ngm_field_eval_knn: workspace too small");
   if (e) return fail(e, "ngm_field_eval_knn: not available for this configuration");
   return check_launch("ngm_field_eval_knn");
 }

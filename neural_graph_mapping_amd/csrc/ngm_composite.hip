@@ -26,7 +26,7 @@ struct SamplerArgs {
   ngm_render_cfg rc;
   ngm_rays rays;
   int S;
-  float* points_cam; float* distances; float* dirs;
+  float* points_cam; float* distances; float* dirs; float* points_world;
 };
 
 __global__ void k_sample_rays(SamplerArgs a) {
@@ -45,13 +45,20 @@ __global__ void k_sample_rays(SamplerArgs a) {
       a.points_cam[3 * o] = rg.dx * t; a.points_cam[3 * o + 1] = rg.dy * t;
       a.points_cam[3 * o + 2] = rg.dz * t;
     }
+    if (a.points_world) {
+      const float* T = a.rays.c2w_per_ray ? a.rays.c2ws + ray * 16 : a.rays.c2ws;
+      const float cx = rg.dx * t, cy = rg.dy * t, cz = rg.dz * t;
+      a.points_world[3 * o] = (T[0] * cx + T[1] * cy + T[2] * cz) + T[3];
+      a.points_world[3 * o + 1] = (T[4] * cx + T[5] * cy + T[6] * cz) + T[7];
+      a.points_world[3 * o + 2] = (T[8] * cx + T[9] * cy + T[10] * cz) + T[11];
+    }
     if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
   }
 }
 
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
-                       float* dirs, hipStream_t st) {
-  SamplerArgs a{*rc, *rays, S, points_cam, distances, dirs};
+                       float* dirs, float* points_world, hipStream_t st) {
+  SamplerArgs a{*rc, *rays, S, points_cam, distances, dirs, points_world};
   const int64_t total = (int64_t)rays->F * rays->R * S;
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(k_sample_rays, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
@@ -71,10 +78,11 @@ struct CompWaveLds {
   float wbuf[CQ_MAXS];
 };
 
+__device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t g) { return a.out4 ? a.out4[g].w : a.geoms[g]; }
 __device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int k, int S, float* docc = nullptr) {
   const int mode = a.rc.geometry_mode;
   const int64_t g = ray * S + k;
-  const float gm = a.geoms[g];
+  const float gm = geom_at(a, g);
   if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY) return occ_pointwise(mode, a.rc.geometry_factor, gm, docc);
   if (k >= S - 1) return 0.f;   // density / neus drop the last sample (rm.py:749,758)
   if (mode == NGM_GEO_DENSITY) {
@@ -83,7 +91,7 @@ __device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int
   }
   const float isd = a.isds ? a.isds[ray] : 1.0f;
   const float t0 = ngm_sigmoid(isd * a.rc.geometry_factor * gm);
-  const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * a.geoms[g + 1]);
+  const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * geom_at(a, g + 1));
   return fmaxf((t0 - t1) / (t0 + 1e-5f), 0.f);
 }
 
@@ -122,7 +130,12 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       carry = __shfl(q, 63, 64);
       const float w = act ? occ * T_excl : 0.f;
       float c0 = 0, c1 = 0, c2 = 0, dp = 0;
-      if (act) { c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g]; }
+      if (act) {
+        if (a.out4) {
+          const float4 o = a.out4[g];
+          c0 = a.rc.color_factor * o.x; c1 = a.rc.color_factor * o.y; c2 = a.rc.color_factor * o.z; dp = -a.pcam[3 * g + 2];
+        } else { c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g]; }
+      }
       if (valid) wl.wbuf[idx] = w;
       if (act && a.weights) a.weights[(rb + rl) * S_eff + k] = w;
       const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
@@ -142,7 +155,13 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const float* ra = wl.ra[rl];
       const float w = valid ? wl.wbuf[idx] : 0.f;
       float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-      if (act) { e0 = ra[0] - a.colors[3 * g]; e1 = ra[1] - a.colors[3 * g + 1]; e2 = ra[2] - a.colors[3 * g + 2]; e3 = ra[3] - a.depths[g]; }
+      if (act) {
+        if (a.out4) {
+          const float4 o = a.out4[g];
+          e0 = ra[0] - a.rc.color_factor * o.x; e1 = ra[1] - a.rc.color_factor * o.y; e2 = ra[2] - a.rc.color_factor * o.z;
+          e3 = ra[3] + a.pcam[3 * g + 2];
+        } else { e0 = ra[0] - a.colors[3 * g]; e1 = ra[1] - a.colors[3 * g + 1]; e2 = ra[2] - a.colors[3 * g + 2]; e3 = ra[3] - a.depths[g]; }
+      }
       const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
                   v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
       const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
@@ -153,6 +172,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
     if (lane < nb) {
       const int64_t ray = rb + lane;
       const float* ra = wl.ra[lane];
+      if (a.rgbd) reinterpret_cast<float4*>(a.rgbd)[ray] = make_float4(ra[0], ra[1], ra[2], ra[3]);
       if (a.C) { a.C[3 * ray] = ra[0]; a.C[3 * ray + 1] = ra[1]; a.C[3 * ray + 2] = ra[2]; }
       if (a.D) a.D[ray] = ra[3];
       if (a.Cv) { a.Cv[3 * ray] = ra[5]; a.Cv[3 * ray + 1] = ra[6]; a.Cv[3 * ray + 2] = ra[7]; }

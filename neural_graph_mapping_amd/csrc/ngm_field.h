@@ -216,6 +216,33 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
   }
 }
 
+// Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
+// (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
+template <int MI, int MH, int L, bool NEED_COS>
+__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z) {
+  using LY = FieldLds<MI, MH, L>;
+  const int hi = lane >> 5;
+  // partner lane (same column j, other half) owns the sample of the other tile
+  const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
+  f32x16 E[2][MI], dummy[MI];
+  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
+  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+  f32x16 Hl[2][MH];
+  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl);
+  float part[2][4];
+  out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float send = hi ? part[0][c] : part[1][c];
+    const float recv = __shfl_xor(send, 32, 64);
+    const float own = hi ? part[1][c] : part[0][c];
+    // fixed summation order: low-feature half first
+    o[c] = (hi ? (recv + own) : (own + recv)) + sm[LY::BOUT + c];
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // dispatch helper: logical (D,H,L) -> compiled (MI,MH,L) instantiation
 struct FieldShape { int MI, MH, L; };
 static inline FieldShape field_shape(const ngm_field_cfg* fc) {

@@ -1,7 +1,216 @@
-// eval path: kNN-blended field evaluation (models.py:347-405) -- placeholder until the fused kernel lands.
-#include "ngm_device.h"
+// Eval path: NeuralFieldSet.forward(use_vmap=False) (models.py:347-405) on gfx950.
+//
+// The reference finds the K nearest field centres of every query point, evaluates each touched field
+// in a Python loop over boolean masks and blends with softmax(-distance_factor * dist).  Here:
+//   k_knn_assign  : brute-force K-nearest (K <= 4, all centres in LDS), radius test, softmax weights;
+//                   per-workgroup LDS histogram -> one global atomic per field per workgroup
+//   k_knn_offsets : exclusive scans over fields (segment offsets, tile offsets)
+//   k_knn_scatter : (point,k) pairs bucketed by field (counting sort)
+//   k_knn_eval    : one workgroup per 4096-pair tile of ONE field: that field's weights resident in
+//                   LDS, MLP on the matrix cores (same eval_64 as the train kernels)
+//   k_knn_blend   : out[p] = sum_k w_k out_{p,k}, or outside_value on all channels
+#include "ngm_field.h"
 #include "ngm_launch.h"
-int ngm_launch_knn(const ngm_field_cfg*, const ngm_params*, int, int64_t, const float*, const float*, const float*, int,
-                   float, float, float*, hipStream_t) {
-  return NGM_E_UNSUPPORTED;
+
+#include <algorithm>
+
+#define KNN_TILE 4096
+#define KNN_MAXK 4
+
+struct KnnArgs {
+  ngm_field_cfg fc;
+  ngm_params pr;
+  int NF, K;
+  int64_t P;
+  const float* points; const float* pos; const float* quat;
+  float distance_factor, outside_value, radius;
+  float* out;
+  // workspace
+  int* pair_field;      // (P*K)  field of the pair, -1 if the point is outside every field
+  float* pair_w;        // (P*K)
+  int* counts;          // (NF)   pairs per field
+  int* cursor;          // (NF)
+  int* seg_off;         // (NF+1)
+  int* tile_off;        // (NF+1)
+  int* sorted;          // (P*K)  pair ids grouped by field
+  float4* pair_out;     // (P*K)
+};
+
+__global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
+  extern __shared__ float smf[];
+  float* cpos = smf;                                   // NF*3
+  int* hist = reinterpret_cast<int*>(smf + 3 * a.NF);  // NF
+  for (int i = threadIdx.x; i < 3 * a.NF; i += blockDim.x) cpos[i] = a.pos[i];
+  for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const int K = a.K;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float x = a.points[3 * p], y = a.points[3 * p + 1], z = a.points[3 * p + 2];
+    float bd[KNN_MAXK]; int bi[KNN_MAXK];
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+    for (int f = 0; f < a.NF; ++f) {
+      const float dx = x - cpos[3 * f], dy = y - cpos[3 * f + 1], dz = z - cpos[3 * f + 2];
+      float d = dx * dx + dy * dy + dz * dz;
+      int id = f;
+      // sorted insertion (stable: equal distances keep the lower field index first)
+#pragma unroll
+      for (int k = 0; k < KNN_MAXK; ++k) {
+        if (k < K && d < bd[k]) { const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti; }
+      }
+    }
+    float dist[KNN_MAXK];
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) dist[k] = sqrtf(bd[k]);
+    const bool inside = dist[0] < a.radius;                      // models.py:369
+    // softmax(-distance_factor * dist) over the K neighbours (models.py:384)
+    float mx = -INFINITY, e[KNN_MAXK], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) if (k < K) mx = fmaxf(mx, -a.distance_factor * dist[k]);
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) { e[k] = (k < K) ? expf(-a.distance_factor * dist[k] - mx) : 0.f; sum += e[k]; }
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) {
+      if (k < K) {
+        a.pair_field[p * K + k] = inside ? bi[k] : -1;
+        a.pair_w[p * K + k] = e[k] / sum;
+        if (inside) atomicAdd(&hist[bi[k]], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.NF; i += blockDim.x)
+    if (hist[i]) atomicAdd(&a.counts[i], hist[i]);
+}
+
+__global__ void k_knn_offsets(KnnArgs a) {
+  // single workgroup; NF is a few hundred at most
+  if (threadIdx.x == 0) {
+    int so = 0, to = 0;
+    for (int f = 0; f < a.NF; ++f) {
+      a.seg_off[f] = so; a.tile_off[f] = to;
+      so += a.counts[f]; to += (a.counts[f] + KNN_TILE - 1) / KNN_TILE;
+      a.cursor[f] = 0;
+    }
+    a.seg_off[a.NF] = so; a.tile_off[a.NF] = to;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
+  const int64_t n = a.P * a.K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = a.pair_field[i];
+    if (f >= 0) {
+      const int slot = atomicAdd(&a.cursor[f], 1);
+      a.sorted[a.seg_off[f] + slot] = (int)i;
+    }
+  }
+}
+
+template <int MI, int MH, int L, bool NEED_COS>
+__global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int total_tiles = a.tile_off[a.NF];
+  if ((int)blockIdx.x >= total_tiles) return;
+  // field of this tile: last f with tile_off[f] <= blockIdx.x
+  int lo = 0, hi = a.NF - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const int f = lo;
+  const int tile = blockIdx.x - a.tile_off[f];
+  const int beg = a.seg_off[f] + tile * KNN_TILE, end = min(a.seg_off[f + 1], beg + KNN_TILE);
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const float px = a.pos[3 * f], py = a.pos[3 * f + 1], pz = a.pos[3 * f + 2];
+  const float qw = a.quat[4 * f], qx = a.quat[4 * f + 1], qy = a.quat[4 * f + 2], qz = a.quat[4 * f + 3];
+  for (int base = beg + wave * 64; base < end; base += NGM_BLOCK) {
+    const int idx = base + lane;
+    const bool valid = idx < end;
+    float x = 0, y = 0, z = 0;
+    int pair = 0;
+    if (valid) {
+      pair = a.sorted[idx];
+      const int64_t p = pair / a.K;
+      Vec3 v{a.points[3 * p] - px, a.points[3 * p + 1] - py, a.points[3 * p + 2] - pz};   // models.py:377-381
+      v = quat_rotate_inv(qw, qx, qy, qz, v);
+      x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
+    }
+    const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+    if (valid) a.pair_out[pair] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_blend(KnnArgs a) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * blockDim.x) {
+    float4 o = make_float4(a.outside_value, a.outside_value, a.outside_value, a.outside_value);   // models.py:401
+    if (a.pair_field[p * a.K] >= 0) {
+      o = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < a.K; ++k) {
+        const float w = a.pair_w[p * a.K + k];
+        const float4 v = a.pair_out[p * a.K + k];
+        o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+      }
+    }
+    reinterpret_cast<float4*>(a.out)[p] = o;
+  }
+}
+
+int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
+  const int64_t n = P * K;
+  return 256 * 8 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16);
+}
+
+template <int MI, int MH, int L>
+static void launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
+  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
+  if (a.fc.encoding == NGM_ENC_NERF) {
+    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
+  }
+}
+
+int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
+                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
+                   void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
+  if (num_fields > 8192 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
+  KnnArgs a;
+  a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.P = P; a.points = points; a.pos = pos; a.quat = quat;
+  a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = fc->field_radius; a.out = out;
+  const int64_t n = P * K;
+  char* w = reinterpret_cast<char*>(((int64_t)workspace + 255) / 256 * 256);
+  auto carve = [&](int64_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
+  a.pair_field = reinterpret_cast<int*>(carve(4 * n));
+  a.pair_w = reinterpret_cast<float*>(carve(4 * n));
+  a.counts = reinterpret_cast<int*>(carve(4 * num_fields));
+  a.cursor = reinterpret_cast<int*>(carve(4 * num_fields));
+  a.seg_off = reinterpret_cast<int*>(carve(4 * (num_fields + 1)));
+  a.tile_off = reinterpret_cast<int*>(carve(4 * (num_fields + 1)));
+  a.sorted = reinterpret_cast<int*>(carve(4 * n));
+  a.pair_out = reinterpret_cast<float4*>(carve(16 * n));
+  (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
+  const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
+  const size_t lds_a = (size_t)num_fields * 16;
+  hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
+  hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
+  const int nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), 0, st, a);
+  const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
+  const FieldShape s = field_shape(fc);
+  if (s.MI == 2 && s.MH == 2 && s.L == 2) launch_eval<2, 2, 2>(a, max_tiles, st);
+#ifndef NGM_FAST_BUILD
+  else if (s.MI == 2 && s.MH == 2 && s.L == 1) launch_eval<2, 2, 1>(a, max_tiles, st);
+  else if (s.MI == 1 && s.MH == 1 && s.L == 1) launch_eval<1, 1, 1>(a, max_tiles, st);
+  else if (s.MI == 1 && s.MH == 1 && s.L == 2) launch_eval<1, 1, 2>(a, max_tiles, st);
+  else if (s.MI == 2 && s.MH == 2 && s.L == 3) launch_eval<2, 2, 3>(a, max_tiles, st);
+#endif
+  else return NGM_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_knn_blend, dim3(std::max(pb, 1)), dim3(256), 0, st, a);
+  return 0;
 }

@@ -76,6 +76,8 @@ struct CompositeArgs {
   int S;
   // separate-tensor source (standalone API)
   const float* colors; const float* geoms; const float* dists; const float* depths; const float* isds;
+  // packed source (eval path): (N,S,4) field outputs + camera-frame points; rgbd output (N,4)
+  const float4* out4; const float* pcam; float* rgbd;
   // outputs fwd
   float* C; float* D; float* Cv; float* Dv; float* term; float* weights;
   // bwd seeds / outputs

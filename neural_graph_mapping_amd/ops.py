@@ -120,13 +120,20 @@ def field_eval(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None
 
 def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.0, outside_value=1.0,
                    field_index=None):
+    """models.py:347-405: kNN-blended evaluation of world points (P,3) over all fields -> (P,4)."""
     _require_gpu(points, pos, quat)
     points = _f32c(points.reshape(-1, 3))
-    out = torch.empty(points.shape[0], 4, device=points.device, dtype=torch.float32)
+    P, NF = points.shape[0], pos.shape[0]
+    out = torch.empty(P, 4, device=points.device, dtype=torch.float32)
+    if P == 0:
+        return out
     ps = params_struct(fc, params, field_index)
-    K.check(K.lib().ngm_field_eval_knn(C.byref(fc), C.byref(ps), pos.shape[0], points.shape[0], _ptr(points),
-                                       _ptr(_f32c(pos)), _ptr(_f32c(quat)), num_knn, distance_factor, outside_value,
-                                       _ptr(out), _stream()), "ngm_field_eval_knn")
+    L = K.lib()
+    wsb = L.ngm_field_eval_knn_workspace(NF, P, num_knn)
+    ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
+    K.check(L.ngm_field_eval_knn(C.byref(fc), C.byref(ps), NF, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)),
+                                 num_knn, distance_factor, outside_value, _ptr(out), _ptr(ws), wsb, _stream()),
+            "ngm_field_eval_knn")
     return out
 
 
@@ -189,6 +196,41 @@ def sample_rays(rc: K.RenderCfg, ijs, near, far, gt=None, u_coarse=None, u_guide
     K.check(K.lib().ngm_sample_rays(C.byref(rc), C.byref(rays), _ptr(pts), _ptr(dist), _ptr(dirs), _stream()),
             "ngm_sample_rays")
     return pts, dist, dirs
+
+
+def sample_rays_world(rc: K.RenderCfg, ijs, c2ws, near=None, far=None, gt=None, u_coarse=None, u_guided=None, seed=0,
+                      near_const=0.0, far_const=8.0):
+    """sampler + utils.transform_points (rm.py:513-547): (points_cam, points_world, distances), each (F,R,S,·)."""
+    keep = []
+    dev = ijs.device
+    if ijs.dim() == 2:
+        ijs = ijs[None]
+    F, R = ijs.shape[0], ijs.shape[1]
+    pos = torch.zeros(F, 3, device=dev)
+    quat = torch.zeros(F, 4, device=dev)
+    rays = make_rays(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const=near_const,
+                     far_const=far_const, keep=keep)
+    S = rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0)
+    pc = torch.empty(F, R, S, 3, device=dev)
+    pw = torch.empty(F, R, S, 3, device=dev)
+    dist = torch.empty(F, R, S, device=dev)
+    K.check(K.lib().ngm_sample_rays_world(C.byref(rc), C.byref(rays), _ptr(pc), _ptr(pw), _ptr(dist), None, _stream()),
+            "ngm_sample_rays_world")
+    return pc, pw, dist
+
+
+def composite_packed(rc: K.RenderCfg, field_out4, dists, points_cam):
+    """_quadrature on the raw (N,S,4) field outputs (eval path): -> rgbd (N,4), Cvar (N,3), Dvar (N), term (N)."""
+    _require_gpu(field_out4, dists, points_cam)
+    S = dists.shape[-1]
+    N = dists.numel() // S
+    dev = dists.device
+    rgbd, cv, dv, term = (torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
+                          torch.empty(N, device=dev))
+    K.check(K.lib().ngm_composite_fwd_packed(C.byref(rc), N, S, _ptr(_f32c(field_out4)), _ptr(_f32c(dists)),
+                                             _ptr(_f32c(points_cam)), _ptr(rgbd), _ptr(cv), _ptr(dv), _ptr(term),
+                                             _stream()), "ngm_composite_fwd_packed")
+    return rgbd, cv, dv, term
 
 
 # ------------------------------------------------------------------------------------------------

@@ -213,6 +213,59 @@ class NeuralGraphRenderer:
         loss["combined"] = total
         return loss
 
+    # -- eval path: render_image / PSNR (rm.py:402-437, 1966-2000; evaluation.py:46-56) ----------
+    def eval_num_samples(self) -> int:
+        """rm.py:199-207: derived from the training sample spacing unless configured."""
+        cfg = self._config
+        if cfg.get("eval_num_samples") is not None:
+            return int(cfg["eval_num_samples"])
+        n_g = cfg.get("num_samples_depth_guided", 0)
+        tau = cfg.get("truncation_distance", 0.1)
+        rho = cfg.get("range_depth_guided") or tau
+        spacing = 2 * rho / n_g if n_g > 0 else 2 * self._field_radius / cfg["num_samples_coarse"]
+        return int((cfg.get("eval_far_distance", 8.0) - cfg.get("eval_near_distance", 0.0)) / spacing)
+
+    @torch.no_grad()
+    def render_image(self, c2w: torch.Tensor, camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None,
+                     seed: int = 0):
+        """render_image (rm.py:402-437): every pixel, eval-style single stratum, kNN-blended fields.
+
+        Returns (rgbds (H,W,4), depth_vars (H,W)).  `u` (H*W, S) optionally supplies the torch.rand draws."""
+        cam = camera or self._camera
+        cfg = self._config
+        S = self.eval_num_samples()
+        rc = make_render_cfg(cam, {**cfg, "num_samples_coarse": S, "num_samples_depth_guided": 0}, guided=False)
+        h, w = cam.height, cam.width
+        dev = self._device
+        ijs = torch.cartesian_prod(torch.arange(h, device=dev), torch.arange(w, device=dev))
+        num = self._global_map_dict["num"]
+        pos = self._global_map_dict["positions"][:num]
+        quat = self._global_map_dict["orientations"][:num]
+        params = {k: v for k, v in self._model.all_fields_params.items() if k != "_neus_sd"}
+        m = self._model
+        block = int(cfg.get("pixel_block_size", 8192))
+        rgbds, dvars = [], []
+        for s0 in range(0, ijs.shape[0], block):
+            ij = ijs[s0:s0 + block]
+            ub = None if u is None else u[s0:s0 + block][None]
+            pc, pw, dist = ops.sample_rays_world(rc, ij, c2w, None, None, None, ub, None, seed + s0,
+                                                 near_const=cfg.get("eval_near_distance", 0.0),
+                                                 far_const=cfg.get("eval_far_distance", 8.0))
+            out4 = ops.field_eval_knn(self._fc, params, pw.view(-1, 3), pos, quat, m._num_knn, m._distance_factor,
+                                      m._outside_value)
+            rgbd, _, dv, _ = ops.composite_packed(rc, out4, dist.view(-1, S), pc.view(-1, S, 3))
+            rgbds.append(rgbd)
+            dvars.append(dv)
+        return torch.cat(rgbds).reshape(h, w, 4), torch.cat(dvars).reshape(h, w)
+
+    @staticmethod
+    def psnr(prediction: torch.Tensor, target: torch.Tensor, crop: int = 0) -> float:
+        """evaluation.psnr (evaluation.py:46-56): clamp to [0,1], optional border crop, data_range 1."""
+        if crop > 0:
+            prediction, target = prediction[crop:-crop, crop:-crop], target[crop:-crop, crop:-crop]
+        mse = ((prediction.clamp(0.0, 1.0) - target.clamp(0.0, 1.0)) ** 2).mean()
+        return float(10.0 * torch.log10(1.0 / mse))
+
     # -- fused fast path -----------------------------------------------------------------------
     def _workspace(self, F, R):
         key = (F, R)

@@ -423,3 +423,44 @@ def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
     loss["combined"].backward()
     for k in po:
         loose_grad_close(res["grads"][k], po[k].grad, k)
+
+
+# ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)
+def test_knn_blend_golden():
+    g = load_golden("g8_knn")
+    fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    params = cu({k: v for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"})
+    out = ops.field_eval_knn(fc, params, g["points"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV), 2, 10.0, 1.0)
+    close(out, g["out"], rtol=2e-4, atol=3e-5)
+    assert torch.equal(out[:5].cpu(), torch.ones(5, 4))
+
+
+@pytest.mark.parametrize("NF,K_,P", [(1, 2, 300), (7, 3, 5000), (40, 2, 70000)])
+def test_knn_blend_vs_oracle(NF, K_, P):
+    torch.manual_seed(NF)
+    fs = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)
+    fc = K.field_cfg(encoding="fourier", dim_enc=32, num_layers=1)
+    params = O.init_params(fs, NF, seed=NF, sigma=3.0)
+    pos = torch.rand(NF, 3) * 3
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
+    pts = torch.rand(P, 3) * 4 - 0.5
+    ref = O.field_set_forward_knn(pts, pos, quat, params, fs, num_knn=K_, distance_factor=10.0, outside_value=1.0)
+    out = ops.field_eval_knn(fc, cu(params), pts.to(DEV), pos.to(DEV), quat.to(DEV), K_, 10.0, 1.0)
+    close(out, ref, rtol=3e-4, atol=3e-5)
+
+
+def test_render_image_and_psnr_golden():
+    g = load_golden("g9_render_image")
+    w, h, fx, fy, cx, cy = [float(x) for x in g["cam"]]
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, eval_far_distance=float(g["eval_far"]),
+               eval_num_samples=int(g["eval_num_samples"]))
+    NF = g["pos"].shape[0]
+    r = make_renderer(fkw, ckw, NF, split_prefix(g, "p::"))
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    cam = Rr.Camera(int(w), int(h), fx, fy, cx, cy, pixel_center=0.0)
+    rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
+    close(rgbd, g["rgbd"], rtol=5e-4, atol=5e-5)
+    close(dvar, g["dvar"], rtol=5e-4, atol=5e-5)
+    p = r.psnr(rgbd[..., :3].cpu(), g["target_rgb"], crop=2)
+    assert abs(p - O.psnr(g["rgbd"][..., :3], g["target_rgb"], crop=2)) < 0.01       # well inside the 0.1 dB bar

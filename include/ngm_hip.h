@@ -66,7 +66,19 @@ typedef struct ngm_field_cfg {
   int32_t dim_out;      /* 4: r,g,b,geometry                                                */
   int32_t scale_mode;   /* ngm_scale_mode, models.py:278-285                                */
   float field_radius;
+  /* permutohedral hash encoding (positional_encodings.py:19-66, config/neural_graph_map.yaml:6-14).
+   * PARITY UNPINNED: the arithmetic of the reference lives in an un-vendored CUDA package; the kernels
+   * implement the published lattice algorithm as restated in oracle/ngm_oracle.py:encode_permuto. */
+  int32_t nr_levels;          /* L <= 16; dim_enc = L * nr_feat_per_level                          */
+  int32_t nr_feat_per_level;  /* 2                                                                 */
+  int32_t log2_hashmap_size;  /* table entries per level T = 2^log2                                */
+  float coarsest_scale, finest_scale; /* sigma_l = geomspace(coarsest, finest, L)                  */
+  float level_scale[16 * 3];  /* per level, per axis i: 1 / (sqrt((i+1)(i+2)) * sigma_l); fill with    */
+                              /* ngm_permuto_fill_scales() (or from numpy.geomspace, as _capi.py does)  */
 } ngm_field_cfg;
+
+/* fills cfg->level_scale from nr_levels / coarsest_scale / finest_scale (double precision) */
+int ngm_permuto_fill_scales(ngm_field_cfg* cfg);
 
 /* Stacked per-field parameters, models.py:245-276 (`all_fields_params` / `vmap_fields_params`).
  * One device pointer per tensor plus the element stride between consecutive fields, so both a
@@ -80,6 +92,10 @@ typedef struct ngm_params {
   const float* b[NGM_MAX_LAYERS + 1]; /* "_linears.{i}.bias" (N, out_i) */
   int64_t b_stride[NGM_MAX_LAYERS + 1];
   const int64_t* field_index;
+  const float* lattice; /* "_encoding.lattice_values" (N, L, T, 2); NULL unless permutohedral */
+  int64_t lattice_stride;
+  const float* shift;   /* "_encoding.random_shift_per_level" (N, L, 3) */
+  int64_t shift_stride;
 } ngm_params;
 
 /* Gradient outputs, same layout rules as ngm_params (row f of each tensor = batch field f). */
@@ -90,6 +106,8 @@ typedef struct ngm_grads {
   int64_t w_stride[NGM_MAX_LAYERS + 1];
   float* b[NGM_MAX_LAYERS + 1];
   int64_t b_stride[NGM_MAX_LAYERS + 1];
+  float* lattice;       /* (F, L, T, 2): accumulated with atomics, zeroed by the backward entry points */
+  int64_t lattice_stride;
 } ngm_grads;
 
 /* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */

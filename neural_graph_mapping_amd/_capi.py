@@ -32,17 +32,20 @@ class FieldCfg(C.Structure):
     _fields_ = [("encoding", C.c_int32), ("dim_enc", C.c_int32), ("raw_coords", C.c_int32),
                 ("num_octaves", C.c_int32), ("start_octave", C.c_int32), ("num_layers", C.c_int32),
                 ("dim_hidden", C.c_int32), ("dim_out", C.c_int32), ("scale_mode", C.c_int32),
-                ("field_radius", C.c_float)]
+                ("field_radius", C.c_float), ("nr_levels", C.c_int32), ("nr_feat_per_level", C.c_int32),
+                ("log2_hashmap_size", C.c_int32), ("coarsest_scale", C.c_float), ("finest_scale", C.c_float),
+                ("level_scale", C.c_float * 48)]
 
 
 class Params(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
-                ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p)]
+                ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p),
+                ("lattice", f32p), ("lattice_stride", C.c_int64), ("shift", f32p), ("shift_stride", C.c_int64)]
 
 
 class Grads(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
-                ("b", LArr), ("b_stride", SArr)]
+                ("b", LArr), ("b_stride", SArr), ("lattice", f32p), ("lattice_stride", C.c_int64)]
 
 
 class RenderCfg(C.Structure):
@@ -95,6 +98,8 @@ def lib():
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     P = C.POINTER
     L.ngm_abi_version.restype = C.c_int
+    L.ngm_permuto_fill_scales.argtypes = [P(FieldCfg)]
+    L.ngm_permuto_fill_scales.restype = C.c_int
     L.ngm_last_error.restype = C.c_char_p
     L.ngm_device_info.argtypes = [P(C.c_int), C.c_char_p, C.c_int]
     L.ngm_sample_rays.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp]
@@ -137,12 +142,16 @@ def lib():
     return L
 
 
-EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_sample_rays", "ngm_sample_rays_world",
+EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto_fill_scales", "ngm_sample_rays", "ngm_sample_rays_world",
             "ngm_composite_fwd_packed",
             "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"]
+
+# parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;
+# torch.optim.Adam skips grad-less parameters, so the sparse Adam must skip them too)
+NO_GRAD_PARAMS = frozenset({"_encoding.random_shift_per_level"})
 
 KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
                   composite_bwd=7)
@@ -162,21 +171,35 @@ def check(rc, what=""):
 # struct builders from plain python values / raw device addresses
 # ------------------------------------------------------------------------------------------------
 def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,
-              num_layers=2, dim_hidden=None, dim_out=4, scale_mode="unit_cube", field_radius=1.0):
+              num_layers=2, dim_hidden=None, dim_out=4, scale_mode="unit_cube", field_radius=1.0,
+              nr_levels=16, nr_feat_per_level=2, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4):
     if encoding == "nerf":
         dim_enc = 6 * num_octaves
     if encoding == "none":
         dim_enc = 3
+    if encoding == "permuto":
+        dim_enc = nr_levels * nr_feat_per_level
     if dim_hidden is None:
         dim_hidden = dim_enc
-    return FieldCfg(ENC[encoding], dim_enc, int(bool(raw_coords)), num_octaves, start_octave,
-                    num_layers, dim_hidden, dim_out, SCALE[scale_mode], float(field_radius))
+    fc = FieldCfg(ENC[encoding], dim_enc, int(bool(raw_coords)), num_octaves, start_octave,
+                  num_layers, dim_hidden, dim_out, SCALE[scale_mode], float(field_radius), nr_levels,
+                  nr_feat_per_level, log2_hashmap_size, float(coarsest_scale), float(finest_scale))
+    if encoding == "permuto":
+        import math
+        import numpy as np
+        sig = np.geomspace(coarsest_scale, finest_scale, num=nr_levels)          # positional_encodings.py:50
+        for lvl in range(min(nr_levels, 16)):
+            for i in range(3):
+                fc.level_scale[3 * lvl + i] = np.float32((1.0 / math.sqrt((i + 1) * (i + 2))) / sig[lvl])
+    return fc
 
 
 def param_names(fc: FieldCfg):
     names = []
     if fc.encoding == ENC["fourier"]:
         names.append("_encoding._linear.weight")
+    if fc.encoding == ENC["permuto"]:
+        names += ["_encoding.lattice_values", "_encoding.random_shift_per_level"]
     for i in range(fc.num_layers + 1):
         names += [f"_linears.{i}.weight", f"_linears.{i}.bias"]
     return names
@@ -186,6 +209,9 @@ def param_shapes(fc: FieldCfg):
     shapes = {}
     if fc.encoding == ENC["fourier"]:
         shapes["_encoding._linear.weight"] = ((fc.dim_enc - 3) if fc.raw_coords else fc.dim_enc, 3)
+    if fc.encoding == ENC["permuto"]:
+        shapes["_encoding.lattice_values"] = (fc.nr_levels, 2 ** fc.log2_hashmap_size, fc.nr_feat_per_level)
+        shapes["_encoding.random_shift_per_level"] = (fc.nr_levels, 3)
     for i in range(fc.num_layers + 1):
         din = fc.dim_enc if i == 0 else fc.dim_hidden
         dout = fc.dim_out if i == fc.num_layers else fc.dim_hidden
@@ -199,6 +225,12 @@ def _fill_ptrs(struct, fc, ptrs, strides):
     if fc.encoding == ENC["fourier"]:
         struct.enc_w = ptrs["_encoding._linear.weight"]
         struct.enc_w_stride = strides["_encoding._linear.weight"]
+    if fc.encoding == ENC["permuto"]:
+        struct.lattice = ptrs["_encoding.lattice_values"]
+        struct.lattice_stride = strides["_encoding.lattice_values"]
+        if hasattr(struct, "shift"):
+            struct.shift = ptrs["_encoding.random_shift_per_level"]
+            struct.shift_stride = strides["_encoding.random_shift_per_level"]
     for i in range(fc.num_layers + 1):
         struct.w[i] = ptrs[f"_linears.{i}.weight"]
         struct.w_stride[i] = strides[f"_linears.{i}.weight"]

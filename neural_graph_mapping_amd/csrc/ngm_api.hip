@@ -27,6 +27,7 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K);
 #include <vector>
 
 static thread_local char g_err[512] = "";
+static int prep_lattice_grad(const ngm_field_cfg* fc, const ngm_grads* grads, int F, FieldBwdArgs& a, hipStream_t st);
 
 // ---- profiling hooks ----------------------------------------------------------------------------
 namespace {
@@ -110,7 +111,12 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
   if (!fc) return fail(NGM_E_INVALID, "field cfg is NULL");
   if (fc->dim_out != 4) return fail(NGM_E_UNSUPPORTED, "dim_out must be 4 (r,g,b,geometry)");
   if (fc->num_layers < 1 || fc->num_layers > NGM_MAX_LAYERS) return fail(NGM_E_UNSUPPORTED, "num_layers out of range");
-  if (fc->encoding == NGM_ENC_PERMUTO) return fail(NGM_E_UNSUPPORTED, "permutohedral encoding: not built yet");
+  if (fc->encoding == NGM_ENC_PERMUTO) {
+    if (fc->nr_feat_per_level != 2 || fc->nr_levels < 1 || fc->nr_levels > 16 || fc->dim_enc != 2 * fc->nr_levels)
+      return fail(NGM_E_UNSUPPORTED, "permutohedral encoding: nr_feat_per_level must be 2, nr_levels <= 16, no concat_points");
+    if (fc->log2_hashmap_size < 4 || fc->log2_hashmap_size > 24) return fail(NGM_E_UNSUPPORTED, "permutohedral: log2_hashmap_size out of range");
+    if (!(fc->level_scale[0] > 0.f)) return fail(NGM_E_INVALID, "permutohedral: level_scale not filled (ngm_permuto_fill_scales)");
+  }
   if (fc->encoding == NGM_ENC_NERF && fc->dim_enc != 6 * fc->num_octaves) return fail(NGM_E_INVALID, "nerf: dim_enc != 6*octaves");
   if (fc->encoding == NGM_ENC_NONE && fc->dim_enc != 3) return fail(NGM_E_INVALID, "no encoding: dim_enc must be 3");
   if (fc->dim_enc < 1 || fc->dim_enc > 64 || fc->dim_hidden < 1 || fc->dim_hidden > 64)
@@ -122,6 +128,7 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
 static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
   if (!pr) return fail(NGM_E_INVALID, "params is NULL");
   if (fc->encoding == NGM_ENC_FOURIER && !pr->enc_w) return fail(NGM_E_INVALID, "fourier encoding needs enc_w");
+  if (fc->encoding == NGM_ENC_PERMUTO && (!pr->lattice || !pr->shift)) return fail(NGM_E_INVALID, "permutohedral encoding needs lattice + shift");
   for (int l = 0; l <= fc->num_layers; ++l)
     if (!pr->w[l] || !pr->b[l]) return fail(NGM_E_INVALID, "missing layer weight/bias pointer");
   return NGM_OK;
@@ -130,6 +137,20 @@ static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
 extern "C" {
 
 int ngm_abi_version(void) { return NGM_ABI_VERSION; }
+
+int ngm_permuto_fill_scales(ngm_field_cfg* cfg) {
+  if (!cfg || cfg->nr_levels < 1 || cfg->nr_levels > 16 || !(cfg->coarsest_scale > 0) || !(cfg->finest_scale > 0))
+    return fail(NGM_E_INVALID, "ngm_permuto_fill_scales: bad configuration");
+  const int L = cfg->nr_levels;
+  const double la = log10((double)cfg->coarsest_scale), lb = log10((double)cfg->finest_scale);
+  for (int l = 0; l < L; ++l) {
+    double sig = (L == 1) ? cfg->coarsest_scale : pow(10.0, la + (lb - la) * (double)l / (double)(L - 1));
+    if (l == 0) sig = cfg->coarsest_scale;
+    if (l == L - 1 && L > 1) sig = cfg->finest_scale;
+    for (int i = 0; i < 3; ++i) cfg->level_scale[3 * l + i] = (float)((1.0 / sqrt((double)((i + 1) * (i + 2)))) / sig);
+  }
+  return NGM_OK;
+}
 const char* ngm_last_error(void) { return g_err; }
 
 int ngm_profile_enable(int32_t on) {
@@ -243,6 +264,8 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   plan_bwd(F, P, &a.per_block, &a.blocks_per_field);
   a.p_pad = param_pad(fcfg);
   a.partials = reinterpret_cast<float*>(align_up((int64_t)workspace, 256));
+  rc = prep_lattice_grad(fcfg, grads, F, a, (hipStream_t)stream);
+  if (rc) return rc;
   rc = ngm_launch_field_bwd(a, a.blocks_per_field * F, (hipStream_t)stream);
   if (rc) return fail(rc, "ngm_field_eval_bwd: no kernel for this (D,H,L)");
   rc = check_launch("ngm_field_eval_bwd");
@@ -350,6 +373,18 @@ int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   return plan_render(fcfg, rcfg, F, R, true, train != 0).total;
 }
 
+// permutohedral: the gradient table is accumulated with atomics -> zero it on the stream first
+static int prep_lattice_grad(const ngm_field_cfg* fc, const ngm_grads* grads, int F, FieldBwdArgs& a, hipStream_t st) {
+  a.lattice_grad = nullptr; a.lattice_grad_stride = 0;
+  if (fc->encoding != NGM_ENC_PERMUTO) return NGM_OK;
+  if (!grads->lattice) return fail(NGM_E_INVALID, "permutohedral: grads.lattice is NULL");
+  const int64_t per = (int64_t)fc->nr_levels * ((int64_t)1 << fc->log2_hashmap_size) * 2;
+  if (grads->lattice_stride < per) return fail(NGM_E_INVALID, "permutohedral: grads.lattice_stride too small");
+  for (int f = 0; f < F; ++f) (void)hipMemsetAsync(grads->lattice + (int64_t)f * grads->lattice_stride, 0, per * 4, st);
+  a.lattice_grad = grads->lattice; a.lattice_grad_stride = grads->lattice_stride;
+  return NGM_OK;
+}
+
 static int check_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const ngm_params* pr, const ngm_rays* rays) {
   int e = check_field_cfg(fc);
   if (e) return e;
@@ -423,6 +458,8 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
+  e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
+  if (e) return e;
   e = ngm_launch_field_bwd(a, a.blocks_per_field * a.F, st);
   if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_field_bwd");

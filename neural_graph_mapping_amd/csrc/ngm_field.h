@@ -40,6 +40,19 @@ __device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg
   const int D = fc.dim_enc, H = fc.dim_hidden;
   // ---- encoding table
   const int nthr = blockDim.x;
+  if (fc.encoding == NGM_ENC_PERMUTO) {
+    // per level: {sx, sy, sz, 0, shift_x, shift_y, shift_z, 0}  (16 levels x 8 floats = the MI==1 table)
+    for (int l = tid; l < 16; l += nthr) {
+      float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l < fc.nr_levels) {
+        const float* hs = pr.shift + row * pr.shift_stride + 3 * l;
+        sc = make_float4(fc.level_scale[3 * l], fc.level_scale[3 * l + 1], fc.level_scale[3 * l + 2], 0.f);
+        sh = make_float4(hs[0], hs[1], hs[2], 0.f);
+      }
+      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l] = sc;
+      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l + 1] = sh;
+    }
+  } else
   for (int f = tid; f < MI * 32; f += nthr) {
     float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
     if (f < D) {
@@ -120,6 +133,135 @@ __device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, floa
       if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Permutohedral-lattice hash encoding (positional_encodings.py:19-66).  PARITY UNPINNED: restates the
+// published algorithm exactly as oracle/ngm_oracle.py:encode_permuto (elevate -> nearest remainder-0
+// point -> rank -> barycentric -> hash the 4 simplex vertices).  FP contraction is off so that the
+// lattice coordinates (up to ~1e5 at the finest level) round exactly like the oracle's torch ops.
+// ------------------------------------------------------------------------------------------------
+struct HashCtx {
+  const float2* tab;     // this field's table: [L][T] float2
+  uint32_t mask;         // T - 1
+  int T, nlev;
+  float* gtab;           // gradient table (backward) or nullptr
+};
+
+__device__ __forceinline__ void permuto_simplex(float x, float y, float z, const float* lp, uint32_t mask,
+                                                uint32_t (&idx)[4], float (&bw)[4]) {
+#pragma clang fp contract(off)
+  const float c0 = (x + lp[4]) * lp[0], c1 = (y + lp[5]) * lp[1], c2 = (z + lp[6]) * lp[2];
+  float el[4];
+  float sm = 0.f;
+  { const float t3 = 3.0f * c2; el[3] = sm - t3; sm = sm + c2; }
+  { const float t2 = 2.0f * c1; el[2] = sm - t2; sm = sm + c1; }
+  { const float t1 = 1.0f * c0; el[1] = sm - t1; sm = sm + c0; }
+  el[0] = sm;
+  int rem0[4], sum = 0;
+  float diff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = el[i] * 0.25f;
+    const float up = ceilf(v) * 4.0f, down = floorf(v) * 4.0f;
+    const float r = ((up - el[i]) < (el[i] - down)) ? up : down;
+    rem0[i] = (int)r;
+    diff[i] = el[i] - r;
+    sum += rem0[i];
+  }
+  sum /= 4;
+  int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) {
+      const bool lt = diff[i] < diff[j];
+      rank[i] += lt ? 1 : 0;
+      rank[j] += lt ? 0 : 1;
+    }
+  float bary[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rank[i] += sum;
+    if (rank[i] < 0) { rank[i] += 4; rem0[i] += 4; }
+    else if (rank[i] > 3) { rank[i] -= 4; rem0[i] -= 4; }
+    const float delta = (el[i] - (float)rem0[i]) * 0.25f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      bary[s] += (3 - rank[i] == s) ? delta : 0.f;
+      bary[s] -= (4 - rank[i] == s) ? delta : 0.f;
+    }
+  }
+  bary[0] = bary[0] + (1.0f + bary[4]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint32_t h = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int key = rem0[i] + r - ((rank[i] > 3 - r) ? 4 : 0);
+      h += (uint32_t)key;
+      h *= 2531011u;
+    }
+    idx[r] = h & mask;
+    bw[r] = bary[r];
+  }
+}
+
+// features of the lane's 8 levels straight into the MFMA B-operand registers of the single 32-feature
+// tile: register r = 4q + 2p + c holds feature c of level 4q + 2*hi + p.
+__device__ __forceinline__ void encode_hash(const float* sm_lvl, const HashCtx& hc, int hi, float x, float y, float z,
+                                            f32x16& E) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int level = 4 * q + 2 * hi + p;
+      float f0 = 0.f, f1 = 0.f;
+      if (level < hc.nlev) {
+        uint32_t idx[4]; float bw[4];
+        permuto_simplex(x, y, z, sm_lvl + 8 * level, hc.mask, idx, bw);
+        const float2* t = hc.tab + (size_t)level * hc.T;
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
+      }
+      E[4 * q + 2 * p] = f0;
+      E[4 * q + 2 * p + 1] = f1;
+    }
+}
+
+// scatter dL/dE of the lane's 8 levels into the gradient table (float atomics in L2)
+__device__ __forceinline__ void scatter_hash_grad(const float* sm_lvl, const HashCtx& hc, int hi, float x, float y, float z,
+                                                  const f32x16& dE, bool valid) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int level = 4 * q + 2 * hi + p;
+      if (level < hc.nlev && valid) {
+        uint32_t idx[4]; float bw[4];
+        permuto_simplex(x, y, z, sm_lvl + 8 * level, hc.mask, idx, bw);
+        float* g = hc.gtab + ((size_t)level * hc.T) * 2;
+        const float d0 = dE[4 * q + 2 * p], d1 = dE[4 * q + 2 * p + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsafeAtomicAdd(g + 2 * idx[r], d0 * bw[r]);
+          unsafeAtomicAdd(g + 2 * idx[r] + 1, d1 * bw[r]);
+        }
+      }
+    }
+}
+
+__device__ __forceinline__ HashCtx make_hash_ctx(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, float* gtab) {
+  HashCtx hc;
+  hc.T = 1 << fc.log2_hashmap_size;
+  hc.mask = (uint32_t)hc.T - 1u;
+  hc.nlev = fc.nr_levels;
+  hc.tab = (fc.encoding == NGM_ENC_PERMUTO) ? reinterpret_cast<const float2*>(pr.lattice + row * pr.lattice_stride) : nullptr;
+  hc.gtab = gtab;
+  return hc;
 }
 
 // One hidden layer on the matrix cores: Y = relu(W X + b), X/Y in C-layout registers, NT sample tiles.
@@ -218,15 +360,21 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
-template <int MI, int MH, int L, bool NEED_COS>
-__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z) {
+template <int MI, int MH, int L, bool NEED_COS, bool HASH = false>
+__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
   const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
   f32x16 E[2][MI], dummy[MI];
-  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
-  encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+  if constexpr (HASH) {
+    static_assert(!HASH || MI == 1, "hash encoding: 2*levels <= 32 features");
+    encode_hash(sm + LY::ENCW, *hc, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0][0]);
+    encode_hash(sm + LY::ENCW, *hc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1][0]);
+  } else {
+    encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
+    encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+  }
   f32x16 Hl[2][MH];
   mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl);
   float part[2][4];

@@ -170,7 +170,7 @@ __device__ __forceinline__ void outer_accum(const float* colbuf, int stride, con
   }
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD>
+template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD, bool HASH>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L>;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   for (int c = 0; c < 4; ++c) { dwo[c] = 0.f; dbo[c] = 0.f; }
   dwf[0] = dwf[1] = dwf[2] = 0.f;
 
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, HASH ? a.lattice_grad + (int64_t)f * a.lattice_grad_stride : nullptr);
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 32; base < end; base += 32 * NGM_WAVES_PER_BLOCK) {
     const int64_t n = base + j;
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     }
     // ---- forward recompute, staging every layer input
     f32x16 E[1][MI], dEa[MI];
-    encode_sample<MI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, hi, x, y, z, E[0], dEa);
+    if constexpr (HASH) encode_hash(sm + LY::ENCW, hc, hi, x, y, z, E[0][0]);
+    else encode_sample<MI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, hi, x, y, z, E[0], dEa);
     WAVE_SYNC();   // previous tile's readers of the staging buffers are done (in-order LDS) - compiler fence
     store_tile<MI>(wl + BL::x_off(0), BL::STR_E, lane, E[0]);
     if (hi == 0) {
@@ -290,6 +292,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
       dbh[l] += colsum<MH>(bufD, BL::STR_D, lane);
       if (l == 0) {
         layer_wgrad<MH, MI>(bufD, BL::STR_D, wl + BL::x_off(0), BL::STR_E, lane, acc0);
+        if constexpr (HASH) {
+          f32x16 dE[MI];
+          layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
+          scatter_hash_grad(sm + LY::ENCW, hc, hi, x, y, z, dE[0], valid);
+        }
         if (ENC_GRAD) {
           f32x16 dE[MI];
           layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
@@ -435,17 +442,18 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
 template <int MI, int MH, int L>
 static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   const size_t lds = BwdLds<MI, MH, L>::TOTAL * sizeof(float);
-  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
-  const bool enc_grad = a.fc.encoding == NGM_ENC_FOURIER;
-#define NGM_LB(NC, EG)                                                                                             \
-  do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)k_field_bwd<MI, MH, L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds);                                                                           \
-    hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);               \
+#define NGM_LB(NC, EG, HS)                                                                                              \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)k_field_bwd<MI, MH, L, NC, EG, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                                \
+    hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG, HS>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);                \
   } while (0)
-  if (enc_grad) NGM_LB(false, true);
-  else if (need_cos) NGM_LB(true, false);
-  else NGM_LB(false, false);
+  if (a.fc.encoding == NGM_ENC_PERMUTO) {
+    if constexpr (MI == 1) NGM_LB(false, false, true);
+    else return NGM_E_UNSUPPORTED;
+  } else if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LB(false, true, false);
+  else if (a.fc.encoding == NGM_ENC_NERF) NGM_LB(true, false, false);
+  else NGM_LB(false, false, false);
 #undef NGM_LB
   return 0;
 }

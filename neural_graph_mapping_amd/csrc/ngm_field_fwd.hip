@@ -18,7 +18,7 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
     px = a.pos[3 * f]; py = a.pos[3 * f + 1]; pz = a.pos[3 * f + 2];
     qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
   }
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 64; base < end; base += NGM_BLOCK) {
     const int64_t idx = base + lane;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -80,7 +81,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L>;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   float ls[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) ls[i] = 0.f;
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
 
   for (int rb = r_beg; rb < r_end; rb += BR) {
     const int nb = min(BR, r_end - rb);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float t = valid ? wl.tbuf[idx] : 0.f;
       float x = 0, y = 0, z = 0;
       if (valid) { x = fmaf(t, rt[3], rt[0]); y = fmaf(t, rt[4], rt[1]); z = fmaf(t, rt[5], rt[2]); }
-      const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z, geom = o.w;
       const float depth = -(rt[6] * t);
       const float occ = valid ? occ_pointwise(mode, gamma, geom, nullptr) : 0.f;
@@ -274,29 +276,33 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+#define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDS)                                                          \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)KERNEL<MI, MH, L, NC, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)(LDS));                                                                       \
+    hipLaunchKernelGGL((KERNEL<MI, MH, L, NC, HS>), dim3(GRID), BLK, LDS, st, a);                                \
+  } while (0)
+
 template <int MI, int MH, int L>
-static int launch_points(const PointsFwdArgs& a, int blocks, bool need_cos, hipStream_t st) {
+static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
   const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
-  if (need_cos) {
-    (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, true>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);
-  }
+  const dim3 blk(NGM_BLOCK);
+  if (a.fc.encoding == NGM_ENC_PERMUTO) {
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, true, blocks, blk, lds);
+    else return NGM_E_UNSUPPORTED;
+  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_field_points_fwd, true, false, blocks, blk, lds);
+  else NGM_LAUNCH_VARIANT(k_field_points_fwd, false, false, blocks, blk, lds);
   return 0;
 }
 template <int MI, int MH, int L>
-static int launch_render(const RenderFwdArgs& a, int blocks, bool need_cos, hipStream_t st) {
+static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   const size_t lds = (FieldLds<MI, MH, L>::TOTAL + a.waves_per_block * RenderWaveLds::floats(a.maxs)) * sizeof(float);
   const dim3 blk(64 * a.waves_per_block);
-  if (need_cos) {
-    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, true>), dim3(blocks), blk, lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false>), dim3(blocks), blk, lds, st, a);
-  }
+  if (a.fc.encoding == NGM_ENC_PERMUTO) {
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, true, blocks, blk, lds);
+    else return NGM_E_UNSUPPORTED;
+  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, false, blocks, blk, lds);
+  else NGM_LAUNCH_VARIANT(k_render_fwd, false, false, blocks, blk, lds);
   return 0;
 }
 
@@ -322,11 +328,9 @@ static int launch_render(const RenderFwdArgs& a, int blocks, bool need_cos, hipS
 
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st) {
   NgmProfScope prof_(NGM_K_POINTS_FWD, st);
-  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
-  NGM_SHAPE_DISPATCH(launch_points, a, blocks, need_cos, st);
+  NGM_SHAPE_DISPATCH(launch_points, a, blocks, st);
 }
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   NgmProfScope prof_(NGM_K_RENDER_FWD, st);
-  const bool need_cos = a.fc.encoding == NGM_ENC_NERF;
-  NGM_SHAPE_DISPATCH(launch_render, a, blocks, need_cos, st);
+  NGM_SHAPE_DISPATCH(launch_render, a, blocks, st);
 }

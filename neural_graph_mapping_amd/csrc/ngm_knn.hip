@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
   }
 }
 
-template <int MI, int MH, int L, bool NEED_COS>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH>
 __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
   const float px = a.pos[3 * f], py = a.pos[3 * f + 1], pz = a.pos[3 * f + 2];
   const float qw = a.quat[4 * f], qx = a.quat[4 * f + 1], qy = a.quat[4 * f + 2], qz = a.quat[4 * f + 3];
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
   for (int base = beg + wave * 64; base < end; base += NGM_BLOCK) {
     const int idx = base + lane;
     const bool valid = idx < end;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS>(sm, lane, x, y, z);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
     if (valid) a.pair_out[pair] = o;
   }
 }
@@ -166,13 +167,17 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
 template <int MI, int MH, int L>
 static void launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
   const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
-  if (a.fc.encoding == NGM_ENC_NERF) {
-    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
-  }
+#define NGM_KE(NC, HS)                                                                                             \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, NC, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                           \
+    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
+  } while (0)
+  if (a.fc.encoding == NGM_ENC_PERMUTO) {
+    if constexpr (MI == 1) NGM_KE(false, true);
+  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_KE(true, false);
+  else NGM_KE(false, false);
+#undef NGM_KE
 }
 
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,

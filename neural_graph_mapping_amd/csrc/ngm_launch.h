@@ -58,6 +58,8 @@ struct FieldBwdArgs {
   const float4* d_out;    // (F,P) float4: dL/d(r,g,b,geometry) raw MLP outputs
   float* partials;        // (F*blocks_per_field, P_pad) per-workgroup gradient partial sums
   int64_t p_pad;          // padded parameter count per field (floats)
+  float* lattice_grad;    // permutohedral: (F, L, T, 2) gradient table (atomics), stride between fields
+  int64_t lattice_grad_stride;
 };
 
 struct GradReduceArgs {

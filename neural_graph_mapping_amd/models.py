@@ -83,24 +83,33 @@ class PositionalEncodingNeRF(PositionalEncoding):
 class PermutohedralEncoding(PositionalEncoding):
     """Multi-resolution permutohedral-lattice hash encoding (positional_encodings.py:19-66).
 
-    The reference delegates to an un-vendored CUDA package; parity is unpinned.  The HIP
-    kernel for it is not built yet: constructing the descriptor works (config compatibility), using
-    it raises."""
+    Same constructor kwargs as the reference wrapper (including its ``appply_random_shift_per_level``
+    spelling).  The reference delegates the arithmetic to the un-vendored CUDA package
+    ``permutohedral_encoding`` -> PARITY UNPINNED; the HIP kernels implement the published
+    lattice algorithm as restated in oracle/ngm_oracle.py:encode_permuto.  Parameters: the hash table
+    ``lattice_values`` (nr_levels, 2**log2_hashmap_size, nr_feat_per_level) ~ N(0, init_scale) and the
+    constant per-level shifts ``random_shift_per_level`` (nr_levels, 3) ~ 10 N(0,1)."""
 
     def __init__(self, pos_dim, log2_hashmap_size, nr_levels, nr_feat_per_level, coarsest_scale, finest_scale,
                  appply_random_shift_per_level=True, concat_points=False, concat_points_scaling=1.0,
                  init_scale=1e-5) -> None:
         super().__init__()
-        self.kw = dict(pos_dim=pos_dim, log2_hashmap_size=log2_hashmap_size, nr_levels=nr_levels,
-                       nr_feat_per_level=nr_feat_per_level, coarsest_scale=coarsest_scale,
-                       finest_scale=finest_scale, concat_points=concat_points)
-        self._out = nr_levels * nr_feat_per_level + (pos_dim if concat_points else 0)
+        if pos_dim != 3 or nr_feat_per_level != 2 or nr_levels > 16 or concat_points:
+            raise NotImplementedError("permutohedral encoding: pos_dim 3, 2 features/level, <= 16 levels, no concat_points")
+        self.kw = dict(log2_hashmap_size=log2_hashmap_size, nr_levels=nr_levels, nr_feat_per_level=nr_feat_per_level,
+                       coarsest_scale=float(coarsest_scale), finest_scale=float(finest_scale))
+        capacity = 2 ** log2_hashmap_size
+        lattice = torch.randn(capacity, nr_levels, nr_feat_per_level) * init_scale
+        self.lattice_values = torch.nn.Parameter(lattice.permute(1, 0, 2).contiguous())
+        shift = 10.0 * torch.randn(nr_levels, 3) if appply_random_shift_per_level else torch.zeros(nr_levels, 3)
+        self.random_shift_per_level = torch.nn.Parameter(shift, requires_grad=False)
+        self._out = nr_levels * nr_feat_per_level
 
     def get_out_dim(self) -> int:
         return self._out
 
     def spec(self):
-        raise NotImplementedError("permutohedral hash encoding: HIP kernel not built yet (parity unpinned)")
+        return dict(encoding="permuto", **self.kw)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -296,7 +296,7 @@ def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, b
 def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=None, lr=1e-3, betas=(0.9, 0.999),
                        eps=1e-15, weight_decay=1e-5):
     """One launch for every parameter tensor of the field set (rows `field_index` updated in place)."""
-    names = K.param_names(fc)
+    names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
     arr = (K.AdamTensor * len(names))()
     for i, n in enumerate(names):
         p, g = params[n], grads[n]

@@ -55,11 +55,17 @@ class CameraSpec:
 @dataclass
 class FieldSpec:
     """Architecture of one NeuralField (models.py:69-128)."""
-    encoding: str = "fourier"          # "fourier" | "nerf" | "none"
+    encoding: str = "fourier"          # "fourier" | "nerf" | "none" | "permuto"
     dim_enc: int = 64                  # encoding width D
     raw_coords: bool = True            # Fourier: cat(x, sin(Wx)) (positional_encodings.py:208-212)
     num_octaves: int = 8               # NeRF octaves (positional_encodings.py:230)
     start_octave: int = 0
+    # permutohedral hash encoding (positional_encodings.py:19-66; PARITY UNPINNED, see encode_permuto)
+    nr_levels: int = 16
+    nr_feat_per_level: int = 2
+    log2_hashmap_size: int = 12
+    coarsest_scale: float = 1.0
+    finest_scale: float = 1e-4
     num_layers: int = 2                # hidden layers L
     dim_hidden: Optional[int] = None   # H; None -> D (models.py:99-100)
     dim_out: int = 4
@@ -67,6 +73,8 @@ class FieldSpec:
     def __post_init__(self):
         if self.encoding == "nerf":
             self.dim_enc = 3 * self.num_octaves * 2
+        if self.encoding == "permuto":
+            self.dim_enc = self.nr_levels * self.nr_feat_per_level
         if self.dim_hidden is None:
             self.dim_hidden = self.dim_enc
 
@@ -81,6 +89,9 @@ class FieldSpec:
         if self.encoding == "fourier":
             n = self.dim_enc - 3 if self.raw_coords else self.dim_enc
             shapes["_encoding._linear.weight"] = (n, 3)
+        if self.encoding == "permuto":
+            shapes["_encoding.lattice_values"] = (self.nr_levels, 2 ** self.log2_hashmap_size, self.nr_feat_per_level)
+            shapes["_encoding.random_shift_per_level"] = (self.nr_levels, 3)
         for i, (di, do) in enumerate(self.layer_dims()):
             shapes[f"_linears.{i}.weight"] = (do, di)
             shapes[f"_linears.{i}.bias"] = (do,)
@@ -216,7 +227,77 @@ def encode(x, params, fs: FieldSpec):
         return torch.cat((torch.sin(sp).reshape(*lead, -1), torch.cos(sp).reshape(*lead, -1)), -1)
     if fs.encoding == "none":
         return x
+    if fs.encoding == "permuto":
+        return encode_permuto(x, params["_encoding.lattice_values"], params["_encoding.random_shift_per_level"], fs)
     raise NotImplementedError(fs.encoding)
+
+
+def permuto_scale_factors(fs: FieldSpec, dtype=torch.float32):
+    """(L,3) per-level, per-axis scale: 1 / (sqrt((i+1)(i+2)) * sigma_l), sigma = geomspace(coarsest, finest, L)
+    (positional_encodings.py:50 for the sigmas; elevation scaling of Adams et al. 2010 / the
+    permutohedral_encoding package)."""
+    import numpy as np
+    sig = torch.tensor(np.geomspace(fs.coarsest_scale, fs.finest_scale, num=fs.nr_levels), dtype=torch.float64)
+    ax = torch.tensor([1.0 / math.sqrt((i + 1) * (i + 2)) for i in range(3)], dtype=torch.float64)
+    return (ax[None, :] / sig[:, None]).to(dtype)
+
+
+def encode_permuto(x, lattice, shift, fs: FieldSpec):
+    """Multi-resolution permutohedral-lattice hash encoding; x (F,P,3) in the field frame, lattice
+    (F,L,T,2), shift (F,L,3) -> (F,P,2L).
+
+    *** PARITY UNPINNED *** The reference only wraps `permutohedral_encoding.PermutoEncoding`
+    (roym899 fork @ bf445adb, pyproject.toml:21), a CUDA package that is not vendored and cannot be
+    built or run here, and the reference has no tests for it.  This is a restatement of the published
+    algorithm (Adams, Baek, Davis 2010 "Fast high-dimensional filtering using the permutohedral
+    lattice"; Rosu & Behnke 2023 "PermutoSDF"): elevate the scaled point onto the hyperplane
+    sum = 0 of R^4, round to the nearest remainder-0 lattice point, rank the residuals to find the
+    enclosing simplex, barycentric weights, hash every simplex vertex key into a table of T entries per
+    level, blend the F=2 features.  It is the definition the HIP kernels are tested against.
+    Differentiable w.r.t. `lattice` only (as the CUDA package: no gradient to positions/shifts here)."""
+    F, P, _ = x.shape
+    L, T = lattice.shape[1], lattice.shape[2]
+    d = 3
+    scale = permuto_scale_factors(fs, x.dtype)                                   # (L,3)
+    cf = (x[:, :, None, :] + shift[:, None, :, :]) * scale[None, None]           # (F,P,L,3)
+    el = x.new_zeros(F, P, L, d + 1)
+    sm = x.new_zeros(F, P, L)
+    for i in range(d, 0, -1):
+        el[..., i] = sm - i * cf[..., i - 1]
+        sm = sm + cf[..., i - 1]
+    el[..., 0] = sm
+    v = el * (1.0 / (d + 1))
+    up, down = torch.ceil(v) * (d + 1), torch.floor(v) * (d + 1)
+    rem0 = torch.where(up - el < el - down, up, down)
+    ssum = torch.div(rem0.sum(-1).to(torch.int64), d + 1, rounding_mode="trunc")
+    diff = el - rem0
+    rank = torch.zeros(F, P, L, d + 1, dtype=torch.int64)
+    for i in range(d):
+        for j in range(i + 1, d + 1):
+            lt = diff[..., i] < diff[..., j]
+            rank[..., i] += lt
+            rank[..., j] += ~lt
+    rank = rank + ssum[..., None]
+    rem0 = rem0.to(torch.int64)
+    low, high = rank < 0, rank > d
+    rem0 = rem0 + low * (d + 1) - high * (d + 1)
+    rank = rank + low * (d + 1) - high * (d + 1)
+    delta = (el - rem0.to(x.dtype)) * (1.0 / (d + 1))
+    bary = x.new_zeros(F, P, L, d + 2)
+    bary.scatter_add_(-1, d - rank, delta)
+    bary.scatter_add_(-1, d + 1 - rank, -delta)
+    bary[..., 0] = bary[..., 0] + 1.0 + bary[..., d + 1]
+    out = x.new_zeros(F, P, L, lattice.shape[-1])
+    fi = torch.arange(F)[:, None, None].expand(F, P, L)
+    li = torch.arange(L)[None, None, :].expand(F, P, L)
+    for r in range(d + 1):
+        key = rem0[..., :d] + r - (rank[..., :d] > d - r) * (d + 1)               # (F,P,L,3) int64
+        h = torch.zeros(F, P, L, dtype=torch.int64)
+        for i in range(d):
+            h = ((h + key[..., i]) * 2531011) & 0xFFFFFFFF                        # uint32 wrap-around
+        idx = h % T
+        out = out + lattice[fi, li, idx] * bary[..., r:r + 1]
+    return out.reshape(F, P, L * lattice.shape[-1])
 
 
 def field_mlp(h, params, fs: FieldSpec):
@@ -419,6 +500,10 @@ def init_params(fs: FieldSpec, num_fields: int, seed=0, mu=0.0, sigma=4.0,
     for name, shape in fs.param_shapes().items():
         if name == "_encoding._linear.weight":
             v = torch.randn(n, *shape, generator=g) * sigma + mu
+        elif name == "_encoding.lattice_values":
+            v = torch.randn(n, *shape, generator=g) * 0.1
+        elif name == "_encoding.random_shift_per_level":
+            v = torch.randn(n, *shape, generator=g) * 10.0
         elif name.endswith("weight"):
             bound = 1.0 / math.sqrt(shape[1])
             v = (torch.rand(n, *shape, generator=g) * 2 - 1) * bound

@@ -464,3 +464,75 @@ def test_render_image_and_psnr_golden():
     close(dvar, g["dvar"], rtol=5e-4, atol=5e-5)
     p = r.psnr(rgbd[..., :3].cpu(), g["target_rgb"], crop=2)
     assert abs(p - O.psnr(g["rgbd"][..., :3], g["target_rgb"], crop=2)) < 0.01       # well inside the 0.1 dB bar
+
+
+# --------------------------------------------------------- permutohedral hash encoding (parity unpinned)
+PERMUTO = dict(encoding="permuto", nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4)
+
+
+@pytest.mark.parametrize("L_", [1, 2])
+@pytest.mark.parametrize("P", [64, 1000])
+def test_permuto_field_eval_vs_oracle(L_, P):
+    """HIP hash encoding + MLP against the oracle's restatement of the published lattice algorithm
+    (NOT against the reference's CUDA package, which cannot run here: parity unpinned)."""
+    torch.manual_seed(P)
+    F = 2
+    fs = O.FieldSpec(num_layers=L_, **PERMUTO)
+    fc = K.field_cfg(num_layers=L_, **PERMUTO)
+    params = O.init_params(fs, F, seed=3)
+    x = torch.rand(F, P, 3)                                          # already in the unit-cube field frame
+    d_out = torch.randn(F, P, 4)
+    po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
+    out_o = O.field_forward_local(x, po, fs)
+    (out_o * d_out).sum().backward()
+    fc_local = K.field_cfg(num_layers=L_, scale_mode="no", **PERMUTO)
+    pg = {k: v.to(DEV).requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
+    out = ops.field_eval(fc_local, pg, x.to(DEV))
+    close(out, out_o.detach(), rtol=1e-3, atol=1e-4)
+    (out * d_out.to(DEV)).sum().backward()
+    for k in po:
+        if po[k].grad is not None:
+            loose_grad_close(pg[k].grad, po[k].grad, k)
+    # table gradient: every touched entry matches, untouched entries are exactly zero
+    gl, rl = pg["_encoding.lattice_values"].grad.cpu(), po["_encoding.lattice_values"].grad
+    assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
+
+
+def test_permuto_fused_train_step_vs_oracle():
+    """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP."""
+    torch.manual_seed(5)
+    F, R, n_c, n_g = 3, 40, 8, 16
+    fs = O.FieldSpec(num_layers=1, **PERMUTO)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
+    pos, quat, t = synth_target(F, R, seed=17)
+    params = O.init_params(fs, F, seed=9)
+    params["_linears.1.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    loss["combined"].backward()
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PermutohedralEncoding",
+        encoding_kwargs=dict(pos_dim=3, log2_hashmap_size=12, nr_levels=16, nr_feat_per_level=2, coarsest_scale=1,
+                             finest_scale=0.0001, init_scale=0.00001), num_layers=1, dim_out=4, neus_initial_sd=1.0),
+        num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
+    cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, truncation_distance=0.1, field_radius=1.0,
+               freespace_weight=40.0, tsdf_weight=50.0, num_samples_coarse=n_c, num_samples_depth_guided=n_g,
+               learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5)
+    cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5)
+    r = Rr.NeuralGraphRenderer(model, cam, cfg, device=DEV)
+    r.add_fields(F)
+    assert set(model.all_fields_params) >= {"_encoding.lattice_values", "_encoding.random_shift_per_level"}
+    for k, v in params.items():
+        model.all_fields_params[k].copy_(v.to(DEV))
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach(), rtol=2e-3, atol=2e-4)
+    close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
+    for k in po:
+        if po[k].grad is not None:
+            loose_grad_close(res["grads"][k], po[k].grad, k)
+    before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
+    r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
+    assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched

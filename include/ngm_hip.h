@@ -106,7 +106,7 @@ typedef struct ngm_grads {
   int64_t w_stride[NGM_MAX_LAYERS + 1];
   float* b[NGM_MAX_LAYERS + 1];
   int64_t b_stride[NGM_MAX_LAYERS + 1];
-  float* lattice;       /* (F, L, T, 2): accumulated with atomics, zeroed by the backward entry points */
+  float* lattice;       /* (F, L, T, 2): fully overwritten by the backward entry points                */
   int64_t lattice_stride;
 } ngm_grads;
 

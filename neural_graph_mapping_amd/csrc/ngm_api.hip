@@ -236,6 +236,19 @@ static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf) {
   *per_block = per;
   *bpf = (int)((P + per - 1) / per);
 }
+// permutohedral backward scratch: dL/dE per sample and level (8 B) + scaled local position (16 B)
+static int64_t hash_scratch_bytes(const ngm_field_cfg* fc, int F, int64_t P) {
+  if (fc->encoding != NGM_ENC_PERMUTO) return 0;
+  const int64_t part = (int64_t)F * fc->nr_levels * 8 * 2 * ((int64_t)1 << fc->log2_hashmap_size) * 4;
+  return align_up((int64_t)fc->nr_levels * F * P * 8, 256) + align_up((int64_t)F * P * 16, 256) + align_up(part, 256);
+}
+static void carve_hash_scratch(const ngm_field_cfg* fc, int F, int64_t P, char* base, FieldBwdArgs& a) {
+  a.hash_dE = nullptr; a.hash_xyz = nullptr; a.hash_part = nullptr;
+  if (fc->encoding != NGM_ENC_PERMUTO) return;
+  a.hash_dE = reinterpret_cast<float2*>(base);
+  a.hash_xyz = reinterpret_cast<float4*>(base + align_up((int64_t)fc->nr_levels * F * P * 8, 256));
+  a.hash_part = reinterpret_cast<float*>(base + align_up((int64_t)fc->nr_levels * F * P * 8, 256) + align_up((int64_t)F * P * 16, 256));
+}
 static int64_t param_pad(const ngm_field_cfg* fc) {
   int64_t e, w[NGM_MAX_LAYERS + 1], b[NGM_MAX_LAYERS + 1];
   return align_up(ngm_param_offsets(fc, &e, w, b), 64);
@@ -245,7 +258,7 @@ int64_t ngm_field_eval_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64
   if (check_field_cfg(fcfg)) return NGM_E_INVALID;
   int64_t per; int bpf;
   plan_bwd(F, P, &per, &bpf);
-  return (int64_t)F * bpf * param_pad(fcfg) * 4 + 256;
+  return align_up((int64_t)F * bpf * param_pad(fcfg) * 4 + 256, 256) + hash_scratch_bytes(fcfg, F, P) + 256;
 }
 
 int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
@@ -264,12 +277,19 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   plan_bwd(F, P, &a.per_block, &a.blocks_per_field);
   a.p_pad = param_pad(fcfg);
   a.partials = reinterpret_cast<float*>(align_up((int64_t)workspace, 256));
+  carve_hash_scratch(fcfg, F, P, reinterpret_cast<char*>(a.partials) + align_up((int64_t)F * a.blocks_per_field * a.p_pad * 4 + 256, 256), a);
   rc = prep_lattice_grad(fcfg, grads, F, a, (hipStream_t)stream);
   if (rc) return rc;
   rc = ngm_launch_field_bwd(a, a.blocks_per_field * F, (hipStream_t)stream);
   if (rc) return fail(rc, "ngm_field_eval_bwd: no kernel for this (D,H,L)");
   rc = check_launch("ngm_field_eval_bwd");
   if (rc) return rc;
+  if (fcfg->encoding == NGM_ENC_PERMUTO) {
+    rc = ngm_launch_hash_grad(a, (hipStream_t)stream);
+    if (rc) return fail(rc, "permutohedral backward: hash table too large for the LDS-staged scatter");
+    rc = check_launch("ngm_hash_grad");
+    if (rc) return rc;
+  }
   GradReduceArgs g;
   g.fc = *fcfg; g.gr = *grads; g.F = F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
   ngm_launch_grad_reduce(g, (hipStream_t)stream);
@@ -325,7 +345,7 @@ struct RenderPlan {
   int S, rays_per_block, blocks_fwd, waves_fwd, maxs;
   int64_t per_block_bwd; int blocks_per_field_bwd;
   int64_t p_pad;
-  int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, total;
+  int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, total;
 };
 static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {
   RenderPlan p;
@@ -362,6 +382,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     p.off_losspart = o; o = align_up(o + (int64_t)p.blocks_fwd * NGM_NUM_LOSS_SUMS * 4, 256);
     plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
+    p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
   }
   p.total = o + 256;
   return p;
@@ -373,14 +394,14 @@ int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   return plan_render(fcfg, rcfg, F, R, true, train != 0).total;
 }
 
-// permutohedral: the gradient table is accumulated with atomics -> zero it on the stream first
+// permutohedral: validate the gradient table (it is fully overwritten by k_hash_reduce)
 static int prep_lattice_grad(const ngm_field_cfg* fc, const ngm_grads* grads, int F, FieldBwdArgs& a, hipStream_t st) {
   a.lattice_grad = nullptr; a.lattice_grad_stride = 0;
   if (fc->encoding != NGM_ENC_PERMUTO) return NGM_OK;
   if (!grads->lattice) return fail(NGM_E_INVALID, "permutohedral: grads.lattice is NULL");
   const int64_t per = (int64_t)fc->nr_levels * ((int64_t)1 << fc->log2_hashmap_size) * 2;
   if (grads->lattice_stride < per) return fail(NGM_E_INVALID, "permutohedral: grads.lattice_stride too small");
-  for (int f = 0; f < F; ++f) (void)hipMemsetAsync(grads->lattice + (int64_t)f * grads->lattice_stride, 0, per * 4, st);
+  (void)st;   // k_hash_reduce overwrites every table entry: no zero-fill
   a.lattice_grad = grads->lattice; a.lattice_grad_stride = grads->lattice_stride;
   return NGM_OK;
 }
@@ -458,12 +479,19 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
+  carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;
   e = ngm_launch_field_bwd(a, a.blocks_per_field * a.F, st);
   if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_field_bwd");
   if (e) return e;
+  if (fcfg->encoding == NGM_ENC_PERMUTO) {
+    e = ngm_launch_hash_grad(a, st);
+    if (e) return fail(e, "permutohedral backward: hash table too large for the LDS-staged scatter");
+    e = check_launch("ngm_hash_grad");
+    if (e) return e;
+  }
   GradReduceArgs g;
   g.fc = *fcfg; g.gr = *grads; g.F = rays->F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
   ngm_launch_grad_reduce(g, st);

@@ -295,7 +295,18 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
         if constexpr (HASH) {
           f32x16 dE[MI];
           layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
-          scatter_hash_grad(sm + LY::ENCW, hc, hi, x, y, z, dE[0], valid);
+          // hand dL/dE to k_hash_grad (level-major, coalesced); table scatter happens there in LDS
+          if (valid) {
+            const int64_t g = (int64_t)f * a.P + n, NP = (int64_t)a.F * a.P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) {
+                const int level = 4 * q + 2 * hi + p;
+                if (level < hc.nlev) a.hash_dE[level * NP + g] = make_float2(dE[0][4 * q + 2 * p], dE[0][4 * q + 2 * p + 1]);
+              }
+            if (hi == 0) a.hash_xyz[g] = make_float4(x, y, z, 0.f);
+          }
         }
         if (ENC_GRAD) {
           f32x16 dE[MI];
@@ -468,4 +479,114 @@ int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   if (s.MI == 1 && s.MH == 1 && s.L == 2) return launch_bwd<1, 1, 2>(a, blocks, st);
 #endif
   return NGM_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Permutohedral table gradient: one workgroup per (field, level, sample chunk).  The level's table
+// gradient (T x 2 floats) lives in LDS; every sample adds its 4 vertices with LDS atomics; the table
+// is then flushed once with global float atomics (chunks <= 8 adds per entry instead of one global
+// atomic per sample-vertex).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long to_fix(float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); }
+
+struct HashGradArgs {
+  ngm_field_cfg fc;
+  ngm_params pr;
+  int F; int64_t P; int chunks; int64_t per_chunk;
+  const float2* dE; const float4* xyz;
+  float* gtab; int64_t gstride;
+  float* part;     // [F][L][chunks][2T] per-workgroup partial tables (plain stores, reduced in fixed order)
+};
+
+__global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
+  // Q23.40 fixed point in LDS: integer LDS atomics run at full bank rate (fp32 LDS atomics measured ~2.5
+  // cycles per LANE regardless of address) and make the table gradient order-independent -> deterministic.
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+  const int chunk = blockIdx.x, level = blockIdx.y, f = blockIdx.z;
+  const int T = 1 << a.fc.log2_hashmap_size;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) tab[i] = 0ull;
+  float lp[8];
+  {
+    const float* hs = a.pr.shift + row * a.pr.shift_stride + 3 * level;
+    lp[0] = a.fc.level_scale[3 * level]; lp[1] = a.fc.level_scale[3 * level + 1]; lp[2] = a.fc.level_scale[3 * level + 2];
+    lp[3] = 0.f; lp[4] = hs[0]; lp[5] = hs[1]; lp[6] = hs[2]; lp[7] = 0.f;
+  }
+  __syncthreads();
+  const int64_t NP = (int64_t)a.F * a.P;
+  const int64_t beg = (int64_t)chunk * a.per_chunk, end = min(a.P, beg + a.per_chunk);
+  const uint32_t mask = (uint32_t)T - 1u;
+  const int lane = threadIdx.x & 63;
+  for (int64_t s0 = beg; s0 < end; s0 += blockDim.x) {      // trip count uniform across the wave (shuffles inside)
+    const int64_t s = s0 + threadIdx.x;
+    const bool valid = s < end;
+    uint32_t idx[4] = {0u, 0u, 0u, 0u}; float bw[4] = {0.f, 0.f, 0.f, 0.f};
+    float2 d = make_float2(0.f, 0.f);
+    if (valid) {
+      const int64_t g = (int64_t)f * a.P + s;
+      const float4 p = a.xyz[g];
+      d = a.dE[level * NP + g];
+      permuto_simplex(p.x, p.y, p.z, lp, mask, idx, bw);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // consecutive lanes = consecutive samples of a ray: at coarse levels they hit the same vertex in long
+      // runs, which would serialise the LDS atomic unit (measured 163 LDS cycles per ds_add_f32).  Reduce
+      // each run inside the wave first (segmented scan) and let its last lane issue ONE atomic.
+      const uint32_t key = valid ? idx[r] : (0x80000000u | (uint32_t)lane);
+      const uint32_t prev = __shfl_up(key, 1, 64);
+      const bool head = (lane == 0) || (key != prev);
+      const unsigned long long hm = __ballot(head);
+      float v0 = d.x * bw[r], v1 = d.y * bw[r];
+      if (__popcll(hm) <= 40) {                                   // wave-uniform
+        const unsigned long long below = hm & ((2ull << lane) - 1ull);
+        const int k = lane - (63 - __clzll(below));
+        v0 = seg_scan_add(v0, k, lane);
+        v1 = seg_scan_add(v1, k, lane);
+        const bool tail = (lane == 63) || ((hm >> (lane + 1)) & 1ull);
+        if (tail && valid) { atomicAdd(&tab[2 * idx[r]], to_fix(v0)); atomicAdd(&tab[2 * idx[r] + 1], to_fix(v1)); }
+      } else if (valid) {
+        atomicAdd(&tab[2 * idx[r]], to_fix(v0));
+        atomicAdd(&tab[2 * idx[r] + 1], to_fix(v1));
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = a.part + (((int64_t)f * a.fc.nr_levels + level) * a.chunks + chunk) * 2 * T;
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) dst[i] = (float)((double)(long long)tab[i] * (1.0 / 1099511627776.0));
+}
+
+// gtab[f][level][i] = sum over chunks (fixed order): overwrites -> no zero-fill of the gradient needed
+__global__ void k_hash_reduce(HashGradArgs a) {
+  const int T = 1 << a.fc.log2_hashmap_size;
+  const int level = blockIdx.y, f = blockIdx.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index
+  if (i >= T / 2) return;
+  const float4* src = reinterpret_cast<const float4*>(a.part + ((int64_t)f * a.fc.nr_levels + level) * a.chunks * 2 * T);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < a.chunks; ++c) {
+    const float4 v = src[(int64_t)c * (T / 2) + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(a.gtab + (int64_t)f * a.gstride + (int64_t)level * T * 2)[i] = s;
+}
+
+int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st) {
+  HashGradArgs a;
+  a.fc = fb.fc; a.pr = fb.pr; a.F = fb.F; a.P = fb.P; a.dE = fb.hash_dE; a.xyz = fb.hash_xyz;
+  a.gtab = fb.lattice_grad; a.gstride = fb.lattice_grad_stride;
+  const int T = 1 << fb.fc.log2_hashmap_size;
+  const size_t lds = (size_t)2 * T * sizeof(unsigned long long);
+  if (lds > 150 * 1024) return NGM_E_UNSUPPORTED;
+  int chunks = (int)((4 * 256 + (int64_t)fb.F * fb.fc.nr_levels - 1) / ((int64_t)fb.F * fb.fc.nr_levels));   // ~4 blocks / CU
+  const int64_t max_chunks = (fb.P + 4095) / 4096;
+  if (chunks > max_chunks) chunks = (int)max_chunks;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 8) chunks = 8;
+  a.chunks = chunks; a.per_chunk = (fb.P + chunks - 1) / chunks;
+  a.part = fb.hash_part;
+  (void)hipFuncSetAttribute((const void*)k_hash_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_hash_grad, dim3(chunks, fb.fc.nr_levels, fb.F), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(k_hash_reduce, dim3((T / 2 + 255) / 256, fb.fc.nr_levels, fb.F), dim3(256), 0, st, a);
+  return 0;
 }

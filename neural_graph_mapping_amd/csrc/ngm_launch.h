@@ -58,9 +58,13 @@ struct FieldBwdArgs {
   const float4* d_out;    // (F,P) float4: dL/d(r,g,b,geometry) raw MLP outputs
   float* partials;        // (F*blocks_per_field, P_pad) per-workgroup gradient partial sums
   int64_t p_pad;          // padded parameter count per field (floats)
-  float* lattice_grad;    // permutohedral: (F, L, T, 2) gradient table (atomics), stride between fields
+  float* lattice_grad;    // permutohedral: (F, L, T, 2) gradient table, stride between fields
   int64_t lattice_grad_stride;
+  float2* hash_dE;        // permutohedral: [L][F*P] dL/d(level features) per sample (level-major: coalesced)
+  float4* hash_xyz;       // permutohedral: [F*P] scaled field-local sample positions
+  float* hash_part;       // permutohedral: [F][L][8][2T] partial gradient tables
 };
+int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st);
 
 struct GradReduceArgs {
   ngm_field_cfg fc;

@@ -276,6 +276,10 @@ def init_params_np(fc, F, seed=0, sigma=4.0):
     for n, shp in K.param_shapes(fc).items():
         if n == "_encoding._linear.weight":
             out[n] = (rng.standard_normal((F,) + shp) * sigma).astype(np.float32)
+        elif n == "_encoding.lattice_values":
+            out[n] = (rng.standard_normal((F,) + shp) * 0.1).astype(np.float32)
+        elif n == "_encoding.random_shift_per_level":
+            out[n] = (rng.standard_normal((F,) + shp) * 10).astype(np.float32)
         else:
             fan_in = shp[1] if len(shp) == 2 else K.param_shapes(fc)[n.replace("bias", "weight")][1]
             b = 1.0 / np.sqrt(fan_in)
@@ -284,9 +288,10 @@ def init_params_np(fc, F, seed=0, sigma=4.0):
     return out
 
 
-def check_time(F=8, R=512, S_c=64, S_g=64, iters=10):
+def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
     L = K.lib()
-    fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    fc = (K.field_cfg(encoding="permuto", num_layers=1) if hash_enc
+          else K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2))
     rc = K.render_cfg(num_samples_coarse=S_c, num_samples_guided=S_g, **NRGBD)
     b = synth_batch(F, R, S_c, S_g)
     params = init_params_np(fc, F)
@@ -323,7 +328,7 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10):
     n = F * R * (S_c + S_g)
     tf /= iters; tb /= iters
     gn = {k: float(np.abs(v.numpy()).max()) for k, v in gdev.items()}
-    record(f"time_F{F}_R{R}_S{S_c + S_g}", fwd_ms=round(tf, 4), bwd_ms=round(tb, 4),
+    record(f"time_{'hash' if hash_enc else 'fourier'}_F{F}_R{R}_S{S_c + S_g}", fwd_ms=round(tf, 4), bwd_ms=round(tb, 4),
            Msamples_per_s=round(n / (tf + tb) / 1e3, 1), loss=float(lout.numpy()[0]),
            sums=[float(x) for x in sums.numpy()[:8]], grad_absmax=gn,
            finite=bool(all(np.isfinite(v.numpy()).all() for v in gdev.values())))
@@ -384,7 +389,8 @@ if __name__ == "__main__":
     for c in todo:
         try:
             {"sampler": check_sampler, "field": check_field, "quad": check_quad, "train": check_train,
-             "time": check_time, "sampler_random": lambda: (check_sampler_random(7, 5), check_sampler_random(64, 64),
+             "time": check_time, "time_hash": lambda: (check_time(hash_enc=True), check_time(F=32, R=512, S_c=8, S_g=16, hash_enc=True)),
+             "sampler_random": lambda: (check_sampler_random(7, 5), check_sampler_random(64, 64),
                                                              check_sampler_random(4, 4))}[c]()
         except Exception:
             traceback.print_exc()

@@ -158,12 +158,12 @@ def main():
     r.set_field_poses(pos.to(dev), quat.to(dev))
     tgt = type(tgt_cpu)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tgt_cpu])
     tgt = tgt._replace(field_ids=torch.arange(F_PER_GPU, device=dev))      # local slots of this rank's fields
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():
         r.process_group = torch.distributed.group.WORLD
 
     # single-GPU: the whole iteration (5 kernels + bookkeeping) is captured once into a hipGraph and replayed;
     # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
-    use_graph = (world == 1) and not args.eager
+    use_graph = (world == 1) and not args.eager and not torch.distributed.is_initialized()
     replay = r.capture_iteration(tgt, seed=7) if use_graph else None
 
     def step(i):
@@ -233,7 +233,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -152,6 +152,37 @@ class NeuralGraphRenderer:
             new_state[k] = {"exp_avg": m, "exp_avg_sq": s}
         self._optim_state = new_state
 
+    # -- checkpoint interchange (rm.py:2147-2173) ------------------------------------------------
+    def save_model(self, path: str) -> None:
+        """torch.save of {map_dict, all_fields_params, state_dict}: the reference's checkpoint layout
+        (optimizer moments are not saved there either)."""
+        torch.save({"map_dict": self._global_map_dict, "all_fields_params": self._model.all_fields_params,
+                    "state_dict": self._model.state_dict()}, path)
+
+    def load_model(self, path: str) -> None:
+        ck = torch.load(path, map_location=self._device)
+        self._model.load_state_dict(ck["state_dict"])
+        self._model.all_fields_params = {k: v.to(self._device) for k, v in ck["all_fields_params"].items()}
+        self._global_map_dict = ck["map_dict"]
+        self._optim_state = {k: {"exp_avg": torch.zeros_like(v), "exp_avg_sq": torch.zeros_like(v)}
+                             for k, v in self._model.all_fields_params.items()}
+
+    @torch.no_grad()
+    def evaluate_points(self, points: torch.Tensor, block_size: Optional[int] = None) -> torch.Tensor:
+        """kNN-blended field values at arbitrary world points (the dense-grid evaluation that
+        _extract_mesh feeds to marching cubes, rm.py:2255-2261, 2320-2332), in blocks."""
+        num = self._global_map_dict["num"]
+        pos = self._global_map_dict["positions"][:num]
+        quat = self._global_map_dict["orientations"][:num]
+        params = {k: v for k, v in self._model.all_fields_params.items() if k != "_neus_sd"}
+        m = self._model
+        lead = points.shape[:-1]
+        pts = points.reshape(-1, 3)
+        block = int(block_size or self._config.get("block_size", 3000000))
+        outs = [ops.field_eval_knn(self._fc, params, pts[s:s + block], pos, quat, m._num_knn, m._distance_factor,
+                                   m._outside_value) for s in range(0, pts.shape[0], block)]
+        return torch.cat(outs).reshape(*lead, 4)
+
     # -- reference-compatible API --------------------------------------------------------------
     def quadrature(self, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):
         return ops.quadrature(self._rc_train, sample_colors, sample_geometries, sample_distances, sample_depths,

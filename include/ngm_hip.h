@@ -304,6 +304,11 @@ int ngm_profile_enable(int32_t on);
 int ngm_profile_reset(void);
 int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 
+/* Debug: with NGM_PHASE_TIMING set in the environment the backward kernel's first wave records its
+ * s_memtime cycles per phase (prologue, inputs, encode, forward, output layer, staging, wgrad, dgrad,
+ * encoding grads, relu mask, -, epilogue, total); this copies the 16 counters of the last launch. */
+int ngm_debug_phase_cycles(unsigned long long* out16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libngm_hip.so")
-SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_composite.hip", "ngm_knn.hip"]
+SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_field_bwd16.hip", "ngm_composite.hip",
+           "ngm_knn.hip"]
 HEADERS = ["ngm_device.h", "ngm_field.h", "ngm_launch.h", "../../include/ngm_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -52,6 +53,7 @@ def build(fast=False, force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     flags = FLAGS + (["-DNGM_FAST_BUILD"] if fast else [])
+    flags += os.environ.get("NGM_HIPCC_EXTRA", "").split()      # e.g. -DNGM_PHASE_TIMING (debug builds)
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))

@@ -2,6 +2,7 @@
 // workspace carving.  No allocation, no synchronisation; everything is enqueued on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/ngm_hip.h"
@@ -77,6 +78,20 @@ static void prof_drain() {
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
+}
+// prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
+static unsigned long long* g_debug_cycles = nullptr;
+static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
+  static const bool force32 = getenv("NGM_BWD32") != nullptr;
+  static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
+  a.debug_cycles = nullptr;
+  if (timing) {
+    if (!g_debug_cycles) { (void)hipMalloc(&g_debug_cycles, 16 * sizeof(unsigned long long)); (void)hipMemset(g_debug_cycles, 0, 128); }
+    a.debug_cycles = g_debug_cycles;
+  }
+  int e = force32 ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd16(a, blocks, st);
+  if (e == NGM_E_UNSUPPORTED) e = ngm_launch_field_bwd(a, blocks, st);
+  return e;
 }
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -171,6 +186,12 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches) {
   if (total_ms) *total_ms = g_prof_ms[kernel_id];
   if (launches) *launches = g_prof_n[kernel_id];
   return NGM_OK;
+}
+
+int ngm_debug_phase_cycles(unsigned long long* out16) {
+  if (!g_debug_cycles || !out16) return NGM_E_INVALID;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(out16, g_debug_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
 }
 
 int ngm_device_info(int* ncu, char* name, int name_len) {
@@ -280,7 +301,7 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   carve_hash_scratch(fcfg, F, P, reinterpret_cast<char*>(a.partials) + align_up((int64_t)F * a.blocks_per_field * a.p_pad * 4 + 256, 256), a);
   rc = prep_lattice_grad(fcfg, grads, F, a, (hipStream_t)stream);
   if (rc) return rc;
-  rc = ngm_launch_field_bwd(a, a.blocks_per_field * F, (hipStream_t)stream);
+  rc = launch_bwd_any(a, a.blocks_per_field * F, (hipStream_t)stream);
   if (rc) return fail(rc, "ngm_field_eval_bwd: no kernel for this (D,H,L)");
   rc = check_launch("ngm_field_eval_bwd");
   if (rc) return rc;
@@ -482,7 +503,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;
-  e = ngm_launch_field_bwd(a, a.blocks_per_field * a.F, st);
+  e = launch_bwd_any(a, a.blocks_per_field * a.F, st);
   if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_field_bwd");
   if (e) return e;

@@ -299,6 +299,7 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const flo
         for (int mo = 0; mo < MOUT; ++mo)
           abuf[(g + 1) & 1][rr][mo] = Wl[((mo * MIN + mi1) * 16 + r1 + rr) * 2 * NGM_WGS];
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this group's MFMAs
     const int mi = (4 * g) / 16, r0 = (4 * g) % 16;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)

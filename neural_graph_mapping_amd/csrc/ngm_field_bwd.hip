@@ -83,6 +83,7 @@ __device__ __forceinline__ void layer_dgrad(const float* __restrict__ W, int lan
         for (int mi = 0; mi < MIN; ++mi)
           abuf[(g + 1) & 1][rr][mi] = Wl[(mo1 * MIN + mi) * 16 * 2 * NGM_WGS + frow(r1 + rr, 0)];
     }
+    __builtin_amdgcn_sched_barrier(0);
     const int mo = (4 * g) / 16, r0 = (4 * g) % 16;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
@@ -119,6 +120,7 @@ __device__ __forceinline__ void layer_wgrad(const float* __restrict__ dbuf, int 
         for (int mi = 0; mi < MIN; ++mi) bv[(g + 1) & 1][tt][mi] = xl[(4 * (g + 1) + tt) * xstr + 32 * mi];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll

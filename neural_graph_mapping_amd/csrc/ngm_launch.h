@@ -63,6 +63,7 @@ struct FieldBwdArgs {
   float2* hash_dE;        // permutohedral: [L][F*P] dL/d(level features) per sample (level-major: coalesced)
   float4* hash_xyz;       // permutohedral: [F*P] scaled field-local sample positions
   float* hash_part;       // permutohedral: [F][L][8][2T] partial gradient tables
+  unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
 };
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st);
 
@@ -112,6 +113,7 @@ struct StashBwdArgs {
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_field_bwd16(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 16-sample tiles, 8 waves; NGM_E_UNSUPPORTED -> fall back
 int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st);

@@ -327,6 +327,14 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
         tf += e[0].elapsed_ms(e[1]); tb += e[1].elapsed_ms(e[2])
     n = F * R * (S_c + S_g)
     tf /= iters; tb /= iters
+    if os.environ.get("NGM_PHASE_TIMING"):
+        buf = (C.c_ulonglong * 16)()
+        L.ngm_debug_phase_cycles.argtypes = [C.c_void_p]
+        if L.ngm_debug_phase_cycles(buf) == 0:
+            names = ["prologue", "inputs", "encode", "fwd", "outlayer", "stage+colsum", "wgrad", "dgrad", "encgrad",
+                     "relumask", "-", "epilogue", "TOTAL"]
+            tot = buf[12] or 1
+            print("phase cycles (wave 0, block 0):", {n: (int(buf[i]), round(100 * buf[i] / tot, 1)) for i, n in enumerate(names)})
     gn = {k: float(np.abs(v.numpy()).max()) for k, v in gdev.items()}
     record(f"time_{'hash' if hash_enc else 'fourier'}_F{F}_R{R}_S{S_c + S_g}", fwd_ms=round(tf, 4), bwd_ms=round(tb, 4),
            Msamples_per_s=round(n / (tf + tb) / 1e3, 1), loss=float(lout.numpy()[0]),

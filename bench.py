@@ -224,7 +224,12 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_field_bwd.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            res["roofline"] = dict(bound="mfma", kernel="k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=achieved,
+            from neural_graph_mapping_amd import _capi
+            variant = _capi.lib().ngm_debug_last_bwd_variant()
+            kname = {0: "k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32, forward recompute)",
+                     1: "k_field_bwd16<4,4,2> (v_mfma_f32_16x16x4_f32, forward recompute)",
+                     2: "k_field_bwd16s<2> (v_mfma_f32_16x16x4_f32, activations from the forward's stash)"}.get(variant, "?")
+            res["roofline"] = dict(bound="mfma", kernel=kname, achieved=achieved,
                                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
                                    traffic=traffic, avg_launch_us=fb["avg_us"], launches_timed=fb["launches"],
                                    timing="HIP events on the launch stream, instrumented pass of the same steps",

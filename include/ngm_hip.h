@@ -309,6 +309,11 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
  * encoding grads, relu mask, -, epilogue, total); this copies the 16 counters of the last launch. */
 int ngm_debug_phase_cycles(unsigned long long* out16);
 
+/* Debug: which MLP backward kernel the last ngm_render_bwd* / ngm_field_eval_bwd call launched:
+ * 0 = k_field_bwd (32-sample tiles, forward recompute), 1 = k_field_bwd16 (16-sample tiles, recompute),
+ * 2 = k_field_bwd16s (16-sample tiles, hidden activations read from the forward's stash), -1 = none yet. */
+int ngm_debug_last_bwd_variant(void);
+
 #ifdef __cplusplus
 }
 #endif

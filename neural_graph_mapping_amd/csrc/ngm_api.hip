@@ -81,6 +81,7 @@ static int fail(int code, const char* msg) {
 }
 // prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
 static unsigned long long* g_debug_cycles = nullptr;
+static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
   static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
@@ -89,8 +90,12 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
     if (!g_debug_cycles) { (void)hipMalloc(&g_debug_cycles, 16 * sizeof(unsigned long long)); (void)hipMemset(g_debug_cycles, 0, 128); }
     a.debug_cycles = g_debug_cycles;
   }
-  int e = force32 ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd16(a, blocks, st);
-  if (e == NGM_E_UNSUPPORTED) e = ngm_launch_field_bwd(a, blocks, st);
+  // order of preference: stashed activations (no forward recompute) -> 16-sample-tile recompute ->
+  // 32-sample-tile recompute
+  int e = (force32 || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd16s(a, blocks, st);
+  g_last_bwd_variant = 2;
+  if (e == NGM_E_UNSUPPORTED && !force32) { e = ngm_launch_field_bwd16(a, blocks, st); g_last_bwd_variant = 1; }
+  if (e == NGM_E_UNSUPPORTED) { e = ngm_launch_field_bwd(a, blocks, st); g_last_bwd_variant = 0; }
   return e;
 }
 static int check_launch(const char* what) {
@@ -187,6 +192,8 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches) {
   if (launches) *launches = g_prof_n[kernel_id];
   return NGM_OK;
 }
+
+int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 
 int ngm_debug_phase_cycles(unsigned long long* out16) {
   if (!g_debug_cycles || !out16) return NGM_E_INVALID;
@@ -366,15 +373,26 @@ struct RenderPlan {
   int S, rays_per_block, blocks_fwd, waves_fwd, maxs;
   int64_t per_block_bwd; int blocks_per_field_bwd;
   int64_t p_pad;
-  int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, total;
+  int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
 };
+// The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
+// has a kernel that consumes them: 49..64-wide hidden layers, 1-2 layers, non-hash encoding.  The
+// backward then skips its forward recompute.  NGM_NO_ACT_STASH=1 turns it off (recompute; saves
+// 256 B * L per sample of workspace).
+static bool act_stash_ok(const ngm_field_cfg* fc) {
+  static const bool off = getenv("NGM_NO_ACT_STASH") != nullptr;
+  if (off) return false;
+  const int th = (fc->dim_hidden + 15) / 16, ti = (fc->dim_enc + 15) / 16;
+  return fc->encoding != NGM_ENC_PERMUTO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2;
+}
+
 static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {
   RenderPlan p;
   memset(&p, 0, sizeof(p));
   p.S = rc->num_samples_coarse + (guided ? rc->num_samples_guided : 0);
   const int ncu = num_cus();
-  // forward: one workgroup per CU-slot; 8 waves (2 per SIMD, VALU of one hides under the MFMAs of the
-  // other) unless the per-wave LDS sample planes would not fit in 160 KiB, then 4 waves
+  // forward: one workgroup per CU-slot; 8 waves (2 per SIMD: latency hiding) unless the per-wave LDS
+  // sample planes would not fit in 160 KiB, then 4 waves
   int waves = 8;
   for (;;) {
     int ch = (ncu + F - 1) / F;
@@ -404,6 +422,10 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
+    if (act_stash_ok(fc)) {
+      p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
+      p.off_act = o; o = align_up(o + fc->num_layers * p.act_layer_stride * 4 + 64, 256);
+    }
   }
   p.total = o + 256;
   return p;
@@ -468,6 +490,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
     a.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
     a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
     a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
+    if (p.act_layer_stride) { a.act = reinterpret_cast<float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
   }
   e = ngm_launch_render_fwd(a, p.blocks_fwd, (hipStream_t)stream);
   if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");
@@ -501,6 +524,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
+  if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;
   e = launch_bwd_any(a, a.blocks_per_field * a.F, st);

@@ -342,12 +342,49 @@ __device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, 
   }
 }
 
+// Hidden-activation stash written by the training forward and consumed by the backward kernel (which
+// then skips the forward recompute: one third of its MFMA work).  fp32, 32*MH floats per sample and layer,
+// tiled so that the forward's stores are fully coalesced:
+//     act[layer][tile = g >> 5][chunk c = feature >> 2][r = g & 31][4 floats],   g = global flat sample index
+// i.e. 16-byte granules (4 consecutive features of one sample); the 32 lanes of a C-layout half-wave hold
+// one chunk of 32 consecutive samples = 512 contiguous bytes per store instruction and half.
+struct ActStash {
+  float* base;            // NULL: nothing is stored
+  int64_t layer_stride;   // floats between layers
+  int64_t g0;             // global sample index of lane 0 of this 64-sample step
+  int nvalid;             // samples of this step that exist (lanes >= nvalid store nothing)
+};
+#define NGM_ACT_CHUNKS(MH) (8 * (MH))     // 16-byte chunks per sample
+
+// C layout: lane (n = lane & 31, hi) holds, for sample column n of tile nt, features
+// 32m + 8g + 4hi + {0..3} in registers 4g..4g+3 -> chunk 8m + 2g + hi, one 16-byte store per (nt, m, g).
+template <int MH, int NT>
+__device__ __forceinline__ void act_store(const ActStash& st, int layer, int lane, const f32x16 (&H)[NT][MH]) {
+  const int n = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int s = 32 * nt + n;
+    if (s < st.nvalid) {
+      const int64_t g = st.g0 + s;
+      float* p = st.base + layer * st.layer_stride + (((g >> 5) * NGM_ACT_CHUNKS(MH) + hi) * 32 + (g & 31)) * 4;
+#pragma unroll
+      for (int m = 0; m < MH; ++m)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(p + (8 * m + 2 * g4) * 128) =
+              make_float4(H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]);
+    }
+  }
+}
+
 // Full forward MLP for NT tiles: E (encoding, C layout) -> partial outputs.  Keeps the last hidden
 // activations in Hlast (needed by the backward kernel for the ReLU mask / output-layer gradient).
 template <int MI, int MH, int L, int NT>
-__device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH]) {
+__device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
+                                        const ActStash* st = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
+  if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
     f32x16 T[NT][MH];
@@ -356,13 +393,15 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
+    if (st && st->base) act_store<MH, NT>(*st, l, lane, Hlast);
   }
 }
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
 template <int MI, int MH, int L, bool NEED_COS, bool HASH = false>
-__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr) {
+__device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
+                                          const ActStash* st = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
@@ -377,7 +416,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
   }
   f32x16 Hl[2][MH];
-  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl);
+  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl, st);
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
   float o[4];

@@ -1,0 +1,471 @@
+// Backward of encoding + MLP for the fused training step, activations taken from the forward's stash
+// (gfx950, 16-sample tiles on v_mfma_f32_16x16x4_f32, 8 waves per workgroup).
+//
+// k_field_bwd16 (ngm_field_bwd16.hip) recomputes the hidden layers of every sample before it can
+// differentiate them: one third of its matrix-core work.  On gfx950 fp32 MFMA and VALU instructions of
+// the waves of one SIMD do not overlap (tools/micro/coexec.hip: a wave of v_mfma_f32_16x16x4_f32 next to
+// a wave of v_fma_f32 takes the SUM of their solo times), so a SIMD's time is the sum of everything
+// it issues and the recompute cannot hide behind anything.  The training forward therefore writes the
+// post-ReLU hidden activations (64 floats per sample and layer, ActStash in ngm_field.h) and this
+// kernel reads them back: 256 instead of 384 MFMAs per 16-sample tile.
+//
+// Data movement: the activation rows, the ray-table entry, d_out and t of the NEXT tile travel HBM -> LDS
+// with global_load_lds_dwordx4 while the current tile is being differentiated (no staging registers;
+// issued from inline asm so that hipcc does not guard every later ds_read with vmcnt(0); the consumer
+// waits with explicit counted s_waitcnt).  LDS tiles use a blocked layout the DMA can fill linearly:
+//   tile[16 samples][64 features] = 4 blocks of (4 rows x 64 floats) + 8 floats of padding per block;
+//   one DMA instruction (64 lanes x 16 B = 1 KiB) fills one block from 4 consecutive stash rows.
+// The weight-gradient MFMAs take k-step t = samples {4b + t : b = 0..3}, one row from every block, so
+// the 8-float block padding spreads the four rows over all 32 banks (2 lanes per bank = the minimum).
+//
+// Supported: dim_enc and dim_hidden in 49..64 (4 tiles each), 1-2 hidden layers, Fourier / NeRF / no
+// encoding, ray mode.  Everything else keeps the recompute kernel.
+#include "ngm_bwd16.h"
+
+// Opaque copy of the lane id: address arithmetic derived from it is redone inside each phase instead of
+// being hoisted out of the tile loop, where a few dozen loop-invariant LDS offsets would each pin a VGPR
+// (the two 64-register accumulator sets leave ~128 registers for everything else).
+__device__ __forceinline__ int phase_lane(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+#define BK_STRIDE 264                     // floats per 4-row block: 4 * 64 + 8
+#define BK_TILE (4 * BK_STRIDE)           // one 16 x 64 tile
+__device__ __forceinline__ int bk_idx(int n, int ft) { return (n >> 2) * BK_STRIDE + (n & 3) * 64 + ft; }
+
+template <int L>
+struct Lds16s {
+  using W = Lds16<4, 4, L>;               // weight region (same layout as the recompute kernel)
+  static constexpr int XE = 0;            // encoding tile
+  static constexpr int act(int l) { return l * BK_TILE; }   // input tile of layer l (l = 1..L); act(L) doubles as dY staging
+  static constexpr int PBUF = (L + 1) * BK_TILE;             // [16][4] xyz
+  static constexpr int OBUF = PBUF + 64;                     // [16][4] d_out
+  static constexpr int INBUF = OBUF + 64;                    // input DMA landing buffer, float4 [4][16]
+  static constexpr int WAVE_TOTAL = INBUF + 256;
+  static constexpr int EPI = B16_WAVES * 4 * 4 * 64;         // epilogue staging
+  static constexpr int BODY = B16_WAVES * WAVE_TOTAL;
+  static constexpr int TOTAL = W::WTOTAL + (BODY > EPI ? BODY : EPI);
+};
+
+// ---- blocked-tile helpers, lane (j = lane & 15, q = lane >> 4) --------------------------------------
+__device__ __forceinline__ void store16b(float* buf, int lane, const f32x4 (&V)[4]) {
+  lane = phase_lane(lane);
+  const int j = lane & 15, q = lane >> 4;
+  float* p = buf + bk_idx(j, 4 * q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) *reinterpret_cast<float4*>(p + 16 * m) = make_float4(V[m][0], V[m][1], V[m][2], V[m][3]);
+}
+__device__ __forceinline__ void load16b(const float* buf, int lane, f32x4 (&V)[4]) {
+  lane = phase_lane(lane);
+  const int j = lane & 15, q = lane >> 4;
+  const float* p = buf + bk_idx(j, 4 * q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 16 * m);
+    V[m][0] = v.x; V[m][1] = v.y; V[m][2] = v.z; V[m][3] = v.w;
+  }
+}
+
+// Weight-gradient accumulate with the accumulator pinned to the AGPR half of the register file.  The
+// 2 x 64 accumulator registers live for the whole kernel; left to the allocator (VGPR-form MFMA, one
+// 256-register pool) it spills a third of them inside the tile loop, every spill store serialised
+// behind its MFMA.  "+a" makes them AGPRs: 128 AGPRs for the accumulators, 128 VGPRs for the rest.
+// No software wait states are needed: an accumulator is only consumed as SrcC of the same opcode
+// (back-to-back accumulate) and by the epilogue, a barrier away.
+__device__ __forceinline__ void mfma16_agpr(f32x4& acc, float a, float b) {
+#ifndef NGM_S_AGPRFORM
+  acc = mfma16(a, b, acc);
+#else
+  asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#endif
+}
+
+// Data-gradient MFMAs in explicit VGPR form.  Once a function uses AGPRs hipcc selects the AGPR form for
+// every builtin MFMA, and dX's 16 destination registers would then compete with the 128 accumulator
+// AGPRs (it spilled 64 of them per tile).  The compiler cannot see into the asm, so the MFMA -> VALU read
+// wait states (11 for an 8-pass MFMA) are supplied by hand: mfma_results_ready() after the last one.
+__device__ __forceinline__ f32x4 mfma16_v0(float a, float b) {
+  f32x4 d;
+  asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ void mfma16_v(f32x4& acc, float a, float b) {
+  asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_ready(f32x4 (&d)[4]) {
+  asm volatile("s_nop 15" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
+
+// dX = W^T dY: k-step (mo, r) uses A[i][k=q] = W[16mo + 4q + r][16mi + i] = block(mo,mi)[row 4(i&3)+(i>>2)][4q + r]
+template <int BLK>
+__device__ __forceinline__ void dgrad16v(const float* __restrict__ W, int lane, const f32x4 (&dY)[4], f32x4 (&dX)[4]) {
+  lane = phase_lane(lane);
+  const int i = lane & 15, q = lane >> 4;
+  const float* Wl = W + (4 * (i & 3) + (i >> 2)) * B16_RS + 4 * q;
+  constexpr int GK = 2, NG = 16 / GK;      // operand groups of 2 k-steps, double buffered
+  float abuf[2][4][GK];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int u = 0; u < GK; ++u) abuf[0][mi][u] = Wl[mi * BLK + u];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int u = 0; u < GK; ++u) {
+          const int k = (g + 1) * GK + u, mo = k >> 2, r = k & 3;
+          abuf[(g + 1) & 1][mi][u] = Wl[(mo * 4 + mi) * BLK + r];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < GK; ++u)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int k = g * GK + u;
+        if (k == 0) dX[mi] = mfma16_v0(abuf[0][mi][0], dY[0][0]);
+        else mfma16_v(dX[mi], abuf[g & 1][mi][u], dY[k >> 2][k & 3]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  mfma_results_ready(dX);
+}
+
+// dW[16mo + o][16mi + c] += sum_s dY[s][o] X[s][c]; k-step t takes samples 4b + t (b = lane >> 4)
+__device__ __forceinline__ void wgrad16b(const float* __restrict__ dbuf, const float* __restrict__ xbuf, int lane,
+                                         f32x4 (&acc)[4][4]) {
+  lane = phase_lane(lane);
+  const int i = lane & 15, q = lane >> 4;
+  const float* dl = dbuf + q * BK_STRIDE + i;
+  const float* xl = xbuf + q * BK_STRIDE + i;
+  float av[2][4], bv[2][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { av[0][m] = dl[16 * m]; bv[0][m] = xl[16 * m]; }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t + 1 < 4) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { av[(t + 1) & 1][m] = dl[64 * (t + 1) + 16 * m]; bv[(t + 1) & 1][m] = xl[64 * (t + 1) + 16 * m]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) mfma16_agpr(acc[mo][mi], av[t & 1][mo], bv[t & 1][mi]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// lane = feature: sum over the tile's 16 samples
+__device__ __forceinline__ float colsum16b(const float* buf, int lane) {
+  lane = phase_lane(lane);
+  float v[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) v[n] = buf[bk_idx(n, 0) + lane];
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) v[k] += v[k + w];
+  return v[0];
+}
+// lane = feature: acc[c] += sum_s col[s][lane] * row4[s][c]
+template <int NC>
+__device__ __forceinline__ void outer16b(const float* colbuf, const float* row4, int lane, float (&acc)[NC]) {
+  lane = phase_lane(lane);
+#pragma unroll
+  for (int k0 = 0; k0 < 16; k0 += 4) {
+    float h[4]; float4 d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h[k] = colbuf[bk_idx(k0 + k, 0) + lane]; d[k] = *reinterpret_cast<const float4*>(row4 + 4 * (k0 + k)); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[0] = fmaf(d[k].x, h[k], acc[0]);
+      acc[1] = fmaf(d[k].y, h[k], acc[1]);
+      acc[2] = fmaf(d[k].z, h[k], acc[2]);
+      if (NC > 3) acc[NC - 1] = fmaf(d[k].w, h[k], acc[NC - 1]);
+    }
+    // pin this batch's FMAs here (they otherwise sink below the later batches' loads and every d row stays live)
+    if (NC > 3) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[NC - 1]));
+    else asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- HBM -> LDS DMA ---------------------------------------------------------------------------------
+// global_load_lds_dwordx4: lane p's 16 bytes land at lds_base + 16 p.  M0 carries the LDS base.  Two address
+// forms: 64-bit per-lane pointer, or wave-uniform base (SGPR pair) + 32-bit per-lane byte offset (cheaper:
+// one VGPR, no 64-bit VALU arithmetic in the tile loop).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+#define DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// Per-field bases (wave-uniform) of everything the tile loop streams in; sample indices inside the loop are
+// 32-bit and relative to the field (the API only selects this kernel when P * 256 B < 4 GiB).
+struct FieldStreams {
+  const char* raytab;     // + 32 B * ray-in-field
+  const char* dout;       // + 16 B * n
+  const char* tpair;      // 16-byte aligned (t,T,t,T) pairs: + 8 B * ((n + par) & ~1)
+  const char* act[2];     // tiled stash (ngm_field.h ActStash), base of the field's first 32-sample tile
+  uint32_t gb;            // (field's first global sample index) & 31
+  uint32_t par;           // parity of the field's first global sample index
+};
+
+// inputs of tile [n0, n0+16): lane group q fetches piece q of sample j (0: ray origin + dir.x, 1: rest of the
+// ray entry, 2: d_out, 3: the aligned stash pair holding t).  One instruction, per-lane 64-bit pointers.
+__device__ __forceinline__ void issue_inputs(const FieldStreams& fs, int S, uint32_t n0, uint32_t end, int lane, uint32_t lds) {
+  const int j = lane & 15, q = lane >> 4;
+  uint32_t n = n0 + j;
+  if (n >= end) n = end - 1;                       // clamp: finite data, its gradient contribution is zeroed via d_out
+  const uint32_t ray = n / (uint32_t)S;
+  const char* src;
+  if (q == 0) src = fs.raytab + 32 * (size_t)ray;
+  else if (q == 1) src = fs.raytab + 32 * (size_t)ray + 16;
+  else if (q == 2) src = fs.dout + 16 * (size_t)n;
+  else src = fs.tpair + 8 * (size_t)((n + fs.par) & ~1u);
+  dma16(src, lds);
+}
+// activation tile (stash slot l-1 = input of layer l) for samples [n0, n0+16): 4 instructions, one block each;
+// lane p fetches granule (sample 4b + (p >> 4), chunk p & 15) of the tiled stash
+__device__ __forceinline__ void issue_act(const char* sbase, uint32_t gb, uint32_t n0, uint32_t end, int lane, uint32_t lds_tile) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    uint32_t n = n0 + 4 * b + (lane >> 4);
+    if (n >= end) n = end - 1;
+    const uint32_t u = n + gb;
+    dma16_so(sbase, (((u >> 5) * 16u + (lane & 15)) * 32u + (u & 31u)) * 16u, lds_tile + b * BK_STRIDE * 4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int L, bool NEED_COS, bool ENC_GRAD>
+__global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  using LY = Lds16s<L>;
+  using LW = typename LY::W;
+  constexpr int BLK = LW::BLK;
+  const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  load_field16<4, 4, L>(sm, a.fc, a.pr, row);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  float* wl = sm + LW::WTOTAL + wave * LY::WAVE_TOTAL;
+  float* bufE = wl + LY::XE;
+  float* bufD = wl + LY::act(L);
+  float* pbuf = wl + LY::PBUF;
+  float* obuf = wl + LY::OBUF;
+  float* inb = wl + LY::INBUF;
+  const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wl);
+
+  f32x4 acc0[4][4];
+  f32x4 accH[(L > 1) ? (L - 1) : 1][4][4];
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      acc0[mo][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < L - 1; ++l) accH[l][mo][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  float dbh[L], dwo[4], dbo[4], dwf[3];
+#pragma unroll
+  for (int l = 0; l < L; ++l) dbh[l] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dwo[c] = 0.f; dbo[c] = 0.f; }
+  dwf[0] = dwf[1] = dwf[2] = 0.f;
+
+  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
+  const uint32_t first = beg + wave * 16;
+  FieldStreams fs;
+  {
+    const int64_t g0 = (int64_t)f * a.P;
+    fs.raytab = reinterpret_cast<const char*>(a.raytab) + 32 * (g0 / a.S);
+    fs.dout = reinterpret_cast<const char*>(a.d_out + g0);
+    fs.tpair = reinterpret_cast<const char*>(a.stashB + (g0 & ~(int64_t)1));
+    fs.par = (uint32_t)(g0 & 1);
+    fs.gb = (uint32_t)(g0 & 31);
+    fs.act[0] = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 2048);
+    fs.act[1] = reinterpret_cast<const char*>(a.act + a.act_layer_stride + (g0 >> 5) * 2048);
+  }
+  // Per-wave LDS tiles: R0 (dY of the last layer, later the encoding), act(1) (layer 1's input, later dY / dE
+  // staging), act(2) (the last hidden activation, L = 2).  DMA issue order per tile: inputs of the next tile at
+  // the start, act(L) as soon as the output layer is done with it, act(1) at the very end (L = 2) -- so the 4
+  // youngest outstanding instructions at a tile start are act(1) and "vmcnt(4)" means "inputs and act(L) landed".
+  float* R0 = wl + LY::XE;
+  float* A1 = wl + LY::act(1);
+  float* AL = wl + LY::act(L);
+  if (first < end) {
+    issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INBUF * 4);
+    issue_act(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::act(L) * 4);
+    if (L == 2) issue_act(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::act(1) * 4);
+  }
+  TICK_DECL;
+  TICK(0);
+  for (uint32_t base = first; base < end; base += 16 * B16_WAVES) {
+    const uint32_t n = base + j, nxt = base + 16 * B16_WAVES;
+    const bool valid = n < end, more = nxt < end;
+    // ---- inputs and the last hidden activation tile (landed while the previous tile was differentiated)
+    if (L == 2) DMA_WAIT(4); else DMA_WAIT(0);
+    {
+      const float4* in4 = reinterpret_cast<const float4*>(inb);
+      const float4 r0 = in4[j], r1 = in4[16 + j], dd = in4[32 + j], sp = in4[48 + j];
+      const uint32_t nc = valid ? n : end - 1;
+      const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
+      const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
+      const float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
+      WAVE_SYNC();
+      if (q == 0) {
+        *reinterpret_cast<float4*>(pbuf + 4 * j) = make_float4(x, y, z, 0.f);
+        *reinterpret_cast<float4*>(obuf + 4 * j) = dout;
+        dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w;
+      }
+      WAVE_SYNC();
+      if (more) issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INBUF * 4);
+    }
+    TICK(1);
+    // ---- output layer: d_out -> dY_L
+    outer16b<4>(AL, obuf, lane, dwo);
+    f32x4 dY[4];
+    {
+      f32x4 Hc[4];
+      load16b(AL, lane, Hc);
+      const float4 dout = *reinterpret_cast<const float4*>(obuf + 4 * j);
+      const float4* w4 = reinterpret_cast<const float4*>(sm + LW::WOUT);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 w = w4[16 * m + 4 * q + r];
+          const float dh = fmaf(w.w, dout.w, fmaf(w.z, dout.z, fmaf(w.y, dout.y, w.x * dout.x)));
+          dY[m][r] = (Hc[m][r] > 0.f) ? dh : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // 4 weight rows at a time: all 16 in flight would be 64 VGPRs at the pressure peak
+      }
+    }
+    WAVE_SYNC();
+    store16b(R0, lane, dY);
+    if (L == 2) {   // the last-hidden tile is dead: land the next tile's copy in it right away
+      if (more) issue_act(fs.act[1], fs.gb, nxt, end, lane, wl_lds + LY::act(2) * 4);
+    }
+    WAVE_SYNC();
+    dbh[L - 1] += colsum16b(R0, lane);
+    TICK(4);
+    float* Dlast = R0;      // tile holding dY of layer 0's output
+    float* Etile = A1;      // tile that will receive the encoding
+    if constexpr (L == 2) {
+      // act(1) of THIS tile was issued at the end of the previous one; younger: inputs(next) + act(2)(next)
+      if (more) DMA_WAIT(5); else DMA_WAIT(0);
+      wgrad16b(R0, A1, lane, accH[0]);
+      TICK(6);
+      f32x4 dX[4], Xl[4];
+      dgrad16v<BLK>(sm + LW::w_off(1), lane, dY, dX);
+      TICK(7);
+      load16b(A1, lane, Xl);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dY[m][r] = (Xl[m][r] > 0.f) ? dX[m][r] : 0.f;
+      WAVE_SYNC();
+      store16b(A1, lane, dY);          // layer 1's input tile now carries dY of layer 0's output
+      WAVE_SYNC();
+      dbh[0] += colsum16b(A1, lane);
+      Dlast = A1; Etile = R0;
+      TICK(9);
+    }
+    // ---- encoding, as late as possible: E and d(enc)/d(arg) are only needed by layer 0's gradients
+    f32x4 dEa[4];
+    {
+      const float4 pt = *reinterpret_cast<const float4*>(pbuf + 4 * j);
+      f32x4 E[4];
+      encode16<4, NEED_COS, ENC_GRAD>(sm + LW::ENCW, q, pt.x, pt.y, pt.z, E, dEa);
+      WAVE_SYNC();
+      store16b(Etile, lane, E);
+      WAVE_SYNC();
+    }
+    TICK(2);
+    wgrad16b(Dlast, Etile, lane, acc0);
+    TICK(6);
+    if (ENC_GRAD) {
+      // dY is re-read from its staging tile: keeping it in registers across the encoding would cost 16 VGPRs
+      // at the kernel's pressure peak (and any spill reload waits for the in-flight DMA as well)
+      f32x4 dE[4], dYr[4];
+      load16b(Dlast, lane, dYr);
+      dgrad16v<BLK>(sm + LW::w_off(0), lane, dYr, dE);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dE[m][r] *= dEa[m][r];
+      TICK(7);
+      WAVE_SYNC();
+      store16b(Dlast, lane, dE);
+      WAVE_SYNC();
+      outer16b<3>(Dlast, pbuf, lane, dwf);
+      TICK(8);
+    }
+    // act(1)'s tile is dead: it receives the next tile's copy
+    WAVE_SYNC();
+    if (more) issue_act(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::act(1) * 4);
+  }
+  DMA_WAIT(0);
+  TICK(10);
+  __syncthreads();
+  bwd16_epilogue<4, 4, L, ENC_GRAD>(a, sm + LW::WTOTAL, acc0, accH, dbh, dwo, dwf, dbo);
+  TICK(11);
+  TICK_REPORT
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int L>
+static int launch_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = (size_t)Lds16s<L>::TOTAL * sizeof(float);
+  if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;
+#define NGM_LB16S(NC, EG)                                                                                             \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)k_field_bwd16s<L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)lds);                                                                              \
+    hipLaunchKernelGGL((k_field_bwd16s<L, NC, EG>), dim3(blocks), dim3(B16_THREADS), lds, st, a);                     \
+  } while (0)
+  if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LB16S(false, true);
+  else if (a.fc.encoding == NGM_ENC_NERF) NGM_LB16S(true, false);
+  else NGM_LB16S(false, false);
+#undef NGM_LB16S
+  return 0;
+}
+
+// returns NGM_E_UNSUPPORTED when the stash variant does not apply (caller falls back to the recompute kernels)
+int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const int TI = (a.fc.dim_enc + 15) / 16, TH = (a.fc.dim_hidden + 15) / 16, L = a.fc.num_layers;
+  if (!a.act || a.points || a.fc.encoding == NGM_ENC_PERMUTO || TI != 4 || TH != 4 || L < 1 || L > 2) return NGM_E_UNSUPPORTED;
+  if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
+  NgmProfScope prof_(NGM_K_FIELD_BWD, st);
+  if (L == 2) return launch_bwd16s<2>(a, blocks, st);
+#ifndef NGM_FAST_BUILD
+  if (L == 1) return launch_bwd16s<1>(a, blocks, st);
+#endif
+  return NGM_E_UNSUPPORTED;
+}

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float t = valid ? wl.tbuf[idx] : 0.f;
       float x = 0, y = 0, z = 0;
       if (valid) { x = fmaf(t, rt[3], rt[0]); y = fmaf(t, rt[4], rt[1]); z = fmaf(t, rt[5], rt[2]); }
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
+      ActStash ast;
+      ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
+      ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast);
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z, geom = o.w;
       const float depth = -(rt[6] * t);
       const float occ = valid ? occ_pointwise(mode, gamma, geom, nullptr) : 0.f;

@@ -38,6 +38,8 @@ struct RenderFwdArgs {
   float4* stashA;         // (F*R*S): colour(3), geometry                      (train) or NULL
   float2* stashB;         // (F*R*S): t, T_exclusive
   float* loss_partials;   // (blocks, 16)
+  float* act;             // hidden-activation stash [L][F*R*S][64] (train, 64-wide hidden layers) or NULL
+  int64_t act_layer_stride;  // floats
 };
 
 // backward of the field MLP for flat samples of each field
@@ -63,6 +65,8 @@ struct FieldBwdArgs {
   float2* hash_dE;        // permutohedral: [L][F*P] dL/d(level features) per sample (level-major: coalesced)
   float4* hash_xyz;       // permutohedral: [F*P] scaled field-local sample positions
   float* hash_part;       // permutohedral: [F][L][8][2T] partial gradient tables
+  const float* act;       // hidden-activation stash written by the forward (ray mode) or NULL = recompute
+  int64_t act_layer_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
 };
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st);
@@ -113,6 +117,7 @@ struct StashBwdArgs {
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st);  // 16-sample tiles, activations from the forward's stash
 int ngm_launch_field_bwd16(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 16-sample tiles, 8 waves; NGM_E_UNSUPPORTED -> fall back
 int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);

@@ -397,14 +397,27 @@ def test_full_size_properties_m1():
 
 @pytest.mark.parametrize("F,R,n_c,n_g", [(1, 5, 3, 0), (2, 33, 1, 1), (5, 7, 8, 16), (1, 1, 128, 0), (3, 130, 20, 4)])
 def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
+    _ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=32, num_layers=1))
+
+
+@pytest.mark.parametrize("F,R,n_c,n_g,layers", [(2, 33, 1, 1, 2), (5, 7, 8, 16, 2), (3, 130, 20, 4, 2), (3, 37, 5, 2, 1),
+                                                (1, 1, 128, 0, 2)])
+def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers):
+    """64-wide layers: the training forward stashes the hidden activations and k_field_bwd16s consumes them
+    (partial 16-sample tiles, fields that start in the middle of a 32-sample stash tile)."""
+    _ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers))
+    from neural_graph_mapping_amd import _capi
+    assert _capi.lib().ngm_debug_last_bwd_variant() == 2
+
+
+def _ragged_case(F, R, n_c, n_g, fkw):
     torch.manual_seed(F * 1000 + R)
-    fkw = dict(encoding="fourier", dim_enc=32, num_layers=1)
     ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
     pos, quat, t = synth_target(F, R, seed=R)
     fs = O.FieldSpec(**fkw)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
     params = O.init_params(fs, F, seed=R, sigma=3.0)
-    params["_linears.1.weight"] *= 2.0
+    params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)

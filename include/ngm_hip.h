@@ -211,11 +211,13 @@ int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 int ngm_composite_fwd_packed(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* field_out4,
                              const float* dists, const float* points_cam, float* rgbd, float* Cvar,
                              float* Dvar, float* term, void* stream);
-/* Backward of C, D, term (and optionally a direct per-sample seed) w.r.t. colors and geoms. */
+/* Backward of C, D, term w.r.t. colors (N,S,3), geoms (N,S) and, in neus mode, the per-ray inverse
+ * standard deviations (N) (d_neus_isds may be NULL).  All four geometry modes. */
 int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors,
                       const float* geoms, const float* dists, const float* depths,
                       const float* neus_isds, const float* dC, const float* dD,
-                      const float* dterm, float* d_colors, float* d_geoms, void* stream);
+                      const float* dterm, float* d_colors, float* d_geoms, float* d_neus_isds,
+                      void* stream);
 
 /* ---- fused render / train step -------------------------------------------------------------
  * ngm_render_fwd replaces NeuralGraphMap._render_ijs(use_vmap=True) (rm.py:439-666): sampler ->

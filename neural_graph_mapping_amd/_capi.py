@@ -112,7 +112,7 @@ def lib():
     L.ngm_field_eval_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
     L.ngm_field_eval_bwd_workspace.restype = i64
     L.ngm_composite_fwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 11 + [vp]
-    L.ngm_composite_bwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 10 + [vp]
+    L.ngm_composite_bwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 11 + [vp]
     L.ngm_render_workspace.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, i32]
     L.ngm_render_workspace.restype = i64
     L.ngm_render_fwd.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), P(Targets),

@@ -354,15 +354,15 @@ int ngm_composite_fwd_packed(const ngm_render_cfg* cfg, int64_t N, int32_t S, co
 
 int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors, const float* geoms,
                       const float* dists, const float* depths, const float* neus_isds, const float* dC, const float* dD,
-                      const float* dterm, float* d_colors, float* d_geoms, void* stream) {
+                      const float* dterm, float* d_colors, float* d_geoms, float* d_neus_isds, void* stream) {
   if (!cfg || !colors || !geoms || !dists || !depths || N < 0) return fail(NGM_E_INVALID, "ngm_composite_bwd: bad argument");
   if (N == 0) return NGM_OK;
   CompositeArgs a;
   memset(&a, 0, sizeof(a));
   a.rc = *cfg; a.N = N; a.S = S; a.colors = colors; a.geoms = geoms; a.dists = dists; a.depths = depths; a.isds = neus_isds;
-  a.dC = dC; a.dD = dD; a.dterm = dterm; a.d_colors = d_colors; a.d_geoms = d_geoms;
+  a.dC = dC; a.dD = dD; a.dterm = dterm; a.d_colors = d_colors; a.d_geoms = d_geoms; a.d_isds = d_neus_isds;
   const int rc = ngm_launch_composite_bwd(a, (hipStream_t)stream);
-  if (rc) return fail(rc, "ngm_composite_bwd: unsupported mode (nrgbd/occupancy only) or S > 1024");
+  if (rc) return fail(rc, "ngm_composite_bwd: S > 1024");
   return check_launch("ngm_composite_bwd");
 }
 
@@ -457,8 +457,8 @@ static int check_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const
   if (!rc || !rays || !rays->ijs || !rays->c2ws || !rays->field_pos || !rays->field_quat)
     return fail(NGM_E_INVALID, "render: NULL ray argument");
   if (rays->F < 1 || rays->R < 1) return fail(NGM_E_INVALID, "render: empty batch");
-  if (rc->geometry_mode != NGM_GEO_NRGBD && rc->geometry_mode != NGM_GEO_OCCUPANCY)
-    return fail(NGM_E_UNSUPPORTED, "fused render: geometry modes nrgbd / occupancy only");
+  if (rc->geometry_mode == NGM_GEO_NEUS)
+    return fail(NGM_E_UNSUPPORTED, "fused render: neus needs the per-field _neus_sd parameter (use ngm_composite_fwd/bwd)");
   const int S = rc->num_samples_coarse + (rays->gt ? rc->num_samples_guided : 0);
   if (S < 1 || S > 1024) return fail(NGM_E_UNSUPPORTED, "fused render: samples per ray must be in [1,1024]");
   return NGM_OK;

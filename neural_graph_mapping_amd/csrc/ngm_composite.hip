@@ -85,14 +85,30 @@ __device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int
   const float gm = geom_at(a, g);
   if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY) return occ_pointwise(mode, a.rc.geometry_factor, gm, docc);
   if (k >= S - 1) return 0.f;   // density / neus drop the last sample (rm.py:749,758)
-  if (mode == NGM_GEO_DENSITY) {
-    const float dl = a.dists[g + 1] - a.dists[g];
-    return 1.0f - expf(-dl * fmaxf(gm, 0.f));
-  }
+  if (mode == NGM_GEO_DENSITY) return occ_density(gm, a.dists[g + 1] - a.dists[g], docc);
   const float isd = a.isds ? a.isds[ray] : 1.0f;
   const float t0 = ngm_sigmoid(isd * a.rc.geometry_factor * gm);
   const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * geom_at(a, g + 1));
   return fmaxf((t0 - t1) / (t0 + 1e-5f), 0.f);
+}
+
+// NeuS (rm.py:753-758): occ_k = max((u_k - u_{k+1}) / (u_k + 1e-5), 0), u = sigmoid(isd * gamma * g).
+// Partial derivatives w.r.t. g_k, g_{k+1} and the ray's inverse standard deviation.
+__device__ __forceinline__ void neus_partials(const CompositeArgs& a, int64_t ray, int k, int S, float* d_self, float* d_next,
+                                              float* d_isd) {
+  *d_self = *d_next = *d_isd = 0.f;
+  if (k >= S - 1) return;
+  const int64_t g = ray * S + k;
+  const float isd = a.isds ? a.isds[ray] : 1.0f, gam = a.rc.geometry_factor;
+  const float g0 = geom_at(a, g), g1 = geom_at(a, g + 1);
+  const float u0 = ngm_sigmoid(isd * gam * g0), u1 = ngm_sigmoid(isd * gam * g1);
+  const float den = u0 + 1e-5f;
+  if ((u0 - u1) / den <= 0.f) return;                     // clamp_min(…, 0): zero gradient (torch: grad 0 at the kink too)
+  const float P = (1e-5f + u1) / (den * den), M = -1.0f / den;
+  const float s0 = u0 * (1.0f - u0), s1 = u1 * (1.0f - u1);
+  *d_self = P * isd * gam * s0;
+  *d_next = M * isd * gam * s1;
+  *d_isd = P * gam * g0 * s0 + M * gam * g1 * s1;
 }
 
 __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, int rays_per_wave) {
@@ -208,13 +224,18 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
 // as a REVERSE segmented scan of affine maps (exact also when 1-o_k = 0, unlike the division form).
 // ================================================================================================
 struct CompBwdLds {
-  float tex[CQ_MAXS];   // exclusive transmittance
+  float tex[CQ_MAXS];   // exclusive transmittance; after the reverse sweep: dL/docc
   float occ[CQ_MAXS];
-  float doc[CQ_MAXS];   // d occ / d geom
+  float doc[CQ_MAXS];   // d occ_k / d geom_k
+  float dnx[CQ_MAXS];   // d occ_k / d geom_{k+1}   (neus)
+  float dis[CQ_MAXS];   // d occ_k / d isd          (neus)
+  float risd[CQ_BR];    // per-ray d isd
 };
 
 __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, int rays_per_wave) {
-  __shared__ CompBwdLds lds[NGM_WAVES_PER_BLOCK];
+  extern __shared__ __attribute__((aligned(16))) float cb_lds_raw[];
+  CompBwdLds* lds = reinterpret_cast<CompBwdLds*>(cb_lds_raw);
+  const bool neus = a.rc.geometry_mode == NGM_GEO_NEUS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   CompBwdLds& wl = lds[wave];
   const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
@@ -232,15 +253,17 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       const bool valid = idx < nsamp;
       const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
       const int k = valid ? idx - rl * S : 0;
-      float dodg0 = 0.f;
+      float dodg0 = 0.f, dnext0 = 0.f, disd0 = 0.f;
       const float occ = valid ? occ_at(a, rb + rl, k, S, &dodg0) : 0.f;
+      if (neus && valid) neus_partials(a, rb + rl, k, S, &dodg0, &dnext0, &disd0);
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
       const float up = __shfl_up(q, 1, 64);
       const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
       carry = __shfl(q, 63, 64);
-      if (valid) { wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0; }
+      if (valid) { wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0; wl.dnx[idx] = dnext0; wl.dis[idx] = disd0; }
     }
+    if (neus && lane < nb) wl.risd[lane] = 0.f;
     WAVE_SYNC();
     // reverse sweep
     float carryQ = 0.f;
@@ -273,20 +296,45 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       if (valid) {
         const float w = occ * T;
         if (a.d_colors) { a.d_colors[3 * g] = w * dC0; a.d_colors[3 * g + 1] = w * dC1; a.d_colors[3 * g + 2] = w * dC2; }
-        if (a.d_geoms) a.d_geoms[g] = T * (ak - Qk) * dodg;
+        if (neus) wl.tex[idx] = T * (ak - Qk);       // dL/docc_k, combined with the neighbour's below
+        else if (a.d_geoms) a.d_geoms[g] = T * (ak - Qk) * dodg;
       }
     }
     WAVE_SYNC();
+    if (neus) {
+      // occ_k depends on g_k and g_{k+1}: d g_k = docc_k * d_self_k + docc_{k-1} * d_next_{k-1}; d isd = sum_k docc_k * d_isd_k
+      for (int base = 0; base < nsamp; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < nsamp;
+        const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
+        const int k = valid ? idx - rl * S : 0;
+        float dg = 0.f, di = 0.f;
+        if (valid) {
+          const float docc = wl.tex[idx];
+          dg = docc * wl.doc[idx];
+          if (k > 0) dg = fmaf(wl.tex[idx - 1], wl.dnx[idx - 1], dg);
+          di = docc * wl.dis[idx];
+          if (a.d_geoms) a.d_geoms[(rb + rl) * S + k] = dg;
+        }
+        const float si = seg_scan_add(di, k, lane);
+        const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+        if (tail) wl.risd[rl] += si;
+        WAVE_SYNC();
+      }
+      if (lane < nb && a.d_isds) a.d_isds[rb + lane] = wl.risd[lane];
+      WAVE_SYNC();
+    }
   }
 }
 
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
   NgmProfScope prof_(NGM_K_COMPOSITE_BWD, st);
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
-  if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
-  hipLaunchKernelGGL(k_composite_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  const size_t lds = sizeof(CompBwdLds) * NGM_WAVES_PER_BLOCK;
+  (void)hipFuncSetAttribute((const void*)k_composite_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_composite_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw);
   return 0;
 }
 
@@ -353,8 +401,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
       }
     }
     const float depth = -(dzc * t);
-    float dodg = 0.f;
-    const float occ = valid ? occ_pointwise(mode, gamma, geom, &dodg) : 0.f;
+    float dodg = 0.f, occ = 0.f;
+    if (valid) {
+      if (mode == NGM_GEO_DENSITY) { if (k < S - 1) occ = occ_density(geom, a.stashB[g + 1].x - t, &dodg); }   // last sample dropped
+      else occ = occ_pointwise(mode, gamma, geom, &dodg);
+    }
     const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * depth + dT;
     float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
     seg_rscan_affine(A, B, kr, lane);
@@ -382,7 +433,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
 
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
   NgmProfScope prof_(NGM_K_STASH_BWD, st);
-  if (a.rc.geometry_mode != NGM_GEO_NRGBD && a.rc.geometry_mode != NGM_GEO_OCCUPANCY) return NGM_E_UNSUPPORTED;
+  if (a.rc.geometry_mode == NGM_GEO_NEUS) return NGM_E_UNSUPPORTED;   // needs the per-field _neus_sd parameter: standalone quadrature only
   int rpw;
   const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);
   hipLaunchKernelGGL(k_stash_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);

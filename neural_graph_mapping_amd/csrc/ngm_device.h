@@ -248,6 +248,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// density mode (rm.py:746-749): occ_k = 1 - exp(-(t_{k+1} - t_k) relu(g_k)); the caller drops the last sample
+__device__ __forceinline__ float occ_density(float g, float dl, float* docc_dg) {
+  const float e = expf(-dl * fmaxf(g, 0.f));
+  if (docc_dg) *docc_dg = (g > 0.f) ? dl * e : 0.f;
+  return 1.0f - e;
+}
+
 // occupancy probability of one sample (rm.py:746-762) and its derivative w.r.t. the geometry value.
 // density/neus need the neighbouring sample and are handled by the callers.
 __device__ __forceinline__ float occ_pointwise(int mode, float gamma, float g, float* docc_dg) {

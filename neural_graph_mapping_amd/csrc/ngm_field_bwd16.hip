@@ -120,7 +120,14 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
     // ---- forward recompute
     f32x4 E[TI], dEa[TI];
     if constexpr (HASH) encode_hash16<TI>(sm + LY::ENCW, hc, q, x, y, z, E);
+#ifdef NGM_ABL_NOVALU
+    else {
+#pragma unroll
+      for (int m = 0; m < TI; ++m) { E[m] = f32x4{x, y, z, x}; dEa[m] = E[m]; }
+    }
+#else
     else encode16<TI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, q, x, y, z, E, dEa);
+#endif
     TICK(2);   // encode (sincos)
     WAVE_SYNC();
     store16<TI>(wl + LY::x_off(0), LY::STR_E, lane, E);
@@ -129,12 +136,22 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
       *reinterpret_cast<float4*>(obuf + 4 * j) = dout;
     }
     f32x4 Hc[TH];
+#ifdef NGM_ABL_NOFWD   // timing ablations (tools/ablate.sh): results are meaningless when any NGM_ABL_* is defined
+#pragma unroll
+    for (int m = 0; m < TH; ++m) Hc[m] = E[m % TI];
+#else
     fwd16<TI, TH, BLK>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hc);
+#endif
 #pragma unroll
     for (int l = 1; l < L; ++l) {
       store16<TH>(wl + LY::x_off(l), LY::STR_H, lane, Hc);
       f32x4 Hn[TH];
+#ifdef NGM_ABL_NOFWD
+#pragma unroll
+      for (int m = 0; m < TH; ++m) Hn[m] = Hc[m];
+#else
       fwd16<TH, TH, BLK>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hc, Hn);
+#endif
 #pragma unroll
       for (int m = 0; m < TH; ++m) Hc[m] = Hn[m];
     }
@@ -142,7 +159,9 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
     // ---- output layer gradients
     store16<TH>(bufD, LY::STR_D, lane, Hc);
     WAVE_SYNC();
+#ifndef NGM_ABL_NOVALU
     outer16<TH, 4>(bufD, LY::STR_D, obuf, lane, dwo);
+#endif
     if (q == 0) { dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w; }
     f32x4 dY[TH];
     {
@@ -162,10 +181,14 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
       WAVE_SYNC();
       store16<TH>(bufD, LY::STR_D, lane, dY);
       WAVE_SYNC();
+#ifndef NGM_ABL_NOVALU
       dbh[l] += colsum16<TH>(bufD, LY::STR_D, lane);
+#endif
       TICK(5);   // stage dY + bias column sums
       if (l == 0) {
+#ifndef NGM_ABL_NOWGRAD
         wgrad16<TH, TI>(bufD, LY::STR_D, wl + LY::x_off(0), LY::STR_E, lane, acc0);
+#endif
         TICK(6); // wgrad MFMA
         if constexpr (HASH) {
           f32x4 dE[TI];
@@ -184,7 +207,12 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
         }
         if (ENC_GRAD) {
           f32x4 dE[TI];
+#ifdef NGM_ABL_NODGRAD
+#pragma unroll
+          for (int m = 0; m < TI; ++m) dE[m] = dY[m % TH];
+#else
           dgrad16<TI, TH, BLK>(sm + LY::w_off(0), lane, dY, dE);
+#endif
 #pragma unroll
           for (int m = 0; m < TI; ++m)
 #pragma unroll
@@ -193,14 +221,23 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
           WAVE_SYNC();
           store16<TI>(bufD, LY::STR_D, lane, dE);
           WAVE_SYNC();
+#ifndef NGM_ABL_NOVALU
           outer16<TI, 3>(bufD, LY::STR_D, pbuf, lane, dwf);
+#endif
           TICK(8); // Fourier matrix grads (VALU)
         }
       } else {
+#ifndef NGM_ABL_NOWGRAD
         wgrad16<TH, TH>(bufD, LY::STR_D, wl + LY::x_off(l), LY::STR_H, lane, accH[l - 1]);
+#endif
         TICK(6);
         f32x4 dX[TH], Xl[TH];
+#ifdef NGM_ABL_NODGRAD
+#pragma unroll
+        for (int m = 0; m < TH; ++m) dX[m] = dY[m];
+#else
         dgrad16<TH, TH, BLK>(sm + LY::w_off(l), lane, dY, dX);
+#endif
         TICK(7);
         load16<TH>(wl + LY::x_off(l), LY::STR_H, lane, Xl);
 #pragma unroll

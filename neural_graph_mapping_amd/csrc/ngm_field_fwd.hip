@@ -173,7 +173,11 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast);
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z, geom = o.w;
       const float depth = -(rt[6] * t);
-      const float occ = valid ? occ_pointwise(mode, gamma, geom, nullptr) : 0.f;
+      float occ = 0.f;
+      if (valid) {
+        if (mode == NGM_GEO_DENSITY) { if (k < S - 1) occ = occ_density(geom, wl.tbuf[idx + 1] - t, nullptr); }   // rm.py:746-749, last sample dropped
+        else occ = occ_pointwise(mode, gamma, geom, nullptr);
+      }
       // transmittance: segmented inclusive product of (1-occ), carried across steps
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;

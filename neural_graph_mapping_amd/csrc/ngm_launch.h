@@ -93,7 +93,7 @@ struct CompositeArgs {
   float* C; float* D; float* Cv; float* Dv; float* term; float* weights;
   // bwd seeds / outputs
   const float* dC; const float* dD; const float* dterm;
-  float* d_colors; float* d_geoms;
+  float* d_colors; float* d_geoms; float* d_isds;
 };
 
 // backward of compositing on the saved per-sample stash of the fused forward; overwrites stashA with

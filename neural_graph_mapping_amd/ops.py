@@ -256,6 +256,8 @@ class _Quadrature(torch.autograd.Function):
                                           _ptr(isd_flat), _ptr(Cc), _ptr(D), _ptr(Cv), _ptr(Dv), _ptr(T), _ptr(W),
                                           _stream()), "ngm_composite_fwd")
         ctx.rc = rc
+        ctx.isd_shape = None if isds is None else tuple(isds.shape)
+        ctx.lead = tuple(lead)
         ctx.save_for_backward(colors, geoms, dists, depths, isd_flat)
         ctx.mark_non_differentiable(Cv, Dv, W)
         return (Cc.view(*lead, 3), D.view(*lead), Cv.view(*lead, 3), Dv.view(*lead), T.view(*lead),
@@ -268,10 +270,15 @@ class _Quadrature(torch.autograd.Function):
         N = geoms.numel() // S
         d_colors = torch.empty_like(colors)
         d_geoms = torch.empty_like(geoms)
+        want_isd = isd_flat is not None and ctx.needs_input_grad[5] and ctx.rc.geometry_mode == K.GEO["neus"]
+        d_isd = torch.empty(N, device=geoms.device) if want_isd else None
         K.check(K.lib().ngm_composite_bwd(C.byref(ctx.rc), N, S, _ptr(colors), _ptr(geoms), _ptr(dists), _ptr(depths),
                                           _ptr(isd_flat), _ptr(_f32c(dC)), _ptr(_f32c(dD)), _ptr(_f32c(dT)),
-                                          _ptr(d_colors), _ptr(d_geoms), _stream()), "ngm_composite_bwd")
-        return None, d_colors, d_geoms, None, None, None
+                                          _ptr(d_colors), _ptr(d_geoms), _ptr(d_isd), _stream()), "ngm_composite_bwd")
+        g_isd = None
+        if want_isd:   # undo the broadcast of neus_isds to one value per ray
+            g_isd = d_isd.view(*ctx.lead, 1).sum_to_size(ctx.isd_shape)
+        return None, d_colors, d_geoms, None, None, g_isd
 
 
 def quadrature(rc: K.RenderCfg, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):

@@ -223,6 +223,65 @@ def test_quadrature_backward_vs_oracle(mode, lead, S):
     grad_close(gg.grad, go.grad, 2e-5, "d_geoms")
 
 
+@pytest.mark.parametrize("mode", ["density", "neus"])
+@pytest.mark.parametrize("lead,S", [((3, 5), 24), ((7,), 128), ((2, 3), 2), ((1,), 200), ((40,), 7)])
+def test_quadrature_backward_neighbour_modes_vs_oracle(mode, lead, S):
+    """density / neus (rm.py:746-758): occ_k depends on the next sample; neus also on the per-ray inverse
+    standard deviation.  Gradients w.r.t. colours, geometry and neus_isds against torch autograd on the oracle."""
+    torch.manual_seed(S + len(mode))
+    colors = torch.rand(*lead, S, 3)
+    geoms = (torch.randn(*lead, S) if mode == "density" else 0.05 * torch.randn(*lead, S).cumsum(-1).flip(-1))
+    dists = torch.sort(torch.rand(*lead, S) * 3 + 0.5, -1)[0]
+    depths = dists * 0.9
+    isds = (0.5 + torch.rand(*lead, 1)) if mode == "neus" else None
+    dC, dD, dT = torch.randn(*lead, 3), torch.randn(*lead), torch.randn(*lead)
+    co, go = colors.clone().requires_grad_(), geoms.clone().requires_grad_()
+    io = isds.clone().requires_grad_() if isds is not None else None
+    Co, Do, _, _, To, _ = O.quadrature(mode, co, go, dists, depths, 20.0, io)
+    ((Co * dC).sum() + (Do * dD).sum() + (To * dT).sum()).backward()
+    rc = K.render_cfg(geometry_mode=mode, geometry_factor=20.0)
+    cg, gg = colors.to(DEV).requires_grad_(), geoms.to(DEV).requires_grad_()
+    ig = isds.to(DEV).requires_grad_() if isds is not None else None
+    Cg, Dg, _, _, Tg, _ = ops.quadrature(rc, cg, gg, dists.to(DEV), depths.to(DEV), ig)
+    close(Cg, Co.detach(), 1e-5, 2e-6)
+    ((Cg * dC.to(DEV)).sum() + (Dg * dD.to(DEV)).sum() + (Tg * dT.to(DEV)).sum()).backward()
+    grad_close(cg.grad, co.grad, 1e-5, "d_colors")
+    grad_close(gg.grad, go.grad, 5e-5, "d_geoms")
+    if ig is not None:
+        assert ig.grad.shape == isds.shape
+        grad_close(ig.grad, io.grad, 1e-4, "d_isds")
+
+
+def test_fused_train_step_density_mode_vs_oracle():
+    """geometry_mode = density in the fused forward / backward (occ_k needs t_{k+1}; last sample dropped)."""
+    F, R, n_c, n_g = 3, 40, 10, 6
+    torch.manual_seed(5)
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode="density",
+               geometry_factor=1.0)
+    pos, quat, t = synth_target(F, R, seed=3)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,
+                      geometry_mode="density", geometry_factor=1.0)
+    params = O.init_params(fs, F, seed=9, sigma=3.0)
+    params["_linears.2.weight"] *= 4.0
+    params["_linears.2.bias"][:, 3] += 1.0           # positive densities on a good share of the samples
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    close(res["prediction"].term_probs, pred["term_probs"].detach())
+    close(res["prediction"].depth_vars, pred["depth_vars"].detach(), rtol=1e-3, atol=1e-5)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        loose_grad_close(res["grads"][k], po[k].grad, k)
+
+
 # ------------------------------------------------------------------------- train step (G6, G7)
 CASES = {
     "g6_train_cfg0": (dict(encoding="fourier", dim_enc=64, num_layers=2), dict(num_samples_coarse=16, num_samples_depth_guided=16)),

@@ -115,7 +115,8 @@ typedef struct ngm_render_cfg {
   int32_t geometry_mode;       /* ngm_geometry_mode, rm.py:746-762            */
   int32_t num_samples_coarse;  /* S_c                                         */
   int32_t num_samples_guided;  /* S_g (0: single stratum, eval style)         */
-  int32_t reserved0;
+  int32_t overwrite_behind_camera; /* != 0: samples with z_cam > 0 get a constant geometry value and no
+                                    * gradient (rm.py:614-622: -100 occupancy/density, 1.0 neus/nrgbd)  */
   float geometry_factor;       /* gamma                                       */
   float color_factor;
   float truncation_distance;   /* tau                                         */

@@ -50,7 +50,7 @@ class Grads(C.Structure):
 
 class RenderCfg(C.Structure):
     _fields_ = [("geometry_mode", C.c_int32), ("num_samples_coarse", C.c_int32),
-                ("num_samples_guided", C.c_int32), ("reserved0", C.c_int32),
+                ("num_samples_guided", C.c_int32), ("overwrite_behind_camera", C.c_int32),
                 ("geometry_factor", C.c_float), ("color_factor", C.c_float),
                 ("truncation_distance", C.c_float), ("range_depth_guided", C.c_float),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
@@ -254,10 +254,11 @@ def render_cfg(geometry_mode="nrgbd", num_samples_coarse=8, num_samples_guided=1
                geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1,
                range_depth_guided=None, fx=554.2562584220408, fy=554.2562584220408, cx=319.5,
                cy=239.5, w_termination=0.0, w_photometric=1.0, w_depth=1.0, w_freespace=40.0,
-               w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8):
+               w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8, overwrite_behind_camera=True):
     if range_depth_guided is None:
         range_depth_guided = truncation_distance
-    return RenderCfg(GEO[geometry_mode], num_samples_coarse, num_samples_guided, 0, geometry_factor,
+    return RenderCfg(GEO[geometry_mode], num_samples_coarse, num_samples_guided, int(bool(overwrite_behind_camera)),
+                     geometry_factor,
                      color_factor, truncation_distance, range_depth_guided, fx, fy, cx, cy,
                      w_termination, w_photometric, w_depth, w_freespace, w_tsdf, huber_delta,
                      term_threshold)

@@ -78,7 +78,12 @@ struct CompWaveLds {
   float wbuf[CQ_MAXS];
 };
 
-__device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t g) { return a.out4 ? a.out4[g].w : a.geoms[g]; }
+__device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t g) {
+  if (!a.out4) return a.geoms[g];
+  // packed eval path = _render_ijs(use_vmap=False): samples behind the camera get a constant (rm.py:614-622)
+  if (a.rc.overwrite_behind_camera && a.pcam[3 * g + 2] > 0.f) return behind_camera_geometry(a.rc.geometry_mode);
+  return a.out4[g].w;
+}
 __device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int k, int S, float* docc = nullptr) {
   const int mode = a.rc.geometry_mode;
   const int64_t g = ray * S + k;
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
       } else if (a.d_geom_samples) {
         dg += a.d_geom_samples[g];
       }
+      if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;   // overwritten sample: no gradient reaches the MLP output
       a.stashA[g] = make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg);
     }
   }

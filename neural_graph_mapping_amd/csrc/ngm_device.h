@@ -248,6 +248,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// geometry value written over samples behind the camera (rm.py:614-622)
+__device__ __forceinline__ float behind_camera_geometry(int mode) {
+  return (mode == NGM_GEO_OCCUPANCY || mode == NGM_GEO_DENSITY) ? -100.0f : 1.0f;
+}
+
 // density mode (rm.py:746-749): occ_k = 1 - exp(-(t_{k+1} - t_k) relu(g_k)); the caller drops the last sample
 __device__ __forceinline__ float occ_density(float g, float dl, float* docc_dg) {
   const float e = expf(-dl * fmaxf(g, 0.f));

@@ -171,8 +171,10 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast);
-      const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z, geom = o.w;
+      const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
       const float depth = -(rt[6] * t);
+      // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622
+      const float geom = (a.rc.overwrite_behind_camera && rt[6] * t > 0.f) ? behind_camera_geometry(mode) : o.w;
       float occ = 0.f;
       if (valid) {
         if (mode == NGM_GEO_DENSITY) { if (k < S - 1) occ = occ_density(geom, wl.tbuf[idx + 1] - t, nullptr); }   // rm.py:746-749, last sample dropped

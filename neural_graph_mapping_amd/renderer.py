@@ -195,13 +195,14 @@ class NeuralGraphRenderer:
         if not use_vmap or field_ids is None:
             raise NotImplementedError("render_ijs: only the training path (use_vmap=True, field_ids given) is fused; "
                                       "use render_image for the kNN evaluation path")
-        if near_distances is not None and not bool((near_distances >= 0).all()):
-            raise NotImplementedError("negative near distances (samples behind the camera) are not supported")
         self._model.set_vmap_fields(field_ids)
         for v in self._model.vmap_fields_params.values():
             v.requires_grad_()
         guided = gt_distances is not None and self._rc_train.num_samples_guided > 0
         rc = self._rc_train if guided else self._rc_plain
+        if not overwrite_samples_behind_camera:                      # default True (rm.py:450); checked per sample
+            rc = K.RenderCfg.from_buffer_copy(rc)
+            rc.overwrite_behind_camera = 0
         pos = self._global_map_dict["positions"][field_ids]
         quat = self._global_map_dict["orientations"][field_ids]
         names = tuple(K.param_names(self._fc))

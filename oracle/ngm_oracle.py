@@ -391,7 +391,7 @@ def quadrature(mode, colors, geoms, dists, depths, geometry_factor=20.0, neus_is
 
 def render_ijs(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs: RenderSpec,
                near, far, gt=None, u_coarse=None, u_guided=None, num_samples=None,
-               neus_isds=None, return_samples=False):
+               neus_isds=None, return_samples=False, overwrite_samples_behind_camera=True):
     """Training-style render (use_vmap=True) of rm.py:439-666.
 
     ijs (F,R,2), c2ws (F,R,4,4) or (4,4), pos (F,3), quat (F,4), near/far/gt (F,R).
@@ -406,6 +406,9 @@ def render_ijs(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs:
     colors = rs.color_factor * out[..., :3]
     geoms = out[..., 3]
     depths = -pts_cam[..., 2]
+    if overwrite_samples_behind_camera and near is not None and not bool((near >= 0).all()):   # rm.py:494-495
+        const = -100.0 if rs.geometry_mode in ("occupancy", "density") else 1.0                # rm.py:614-622
+        geoms = torch.where(pts_cam[..., 2] > 0, torch.full_like(geoms, const), geoms)
     tau = rs.truncation_distance
     fs_vec = ts_vec = fs_mask = ts_mask = None
     if rs.freespace_weight != 0.0 and gt is not None:               # rm.py:624-630

@@ -56,21 +56,23 @@ def look_at_c2w(eye, target, gen):
     return T
 
 
-def synth_target(F, R, cam, pos, gen, radius=1.0, invalid_frac=0.15):
-    """Synthetic Target in the spirit of _sample_target_mv (rm.py:1383-1459)."""
+def synth_target(F, R, cam, pos, gen, radius=1.0, invalid_frac=0.15, inside=False):
+    """Synthetic Target in the spirit of _sample_target_mv (rm.py:1383-1459).  inside=True puts the cameras
+    inside the field sphere and leaves near unclamped (negative): samples behind the camera (rm.py:614-622)."""
     ijs = torch.stack([torch.randint(0, cam.height, (F, R), generator=gen),
                        torch.randint(0, cam.width, (F, R), generator=gen)], -1)
     eye_dir = torch.nn.functional.normalize(torch.randn(F, R, 3, generator=gen), dim=-1)
-    dist = 2.0 + torch.rand(F, R, 1, generator=gen)
+    dist = (0.3 + 0.6 * torch.rand(F, R, 1, generator=gen)) if inside else (2.0 + torch.rand(F, R, 1, generator=gen))
     eye = pos[:, None, :] + eye_dir * dist
     tgt = pos[:, None, :] + 0.3 * torch.randn(F, R, 3, generator=gen)
     c2ws = look_at_c2w(eye, tgt, gen)
     dirs = cam.ijs_to_directions(ijs)
     pos_c = utils.transform_points(pos[:, None, :], c2ws, inv=True)
     center = (pos_c * dirs).sum(-1)
-    near = (center - radius).clamp_min(0.0)
+    near = (center - radius) if inside else (center - radius).clamp_min(0.0)
     far = (center + radius).clamp_min(0.0)
-    gt = near + (far - near) * (0.1 + 0.8 * torch.rand(F, R, generator=gen))
+    gt_lo = near.clamp_min(0.05) if inside else near
+    gt = gt_lo + (far - gt_lo) * (0.1 + 0.8 * torch.rand(F, R, generator=gen))
     sel = torch.rand(F, R, generator=gen)
     gt = torch.where(sel < invalid_frac, torch.zeros_like(gt), gt)           # missing depth
     gt = torch.where((sel >= invalid_frac) & (sel < invalid_frac + 0.05), far + 0.3, gt)
@@ -193,7 +195,7 @@ def g5_quadrature():
 
 
 def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, dim_enc=64,
-                termination_weight=0.0, perturb=True, save_samples=False):
+                termination_weight=0.0, perturb=True, save_samples=False, inside=False):
     cam = camera.Camera(**NRGBD_CAMERA)
     gen = torch.Generator().manual_seed(seed)
     pos = 0.5 * torch.randn(F, 3, generator=gen)
@@ -210,7 +212,7 @@ def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, di
                 v.add_(0.05 * torch.randn(v.shape, generator=gen))
         # make geometry non-trivial: larger last-layer weights
         model.all_fields_params[f"_linears.{num_layers}.weight"].mul_(2.0)
-    t = synth_target(F, R, cam, pos, gen)
+    t = synth_target(F, R, cam, pos, gen, inside=inside)
     fids = torch.arange(F)
     target = make_target(t, fids)
     torch.manual_seed(seed + 1000)
@@ -236,6 +238,12 @@ def g6_train():
     _train_case("g6_train_3field", F=3, R=24, n_c=8, n_g=16, seed=61, termination_weight=0.5)
     _train_case("g6_train_nerf_l1", F=2, R=16, n_c=8, n_g=8, seed=62, encoding="nerf",
                 num_layers=1)
+
+
+def g10_behind_camera():
+    """Cameras inside the field sphere, near < 0: _render_ijs overwrites the geometry of the samples behind the
+    camera (rm.py:494-495, 614-622) and no gradient flows through them."""
+    _train_case("g10_train_behind_camera", F=2, R=48, n_c=12, n_g=8, seed=70, termination_weight=0.5, inside=True)
 
 
 def g7_adam():
@@ -334,11 +342,10 @@ def g9_render_image():
 
 
 if __name__ == "__main__":
-    g1_directions()
-    g2_g3_sampling()
-    g4_field_forward()
-    g5_quadrature()
-    g6_train()
-    g7_adam()
-    g8_knn()
-    g9_render_image()
+    import sys
+    cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
+             g10_behind_camera]
+    only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
+    for fn in cases:
+        if not only or fn.__name__ in only:
+            fn()

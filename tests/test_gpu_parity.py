@@ -288,6 +288,9 @@ CASES = {
     "g6_train_3field": (dict(encoding="fourier", dim_enc=64, num_layers=2),
                         dict(num_samples_coarse=8, num_samples_depth_guided=16, termination_weight=0.5)),
     "g6_train_nerf_l1": (dict(encoding="nerf", num_octaves=8, num_layers=1), dict(num_samples_coarse=8, num_samples_depth_guided=8)),
+    # cameras inside the field, near < 0: geometry of samples behind the camera overwritten (rm.py:614-622)
+    "g10_train_behind_camera": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                                dict(num_samples_coarse=12, num_samples_depth_guided=8, termination_weight=0.5)),
 }
 
 

@@ -289,6 +289,42 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
                        float outside_value, float* out, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* ---- training-target sampler -------------------------------------------------------
+ * Device part of NeuralGraphMap._sample_target_mv (rm.py:1259-1459).  The random draws stay with the caller
+ * (torch.multinomial / randn / rand on its generator, as in the reference); the keyframe store is read in place. */
+typedef struct ngm_keyframes {
+  int32_t num_frames;            /* len(_c_c2w_tensor)                                              */
+  int32_t height, width;         /* keyframe image size                                              */
+  int32_t reserved0;
+  const float* c2ws;             /* (num_frames,4,4) current keyframe poses, rm.py:1711-1713          */
+  const float* rgbd;             /* (N_store,height,width,4) keyframe RGB-D store [r,g,b,depth]       */
+  const int64_t* frame_to_store; /* (num_frames) _frame_cid_to_ncid, rm.py:1703                       */
+  float fx, fy, cx, cy;          /* intrinsics at pixel centre 0 (camera.py:188)                      */
+} ngm_keyframes;
+
+/* outputs of ngm_target_rays = the reference's Target record (rm.py:43-58) for F fields x R rays */
+typedef struct ngm_target_out {
+  int64_t* ijs;        /* (F,R,2) [row, col]        */
+  float* c2ws;         /* (F,R,4,4) or NULL         */
+  float* near;         /* (F,R)                     */
+  float* far;          /* (F,R)                     */
+  float* gt;           /* (F,R) ray distance of the keyframe depth, 0 = missing */
+  float* rgbds;        /* (F,R,4)                   */
+  uint8_t* rgb_mask;   /* (F,R)                     */
+  uint8_t* depth_mask; /* (F,R)                     */
+  float* term_probs;   /* (F,R)                     */
+  uint8_t* term_mask;  /* (F,R)                     */
+} ngm_target_out;
+
+/* rm.py:1321-1392: kf_mask (F,num_frames) u8 = keyframe sees the field; bbox (F,num_frames,4) =
+ * (min_x, min_y, max_x, max_y) of the projected sphere samples, clamped to the image. */
+int ngm_target_visibility(const ngm_keyframes* kf, int32_t F, const float* field_pos, int32_t num_offsets,
+                          const float* offsets, float radius, uint8_t* kf_mask, float* bbox, void* stream);
+/* rm.py:1394-1459: frame_cids (F,R) i64 = sampled keyframe per ray, u_xy (F,R,2) = pixel uniforms. */
+int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* field_pos, float radius,
+                    const float* bbox, const int64_t* frame_cids, const float* u_xy,
+                    const ngm_target_out* out, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------
  * When enabled, every launch of the listed kernels is bracketed by hipEvents recorded on the launch
  * stream; ngm_profile_read() synchronises them and returns the accumulated device time. */

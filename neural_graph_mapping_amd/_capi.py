@@ -82,6 +82,17 @@ class Prediction(C.Structure):
     _fields_ = [("rgbds", f32p), ("color_vars", f32p), ("depth_vars", f32p), ("term_probs", f32p)]
 
 
+class Keyframes(C.Structure):
+    _fields_ = [("num_frames", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("reserved0", C.c_int32),
+                ("c2ws", f32p), ("rgbd", f32p), ("frame_to_store", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class TargetOut(C.Structure):
+    _fields_ = [("ijs", C.c_void_p), ("c2ws", f32p), ("near", f32p), ("far", f32p), ("gt", f32p), ("rgbds", f32p),
+                ("rgb_mask", C.c_void_p), ("depth_mask", C.c_void_p), ("term_probs", f32p), ("term_mask", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -130,6 +141,10 @@ def lib():
     L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp, i64, vp]
     L.ngm_field_eval_knn_workspace.argtypes = [i32, i64, i32]
     L.ngm_field_eval_knn_workspace.restype = i64
+    L.ngm_target_visibility.argtypes = [P(Keyframes), i32, vp, i32, vp, f32, vp, vp, vp]
+    L.ngm_target_rays.argtypes = [P(Keyframes), i32, i32, vp, f32, vp, vp, vp, P(TargetOut), vp]
+    L.ngm_target_visibility.restype = C.c_int
+    L.ngm_target_rays.restype = C.c_int
     L.ngm_profile_enable.argtypes = [i32]
     L.ngm_profile_read.argtypes = [i32, P(C.c_double), P(i64)]
     for name in ("ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"):
@@ -148,7 +163,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_last_bwd_variant"]
+            "ngm_debug_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;
 # torch.optim.Adam skips grad-less parameters, so the sparse Adam must skip them too)

@@ -193,6 +193,35 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches) {
   return NGM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// training-target sampler
+// ------------------------------------------------------------------------------------------------
+static int check_keyframes(const ngm_keyframes* kf) {
+  if (!kf || !kf->c2ws || !kf->rgbd || !kf->frame_to_store) return fail(NGM_E_INVALID, "target sampler: NULL keyframe argument");
+  if (kf->num_frames < 1 || kf->height < 1 || kf->width < 1) return fail(NGM_E_INVALID, "target sampler: empty keyframe set");
+  return NGM_OK;
+}
+int ngm_target_visibility(const ngm_keyframes* kf, int32_t F, const float* field_pos, int32_t num_offsets, const float* offsets,
+                          float radius, uint8_t* kf_mask, float* bbox, void* stream) {
+  int e = check_keyframes(kf);
+  if (e) return e;
+  if (F < 0 || num_offsets < 1 || !field_pos || !offsets || !kf_mask || !bbox) return fail(NGM_E_INVALID, "ngm_target_visibility: bad argument");
+  if (F == 0) return NGM_OK;
+  ngm_launch_target_visibility(*kf, F, field_pos, num_offsets, offsets, radius, kf_mask, bbox, (hipStream_t)stream);
+  return check_launch("ngm_target_visibility");
+}
+int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* field_pos, float radius, const float* bbox,
+                    const int64_t* frame_cids, const float* u_xy, const ngm_target_out* out, void* stream) {
+  int e = check_keyframes(kf);
+  if (e) return e;
+  if (F < 0 || R < 1 || !field_pos || !bbox || !frame_cids || !u_xy || !out || !out->ijs || !out->near || !out->far || !out->gt ||
+      !out->rgbds || !out->rgb_mask || !out->depth_mask || !out->term_probs || !out->term_mask)
+    return fail(NGM_E_INVALID, "ngm_target_rays: bad argument");
+  if (F == 0) return NGM_OK;
+  ngm_launch_target_rays(*kf, F, R, field_pos, radius, bbox, frame_cids, u_xy, *out, (hipStream_t)stream);
+  return check_launch("ngm_target_rays");
+}
+
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 
 int ngm_debug_phase_cycles(unsigned long long* out16) {

@@ -124,6 +124,11 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st);
 
+int ngm_launch_target_visibility(const ngm_keyframes& kf, int F, const float* field_pos, int num_offsets, const float* offsets,
+                                 float radius, uint8_t* kf_mask, float* bbox, hipStream_t st);
+int ngm_launch_target_rays(const ngm_keyframes& kf, int F, int R, const float* field_pos, float radius, const float* bbox,
+                           const int64_t* frame_cids, const float* u_xy, const ngm_target_out& o, hipStream_t st);
+
 // flat parameter vector layout of one field: [enc_w][w0][b0]...[wL][bL]
 __host__ __device__ static inline int64_t ngm_param_offsets(const ngm_field_cfg* fc, int64_t* enc_off, int64_t* w_off, int64_t* b_off) {
   int64_t o = 0;

@@ -312,3 +312,54 @@ def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=Non
     K.check(K.lib().ngm_adam_sparse_multi(arr, len(names), _ptr(field_index), grads[names[0]].shape[0], int(step),
                                           _ptr(step_dev), lr, betas[0], betas[1], eps, weight_decay, _stream()),
             "ngm_adam_sparse_multi")
+
+
+# ------------------------------------------------------------------------------------------------
+# training-target sampler, device part (rm.py:1321-1459)
+# ------------------------------------------------------------------------------------------------
+def keyframes_struct(c2ws, rgbd_store, frame_to_store, fx, fy, cx, cy) -> K.Keyframes:
+    """c2ws (Nc,4,4), rgbd_store (N,H,W,4), frame_to_store (Nc,) int64; intrinsics at pixel centre 0."""
+    _require_gpu(c2ws, rgbd_store, frame_to_store)
+    assert c2ws.is_contiguous() and rgbd_store.is_contiguous() and frame_to_store.dtype == torch.int64
+    kf = K.Keyframes()
+    kf.num_frames, kf.height, kf.width = c2ws.shape[0], rgbd_store.shape[1], rgbd_store.shape[2]
+    kf.c2ws = C.cast(c2ws.data_ptr(), K.f32p)
+    kf.rgbd = C.cast(rgbd_store.data_ptr(), K.f32p)
+    kf.frame_to_store = frame_to_store.data_ptr()
+    kf.fx, kf.fy, kf.cx, kf.cy = float(fx), float(fy), float(cx), float(cy)
+    return kf
+
+
+def target_visibility(kf: K.Keyframes, field_pos, offsets, radius):
+    """(kf_mask (F,Nc) bool, bbox (F,Nc,4) [min_x, min_y, max_x, max_y] clamped to the image)."""
+    field_pos, offsets = _f32c(field_pos), _f32c(offsets)
+    F, Nc = field_pos.shape[0], kf.num_frames
+    mask = torch.empty(F, Nc, dtype=torch.uint8, device=field_pos.device)
+    bbox = torch.empty(F, Nc, 4, device=field_pos.device)
+    K.check(K.lib().ngm_target_visibility(C.byref(kf), F, _ptr(field_pos), offsets.shape[0], _ptr(offsets), float(radius),
+                                          _ptr(mask), _ptr(bbox), _stream()), "ngm_target_visibility")
+    return mask.bool(), bbox
+
+
+def target_rays(kf: K.Keyframes, field_pos, radius, bbox, frame_cids, u_xy):
+    """Per-ray targets (rm.py:1394-1459) as a dict keyed like the reference's Target record."""
+    field_pos, bbox, u_xy = _f32c(field_pos), _f32c(bbox), _f32c(u_xy)
+    frame_cids = frame_cids.contiguous()
+    F, R = frame_cids.shape
+    dev = field_pos.device
+    o = dict(ijs=torch.empty(F, R, 2, dtype=torch.int64, device=dev), c2ws=torch.empty(F, R, 4, 4, device=dev),
+             near=torch.empty(F, R, device=dev), far=torch.empty(F, R, device=dev), gt=torch.empty(F, R, device=dev),
+             rgbds=torch.empty(F, R, 4, device=dev), rgb_mask=torch.empty(F, R, dtype=torch.uint8, device=dev),
+             depth_mask=torch.empty(F, R, dtype=torch.uint8, device=dev), term_probs=torch.empty(F, R, device=dev),
+             term_mask=torch.empty(F, R, dtype=torch.uint8, device=dev))
+    out = K.TargetOut()
+    out.ijs = o["ijs"].data_ptr()
+    for k in ("c2ws", "near", "far", "gt", "rgbds", "term_probs"):
+        setattr(out, k, C.cast(o[k].data_ptr(), K.f32p))
+    for k in ("rgb_mask", "depth_mask", "term_mask"):
+        setattr(out, k, o[k].data_ptr())
+    K.check(K.lib().ngm_target_rays(C.byref(kf), F, R, _ptr(field_pos), float(radius), _ptr(bbox), _ptr(frame_cids),
+                                    _ptr(u_xy), C.byref(out), _stream()), "ngm_target_rays")
+    for k in ("rgb_mask", "depth_mask", "term_mask"):
+        o[k] = o[k].bool()
+    return o

@@ -245,6 +245,52 @@ class NeuralGraphRenderer:
         loss["combined"] = total
         return loss
 
+    # -- training-target sampler (rm.py:1259-1459) ------------------------------------------------
+    @torch.no_grad()
+    def sample_target_mv(self, current_field_ids, c_c2w, nc_rgbd, frame_cid_to_ncid, num_train_fields, num_rays_per_field,
+                         num_fields=None, camera: Optional[Camera] = None, draws: Optional[dict] = None) -> Target:
+        """NeuralGraphMap._sample_target_mv: choose the fields to train, find the keyframes that see them, sample
+        keyframes and pixels, collect the RGB-D supervision.  State that the reference keeps on `self` is passed in:
+        c_c2w (Nc,4,4) = _c_c2w_tensor, nc_rgbd (N,H,W,4) = _nc_rgbd_tensor, frame_cid_to_ncid (Nc,).
+        The random draws are made with torch on this device in the reference's order (multinomial, multinomial,
+        randn, multinomial, rand); `draws` (dict: subset_observed, subset_random, offsets, frame_cids, u_xy)
+        replays recorded ones.  The geometry between the draws runs in two HIP kernels."""
+        cam = camera or self._camera
+        dev = self._device
+        radius = self._field_radius + 0.0
+        num_fields = self._global_map_dict["num"] if num_fields is None else num_fields
+        d = draws or {}
+        cur = current_field_ids.to(dev)
+        n_obs = min(num_train_fields // 2, len(cur))
+        sub_obs = d["subset_observed"].to(dev) if draws else torch.multinomial(torch.ones(len(cur), device=dev), n_obs)
+        obs_ids = cur[sub_obs]
+        n_rand = min(num_train_fields - len(obs_ids), num_fields - len(obs_ids))
+        if n_rand > 0:
+            dist = torch.ones(num_fields, device=dev)
+            dist[obs_ids] = 0.0
+            sub_rand = d["subset_random"].to(dev) if draws else torch.multinomial(dist, n_rand)
+            field_ids = torch.unique(torch.cat((torch.arange(num_fields, device=dev)[sub_rand], obs_ids)))
+        else:
+            field_ids = obs_ids
+        pos_w = self._global_map_dict["positions"][field_ids].contiguous()
+        if draws:
+            offsets = d["offsets"].to(dev)
+        else:
+            offsets = torch.randn((20, 3), device=dev)
+            offsets /= torch.linalg.norm(offsets, dim=-1, keepdim=True)
+        fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
+        kf = ops.keyframes_struct(c_c2w.contiguous(), nc_rgbd, frame_cid_to_ncid, fx, fy, cx, cy)
+        kf_mask, bbox = ops.target_visibility(kf, pos_w, offsets, radius)
+        fmask = kf_mask.any(-1)                                    # fields no keyframe sees are dropped (rm.py:1365-1379)
+        kf_mask, field_ids, pos_w, bbox = kf_mask[fmask], field_ids[fmask], pos_w[fmask].contiguous(), bbox[fmask].contiguous()
+        F, R = len(field_ids), num_rays_per_field
+        frame_cids = d["frame_cids"].to(dev) if draws else torch.multinomial(kf_mask.float(), R, replacement=True)
+        u_xy = d["u_xy"].to(dev) if draws else torch.rand(F, R, 2, device=dev)
+        o = ops.target_rays(kf, pos_w, radius, bbox, frame_cids, u_xy)
+        return Target(ijs=o["ijs"], c2ws=o["c2ws"], near_distances=o["near"], far_distances=o["far"],
+                      gt_distances=o["gt"], field_ids=field_ids, rgbds=o["rgbds"], rgb_mask=o["rgb_mask"],
+                      depth_mask=o["depth_mask"], term_probs=o["term_probs"], term_mask=o["term_mask"])
+
     # -- eval path: render_image / PSNR (rm.py:402-437, 1966-2000; evaluation.py:46-56) ----------
     def eval_num_samples(self) -> int:
         """rm.py:199-207: derived from the training sample spacing unless configured."""

@@ -163,8 +163,10 @@ def sample_rays(ijs, cam: CameraSpec, near, far, gt, spec: RenderSpec, u_coarse,
     return pts, t, dirs
 
 
-def transform_points(p, T):
-    """p_w = R p + t (utils.py:276-286, non-inverse branch)."""
+def transform_points(p, T, inv=False):
+    """p_w = R p + t, or with inv: p_c = R^T (p - t) (utils.py:276-286)."""
+    if inv:
+        return torch.einsum("...kd,...k->...d", T[..., :3, :3], p - T[..., :3, 3])
     return torch.einsum("...dk,...k->...d", T[..., :3, :3], p) + T[..., :3, 3]
 
 
@@ -426,6 +428,99 @@ def render_ijs(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs:
         pred.update(sample_distances=t, sample_outs=out, sample_weights=w, points_world=pts_w,
                     freespace_mask=fs_mask, tsdf_mask=ts_mask)
     return pred
+
+
+# ----------------------------------------------------------------------------------------
+# training-target sampler (rm.py:1259-1459)
+# ----------------------------------------------------------------------------------------
+
+
+def project_points_opengl(points_cam, cam: CameraSpec, pixel_center: float = 0.5):
+    """Camera.project_points(points, "opengl") (camera.py:119-154, matrix :176-180): continuous (x, y)
+    image coordinates for the given pixel-centre convention (cam.cx/cy are stored for pixel centre 0)."""
+    cx, cy = cam.cx + pixel_center, cam.cy + pixel_center
+    M = torch.tensor([[cam.fx, 0, -cx], [0, -cam.fy, -cy], [0, 0, -1]], dtype=torch.float)
+    h = torch.einsum("oi,...i->...o", M, points_cam)
+    return h[..., :2] / h[..., 2].unsqueeze(-1)
+
+
+def depth_to_distance(depths, ijs, cam: CameraSpec):
+    """camera.py:319-340: depth along z / z-component of the unit OpenCV ray direction."""
+    dx = (ijs[..., 1] - cam.cx) / cam.fx
+    dy = (ijs[..., 0] - cam.cy) / cam.fy
+    d = torch.nn.functional.normalize(torch.stack([dx, dy, torch.ones_like(dx)], -1), dim=-1)
+    return depths / d[..., 2]
+
+
+def sample_target_mv(cam: CameraSpec, c_c2w, nc_rgbd, frame_cid_to_ncid, positions, num_fields, current_field_ids,
+                     num_train_fields, num_rays_per_field, field_radius, draws=None):
+    """NeuralGraphMap._sample_target_mv (rm.py:1259-1459): pick fields, find the keyframes that see them,
+    sample keyframes and pixels per field and collect the supervision targets.
+
+    Randomness: with draws=None the same torch RNG calls as the reference are made in the same order (global
+    generator), so after torch.manual_seed(s) the result equals the reference's; otherwise `draws` supplies
+    them: dict(subset_observed, subset_random (or None), offsets (20,3) normalised, frame_cids (F,R), u_xy (F,R,2)).
+    Returns (target dict, draws dict, aux dict with the visibility mask / boxes before filtering)."""
+    radius = field_radius + 0.0
+    num_field_samples = 20
+    d = {} if draws is None else draws
+    cur = current_field_ids
+    n_obs = min(num_train_fields // 2, len(cur))
+    sub_obs = d["subset_observed"] if draws is not None else torch.multinomial(torch.ones(len(cur)), n_obs)
+    obs_ids = cur[sub_obs]
+    n_rand = min(num_train_fields - len(obs_ids), num_fields - len(obs_ids))
+    sub_rand = None
+    if n_rand > 0:
+        dist = torch.ones(num_fields)
+        dist[obs_ids] = 0.0
+        sub_rand = d["subset_random"] if draws is not None else torch.multinomial(dist, n_rand)
+        field_ids = torch.unique(torch.cat((torch.arange(num_fields)[sub_rand], obs_ids)))
+    else:
+        field_ids = obs_ids
+    pos_w = positions[field_ids]
+    if draws is not None:
+        offsets = d["offsets"]
+    else:
+        offsets = torch.randn((num_field_samples, 3))
+        offsets = offsets / torch.linalg.norm(offsets, dim=-1, keepdim=True)
+    samples_w = pos_w.unsqueeze(1) + offsets * radius * 1.0                           # (F,20,3)
+    samples_c = transform_points(samples_w.unsqueeze(-2), c_c2w, inv=True)            # (F,20,Nc,3)
+    depths = -samples_c[..., 2]
+    xy = project_points_opengl(samples_c, cam)                                        # (F,20,Nc,2)
+    xi = xy.int()
+    valid = (xi[..., 0] >= 0) & (xi[..., 0] < cam.width) & (xi[..., 1] >= 0) & (xi[..., 1] < cam.height)
+    F, Nc = len(field_ids), c_c2w.shape[0]
+    cids = torch.arange(Nc).expand(F, num_field_samples, -1)
+    kf_depths = torch.zeros_like(depths)
+    kf_depths[valid] = nc_rgbd[frame_cid_to_ncid[cids[valid]], xi[..., 1][valid].long(), xi[..., 0][valid].long(), 3]
+    kf_mask = (depths > 0).any(-2) & (depths < kf_depths).any(-2) & valid.any(-2)     # (F,Nc)
+    fmask = kf_mask.any(-1)
+    aux = dict(field_ids_all=field_ids, kf_mask_all=kf_mask, min_xy_all=xy.min(1)[0], max_xy_all=xy.max(1)[0])
+    kf_mask, field_ids, pos_w, xy = kf_mask[fmask], field_ids[fmask], pos_w[fmask], xy[fmask]
+    F, R = len(field_ids), num_rays_per_field
+    frame_cids = d["frame_cids"] if draws is not None else torch.multinomial(kf_mask.float(), R, replacement=True)
+    wh = torch.tensor((cam.width, cam.height), dtype=torch.float)
+    min_xy = xy.min(1)[0].clamp_min(0.0)
+    max_xy = torch.minimum(xy.max(1)[0], wh)
+    idx = frame_cids[..., None].expand(-1, -1, 2)
+    tmin, tmax = torch.gather(min_xy, 1, idx), torch.gather(max_xy, 1, idx)
+    u_xy = d["u_xy"] if draws is not None else torch.rand(F, R, 2)
+    jis = torch.minimum(((tmax - tmin) * u_xy + tmin).int(), torch.tensor((cam.width - 1, cam.height - 1), dtype=torch.int32))
+    ijs = torch.stack((jis[..., 1], jis[..., 0]), -1)
+    c2ws = c_c2w[frame_cids]
+    pos_c = transform_points(pos_w.unsqueeze(1), c2ws, inv=True)
+    dirs = ijs_to_directions(ijs, cam)
+    center = (pos_c * dirs).sum(-1)
+    near = (center - radius).clamp_min(0.0)
+    far = (center + radius).clamp_min(0.0)
+    rgbds = nc_rgbd[frame_cid_to_ncid[frame_cids], ijs[..., 0].long(), ijs[..., 1].long()]
+    gt = depth_to_distance(rgbds[..., 3], ijs, cam)
+    vd = gt != 0.0
+    target = dict(ijs=ijs, c2ws=c2ws, near=near, far=far, gt=gt, field_ids=field_ids, rgbds=rgbds,
+                  rgb_mask=(rgbds[..., :2] != 0.0).any(-1), depth_mask=(gt > near) & (gt < far) & vd,
+                  term_probs=(gt < far).float(), term_mask=(gt > near) & vd)
+    used = dict(subset_observed=sub_obs, subset_random=sub_rand, offsets=offsets, frame_cids=frame_cids, u_xy=u_xy)
+    return target, used, aux
 
 
 # ----------------------------------------------------------------------------------------

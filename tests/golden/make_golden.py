@@ -240,6 +240,66 @@ def g6_train():
                 num_layers=1)
 
 
+def g11_target_sampler():
+    """_sample_target_mv (rm.py:1259-1459) on a synthetic keyframe store; the torch RNG draws made inside are
+    recorded by wrapping torch.multinomial / randn / rand so that other implementations can replay them."""
+    W, H = 64, 48
+    cam = camera.Camera(width=W, height=H, fx=55.0, fy=55.0, cx=31.5, cy=23.5, pixel_center=0.0)
+    gen = torch.Generator().manual_seed(110)
+    NF, NC = 12, 6
+    grid = torch.stack(torch.meshgrid(torch.arange(3.0), torch.arange(2.0), torch.arange(2.0), indexing="ij"), -1).reshape(-1, 3)
+    pos = grid * 1.1 + 0.05 * torch.randn(NF, 3, generator=gen)
+    quat = rand_quats(NF, gen)
+    cfg = make_config(num_samples_coarse=4, num_samples_depth_guided=4)
+    cfg["num_train_fields"], cfg["num_rays_per_field"] = 8, 16
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=110)
+    ngm._camera = cam
+    eye = pos.mean(0) + torch.nn.functional.normalize(torch.randn(NC, 3, generator=gen), dim=-1) * (3.0 + torch.rand(NC, 1, generator=gen))
+    c2w = look_at_c2w(eye[None], (pos.mean(0) + 0.5 * torch.randn(NC, 3, generator=gen))[None], gen)[0]
+    rgbd = torch.rand(NC + 2, H, W, 4, generator=gen)
+    rgbd[..., 3] = 2.0 + 3.0 * rgbd[..., 3]                       # depth 2..5 m: some fields in front, some behind
+    rgbd[:, :8, :10, 3] = 0.0                                     # missing depth
+    rgbd[:, :4, :5, :3] = 0.0                                     # black corner: rgb_mask false
+    ngm._c_c2w_tensor = c2w
+    ngm._nc_rgbd_tensor = rgbd
+    ngm._frame_cid_to_ncid = torch.tensor([0, 2, 3, 5, 6, 7])
+    ngm._rerun_field_details = None
+    cur = torch.tensor([1, 4, 5, 7, 10])
+    rec = {}
+    orig = dict(multinomial=torch.multinomial, randn=torch.randn, rand=torch.rand)
+    count = dict(multinomial=0)
+
+    def wrap(name):
+        def f(*a, **k):
+            out = orig[name](*a, **k)
+            if name == "multinomial":
+                rec[["subset_observed", "subset_random", "frame_cids"][count["multinomial"]]] = out
+                count["multinomial"] += 1
+            elif name == "randn":
+                rec["offsets_raw"] = out.clone()          # the reference normalises `out` in place afterwards
+            else:
+                rec["u_xy"] = out
+            return out
+        return f
+    torch.manual_seed(111)
+    torch.multinomial, torch.randn, torch.rand = wrap("multinomial"), wrap("randn"), wrap("rand")
+    try:
+        t = ngm._sample_target_mv(cur)
+    finally:
+        torch.multinomial, torch.randn, torch.rand = orig["multinomial"], orig["randn"], orig["rand"]
+    assert count["multinomial"] == 3
+    off = rec["offsets_raw"] / torch.linalg.norm(rec["offsets_raw"], dim=-1, keepdim=True)
+    save("g11_target_sampler", width=np.int64(W), height=np.int64(H), fx=np.float32(55.0), fy=np.float32(55.0),
+         cx=np.float32(31.5), cy=np.float32(23.5), positions=pos, c_c2w=c2w, nc_rgbd=rgbd,
+         frame_cid_to_ncid=ngm._frame_cid_to_ncid, current_field_ids=cur, num_fields=np.int64(NF),
+         num_train_fields=np.int64(8), num_rays_per_field=np.int64(16), field_radius=np.float32(1.0), seed=np.int64(111),
+         d_subset_observed=rec["subset_observed"], d_subset_random=rec["subset_random"], d_offsets=off,
+         d_frame_cids=rec["frame_cids"], d_u_xy=rec["u_xy"],
+         o_ijs=t.ijs, o_c2ws=t.c2ws, o_near=t.near_distances, o_far=t.far_distances, o_gt=t.gt_distances,
+         o_field_ids=t.field_ids, o_rgbds=t.rgbds, o_rgb_mask=t.rgb_mask, o_depth_mask=t.depth_mask,
+         o_term_probs=t.term_probs, o_term_mask=t.term_mask)
+
+
 def g10_behind_camera():
     """Cameras inside the field sphere, near < 0: _render_ijs overwrites the geometry of the samples behind the
     camera (rm.py:494-495, 614-622) and no gradient flows through them."""
@@ -344,7 +404,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera]
+             g10_behind_camera, g11_target_sampler]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -611,3 +611,35 @@ def test_permuto_fused_train_step_vs_oracle():
     before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
     r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
     assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched
+
+
+# ------------------------------------------------------------------ training-target sampler (G11)
+def test_target_sampler_golden():
+    """_sample_target_mv (rm.py:1259-1459) with the reference's recorded draws: pixel indices, field ids and masks
+    must be identical, distances / poses / RGB-D within fp32 round-off."""
+    g = load_golden("g11_target_sampler")
+    fkw = dict(encoding="fourier", dim_enc=32, num_layers=1)
+    r = make_renderer(fkw, dict(num_samples_coarse=4, num_samples_depth_guided=4), int(g["num_fields"]))
+    r.set_field_poses(g["positions"].to(DEV), torch.zeros(int(g["num_fields"]), 4, device=DEV))
+    cam = Rr.Camera(int(g["width"]), int(g["height"]), float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]),
+                    pixel_center=0.0)
+    draws = dict(subset_observed=g["d_subset_observed"], subset_random=g["d_subset_random"], offsets=g["d_offsets"],
+                 frame_cids=g["d_frame_cids"], u_xy=g["d_u_xy"])
+    t = r.sample_target_mv(g["current_field_ids"], g["c_c2w"].to(DEV), g["nc_rgbd"].to(DEV).contiguous(),
+                           g["frame_cid_to_ncid"].to(DEV), int(g["num_train_fields"]), int(g["num_rays_per_field"]),
+                           camera=cam, draws=draws)
+    assert torch.equal(t.field_ids.cpu(), g["o_field_ids"])
+    assert torch.equal(t.ijs.cpu(), g["o_ijs"].long())
+    for a, b in ((t.c2ws, "o_c2ws"), (t.near_distances, "o_near"), (t.far_distances, "o_far"), (t.gt_distances, "o_gt"),
+                 (t.rgbds, "o_rgbds"), (t.term_probs, "o_term_probs")):
+        close(a, g[b], rtol=2e-6, atol=2e-6)
+    for a, b in ((t.rgb_mask, "o_rgb_mask"), (t.depth_mask, "o_depth_mask"), (t.term_mask, "o_term_mask")):
+        assert torch.equal(a.cpu(), g[b]), b
+    # own draws on the device: structural checks only (the stream differs from the CPU generator's)
+    torch.manual_seed(3)
+    t2 = r.sample_target_mv(g["current_field_ids"], g["c_c2w"].to(DEV), g["nc_rgbd"].to(DEV).contiguous(),
+                            g["frame_cid_to_ncid"].to(DEV), int(g["num_train_fields"]), int(g["num_rays_per_field"]),
+                            camera=cam)
+    assert t2.ijs.shape[1:] == (16, 2) and t2.ijs.shape[0] == len(t2.field_ids) <= 8
+    assert bool((t2.near_distances <= t2.far_distances).all()) and bool((t2.near_distances >= 0).all())
+    assert bool((t2.ijs[..., 0] < 48).all()) and bool((t2.ijs[..., 1] < 64).all()) and bool((t2.ijs >= 0).all())

@@ -266,15 +266,19 @@ int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t str
                     float eps, float weight_decay, void* stream);
 
 /* All parameter tensors of a field set in ONE launch.  `step_dev` (optional device int64) overrides
- * `step` so that a captured hipGraph advances the bias correction on every replay. */
+ * `step` so that a captured hipGraph advances the bias correction on every replay.  End-of-iteration
+ * bookkeeping can ride along: with advance_step_dev != 0 the kernel does ++*step_dev, and with a non-NULL
+ * advance_philox_offset_dev ++*that, once every block has finished (same effect as ngm_step_advance, but
+ * measured slower than the separate launch on MI355X: every block fences its stores first). */
 typedef struct ngm_adam_tensor {
   float* param; float* exp_avg; float* exp_avg_sq; /* (N, numel) rows with `stride` elements between fields */
   const float* grad;                               /* (F, numel) rows with `grad_stride`                    */
   int64_t stride, grad_stride, numel;
 } ngm_adam_tensor;
 int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, const int64_t* field_index,
-                          int32_t F, int64_t step, const int64_t* step_dev, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, void* stream);
+                          int32_t F, int64_t step, int64_t* step_dev, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int32_t advance_step_dev,
+                          uint64_t* advance_philox_offset_dev, void* stream);
 /* ++*step_dev, ++*philox_offset_dev on the stream (either may be NULL): end-of-iteration bookkeeping
  * for graph-captured training loops. */
 int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* stream);

@@ -134,7 +134,7 @@ def lib():
                                         P(Grads), vp, i64, vp]
     L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
-    L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp]
+    L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, i32, vp, vp]
     L.ngm_step_advance.argtypes = [vp, vp, vp]
     L.ngm_adam_sparse_multi.restype = C.c_int
     L.ngm_step_advance.restype = C.c_int

@@ -17,7 +17,8 @@ int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const floa
                     const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
                     float eps, float wd, hipStream_t st);
 int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* field_index, int F, int64_t step,
-                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd, hipStream_t st);
+                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd,
+                          int64_t* advance_step, uint64_t* advance_offset, hipStream_t st);
 int ngm_launch_step_advance(int64_t* step_dev, uint64_t* off_dev, hipStream_t st);
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
@@ -582,13 +583,8 @@ int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   StashBwdArgs sb;
   memset(&sb, 0, sizeof(sb));
   sb.seed_mode = 0; sb.tg = *targets; sb.pred = *pred; sb.loss_sums = loss_sums;
-  e = render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
-  if (e) return e;
-  if (loss_out) {
-    ngm_launch_loss_values(rcfg, loss_sums, loss_out, (hipStream_t)stream);
-    e = check_launch("ngm_loss_values");
-  }
-  return e;
+  sb.loss_out = loss_out;      // written by the compositing-backward kernel (no separate launch)
+  return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
@@ -626,15 +622,15 @@ int ngm_adam_sparse(float* param, float* exp_avg, float* exp_avg_sq, int64_t str
 }
 
 int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, const int64_t* field_index, int32_t F,
-                          int64_t step, const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, void* stream) {
+                          int64_t step, int64_t* step_dev, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int32_t advance_step_dev, uint64_t* advance_philox_offset_dev, void* stream) {
   if (!tensors || num_tensors < 1 || num_tensors > 2 * (NGM_MAX_LAYERS + 1) + 2 || F < 1 || (step < 1 && !step_dev))
     return fail(NGM_E_INVALID, "ngm_adam_sparse_multi: bad argument");
   for (int i = 0; i < num_tensors; ++i)
     if (!tensors[i].param || !tensors[i].exp_avg || !tensors[i].exp_avg_sq || !tensors[i].grad || tensors[i].numel < 1)
       return fail(NGM_E_INVALID, "ngm_adam_sparse_multi: NULL tensor");
   ngm_launch_adam_multi(tensors, num_tensors, field_index, F, step, step_dev, lr, beta1, beta2, eps, weight_decay,
-                        (hipStream_t)stream);
+                        (advance_step_dev && step_dev) ? step_dev : nullptr, advance_philox_offset_dev, (hipStream_t)stream);
   return check_launch("ngm_adam_sparse_multi");
 }
 

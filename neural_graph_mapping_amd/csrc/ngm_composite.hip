@@ -347,6 +347,8 @@ int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
 // Backward of compositing + losses on the fused forward's stash.  Reads (colour, geometry | t, T),
 // overwrites stashA with dL/d(raw MLP outputs) for the MFMA backward kernel.
 // ================================================================================================
+__device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out);
+
 __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int rays_per_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t N = (int64_t)a.F * a.R;
@@ -367,6 +369,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     k_fs = n_fs > 0 ? a.rc.w_freespace * 2.0f / n_fs : 0.f;
     k_ts = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
   }
+  // the loss scalars ride along (one thread; saves a launch in the training step)
+  if (a.loss_out && a.seed_mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) loss_values_from_sums(a.rc, a.loss_sums, a.loss_out);
   const int64_t nsamp_all = (r_end - r_beg) * S;
   float carryQ = 0.f;
   const int64_t nsteps = (nsamp_all + 63) / 64;
@@ -450,8 +454,7 @@ int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
 // loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination,
 // photometric, depth, freespace, tsdf.  Empty selections contribute 0 (the reference yields NaN).
 // ================================================================================================
-__global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out) {
   const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
               n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
   const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
@@ -462,6 +465,10 @@ __global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) 
   out[1] = lt; out[2] = lp; out[3] = ld; out[4] = lf; out[5] = ls;
   out[0] = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld + rc.w_freespace * lf + rc.w_tsdf * ls;
   out[6] = 0.f; out[7] = 0.f;
+}
+__global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  loss_values_from_sums(rc, sums, out);
 }
 int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st) {
   hipLaunchKernelGGL(k_loss_values, dim3(1), dim3(64), 0, st, *rc, sums, out);
@@ -540,7 +547,10 @@ struct AdamMultiK {
   const int64_t* step_dev;
   int64_t step;
   float lr, beta1, beta2, eps, wd;
+  int64_t* advance_step;      // non-NULL: ++*advance_step once every block has read it
+  uint64_t* advance_offset;   // non-NULL: ++*advance_offset likewise (Philox offset of the next iteration)
 };
+__device__ unsigned int g_adam_blocks_done = 0;
 __global__ void k_adam_multi(AdamMultiK a) {
   const ngm_adam_tensor& t = a.t[blockIdx.z];
   const int f = blockIdx.y;
@@ -557,15 +567,31 @@ __global__ void k_adam_multi(AdamMultiK a) {
     t.exp_avg[o] = mn; t.exp_avg_sq[o] = vn;
     t.param[o] = p - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
   }
+  // end-of-iteration bookkeeping by the last block to finish (all blocks have read the step by then)
+  if (a.advance_step || a.advance_offset) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+      if (atomicAdd(&g_adam_blocks_done, 1u) == total - 1) {
+        if (a.advance_step) *a.advance_step += 1;
+        if (a.advance_offset) *a.advance_offset += 1;
+        g_adam_blocks_done = 0;
+        __threadfence();
+      }
+    }
+  }
 }
 int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* field_index, int F, int64_t step,
-                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd, hipStream_t st) {
+                          const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd,
+                          int64_t* advance_step, uint64_t* advance_offset, hipStream_t st) {
   NgmProfScope prof_(NGM_K_ADAM, st);
   AdamMultiK a;
   int64_t mx = 1;
   for (int i = 0; i < n; ++i) { a.t[i] = tensors[i]; mx = std::max<int64_t>(mx, tensors[i].numel); }
   a.n = n; a.field_index = field_index; a.step_dev = step_dev; a.step = step;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
+  a.advance_step = advance_step; a.advance_offset = advance_offset;
   dim3 grid((unsigned)std::min<int64_t>((mx + 255) / 256, 16), (unsigned)F, (unsigned)n);
   hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, st, a);
   return 0;

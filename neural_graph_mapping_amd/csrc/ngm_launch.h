@@ -112,6 +112,7 @@ struct StashBwdArgs {
   const float* d_rgbds;       // (F,R,4)
   const float* d_term;        // (F,R)
   const float* d_geom_samples;// (F,R,S) or NULL
+  float* loss_out;            // (8) loss scalars from loss_sums (seed mode 0) or NULL
 };
 
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);

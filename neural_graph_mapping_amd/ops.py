@@ -301,7 +301,7 @@ def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, b
 
 
 def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=None, lr=1e-3, betas=(0.9, 0.999),
-                       eps=1e-15, weight_decay=1e-5):
+                       eps=1e-15, weight_decay=1e-5, advance=False, philox_offset_dev=None):
     """One launch for every parameter tensor of the field set (rows `field_index` updated in place)."""
     names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
     arr = (K.AdamTensor * len(names))()
@@ -310,7 +310,9 @@ def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=Non
         arr[i] = K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
                               g.data_ptr(), p.stride(0), g.stride(0), g[0].numel())
     K.check(K.lib().ngm_adam_sparse_multi(arr, len(names), _ptr(field_index), grads[names[0]].shape[0], int(step),
-                                          _ptr(step_dev), lr, betas[0], betas[1], eps, weight_decay, _stream()),
+                                          _ptr(step_dev), lr, betas[0], betas[1], eps, weight_decay,
+                                          int(bool(advance and step_dev is not None)),
+                                          _ptr(philox_offset_dev) if advance else None, _stream()),
             "ngm_adam_sparse_multi")
 
 

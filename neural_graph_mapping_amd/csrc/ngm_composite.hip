@@ -78,6 +78,9 @@ struct CompWaveLds {
   float wbuf[CQ_MAXS];
 };
 
+struct Rgb3 { float x, y, z; };   // 12-byte element: one global_load_dwordx3 per lane instead of three strided dword loads
+__device__ __forceinline__ Rgb3 load_rgb(const float* colors, int64_t g) { return *reinterpret_cast<const Rgb3*>(colors + 3 * g); }
+
 __device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t g) {
   if (!a.out4) return a.geoms[g];
   // packed eval path = _render_ijs(use_vmap=False): samples behind the camera get a constant (rm.py:614-622)
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
         if (a.out4) {
           const float4 o = a.out4[g];
           c0 = a.rc.color_factor * o.x; c1 = a.rc.color_factor * o.y; c2 = a.rc.color_factor * o.z; dp = -a.pcam[3 * g + 2];
-        } else { c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g]; }
+        } else { const Rgb3 c = load_rgb(a.colors, g); c0 = c.x; c1 = c.y; c2 = c.z; dp = a.depths[g]; }
       }
       if (valid) wl.wbuf[idx] = w;
       if (act && a.weights) a.weights[(rb + rl) * S_eff + k] = w;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
           const float4 o = a.out4[g];
           e0 = ra[0] - a.rc.color_factor * o.x; e1 = ra[1] - a.rc.color_factor * o.y; e2 = ra[2] - a.rc.color_factor * o.z;
           e3 = ra[3] + a.pcam[3 * g + 2];
-        } else { e0 = ra[0] - a.colors[3 * g]; e1 = ra[1] - a.colors[3 * g + 1]; e2 = ra[2] - a.colors[3 * g + 2]; e3 = ra[3] - a.depths[g]; }
+        } else { const Rgb3 c = load_rgb(a.colors, g); e0 = ra[0] - c.x; e1 = ra[1] - c.y; e2 = ra[2] - c.z; e3 = ra[3] - a.depths[g]; }
       }
       const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
                   v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
 }
 
 static int comp_grid(int64_t N, int S, int* rays_per_wave) {
-  // enough waves to fill the chip (256 CUs x 8 waves), whole rays per wave
-  const int64_t target_waves = 256 * 8;
+  // HBM-bound: enough waves to hide memory latency (256 CUs x 24 waves; LDS allows 7 blocks of 4 waves per CU),
+  // whole rays per wave
+  const int64_t target_waves = 256 * 24;
   int64_t rpw = (N + target_waves - 1) / target_waves;
   if (rpw < 1) rpw = 1;
   *rays_per_wave = (int)rpw;
@@ -228,21 +232,24 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
 // with a_k = dC.c_k + dD d_k + dterm and the suffix recursion Q_{k-1} = a_k o_k + (1-o_k) Q_k, evaluated
 // as a REVERSE segmented scan of affine maps (exact also when 1-o_k = 0, unlike the division form).
 // ================================================================================================
+// per-wave LDS planes of CQ_MAXS floats each: exclusive transmittance (later dL/docc), occ, d occ_k / d geom_k and, in
+// neus mode only, d occ_k / d geom_{k+1}, d occ_k / d isd and the per-ray d isd accumulators.  The plane count is
+// chosen at launch (3 or 5): the two extra planes would otherwise halve the occupancy of this HBM-bound kernel.
 struct CompBwdLds {
-  float tex[CQ_MAXS];   // exclusive transmittance; after the reverse sweep: dL/docc
-  float occ[CQ_MAXS];
-  float doc[CQ_MAXS];   // d occ_k / d geom_k
-  float dnx[CQ_MAXS];   // d occ_k / d geom_{k+1}   (neus)
-  float dis[CQ_MAXS];   // d occ_k / d isd          (neus)
-  float risd[CQ_BR];    // per-ray d isd
+  float* tex; float* occ; float* doc; float* dnx; float* dis; float* risd;
+  __device__ __forceinline__ CompBwdLds(float* base, bool neus) {
+    tex = base; occ = base + CQ_MAXS; doc = base + 2 * CQ_MAXS;
+    dnx = neus ? base + 3 * CQ_MAXS : nullptr; dis = neus ? base + 4 * CQ_MAXS : nullptr;
+    risd = neus ? base + 5 * CQ_MAXS : nullptr;
+  }
+  static __host__ __device__ int floats(bool neus) { return neus ? 5 * CQ_MAXS + CQ_BR : 3 * CQ_MAXS; }
 };
 
 __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, int rays_per_wave) {
   extern __shared__ __attribute__((aligned(16))) float cb_lds_raw[];
-  CompBwdLds* lds = reinterpret_cast<CompBwdLds*>(cb_lds_raw);
   const bool neus = a.rc.geometry_mode == NGM_GEO_NEUS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  CompBwdLds& wl = lds[wave];
+  CompBwdLds wl(cb_lds_raw + wave * CompBwdLds::floats(neus), neus);
   const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
   const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
   const int S = a.S;
@@ -266,7 +273,10 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       const float up = __shfl_up(q, 1, 64);
       const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
       carry = __shfl(q, 63, 64);
-      if (valid) { wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0; wl.dnx[idx] = dnext0; wl.dis[idx] = disd0; }
+      if (valid) {
+        wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0;
+        if (neus) { wl.dnx[idx] = dnext0; wl.dis[idx] = disd0; }
+      }
     }
     if (neus && lane < nb) wl.risd[lane] = 0.f;
     WAVE_SYNC();
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       float c0 = 0, c1 = 0, c2 = 0, dp = 0, T = 0, occ = 0, dodg = 0;
       float dC0 = 0, dC1 = 0, dC2 = 0, dD = 0, dT = 0;
       if (valid) {
-        c0 = a.colors[3 * g]; c1 = a.colors[3 * g + 1]; c2 = a.colors[3 * g + 2]; dp = a.depths[g];
+        const Rgb3 c = load_rgb(a.colors, g); c0 = c.x; c1 = c.y; c2 = c.z; dp = a.depths[g];
         T = wl.tex[idx]; occ = wl.occ[idx]; dodg = wl.doc[idx];
         if (a.dC) { dC0 = a.dC[3 * ray]; dC1 = a.dC[3 * ray + 1]; dC2 = a.dC[3 * ray + 2]; }
         if (a.dD) dD = a.dD[ray];
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       carryQ = __shfl(Qbefore, 0, 64);
       if (valid) {
         const float w = occ * T;
-        if (a.d_colors) { a.d_colors[3 * g] = w * dC0; a.d_colors[3 * g + 1] = w * dC1; a.d_colors[3 * g + 2] = w * dC2; }
+        if (a.d_colors) *reinterpret_cast<Rgb3*>(a.d_colors + 3 * g) = Rgb3{w * dC0, w * dC1, w * dC2};
         if (neus) wl.tex[idx] = T * (ak - Qk);       // dL/docc_k, combined with the neighbour's below
         else if (a.d_geoms) a.d_geoms[g] = T * (ak - Qk) * dodg;
       }
@@ -337,7 +347,7 @@ int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
-  const size_t lds = sizeof(CompBwdLds) * NGM_WAVES_PER_BLOCK;
+  const size_t lds = sizeof(float) * CompBwdLds::floats(a.rc.geometry_mode == NGM_GEO_NEUS) * NGM_WAVES_PER_BLOCK;
   (void)hipFuncSetAttribute((const void*)k_composite_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_composite_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw);
   return 0;

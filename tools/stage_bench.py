@@ -1,0 +1,115 @@
+"""Standalone stage throughput on the GPU (which roofline each stage sits on).
+
+    python tools/stage_bench.py [--rays 262144] [--samples 128] [--out gpurun_out/stages.json]
+
+Times the standalone C-ABI entry points with HIP events (torch.cuda.Event on the launch stream = torch's
+current stream, which is the stream the ops launch on) on a batch large enough to leave the latency regime,
+and reports achieved GB/s against the algorithmic bytes of SURVEY 8(d) for the HBM-bound stages and TFLOP/s
+for the MLP stage.  Prints one JSON object.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neural_graph_mapping_amd import _capi as K  # noqa: E402
+from neural_graph_mapping_amd import ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3      # seconds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=262144)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    N, S = a.rays, a.samples
+    F, R = 64, N // 64
+    res = dict(device=torch.cuda.get_device_name(0), rays=N, samples_per_ray=S, stages={})
+
+    def add(name, secs, bytes_=None, flops=None, note=""):
+        d = dict(us=round(secs * 1e6, 1), note=note)
+        if bytes_ is not None:
+            d.update(algorithmic_MB=round(bytes_ / 1e6, 1), GBps=round(bytes_ / secs / 1e9, 1),
+                     frac_of_hbm_peak=round(bytes_ / secs / 1e9 / HBM_PEAK_GBS, 3))
+        if flops is not None:
+            d.update(algorithmic_GFLOP=round(flops / 1e9, 2), TFLOPs=round(flops / secs / 1e12, 1),
+                     frac_of_f32_mfma_peak=round(flops / secs / 1e12 / MFMA_F32_PEAK_TF, 3))
+        res["stages"][name] = d
+
+    # ---- compositor (k_composite_fwd / k_composite_bwd): 24 B/sample in + 36 B/ray out; bwd 24 B + 36 B/ray in, 16 B out
+    rc = K.render_cfg(geometry_mode="nrgbd", geometry_factor=20.0)
+    colors = torch.rand(N, S, 3, device=dev)
+    geoms = 0.1 * torch.randn(N, S, device=dev)
+    dists = torch.sort(torch.rand(N, S, device=dev) * 3 + 0.5, -1)[0]
+    depths = dists * 0.9
+    add("composite_fwd", timeit(lambda: ops.quadrature(rc, colors, geoms, dists, depths)), bytes_=N * S * 24 + N * (36 + 4 * S),
+        note="k_composite_fwd incl. the (N,S) weights output")
+    cg, gg = colors.clone().requires_grad_(), geoms.clone().requires_grad_()
+    Cc, D, _, _, T, _ = ops.quadrature(rc, cg, gg, dists, depths)
+    seeds = (torch.randn_like(Cc), torch.randn_like(D), torch.randn_like(T))
+
+    def comp_bwd():
+        torch.autograd.grad((Cc, D, T), (cg, gg), seeds, retain_graph=True)
+    add("composite_bwd", timeit(comp_bwd), bytes_=N * S * 40 + N * 36, note="k_composite_bwd via autograd (includes torch's grad bookkeeping)")
+    del colors, geoms, depths, cg, gg, Cc, D, T
+
+    # ---- sampler (k_sample_rays): ~(104 + 4S)/S B read + 16 B written per sample
+    rcs = K.render_cfg(num_samples_coarse=S // 2, num_samples_guided=S // 2)
+    ijs = torch.stack([torch.randint(0, 480, (F, R), device=dev), torch.randint(0, 640, (F, R), device=dev)], -1)
+    near = torch.rand(F, R, device=dev) + 0.5
+    far = near + 2.0
+    gt = near + 2.0 * torch.rand(F, R, device=dev)
+    add("sample_rays", timeit(lambda: ops.sample_rays(rcs, ijs, near, far, gt, seed=1)), bytes_=N * S * 16 + N * 44,
+        note="k_sample_rays, in-kernel Philox jitter, rank merge of the two strata; includes the output allocation")
+
+    # ---- field evaluation (encode + MLP), forward and backward on flat points
+    fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    P = N * S // F // 8                       # 1/8 of the samples: the output tensors are (F,P,4)
+    params = {}
+    for n, shp in K.param_shapes(fc).items():
+        params[n] = (0.3 * torch.randn(F, *shp, device=dev)).requires_grad_()
+    pts = torch.rand(F, P, 3, device=dev)
+    pos = torch.zeros(F, 3, device=dev)
+    quat = torch.zeros(F, 4, device=dev)
+    quat[:, 0] = 1
+    nsamp = F * P
+    with torch.no_grad():
+        add("field_eval_fwd", timeit(lambda: ops.field_eval(fc, params, pts, pos, quat)), flops=nsamp * 16896,
+            bytes_=nsamp * 28, note="k_field_points_fwd: Fourier(64) + 2x64 MLP, 16 896 flop/sample")
+    out = ops.field_eval(fc, params, pts, pos, quat)
+    go = torch.randn_like(out)
+
+    def fbwd():
+        torch.autograd.grad(out, list(params.values()), go, retain_graph=True)
+    add("field_eval_bwd", timeit(fbwd, iters=10), flops=nsamp * 33792, bytes_=nsamp * 28,
+        note="point-mode backward (k_field_bwd16, recomputes the forward), 33 792 algorithmic flop/sample")
+    print(json.dumps(res))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,7 @@ class FieldSpec:
     num_layers: int = 2                # hidden layers L
     dim_hidden: Optional[int] = None   # H; None -> D (models.py:99-100)
     dim_out: int = 4
+    skip_mode: str = "no"              # "no" | "add" | "concat" | "rezero" (models.py:159-180)
 
     def __post_init__(self):
         if self.encoding == "nerf":
@@ -79,7 +80,8 @@ class FieldSpec:
             self.dim_hidden = self.dim_enc
 
     def layer_dims(self):
-        dims_in = [self.dim_enc] + [self.dim_hidden] * self.num_layers
+        mlp_in = self.dim_hidden + (self.dim_enc if self.skip_mode == "concat" else 0)   # models.py:105-110
+        dims_in = [self.dim_enc] + [mlp_in] * self.num_layers
         dims_out = [self.dim_hidden] * self.num_layers + [self.dim_out]
         return list(zip(dims_in, dims_out))
 
@@ -92,6 +94,8 @@ class FieldSpec:
         if self.encoding == "permuto":
             shapes["_encoding.lattice_values"] = (self.nr_levels, 2 ** self.log2_hashmap_size, self.nr_feat_per_level)
             shapes["_encoding.random_shift_per_level"] = (self.nr_levels, 3)
+        if self.skip_mode == "rezero":
+            shapes["_rezero"] = (self.num_layers,)                   # models.py:112-113
         for i, (di, do) in enumerate(self.layer_dims()):
             shapes[f"_linears.{i}.weight"] = (do, di)
             shapes[f"_linears.{i}.bias"] = (do,)
@@ -303,14 +307,30 @@ def encode_permuto(x, lattice, shift, fs: FieldSpec):
 
 
 def field_mlp(h, params, fs: FieldSpec):
-    """skip_mode 'no' (models.py:148-157): relu on all but the last layer."""
+    """NeuralField.forward (models.py:143-182): relu on all but the last layer, then the skip connection:
+    concat appends the encoding, add adds it to the first D units, rezero scales by a learnt per-layer scalar and
+    adds the layer's own input (the encoding for layer 0)."""
     n = fs.num_layers
+    D = fs.dim_enc
+    enc = h
     for i in range(n + 1):
+        prev = h
         W = params[f"_linears.{i}.weight"]
         b = params[f"_linears.{i}.bias"]
         h = torch.einsum("fpi,foi->fpo", h, W) + b.unsqueeze(-2)
-        if i < n:
-            h = torch.relu(h)
+        if i == n:
+            break
+        h = torch.relu(h)
+        if fs.skip_mode == "concat":
+            h = torch.cat((h, enc), -1)
+        elif fs.skip_mode == "add":
+            h = torch.cat((h[..., :D] + enc, h[..., D:]), -1)
+        elif fs.skip_mode == "rezero":
+            rz = params["_rezero"][:, i].view(-1, 1, 1)
+            if i == 0:
+                h = torch.cat((rz * h[..., :D] + prev, rz * h[..., D:]), -1)
+            else:
+                h = rz * h + prev
     return h
 
 
@@ -602,6 +622,8 @@ def init_params(fs: FieldSpec, num_fields: int, seed=0, mu=0.0, sigma=4.0,
             v = torch.randn(n, *shape, generator=g) * 0.1
         elif name == "_encoding.random_shift_per_level":
             v = torch.randn(n, *shape, generator=g) * 10.0
+        elif name == "_rezero":
+            v = 0.5 * torch.randn(n, *shape, generator=g)            # the reference initialises zeros (models.py:131-132)
         elif name.endswith("weight"):
             bound = 1.0 / math.sqrt(shape[1])
             v = (torch.rand(n, *shape, generator=g) * 2 - 1) * bound

@@ -97,7 +97,7 @@ NRGBD_CAMERA = dict(width=640, height=480, fx=554.2562584220408, fy=554.25625842
                     cx=319.5, cy=239.5, pixel_center=0.0)
 
 
-def make_config(*, encoding="fourier", dim_enc=64, num_layers=2, dim_mlp_out=None,
+def make_config(*, skip_mode="no", encoding="fourier", dim_enc=64, num_layers=2, dim_mlp_out=None,
                 num_octaves=8, fourier_mu=0.0, fourier_sigma=4.0,
                 geometry_mode="nrgbd", num_samples_coarse=16, num_samples_depth_guided=16,
                 geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1,
@@ -122,7 +122,7 @@ def make_config(*, encoding="fourier", dim_enc=64, num_layers=2, dim_mlp_out=Non
             field_type="neural_graph_mapping.models.NeuralField",
             field_kwargs=dict(
                 encoding_type=enc_type, encoding_kwargs=enc_kwargs, num_layers=num_layers,
-                dim_out=4, dim_mlp_out=dim_mlp_out, skip_mode="no",
+                dim_out=4, dim_mlp_out=dim_mlp_out, skip_mode=skip_mode,
                 initial_geometry_bias=0.0, neus_initial_sd=neus_initial_sd,
             ),
             num_knn=2, distance_factor=10.0, field_radius=field_radius,
@@ -153,7 +153,19 @@ def make_config(*, encoding="fourier", dim_enc=64, num_layers=2, dim_mlp_out=Non
 def build_map(rm, cfg, num_fields, positions, orientations, seed=0):
     """Construct the reference NeuralGraphMap on CPU with `num_fields` fields."""
     torch.manual_seed(seed)
-    ngm = rm.NeuralGraphMap(cfg)
+    # NeuralField creates its rezero scalars with device="cuda" (models.py:113): there is no GPU in the build
+    # container, so torch.empty is asked for the CPU instead while the model is constructed
+    real_empty = torch.empty
+
+    def cpu_empty(*a, **k):
+        if k.get("device") == "cuda":
+            k["device"] = "cpu"
+        return real_empty(*a, **k)
+    torch.empty = cpu_empty
+    try:
+        ngm = rm.NeuralGraphMap(cfg)
+    finally:
+        torch.empty = real_empty
     ngm._optimizer = None
     n = num_fields
     if ngm._global_map_dict["positions"].shape[0] < n:

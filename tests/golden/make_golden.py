@@ -300,6 +300,36 @@ def g11_target_sampler():
          o_term_probs=t.term_probs, o_term_mask=t.term_mask)
 
 
+def g12_skip_modes():
+    """NeuralField skip connections (models.py:159-180): vmapped forward and d(sum out * seed)/d(params) for
+    add / concat / rezero; H > D exercises the partial add (first D units only)."""
+    # (rezero cannot be pinned: the reference's own constructor raises for it -- reset_parameters() calls
+    #  self._rezero.zero_() on a leaf parameter outside no_grad, models.py:131-132)
+    for mode, dim_enc, dim_mlp in (("add", 32, 48), ("concat", 32, 32), ("add", 64, None), ("concat", 64, None)):
+        F, P = 3, 40
+        gen = torch.Generator().manual_seed(120 + len(mode) + dim_enc)
+        pos = 0.5 * torch.randn(F, 3, generator=gen)
+        quat = rand_quats(F, gen)
+        cfg = make_config(encoding="fourier", dim_enc=dim_enc, num_layers=2, dim_mlp_out=dim_mlp, skip_mode=mode)
+        ngm = build_map(rm, cfg, F, pos, quat, seed=120)
+        model = ngm._model
+        for k, v in model.all_fields_params.items():
+            if v.dim() > 1 and k != "_rezero":
+                v.add_(0.05 * torch.randn(v.shape, generator=gen))
+        q = pos[:, None, :] + 0.4 * torch.randn(F, P, 3, generator=gen)
+        model.set_vmap_fields(torch.arange(F))
+        vp = model.vmap_fields_params
+        for v in vp.values():
+            v.requires_grad_()
+        out = model(q, pos, quat, field_ids=torch.arange(F), use_vmap=True)
+        seed = torch.randn(out.shape, generator=gen)
+        (out * seed).sum().backward()
+        arrays = {"p::" + k: v.detach() for k, v in vp.items()}
+        arrays.update({"g::" + k: v.grad for k, v in vp.items() if v.grad is not None})
+        save(f"g12_skip_{mode}_D{dim_enc}", query=q, pos=pos, quat=quat, out=out.detach(), seed=seed,
+             dim_hidden=np.int64(dim_mlp or dim_enc), **arrays)
+
+
 def g10_behind_camera():
     """Cameras inside the field sphere, near < 0: _render_ijs overwrites the geometry of the samples behind the
     camera (rm.py:494-495, 614-622) and no gradient flows through them."""
@@ -404,7 +434,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

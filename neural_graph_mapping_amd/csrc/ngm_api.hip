@@ -144,6 +144,9 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
     return fail(NGM_E_UNSUPPORTED, "dim_enc / dim_hidden must be <= 64");
   if (((fc->dim_enc + 31) / 32) != ((fc->dim_hidden + 31) / 32) && !(fc->dim_enc <= 32 && fc->dim_hidden <= 32))
     return fail(NGM_E_UNSUPPORTED, "dim_enc and dim_hidden must pad to the same multiple of 32");
+  if (fc->skip_mode != NGM_SKIP_NO && fc->skip_mode != NGM_SKIP_ADD) return fail(NGM_E_UNSUPPORTED, "skip_mode: only no / add");
+  if (fc->skip_mode == NGM_SKIP_ADD && (fc->dim_hidden < fc->dim_enc || fc->encoding == NGM_ENC_PERMUTO))
+    return fail(NGM_E_UNSUPPORTED, "skip_mode add: needs dim_hidden >= dim_enc and a non-hash encoding");
   return NGM_OK;
 }
 static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
@@ -413,7 +416,8 @@ static bool act_stash_ok(const ngm_field_cfg* fc) {
   static const bool off = getenv("NGM_NO_ACT_STASH") != nullptr;
   if (off) return false;
   const int th = (fc->dim_hidden + 15) / 16, ti = (fc->dim_enc + 15) / 16;
-  return fc->encoding != NGM_ENC_PERMUTO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2;
+  return fc->encoding != NGM_ENC_PERMUTO && fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 &&
+         fc->num_layers <= 2;   // with a skip connection the stashed activation no longer tells the ReLU mask
 }
 
 static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {

@@ -379,11 +379,26 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
 
 // Full forward MLP for NT tiles: E (encoding, C layout) -> partial outputs.  Keeps the last hidden
 // activations in Hlast (needed by the backward kernel for the ReLU mask / output-layer gradient).
+// skip connection "add" (models.py:162-169): the encoding is added to the first D units of every hidden layer's
+// output; padded encoding features are 0, so whole tiles can be added
+template <int MI, int MH, int NT>
+__device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[NT][MI]) {
+  if constexpr (MI <= MH) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[nt][m][r] += E[nt][m][r];
+  }
+}
+
 template <int MI, int MH, int L, int NT>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
-                                        const ActStash* st = nullptr) {
+                                        const ActStash* st = nullptr, bool add_enc = false) {
   using LY = FieldLds<MI, MH, L>;
   layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
+  if (add_enc) skip_add<MI, MH, NT>(Hlast, E);
   if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
@@ -393,6 +408,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
+    if (add_enc) skip_add<MI, MH, NT>(Hlast, E);
     if (st && st->base) act_store<MH, NT>(*st, l, lane, Hlast);
   }
 }
@@ -401,7 +417,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
 template <int MI, int MH, int L, bool NEED_COS, bool HASH = false>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
-                                          const ActStash* st = nullptr) {
+                                          const ActStash* st = nullptr, bool add_enc = false) {
   using LY = FieldLds<MI, MH, L>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
@@ -416,7 +432,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
   }
   f32x16 Hl[2][MH];
-  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl, st);
+  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl, st, add_enc);
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
   float o[4];

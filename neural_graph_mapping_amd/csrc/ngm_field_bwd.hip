@@ -33,6 +33,18 @@ struct BwdLds {
   static constexpr int TOTAL = LY::TOTAL + NGM_WAVES_PER_BLOCK * WAVE_TOTAL;
 };
 
+// one bit per C-layout register: register r of tile m is positive -> bit 16 m + r
+template <int M>
+__device__ __forceinline__ uint32_t relu_bits(const f32x16 (&H)[M]) {
+  static_assert(M * 16 <= 32, "one 32-bit mask per layer");
+  uint32_t b = 0;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b |= (H[m][r] > 0.f ? 1u : 0u) << (16 * m + r);
+  return b;
+}
+
 // C-layout registers -> staging buffer [sample][feature]; one 16-byte store per 4 registers
 template <int M>
 __device__ __forceinline__ void store_tile(float* buf, int stride, int lane, const f32x16 (&V)[M]) {
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   dwf[0] = dwf[1] = dwf[2] = 0.f;
 
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, HASH ? a.lattice_grad + (int64_t)f * a.lattice_grad_stride : nullptr);
+  const bool add_enc = !HASH && MI <= MH && a.fc.skip_mode == NGM_SKIP_ADD;
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 32; base < end; base += 32 * NGM_WAVES_PER_BLOCK) {
     const int64_t n = base + j;
@@ -259,6 +272,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     }
     f32x16 Hc[1][MH];
     layer_fwd<MI, MH, 1>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hc);
+    // skip_mode "add": in_{l+1} = relu(z_l) + [enc; 0] (models.py:162-169).  The ReLU mask can then no longer be read
+    // off the staged layer input, so it is kept as one bit per register (MH * 16 <= 32 bits per layer).
+    uint32_t rmask[L];
+    rmask[0] = relu_bits<MH>(Hc[0]);
+    if (add_enc) skip_add<MI, MH, 1>(Hc, E);
 #pragma unroll
     for (int l = 1; l < L; ++l) {
       store_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Hc[0]);
@@ -266,7 +284,14 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
       layer_fwd<MH, MH, 1>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hc, Hn);
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hc[0][m] = Hn[0][m];
+      rmask[l] = relu_bits<MH>(Hc[0]);
+      if (add_enc) skip_add<MI, MH, 1>(Hc, E);
     }
+    f32x16 dEsum[MI];          // add mode: gradient reaching the encoding through the skip connections
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dEsum[mi][r] = 0.f;
     // ---- output layer gradients (VALU, lane = hidden feature)
     store_tile<MH>(bufD, BL::STR_D, lane, Hc[0]);
     WAVE_SYNC();
@@ -282,7 +307,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
         for (int r = 0; r < 16; ++r) {
           const float4 w = w4[32 * mi + frow(r, 0) + 4 * hi];
           const float dh = fmaf(w.w, dout.w, fmaf(w.z, dout.z, fmaf(w.y, dout.y, w.x * dout.x)));
-          dY[mi][r] = (Hc[0][mi][r] > 0.f) ? dh : 0.f;
+          if (add_enc && mi < MI) dEsum[mi < MI ? mi : 0][r] += dh;
+          dY[mi][r] = ((rmask[L - 1] >> (16 * mi + r)) & 1u) ? dh : 0.f;
         }
     }
     // ---- hidden layers, last to first
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dE[mi][r] *= dEa[mi][r];
+            for (int r = 0; r < 16; ++r) dE[mi][r] = (dE[mi][r] + dEsum[mi][r]) * dEa[mi][r];
           WAVE_SYNC();
           store_tile<MI>(bufD, BL::STR_D, lane, dE);
           WAVE_SYNC();
@@ -326,11 +352,22 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
         layer_wgrad<MH, MH>(bufD, BL::STR_D, wl + BL::x_off(l), BL::STR_H, lane, accH[l - 1]);
         f32x16 dX[MH], Xl[MH];
         layer_dgrad<MH, MH>(sm + LY::w_off(l), lane, dY, dX);
-        load_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Xl);
+        if (add_enc) {
+          // dX = gradient w.r.t. in_l = relu(z_{l-1}) + [enc; 0]
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi)
+          for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dY[mi][r] = (Xl[mi][r] > 0.f) ? dX[mi][r] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+              if (mi < MI) dEsum[mi < MI ? mi : 0][r] += dX[mi][r];
+              dY[mi][r] = ((rmask[l - 1] >> (16 * mi + r)) & 1u) ? dX[mi][r] : 0.f;
+            }
+        } else {
+          load_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Xl);
+#pragma unroll
+          for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dY[mi][r] = (Xl[mi][r] > 0.f) ? dX[mi][r] : 0.f;
+        }
       }
     }
   }

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, nullptr, a.fc.skip_mode == NGM_SKIP_ADD);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       ActStash ast;
       ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast, a.fc.skip_mode == NGM_SKIP_ADD);
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
       const float depth = -(rt[6] * t);
       // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, nullptr, a.fc.skip_mode == NGM_SKIP_ADD);
     if (valid) a.pair_out[pair] = o;
   }
 }

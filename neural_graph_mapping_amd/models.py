@@ -120,8 +120,9 @@ class NeuralField(torch.nn.Module):
                  dim_mlp_out: Optional[int] = None, skip_mode: Literal["no", "add", "concat", "rezero"] = "no",
                  initial_geometry_bias: float = 0.0, neus_initial_sd: Optional[float] = None) -> None:
         super().__init__()
-        if skip_mode != "no":
-            raise NotImplementedError(f"skip_mode={skip_mode!r}: only 'no' has a kernel so far")
+        if skip_mode not in K.SKIP:
+            raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no' and 'add' have kernels ('concat' is not built; the "
+                                      "reference's own constructor raises for 'rezero', models.py:131-132)")
         self._encoding = str_to_object(encoding_type)(**encoding_kwargs)
         self._dim_encoding = self._encoding.get_out_dim()
         self._dim_out = dim_out
@@ -138,7 +139,8 @@ class NeuralField(torch.nn.Module):
 
     def field_cfg(self, scale_mode="no", field_radius=1.0) -> K.FieldCfg:
         return K.field_cfg(num_layers=self._num_layers, dim_hidden=self._dim_mlp_out, dim_out=self._dim_out,
-                           scale_mode=scale_mode, field_radius=field_radius or 1.0, **self._encoding.spec())
+                           scale_mode=scale_mode, field_radius=field_radius or 1.0, skip_mode=self._skip_mode,
+                           **self._encoding.spec())
 
     def numel(self) -> int:
         return sum(p.numel() for p in self.parameters())

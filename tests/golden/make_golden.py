@@ -305,7 +305,7 @@ def g12_skip_modes():
     add / concat / rezero; H > D exercises the partial add (first D units only)."""
     # (rezero cannot be pinned: the reference's own constructor raises for it -- reset_parameters() calls
     #  self._rezero.zero_() on a leaf parameter outside no_grad, models.py:131-132)
-    for mode, dim_enc, dim_mlp in (("add", 32, 48), ("concat", 32, 32), ("add", 64, None), ("concat", 64, None)):
+    for mode, dim_enc, dim_mlp in (("add", 32, 48), ("concat", 32, 32), ("add", 64, None), ("concat", 64, None), ("add", 61, 64)):
         F, P = 3, 40
         gen = torch.Generator().manual_seed(120 + len(mode) + dim_enc)
         pos = 0.5 * torch.randn(F, 3, generator=gen)

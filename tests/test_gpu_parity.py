@@ -140,6 +140,48 @@ def test_field_forward_golden(enc):
     close(out, g["out"], rtol=2e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("name", ["g12_skip_add_D64", "g12_skip_add_D61"])
+def test_skip_add_golden(name):
+    """skip_mode "add" (models.py:162-169) against the reference: forward and every parameter gradient.
+    D61: dim_enc 61 < dim_hidden 64, only the first 61 units receive the encoding."""
+    g = load_golden(name)
+    D = int(name.split("D")[-1])
+    fc = K.field_cfg(encoding="fourier", dim_enc=D, dim_hidden=int(g["dim_hidden"]), num_layers=2, skip_mode="add")
+    params = {k: v.to(DEV).requires_grad_() for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"}
+    out = ops.field_eval(fc, params, g["query"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV))
+    close(out, g["out"], rtol=2e-4, atol=3e-5)
+    (out * g["seed"].to(DEV)).sum().backward()
+    from neural_graph_mapping_amd import _capi
+    assert _capi.lib().ngm_debug_last_bwd_variant() == 0          # skip connections run on the 32-sample-tile kernel
+    for k, gr in split_prefix(g, "g::").items():
+        grad_close(params[k].grad, gr, 2e-3, k)
+
+
+def test_skip_add_fused_train_step_vs_oracle():
+    """skip_mode "add" through the fused render / train step."""
+    F, R, n_c, n_g = 2, 33, 6, 10
+    torch.manual_seed(8)
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2, skip_mode="add")
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos, quat, t = synth_target(F, R, seed=4)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params = O.init_params(fs, F, seed=11, sigma=3.0)
+    params["_linears.2.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        loose_grad_close(res["grads"][k], po[k].grad, k)
+
+
 FIELD_CASES = [dict(encoding="fourier", dim_enc=64, num_layers=2), dict(encoding="fourier", dim_enc=32, num_layers=2),
                dict(encoding="fourier", dim_enc=32, num_layers=1), dict(encoding="nerf", num_octaves=8, num_layers=1),
                dict(encoding="fourier", dim_enc=64, num_layers=1, raw_coords=False),
@@ -302,7 +344,8 @@ def make_renderer(fkw, ckw, num_fields, params=None):
         et = "neural_graph_mapping.positional_encodings.PositionalEncodingNeRF"
         ek = dict(dim_in=3, num_octaves=fkw["num_octaves"], start_octave=0)
     model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
-        encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0), num_knn=2,
+        encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0,
+        skip_mode=fkw.get("skip_mode", "no")), num_knn=2,
         distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
                termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,

@@ -393,12 +393,14 @@ __device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[
   }
 }
 
-template <int MI, int MH, int L, int NT>
+// ADD is a template parameter on purpose: as a run-time flag it kept the encoding registers alive through every
+// layer of the default path as well and cost the fused forward 14 us.
+template <int MI, int MH, int L, int NT, bool ADD = false>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
-                                        const ActStash* st = nullptr, bool add_enc = false) {
+                                        const ActStash* st = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
-  if (add_enc) skip_add<MI, MH, NT>(Hlast, E);
+  if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
   if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
@@ -408,16 +410,16 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
-    if (add_enc) skip_add<MI, MH, NT>(Hlast, E);
+    if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
     if (st && st->base) act_store<MH, NT>(*st, l, lane, Hlast);
   }
 }
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
-template <int MI, int MH, int L, bool NEED_COS, bool HASH = false>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, bool ADD = false>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
-                                          const ActStash* st = nullptr, bool add_enc = false) {
+                                          const ActStash* st = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
@@ -432,7 +434,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
   }
   f32x16 Hl[2][MH];
-  mlp_fwd<MI, MH, L, 2>(sm, lane, E, Hl, st, add_enc);
+  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, st);
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
   float o[4];

@@ -18,7 +18,7 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS, bool HASH>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, nullptr, a.fc.skip_mode == NGM_SKIP_ADD);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -81,7 +81,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L>;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       ActStash ast;
       ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, &ast, a.fc.skip_mode == NGM_SKIP_ADD);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast);
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
       const float depth = -(rt[6] * t);
       // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622
@@ -285,11 +285,21 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-#define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDS)                                                          \
-  do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)KERNEL<MI, MH, L, NC, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)(LDS));                                                                       \
-    hipLaunchKernelGGL((KERNEL<MI, MH, L, NC, HS>), dim3(GRID), BLK, LDS, st, a);                                \
+// the skip-add variants exist for the non-hash encodings only
+#define NGM_LAUNCH_ONE(KERNEL, NC, HS, AD, GRID, BLK, LDS)                                                              \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)KERNEL<MI, MH, L, NC, HS, AD>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)(LDS));                                                                             \
+    hipLaunchKernelGGL((KERNEL<MI, MH, L, NC, HS, AD>), dim3(GRID), BLK, LDS, st, a);                                  \
+  } while (0)
+#define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDS)                                   \
+  do {                                                                                       \
+    if constexpr (!(HS)) {                                                                   \
+      if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, true, GRID, BLK, LDS); \
+      else NGM_LAUNCH_ONE(KERNEL, NC, HS, false, GRID, BLK, LDS);                            \
+    } else {                                                                                 \
+      NGM_LAUNCH_ONE(KERNEL, NC, HS, false, GRID, BLK, LDS);                                 \
+    }                                                                                        \
   } while (0)
 
 template <int MI, int MH, int L>

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
   }
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
 __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH>(sm, lane, x, y, z, &hc, nullptr, a.fc.skip_mode == NGM_SKIP_ADD);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc);
     if (valid) a.pair_out[pair] = o;
   }
 }
@@ -167,16 +167,17 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
 template <int MI, int MH, int L>
 static void launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
   const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
-#define NGM_KE(NC, HS)                                                                                             \
-  do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, NC, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds);                                                                           \
-    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
+#define NGM_KE(NC, HS, AD)                                                                                             \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, NC, HS, AD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                               \
+    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS, AD>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
   } while (0)
+  const bool add = a.fc.skip_mode == NGM_SKIP_ADD;
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_KE(false, true);
-  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_KE(true, false);
-  else NGM_KE(false, false);
+    if constexpr (MI == 1) NGM_KE(false, true, false);
+  } else if (a.fc.encoding == NGM_ENC_NERF) { if (add) NGM_KE(true, false, true); else NGM_KE(true, false, false); }
+  else { if (add) NGM_KE(false, false, true); else NGM_KE(false, false, false); }
 #undef NGM_KE
 }
 

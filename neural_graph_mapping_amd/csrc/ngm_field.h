@@ -434,7 +434,14 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
   }
   f32x16 Hl[2][MH];
+#ifdef NGM_ABLF_NOMFMA   // timing ablation: encoding and output layer without the hidden layers
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
+#else
   mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, st);
+#endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
   float o[4];

@@ -152,7 +152,11 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       RayGeom g;
       g.near = wl.rt[rl][7]; g.far = wl.rt[rl][8]; g.gnear = wl.rt[rl][9]; g.gfar = wl.rt[rl][10];
       float t; int rank;
+#ifdef NGM_ABLF_NOSAMPLER   // timing ablations of the fused forward (results meaningless when defined)
+      t = g.near + (g.far - g.near) * (float)e / (float)S; rank = e;
+#else
       sample_rank(a.rc, a.rays, g, ray, e, S_c, S_g, &t, &rank);
+#endif
       wl.tbuf[rl * S + rank] = t;
     }
     WAVE_SYNC();
@@ -168,9 +172,17 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       float x = 0, y = 0, z = 0;
       if (valid) { x = fmaf(t, rt[3], rt[0]); y = fmaf(t, rt[4], rt[1]); z = fmaf(t, rt[5], rt[2]); }
       ActStash ast;
+#ifdef NGM_ABLF_NOACT
+      ast.base = nullptr; ast.layer_stride = 0;
+#else
       ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
+#endif
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
+#ifdef NGM_ABLF_NOMLP
+      const float4 o = make_float4(x, y, z, x * y);
+#else
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast);
+#endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
       const float depth = -(rt[6] * t);
       // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622
@@ -215,7 +227,11 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       WAVE_SYNC();
     }
     // ---- (4) variance pass around the finished means (rm.py:781-790)
+#ifdef NGM_ABLF_NOVAR
+    for (int base = 0; base < 0; base += 64) {
+#else
     for (int base = 0; base < nsamp; base += 64) {
+#endif
       const int idx = base + lane;
       const bool valid = idx < nsamp;
       const int rl = valid ? fdiv_idx(idx, inv_s, S) : 0;

@@ -686,3 +686,18 @@ def test_target_sampler_golden():
     assert t2.ijs.shape[1:] == (16, 2) and t2.ijs.shape[0] == len(t2.field_ids) <= 8
     assert bool((t2.near_distances <= t2.far_distances).all()) and bool((t2.near_distances >= 0).all())
     assert bool((t2.ijs[..., 0] < 48).all()) and bool((t2.ijs[..., 1] < 64).all()) and bool((t2.ijs >= 0).all())
+
+
+# ------------------------------------------------------------------ end to end: sampler -> train -> kNN render
+def test_end_to_end_synthetic_fit():
+    """examples/fit_synthetic.py: keyframe store -> training-target sampler -> fused training step -> render_image.
+    The loss must fall and the re-rendered keyframe must approach the synthetic scan."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fit_synthetic", os.path.join(root, "examples", "fit_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses, psnr, derr = mod.main(iters=200, device=str(DEV), quiet=True)
+    assert losses[-1] < 0.25 * losses[0], losses
+    assert psnr > 14.0 and derr < 0.3, (psnr, derr)

@@ -211,6 +211,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
       : "memory");
 }
 __device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint32_t lds_base) {
+#ifdef NGM_ABLS_NODMA   // timing ablation: no activation DMA at all (results meaningless)
+  return;
+#endif
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -313,16 +316,18 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
     fs.act[1] = reinterpret_cast<const char*>(a.act + a.act_layer_stride + (g0 >> 5) * 2048);
   }
   // Per-wave LDS tiles: R0 (dY of the last layer, later the encoding), act(1) (layer 1's input, later dY / dE
-  // staging), act(2) (the last hidden activation, L = 2).  DMA issue order per tile: inputs of the next tile at
-  // the start, act(L) as soon as the output layer is done with it, act(1) at the very end (L = 2) -- so the 4
-  // youngest outstanding instructions at a tile start are act(1) and "vmcnt(4)" means "inputs and act(L) landed".
+  // staging), act(2) (the last hidden activation, L = 2).  DMA schedule (L = 2), every wait a plain vmcnt(0) at a
+  // point where only long-issued transfers are outstanding (counted waits proved fragile: a register spill the
+  // compiler drops between two DMA batches shifts the count onto transfers that were only just issued):
+  //   tile start      wait -> inputs(t), act(2)(t) are there;  issue act(1)(t) into its (free) tile
+  //   before layer 1  wait -> act(1)(t) is there;               issue inputs(t+1), act(2)(t+1) (their tiles are free)
+  // L = 1: inputs(t+1) after the inputs are read, act(1)(t+1) at the tile end (its tile doubles as E staging).
   float* R0 = wl + LY::XE;
   float* A1 = wl + LY::act(1);
   float* AL = wl + LY::act(L);
   if (first < end) {
     issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INBUF * 4);
     issue_act(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::act(L) * 4);
-    if (L == 2) issue_act(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::act(1) * 4);
   }
   TICK_DECL;
   TICK(0);
@@ -330,7 +335,11 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
     const uint32_t n = base + j, nxt = base + 16 * B16_WAVES;
     const bool valid = n < end, more = nxt < end;
     // ---- inputs and the last hidden activation tile (landed while the previous tile was differentiated)
-    if (L == 2) DMA_WAIT(4); else DMA_WAIT(0);
+    TICK(10);   // loop back-edge
+    DMA_WAIT(0);
+    TICK(3);    // wait for inputs + last hidden tile
+    if (L == 2) issue_act(fs.act[0], fs.gb, base, end, lane, wl_lds + LY::act(1) * 4);
+    TICK(5);    // issue act(1)
     {
       const float4* in4 = reinterpret_cast<const float4*>(inb);
       const float4 r0 = in4[j], r1 = in4[16 + j], dd = in4[32 + j], sp = in4[48 + j];
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
         dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w;
       }
       WAVE_SYNC();
-      if (more) issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INBUF * 4);
+      if (L == 1 && more) issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INBUF * 4);
     }
     TICK(1);
     // ---- output layer: d_out -> dY_L
@@ -369,17 +378,20 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
     }
     WAVE_SYNC();
     store16b(R0, lane, dY);
-    if (L == 2) {   // the last-hidden tile is dead: land the next tile's copy in it right away
-      if (more) issue_act(fs.act[1], fs.gb, nxt, end, lane, wl_lds + LY::act(2) * 4);
-    }
     WAVE_SYNC();
     dbh[L - 1] += colsum16b(R0, lane);
     TICK(4);
     float* Dlast = R0;      // tile holding dY of layer 0's output
     float* Etile = A1;      // tile that will receive the encoding
     if constexpr (L == 2) {
-      // act(1) of THIS tile was issued at the end of the previous one; younger: inputs(next) + act(2)(next)
-      if (more) DMA_WAIT(5); else DMA_WAIT(0);
+      TICK(4);
+      DMA_WAIT(0);                                   // act(1) of this tile (issued at the tile start)
+      TICK(0);    // wait for act(1)
+      if (more) {                                    // INBUF and the last-hidden tile are free: next tile's copies
+        issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INBUF * 4);
+        issue_act(fs.act[1], fs.gb, nxt, end, lane, wl_lds + LY::act(2) * 4);
+      }
+      TICK(9);    // issue inputs + act(2) of the next tile
       wgrad16b(R0, A1, lane, accH[0]);
       TICK(6);
       f32x4 dX[4], Xl[4];
@@ -427,9 +439,9 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
       outer16b<3>(Dlast, pbuf, lane, dwf);
       TICK(8);
     }
-    // act(1)'s tile is dead: it receives the next tile's copy
+    // L = 1: the activation tile doubled as E staging and is free only now
     WAVE_SYNC();
-    if (more) issue_act(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::act(1) * 4);
+    if (L == 1 && more) issue_act(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::act(1) * 4);
   }
   DMA_WAIT(0);
   TICK(10);

@@ -515,12 +515,14 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers):
     assert _capi.lib().ngm_debug_last_bwd_variant() == 2
 
 
-def _ragged_case(F, R, n_c, n_g, fkw):
+def _ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0):
     torch.manual_seed(F * 1000 + R)
-    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geometry_mode,
+               geometry_factor=geometry_factor)
     pos, quat, t = synth_target(F, R, seed=R)
     fs = O.FieldSpec(**fkw)
-    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,
+                      geometry_mode=geometry_mode, geometry_factor=geometry_factor)
     params = O.init_params(fs, F, seed=R, sigma=3.0)
     params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
@@ -701,3 +703,23 @@ def test_end_to_end_synthetic_fit():
     losses, psnr, derr = mod.main(iters=200, device=str(DEV), quiet=True)
     assert losses[-1] < 0.25 * losses[0], losses
     assert psnr > 14.0 and derr < 0.3, (psnr, derr)
+
+
+# ------------------------------------------------------------------ randomised differential sweep
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fused_train_random_shapes_vs_oracle(seed):
+    """Random batch shapes, sample counts, widths, layer counts and geometry modes against the oracle: exercises
+    partial tiles, fields starting mid stash tile, S not a multiple of anything, every backward kernel variant."""
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    F, R, n_c, n_g = ri(1, 6), ri(1, 90), ri(1, 14), ri(0, 14)
+    wide = seed % 2 == 0
+    fkw = dict(encoding="fourier", dim_enc=64 if wide else 32, num_layers=ri(1, 2))
+    if seed % 5 == 3:
+        fkw["skip_mode"] = "add"
+    mode = ["nrgbd", "occupancy", "density"][seed % 3]
+    if n_c + n_g < 2 and mode == "density":
+        n_c += 1                                                   # density drops the last sample
+    _ragged_case(F, R, n_c, n_g, fkw, geometry_mode=mode, geometry_factor=20.0 if mode != "density" else 1.0)

@@ -78,3 +78,63 @@ def init_from_env(backend: Optional[str] = None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation path: rays cross several fields (kNN blend), so every rank needs every field
+# ------------------------------------------------------------------------------------------------
+def gather_field_params(local_params: dict, num_fields: int, group=None) -> dict:
+    """All-gather the stacked parameter dictionaries of a field-per-GPU sharded map into the global order.
+
+    Rank r stores field g = slot * world + r at local slot `slot` (local_field_slots); the result has row g for
+    every g < num_fields on every rank.  One all_gather per parameter tensor (106 MB for 200 hash fields, 7 MB
+    for Fourier fields); ranks with fewer fields pad their block."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return {k: v[:num_fields] for k, v in local_params.items()}
+    per_rank = (num_fields + world - 1) // world
+    out = {}
+    for k, v in local_params.items():
+        pad = torch.zeros((per_rank,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[: min(per_rank, v.shape[0])] = v[:per_rank]
+        blocks = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(blocks, pad, group=group)
+        # blocks[r][slot] is field slot * world + r  ->  interleave
+        out[k] = torch.stack(blocks, 1).reshape((per_rank * world,) + tuple(v.shape[1:]))[:num_fields].contiguous()
+    return out
+
+
+def pixel_shard(num_pixels: int, rank: int, world_size: int):
+    """Contiguous slice [begin, end) of the flattened image this rank renders."""
+    per = (num_pixels + world_size - 1) // world_size
+    return min(num_pixels, rank * per), min(num_pixels, (rank + 1) * per)
+
+
+def gather_image(local_rows: torch.Tensor, num_pixels: int, group=None, dst: int = 0) -> Optional[torch.Tensor]:
+    """Collect the per-rank pixel slices (pixel_shard order) on rank `dst`; other ranks get None."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return local_rows
+    per = (num_pixels + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+    pad[: local_rows.shape[0]] = local_rows
+    blocks = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(blocks, pad, group=group)
+    if dist.get_rank(group) != dst:
+        return None
+    return torch.cat(blocks)[:num_pixels]
+
+
+def render_image_sharded(renderer, c2w, num_fields: int, camera=None, group=None, dst: int = 0):
+    """render_image (rm.py:402-437) on a field-per-GPU sharded map: all-gather the field parameters once, every
+    rank renders its slice of the pixels with the kNN-blended evaluation kernels, rank `dst` receives the image."""
+    cam = camera or renderer._camera
+    rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    full = gather_field_params(renderer._model.all_fields_params, num_fields, group)
+    b, e = pixel_shard(cam.height * cam.width, rank, world)
+    rgbd, dvar = renderer.render_pixels(c2w, b, e, params=full, camera=cam)
+    img = gather_image(torch.cat([rgbd, dvar[:, None]], -1), cam.height * cam.width, group, dst)
+    if img is None:
+        return None, None
+    return img[:, :4].reshape(cam.height, cam.width, 4), img[:, 4].reshape(cam.height, cam.width)

@@ -304,29 +304,32 @@ class NeuralGraphRenderer:
         return int((cfg.get("eval_far_distance", 8.0) - cfg.get("eval_near_distance", 0.0)) / spacing)
 
     @torch.no_grad()
-    def render_image(self, c2w: torch.Tensor, camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None,
-                     seed: int = 0):
-        """render_image (rm.py:402-437): every pixel, eval-style single stratum, kNN-blended fields.
-
-        Returns (rgbds (H,W,4), depth_vars (H,W)).  `u` (H*W, S) optionally supplies the torch.rand draws."""
+    def render_pixels(self, c2w: torch.Tensor, begin: int, end: int, params: Optional[dict] = None,
+                      camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None, seed: int = 0):
+        """Pixels [begin, end) of the flattened (row-major) image, eval-style single stratum, kNN-blended fields
+        (the loop body of render_image, rm.py:402-437).  `params` overrides the model's stacked parameters (the
+        all-gathered set on a sharded map).  Returns (rgbds (n,4), depth_vars (n,))."""
         cam = camera or self._camera
         cfg = self._config
         S = self.eval_num_samples()
         rc = make_render_cfg(cam, {**cfg, "num_samples_coarse": S, "num_samples_depth_guided": 0}, guided=False)
-        h, w = cam.height, cam.width
+        w = cam.width
         dev = self._device
-        ijs = torch.cartesian_prod(torch.arange(h, device=dev), torch.arange(w, device=dev))
+        idx = torch.arange(begin, end, device=dev)
+        ijs = torch.stack((idx // w, idx % w), -1)
         num = self._global_map_dict["num"]
         pos = self._global_map_dict["positions"][:num]
         quat = self._global_map_dict["orientations"][:num]
-        params = {k: v for k, v in self._model.all_fields_params.items() if k != "_neus_sd"}
+        if params is None:
+            params = self._model.all_fields_params
+        params = {k: v for k, v in params.items() if k != "_neus_sd"}
         m = self._model
         block = int(cfg.get("pixel_block_size", 8192))
         rgbds, dvars = [], []
         for s0 in range(0, ijs.shape[0], block):
             ij = ijs[s0:s0 + block]
-            ub = None if u is None else u[s0:s0 + block][None]
-            pc, pw, dist = ops.sample_rays_world(rc, ij, c2w, None, None, None, ub, None, seed + s0,
+            ub = None if u is None else u[begin + s0:begin + s0 + block][None]
+            pc, pw, dist = ops.sample_rays_world(rc, ij, c2w, None, None, None, ub, None, seed + begin + s0,
                                                  near_const=cfg.get("eval_near_distance", 0.0),
                                                  far_const=cfg.get("eval_far_distance", 8.0))
             out4 = ops.field_eval_knn(self._fc, params, pw.view(-1, 3), pos, quat, m._num_knn, m._distance_factor,
@@ -334,7 +337,19 @@ class NeuralGraphRenderer:
             rgbd, _, dv, _ = ops.composite_packed(rc, out4, dist.view(-1, S), pc.view(-1, S, 3))
             rgbds.append(rgbd)
             dvars.append(dv)
-        return torch.cat(rgbds).reshape(h, w, 4), torch.cat(dvars).reshape(h, w)
+        if not rgbds:
+            return torch.empty(0, 4, device=dev), torch.empty(0, device=dev)
+        return torch.cat(rgbds), torch.cat(dvars)
+
+    @torch.no_grad()
+    def render_image(self, c2w: torch.Tensor, camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None,
+                     seed: int = 0):
+        """render_image (rm.py:402-437): every pixel, eval-style single stratum, kNN-blended fields.
+
+        Returns (rgbds (H,W,4), depth_vars (H,W)).  `u` (H*W, S) optionally supplies the torch.rand draws."""
+        cam = camera or self._camera
+        rgbd, dv = self.render_pixels(c2w, 0, cam.height * cam.width, camera=cam, u=u, seed=seed)
+        return rgbd.reshape(cam.height, cam.width, 4), dv.reshape(cam.height, cam.width)
 
     @staticmethod
     def psnr(prediction: torch.Tensor, target: torch.Tensor, crop: int = 0) -> float:

@@ -82,3 +82,33 @@ def test_two_rank_field_sharding_matches_single_process(tmp_path):
     assert sorted(seen) == list(range(g["pos"].shape[0]))
     assert torch.equal(torch.load(os.path.join(tmp_path, "rank0.pt"))["sums"],
                        torch.load(os.path.join(tmp_path, "rank1.pt"))["sums"])
+
+
+# ------------------------------------------------------------------ evaluation path collectives
+def _eval_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env(backend="gloo")
+    NF, npix = 7, 101                                        # odd counts: ranks hold 4 and 3 fields, 51 and 50 pixels
+    glob = {"w": torch.arange(NF * 6, dtype=torch.float32).view(NF, 2, 3), "b": torch.arange(NF, dtype=torch.float32).view(NF, 1)}
+    slots = D.local_field_slots(NF, rank, world)
+    local = {k: v[slots].clone() for k, v in glob.items()}
+    full = D.gather_field_params(local, NF)
+    ok = all(torch.equal(full[k], glob[k]) for k in glob)
+    b, e = D.pixel_shard(npix, rank, world)
+    rows = torch.stack([torch.arange(b, e, dtype=torch.float32), torch.full((e - b,), float(rank))], -1)
+    img = D.gather_image(rows, npix, dst=0)
+    torch.save(dict(ok=ok, img=img, shard=(b, e)), os.path.join(out, f"eval{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_eval_gather_interleaves_fields_and_pixels(tmp_path):
+    world = 2
+    mp.spawn(_eval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"eval{r}.pt")) for r in range(world))
+    assert r0["ok"] and r1["ok"]                              # every rank ends up with all fields in global order
+    assert r1["img"] is None and r0["img"].shape == (101, 2)
+    assert torch.equal(r0["img"][:, 0], torch.arange(101, dtype=torch.float32))
+    assert r0["shard"] == (0, 51) and r1["shard"] == (51, 101)
+    assert torch.equal(r0["img"][:, 1], torch.cat([torch.zeros(51), torch.ones(50)]))

@@ -63,14 +63,20 @@ def synth_target(F, Rn, seed, field_offset=0):
     return pos, quat, tgt
 
 
-def build_renderer(device, num_fields):
+def build_renderer(device, num_fields, variant="fourier"):
     from neural_graph_mapping_amd import models as M
     from neural_graph_mapping_amd import renderer as Rr
     torch.manual_seed(0)
+    if variant == "hash":      # V-Hash of SURVEY 8d = the reference's default network (config/neural_graph_map.yaml:6-20)
+        enc = dict(encoding_type="neural_graph_mapping.positional_encodings.PermutohedralEncoding",
+                   encoding_kwargs=dict(pos_dim=3, log2_hashmap_size=12, nr_levels=16, nr_feat_per_level=2, coarsest_scale=1.0,
+                                        finest_scale=0.0001, appply_random_shift_per_level=True, concat_points=False,
+                                        concat_points_scaling=1.0), num_layers=1)
+    else:
+        enc = dict(encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+                   encoding_kwargs=dict(dim_in=3, dim_out=D_ENC, mu=0.0, sigma=4.0, raw_coords=True), num_layers=N_LAYERS)
     model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
-        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
-        encoding_kwargs=dict(dim_in=3, dim_out=D_ENC, mu=0.0, sigma=4.0, raw_coords=True), num_layers=N_LAYERS, dim_out=4,
-        dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0), num_knn=2,
+        **enc, dim_out=4, dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0), num_knn=2,
         distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(device)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
                termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
@@ -138,6 +144,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--variant", choices=["fourier", "hash"], default="fourier",
+                    help="field network: fourier = the headline M1 workload (default); hash = the reference's default "
+                         "permutohedral-hash network on the same batch (auxiliary measurement)")
     args = ap.parse_args()
 
     from neural_graph_mapping_amd import _capi as K
@@ -153,7 +162,7 @@ def main():
 
     # field-per-GPU sharding: rank r owns global fields r, r+world, ... ; local slot = id // world
     nf_global = F_PER_GPU * world
-    r = build_renderer(dev, F_PER_GPU)
+    r = build_renderer(dev, F_PER_GPU, args.variant)
     pos, quat, tgt_cpu = synth_target(F_PER_GPU, R, seed=1000 + rank)
     r.set_field_poses(pos.to(dev), quat.to(dev))
     tgt = type(tgt_cpu)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tgt_cpu])
@@ -213,12 +222,14 @@ def main():
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
                    config=dict(workload="M1: 8 fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
-                                        "Fourier(64,raw)+2x64 MLP, nrgbd compositing, NRGBD intrinsics",
+                                        + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
+                                           "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
+                                        + ", nrgbd compositing, NRGBD intrinsics",
                                fields_per_gpu=F_PER_GPU, rays_per_field=R, samples_per_ray=S_C + S_G,
                                sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox",
                                launch="hipGraph replay" if use_graph else "eager", final_loss=loss))
         fb = kern.get("field_bwd")
-        if fb:
+        if fb and args.variant == "fourier":
             achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_field_bwd.json")

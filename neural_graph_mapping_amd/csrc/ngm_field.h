@@ -123,8 +123,9 @@ __device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, floa
     for (int r = 0; r < 16; ++r) {
       const float4 w = tab[32 * mi + frow(r, 0) + 4 * hi];
       const float arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
-      float s, c;
-      ngm_sincosf(arg, &s, &c);
+      float s, c = 0.f;
+      if constexpr (!NEED_COS && !WITH_DERIV) s = ngm_sinf(arg);     // forward of the Fourier encoding: sine only
+      else ngm_sincosf(arg, &s, &c);
       float v = s, d = c;
       if (NEED_COS) { const bool is_cos = (w.w == NGM_FK_COS); v = is_cos ? c : s; d = is_cos ? -s : c; }
       if (mi == 0 && r < 3) { const bool raw = (w.w == NGM_FK_RAW); v = raw ? arg : v; d = raw ? 0.f : d; }

@@ -96,15 +96,33 @@ __global__ void k_knn_offsets(KnnArgs a) {
   }
 }
 
+// Counting-sort scatter in two levels: every workgroup ranks its SC_ITEMS * 256 pairs per field with LDS atomics,
+// reserves one contiguous range per field with ONE global atomic, then writes.  (One global atomic per pair on the
+// per-field cursor serialised badly -- neighbouring pixels hit the same field -- and took 80 % of render_image.)
+#define SC_ITEMS 8
 __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
+  extern __shared__ int sc_lds[];
+  int* hist = sc_lds;            // NF: pairs of this workgroup per field, then the reserved global base
   const int64_t n = a.P * a.K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int f = a.pair_field[i];
-    if (f >= 0) {
-      const int slot = atomicAdd(&a.cursor[f], 1);
-      a.sorted[a.seg_off[f] + slot] = (int)i;
-    }
+  for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (SC_ITEMS * 256);
+  int fld[SC_ITEMS], rnk[SC_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    fld[k] = (i < n) ? a.pair_field[i] : -1;
+    rnk[k] = (fld[k] >= 0) ? atomicAdd(&hist[fld[k]], 1) : 0;
   }
+  __syncthreads();
+  for (int f = threadIdx.x; f < a.NF; f += blockDim.x) {
+    const int c = hist[f];
+    hist[f] = a.seg_off[f] + (c ? atomicAdd(&a.cursor[f], c) : 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; ++k)
+    if (fld[k] >= 0) a.sorted[hist[fld[k]] + rnk[k]] = (int)(base + k * 256 + threadIdx.x);
 }
 
 template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
@@ -205,8 +223,8 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   const size_t lds_a = (size_t)num_fields * 16;
   hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
-  const int nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), 0, st, a);
+  const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
+  hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), (size_t)num_fields * 4, st, a);
   const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
   const FieldShape s = field_shape(fc);
   if (s.MI == 2 && s.MH == 2 && s.L == 2) launch_eval<2, 2, 2>(a, max_tiles, st);

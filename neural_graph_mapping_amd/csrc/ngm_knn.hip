@@ -37,10 +37,10 @@ struct KnnArgs {
 };
 
 __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
-  extern __shared__ float smf[];
-  float* cpos = smf;                                   // NF*3
-  int* hist = reinterpret_cast<int*>(smf + 3 * a.NF);  // NF
-  for (int i = threadIdx.x; i < 3 * a.NF; i += blockDim.x) cpos[i] = a.pos[i];
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  float4* cpos = reinterpret_cast<float4*>(smf);       // NF centres, one 16-byte broadcast read each
+  int* hist = reinterpret_cast<int*>(smf + 4 * a.NF);  // NF
+  for (int i = threadIdx.x; i < a.NF; i += blockDim.x) cpos[i] = make_float4(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2], 0.f);
   for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   const int K = a.K;
@@ -49,14 +49,19 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
     float bd[KNN_MAXK]; int bi[KNN_MAXK];
 #pragma unroll
     for (int k = 0; k < KNN_MAXK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+    float worst = INFINITY;                                   // bd[K-1]: most centres are farther and skip the insertion
     for (int f = 0; f < a.NF; ++f) {
-      const float dx = x - cpos[3 * f], dy = y - cpos[3 * f + 1], dz = z - cpos[3 * f + 2];
+      const float4 c = cpos[f];
+      const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
       float d = dx * dx + dy * dy + dz * dz;
-      int id = f;
-      // sorted insertion (stable: equal distances keep the lower field index first)
+      if (d < worst) {
+        int id = f;
+        // sorted insertion (stable: equal distances keep the lower field index first)
 #pragma unroll
-      for (int k = 0; k < KNN_MAXK; ++k) {
-        if (k < K && d < bd[k]) { const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti; }
+        for (int k = 0; k < KNN_MAXK; ++k) {
+          if (k < K && d < bd[k]) { const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti; }
+        }
+        worst = (K == 1) ? bd[0] : (K == 2) ? bd[1] : (K == 3) ? bd[2] : bd[3];
       }
     }
     float dist[KNN_MAXK];
@@ -220,7 +225,7 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   a.pair_out = reinterpret_cast<float4*>(carve(16 * n));
   (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
   const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
-  const size_t lds_a = (size_t)num_fields * 16;
+  const size_t lds_a = (size_t)num_fields * 20;
   hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));

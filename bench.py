@@ -170,9 +170,10 @@ def main():
     if world > 1 or torch.distributed.is_initialized():
         r.process_group = torch.distributed.group.WORLD
 
-    # single-GPU: the whole iteration (5 kernels + bookkeeping) is captured once into a hipGraph and replayed;
+    # the whole iteration (7 kernels) is captured once into a hipGraph and replayed;
     # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
-    use_graph = (world == 1) and not args.eager and not torch.distributed.is_initialized()
+    # multi-GPU: two graphs around the loss all-reduce (renderer.capture_iteration); --eager launches every kernel
+    use_graph = not args.eager
     replay = r.capture_iteration(tgt, seed=7) if use_graph else None
 
     def step(i):
@@ -227,7 +228,8 @@ def main():
                                         + ", nrgbd compositing, NRGBD intrinsics",
                                fields_per_gpu=F_PER_GPU, rays_per_field=R, samples_per_ray=S_C + S_G,
                                sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox",
-                               launch="hipGraph replay" if use_graph else "eager", final_loss=loss))
+                               launch=("eager" if (not use_graph or getattr(replay, "graph", None) is None) else
+                                       "hipGraph replay" if r.process_group is None else "2 hipGraphs + all-reduce"), final_loss=loss))
         fb = kern.get("field_bwd")
         if fb and args.variant == "fourier":
             achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12

@@ -379,6 +379,14 @@ class NeuralGraphRenderer:
         update=False, also the gradients.  Every launch is asynchronous on the current stream and the
         sequence is hipGraph-capturable (device-side step / jitter counters, no allocation after the
         first call with a given batch shape)."""
+        ctx = self._iteration_forward(target, u_coarse, u_guided, seed)
+        if self.process_group is not None:
+            # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
+            torch.distributed.all_reduce(ctx["w"]["sums"], group=self.process_group)
+        return self._iteration_backward(ctx, update)
+
+    def _iteration_forward(self, target: Target, u_coarse=None, u_guided=None, seed=0) -> dict:
+        """First half of the iteration: fused forward + local loss sums (everything before the all-reduce)."""
         L = K.lib()
         fc, rc = self._fc, self._rc_train
         fids = target.field_ids
@@ -396,15 +404,22 @@ class NeuralGraphRenderer:
         tm = target.term_mask
         if tm is not None and tm.dtype == torch.bool:
             tm = tm.view(torch.uint8)
-        tg = K.Targets(ops._ptr(ops._f32c(target.rgbds)), dm.data_ptr(), ops._ptr(tm), ops._ptr(target.term_probs))
+        rgbds_t = ops._f32c(target.rgbds)
+        tg = K.Targets(ops._ptr(rgbds_t), dm.data_ptr(), ops._ptr(tm), ops._ptr(target.term_probs))
         pred = K.Prediction(w["rgbds"].data_ptr(), w["color_vars"].data_ptr(), w["depth_vars"].data_ptr(),
                             w["term_probs"].data_ptr())
         st = ops._stream()
         K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                  w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
-        if self.process_group is not None:
-            # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
-            torch.distributed.all_reduce(w["sums"], group=self.process_group)
+        return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp,
+                    keep=(keep, dm, tm, rgbds_t, target))
+
+    def _iteration_backward(self, ctx: dict, update=True) -> dict:
+        """Second half: compositing + MLP backward with the (global) loss sums, sparse Adam, counters."""
+        L = K.lib()
+        fc, rc, ps, rays, tg, pred, w, F, fids, allp = (ctx[k] for k in ("fc", "rc", "ps", "rays", "tg", "pred", "w", "F",
+                                                                         "fids", "allp"))
+        st = ops._stream()
         if "grads" not in w:
             w["grads"], w["gs"], w["gflat"] = ops.alloc_grads(fc, F, self._device)
         grads, gs = w["grads"], w["gs"]
@@ -429,23 +444,53 @@ class NeuralGraphRenderer:
         return loss
 
     def capture_iteration(self, target: Target, seed=0):
-        """Capture optimization_iteration(target) into a hipGraph (torch.cuda.CUDAGraph); the returned
-        callable replays it.  Tensors of `target` are read in place at every replay; the Adam step counter
-        and the Philox jitter offset live on the device and advance inside the graph."""
+        """Capture optimization_iteration(target) into hipGraphs (torch.cuda.CUDAGraph); the returned callable
+        replays it.  Tensors of `target` are read in place at every replay; the Adam step counter and the Philox
+        jitter offset live on the device and advance inside the graph.  With a process group the iteration becomes
+        two graphs (before / after the loss all-reduce) and the 64-byte collective is issued between the replays."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):                                # warm-up on a side stream (allocations, lazy init)
                 out = self.optimization_iteration(target, seed=seed)
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.optimization_iteration(target, seed=seed)
-        self._step -= 1                                       # the capture pass records, it does not execute
+        if self.process_group is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.optimization_iteration(target, seed=seed)
+            self._step -= 1                                   # the capture pass records, it does not execute
 
-        def replay():
-            graph.replay()
+            def replay():
+                graph.replay()
+                self._step += 1
+                return out
+            replay.graph = graph
+            return replay
+        # thread-local capture mode: the process group's watchdog thread may touch the HIP runtime meanwhile
+        step0 = self._step
+        try:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                ctx = self._iteration_forward(target, None, None, seed)
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                out = self._iteration_backward(ctx, True)
+        except RuntimeError:
+            # capture refused (runtime / collective library combination): plain launches still work
+            self._step = step0
+            torch.cuda.synchronize()
+
+            def eager():
+                return self.optimization_iteration(target, seed=seed)
+            eager.graph = None
+            return eager
+        self._step -= 1
+        sums, group = ctx["w"]["sums"], self.process_group
+
+        def replay2():
+            g1.replay()
+            torch.distributed.all_reduce(sums, group=group)
+            g2.replay()
             self._step += 1
             return out
-        replay.graph = graph
-        return replay
+        replay2.graph = (g1, g2)
+        return replay2

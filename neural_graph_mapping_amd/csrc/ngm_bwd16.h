@@ -47,9 +47,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // LDS layout (floats).  TI/TH = ceil(D/16), ceil(H/16).
-template <int TI, int TH, int L>
+template <int TI, int TH, int L, int RS = B16_RS>
 struct Lds16 {
-  static constexpr int BLK = 16 * B16_RS;                                     // one 16x16 block
+  static constexpr int BLK = 16 * RS;                                     // one 16x16 block
   static constexpr int ENCW = 0;                                              // float4[TI*16]
   static constexpr int w_off(int l) {
     int o = TI * 16 * 4;
@@ -73,9 +73,9 @@ struct Lds16 {
 };
 
 // weights -> LDS: block (mo, mi) holds W[16mo + o][16mi + c] at row krow(c) = 4*(c&3) + (c>>2), col o
-template <int TI, int TH, int L>
+template <int TI, int TH, int L, int RS = B16_RS>
 __device__ __forceinline__ void load_field16(float* sm, const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
-  using LY = Lds16<TI, TH, L>;
+  using LY = Lds16<TI, TH, L, RS>;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int D = fc.dim_enc, H = fc.dim_hidden;
   if (fc.encoding == NGM_ENC_PERMUTO) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void load_field16(float* sm, const ngm_field_cfg& fc,
       const int o = e / ncol, c = e - o * ncol;
       const float v = (o < H && c < Din) ? W[(int64_t)o * Din + c] : 0.f;
       const int mo = o >> 4, ol = o & 15, mi = c >> 4, cl = c & 15;
-      dst[(mo * TIN + mi) * LY::BLK + (4 * (cl & 3) + (cl >> 2)) * B16_RS + ol] = v;
+      dst[(mo * TIN + mi) * LY::BLK + (4 * (cl & 3) + (cl >> 2)) * RS + ol] = v;
     }
     for (int o = tid; o < TH * 16; o += nthr) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
   }

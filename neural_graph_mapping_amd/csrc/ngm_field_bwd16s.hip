@@ -34,9 +34,15 @@ __device__ __forceinline__ int phase_lane(int lane) {
 #define BK_TILE (4 * BK_STRIDE)           // one 16 x 64 tile
 __device__ __forceinline__ int bk_idx(int n, int ft) { return (n >> 2) * BK_STRIDE + (n & 3) * 64 + ft; }
 
+// Row stride of the 16x16 weight blocks in this kernel: only the data-gradient MFMAs read them, four consecutive
+// outputs at a time.  20 floats = 16-byte aligned rows -> one ds_read_b128 serves four k-steps and the 64 lanes spread
+// evenly over the eight 4-bank groups ((5 p + q) mod 8); with the 17 of the recompute kernel the same reads compile to
+// unaligned b96/b32 mixes and some banks are hit four times.
+#define S16_RS 20
+
 template <int L>
 struct Lds16s {
-  using W = Lds16<4, 4, L>;               // weight region (same layout as the recompute kernel)
+  using W = Lds16<4, 4, L, S16_RS>;       // weight region
   static constexpr int XE = 0;            // encoding tile
   static constexpr int act(int l) { return l * BK_TILE; }   // input tile of layer l (l = 1..L); act(L) doubles as dY staging
   static constexpr int PBUF = (L + 1) * BK_TILE;             // [16][4] xyz
@@ -102,32 +108,26 @@ template <int BLK>
 __device__ __forceinline__ void dgrad16v(const float* __restrict__ W, int lane, const f32x4 (&dY)[4], f32x4 (&dX)[4]) {
   lane = phase_lane(lane);
   const int i = lane & 15, q = lane >> 4;
-  const float* Wl = W + (4 * (i & 3) + (i >> 2)) * B16_RS + 4 * q;
-  constexpr int GK = 2, NG = 16 / GK;      // operand groups of 2 k-steps, double buffered
-  float abuf[2][4][GK];
+  const float* Wl = W + (4 * (i & 3) + (i >> 2)) * S16_RS + 4 * q;
+  // one 16-byte read = the A operands of the four k-steps (mo, r = 0..3) of tile mi; double buffered over mo
+  float4 abuf[2][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 4; ++mi) abuf[0][mi] = *reinterpret_cast<const float4*>(Wl + mi * BLK);
 #pragma unroll
-    for (int u = 0; u < GK; ++u) abuf[0][mi][u] = Wl[mi * BLK + u];
+  for (int mo = 0; mo < 4; ++mo) {
+    if (mo + 1 < 4) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int u = 0; u < GK; ++u) {
-          const int k = (g + 1) * GK + u, mo = k >> 2, r = k & 3;
-          abuf[(g + 1) & 1][mi][u] = Wl[(mo * 4 + mi) * BLK + r];
-        }
+      for (int mi = 0; mi < 4; ++mi) abuf[(mo + 1) & 1][mi] = *reinterpret_cast<const float4*>(Wl + ((mo + 1) * 4 + mi) * BLK);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < GK; ++u)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const int k = g * GK + u;
-        if (k == 0) dX[mi] = mfma16_v0(abuf[0][mi][0], dY[0][0]);
-        else mfma16_v(dX[mi], abuf[g & 1][mi][u], dY[k >> 2][k & 3]);
+        const float4 a4 = abuf[mo & 1][mi];
+        const float av = (r == 0) ? a4.x : (r == 1) ? a4.y : (r == 2) ? a4.z : a4.w;
+        if (mo == 0 && r == 0) dX[mi] = mfma16_v0(av, dY[0][0]);
+        else mfma16_v(dX[mi], av, dY[mo][r]);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   constexpr int BLK = LW::BLK;
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field16<4, 4, L>(sm, a.fc, a.pr, row);
+  load_field16<4, 4, L, S16_RS>(sm, a.fc, a.pr, row);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;

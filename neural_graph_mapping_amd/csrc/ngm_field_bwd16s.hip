@@ -30,9 +30,15 @@ __device__ __forceinline__ int phase_lane(int lane) {
   return lane;
 }
 
-#define BK_STRIDE 264                     // floats per 4-row block: 4 * 64 + 8
+// Blocked, swizzled tile: sample n = 4 b + r lives in block b (stride 272 floats = 16 banks), row r (64 floats), and
+// its 16-byte chunk c = feature / 4 sits at chunk position c ^ 2r.  A 32-lane half-wave of every access pattern then
+// touches 32 different banks: the wgrad operand reads (one row of two blocks: bank offset 16 apart), the C-layout b128
+// accesses (4 rows of a block differ in chunk position) and the lane = feature reads (a permutation of one row).
+#define BK_STRIDE 272
 #define BK_TILE (4 * BK_STRIDE)           // one 16 x 64 tile
-__device__ __forceinline__ int bk_idx(int n, int ft) { return (n >> 2) * BK_STRIDE + (n & 3) * 64 + ft; }
+__device__ __forceinline__ int bk_idx(int n, int ft) {
+  return (n >> 2) * BK_STRIDE + (n & 3) * 64 + ((((ft >> 2) ^ (2 * (n & 3)))) << 2) + (ft & 3);
+}
 
 // Row stride of the 16x16 weight blocks in this kernel: only the data-gradient MFMAs read them, four consecutive
 // outputs at a time.  20 floats = 16-byte aligned rows -> one ds_read_b128 serves four k-steps and the 64 lanes spread
@@ -58,17 +64,15 @@ struct Lds16s {
 __device__ __forceinline__ void store16b(float* buf, int lane, const f32x4 (&V)[4]) {
   lane = phase_lane(lane);
   const int j = lane & 15, q = lane >> 4;
-  float* p = buf + bk_idx(j, 4 * q);
 #pragma unroll
-  for (int m = 0; m < 4; ++m) *reinterpret_cast<float4*>(p + 16 * m) = make_float4(V[m][0], V[m][1], V[m][2], V[m][3]);
+  for (int m = 0; m < 4; ++m) *reinterpret_cast<float4*>(buf + bk_idx(j, 16 * m + 4 * q)) = make_float4(V[m][0], V[m][1], V[m][2], V[m][3]);
 }
 __device__ __forceinline__ void load16b(const float* buf, int lane, f32x4 (&V)[4]) {
   lane = phase_lane(lane);
   const int j = lane & 15, q = lane >> 4;
-  const float* p = buf + bk_idx(j, 4 * q);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const float4 v = *reinterpret_cast<const float4*>(p + 16 * m);
+    const float4 v = *reinterpret_cast<const float4*>(buf + bk_idx(j, 16 * m + 4 * q));
     V[m][0] = v.x; V[m][1] = v.y; V[m][2] = v.z; V[m][3] = v.w;
   }
 }
@@ -139,16 +143,22 @@ __device__ __forceinline__ void wgrad16b(const float* __restrict__ dbuf, const f
                                          f32x4 (&acc)[4][4]) {
   lane = phase_lane(lane);
   const int i = lane & 15, q = lane >> 4;
-  const float* dl = dbuf + q * BK_STRIDE + i;
-  const float* xl = xbuf + q * BK_STRIDE + i;
+  // row t of block q, feature 16 m + i: chunk position (4 m + (i >> 2)) ^ 2 t = 4 (m ^ (t >> 1)) + ((i >> 2) ^ 2 (t & 1))
+  const int e0 = q * BK_STRIDE + ((i >> 2) << 2) + (i & 3), e1 = q * BK_STRIDE + (((i >> 2) ^ 2) << 2) + (i & 3);
+  const float* dl[2] = {dbuf + e0, dbuf + e1};
+  const float* xl[2] = {xbuf + e0, xbuf + e1};
   float av[2][4], bv[2][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) { av[0][m] = dl[16 * m]; bv[0][m] = xl[16 * m]; }
+  for (int m = 0; m < 4; ++m) { av[0][m] = dl[0][16 * m]; bv[0][m] = xl[0][16 * m]; }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t + 1 < 4) {
+      const int t1 = t + 1;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { av[(t + 1) & 1][m] = dl[64 * (t + 1) + 16 * m]; bv[(t + 1) & 1][m] = xl[64 * (t + 1) + 16 * m]; }
+      for (int m = 0; m < 4; ++m) {
+        av[t1 & 1][m] = dl[t1 & 1][64 * t1 + 16 * (m ^ (t1 >> 1))];
+        bv[t1 & 1][m] = xl[t1 & 1][64 * t1 + 16 * (m ^ (t1 >> 1))];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -164,7 +174,7 @@ __device__ __forceinline__ float colsum16b(const float* buf, int lane) {
   lane = phase_lane(lane);
   float v[16];
 #pragma unroll
-  for (int n = 0; n < 16; ++n) v[n] = buf[bk_idx(n, 0) + lane];
+  for (int n = 0; n < 16; ++n) v[n] = buf[bk_idx(n, lane)];
 #pragma unroll
   for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
@@ -179,7 +189,7 @@ __device__ __forceinline__ void outer16b(const float* colbuf, const float* row4,
   for (int k0 = 0; k0 < 16; k0 += 4) {
     float h[4]; float4 d[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { h[k] = colbuf[bk_idx(k0 + k, 0) + lane]; d[k] = *reinterpret_cast<const float4*>(row4 + 4 * (k0 + k)); }
+    for (int k = 0; k < 4; ++k) { h[k] = colbuf[bk_idx(k0 + k, lane)]; d[k] = *reinterpret_cast<const float4*>(row4 + 4 * (k0 + k)); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       acc[0] = fmaf(d[k].x, h[k], acc[0]);
@@ -260,7 +270,8 @@ __device__ __forceinline__ void issue_act(const char* sbase, uint32_t gb, uint32
     uint32_t n = n0 + 4 * b + (lane >> 4);
     if (n >= end) n = end - 1;
     const uint32_t u = n + gb;
-    dma16_so(sbase, (((u >> 5) * 16u + (lane & 15)) * 32u + (u & 31u)) * 16u, lds_tile + b * BK_STRIDE * 4);
+    // LDS position lane -> (row lane >> 4, chunk position lane & 15) holds logical chunk (lane & 15) ^ 2 row
+    dma16_so(sbase, (((u >> 5) * 16u + ((lane & 15) ^ (2 * (lane >> 4)))) * 32u + (u & 31u)) * 16u, lds_tile + b * BK_STRIDE * 4);
   }
 }
 

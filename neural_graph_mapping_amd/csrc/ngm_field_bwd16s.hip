@@ -22,13 +22,9 @@
 // encoding, ray mode.  Everything else keeps the recompute kernel.
 #include "ngm_bwd16.h"
 
-// Opaque copy of the lane id: address arithmetic derived from it is redone inside each phase instead of
-// being hoisted out of the tile loop, where a few dozen loop-invariant LDS offsets would each pin a VGPR
-// (the two 64-register accumulator sets leave ~128 registers for everything else).
-__device__ __forceinline__ int phase_lane(int lane) {
-  asm volatile("" : "+v"(lane));
-  return lane;
-}
+// (An earlier build re-derived every lane-dependent LDS offset inside each phase from an opaque copy of the lane id, to
+// keep loop-invariant offsets out of registers while the kernel was spilling.  With the spills gone -- aligned weight
+// rows, late encoding -- letting the compiler hoist them is 4 % faster.)
 
 // Blocked, swizzled tile: sample n = 4 b + r lives in block b (stride 272 floats = 16 banks), row r (64 floats), and
 // its 16-byte chunk c = feature / 4 sits at chunk position c ^ 2r.  A 32-lane half-wave of every access pattern then
@@ -62,13 +58,11 @@ struct Lds16s {
 
 // ---- blocked-tile helpers, lane (j = lane & 15, q = lane >> 4) --------------------------------------
 __device__ __forceinline__ void store16b(float* buf, int lane, const f32x4 (&V)[4]) {
-  lane = phase_lane(lane);
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int m = 0; m < 4; ++m) *reinterpret_cast<float4*>(buf + bk_idx(j, 16 * m + 4 * q)) = make_float4(V[m][0], V[m][1], V[m][2], V[m][3]);
 }
 __device__ __forceinline__ void load16b(const float* buf, int lane, f32x4 (&V)[4]) {
-  lane = phase_lane(lane);
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -110,7 +104,6 @@ __device__ __forceinline__ void mfma_results_ready(f32x4 (&d)[4]) {
 // dX = W^T dY: k-step (mo, r) uses A[i][k=q] = W[16mo + 4q + r][16mi + i] = block(mo,mi)[row 4(i&3)+(i>>2)][4q + r]
 template <int BLK>
 __device__ __forceinline__ void dgrad16v(const float* __restrict__ W, int lane, const f32x4 (&dY)[4], f32x4 (&dX)[4]) {
-  lane = phase_lane(lane);
   const int i = lane & 15, q = lane >> 4;
   const float* Wl = W + (4 * (i & 3) + (i >> 2)) * S16_RS + 4 * q;
   // one 16-byte read = the A operands of the four k-steps (mo, r = 0..3) of tile mi; double buffered over mo
@@ -141,7 +134,6 @@ __device__ __forceinline__ void dgrad16v(const float* __restrict__ W, int lane, 
 // dW[16mo + o][16mi + c] += sum_s dY[s][o] X[s][c]; k-step t takes samples 4b + t (b = lane >> 4)
 __device__ __forceinline__ void wgrad16b(const float* __restrict__ dbuf, const float* __restrict__ xbuf, int lane,
                                          f32x4 (&acc)[4][4]) {
-  lane = phase_lane(lane);
   const int i = lane & 15, q = lane >> 4;
   // row t of block q, feature 16 m + i: chunk position (4 m + (i >> 2)) ^ 2 t = 4 (m ^ (t >> 1)) + ((i >> 2) ^ 2 (t & 1))
   const int e0 = q * BK_STRIDE + ((i >> 2) << 2) + (i & 3), e1 = q * BK_STRIDE + (((i >> 2) ^ 2) << 2) + (i & 3);
@@ -171,7 +163,6 @@ __device__ __forceinline__ void wgrad16b(const float* __restrict__ dbuf, const f
 
 // lane = feature: sum over the tile's 16 samples
 __device__ __forceinline__ float colsum16b(const float* buf, int lane) {
-  lane = phase_lane(lane);
   float v[16];
 #pragma unroll
   for (int n = 0; n < 16; ++n) v[n] = buf[bk_idx(n, lane)];
@@ -184,7 +175,6 @@ __device__ __forceinline__ float colsum16b(const float* buf, int lane) {
 // lane = feature: acc[c] += sum_s col[s][lane] * row4[s][c]
 template <int NC>
 __device__ __forceinline__ void outer16b(const float* colbuf, const float* row4, int lane, float (&acc)[NC]) {
-  lane = phase_lane(lane);
 #pragma unroll
   for (int k0 = 0; k0 < 16; k0 += 4) {
     float h[4]; float4 d[4];

@@ -229,7 +229,7 @@ __device__ __forceinline__ void fwd16(const float* __restrict__ W, const float* 
 #pragma unroll
   for (int mo = 0; mo < TOUT; ++mo)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Y[mo][r] = fmaxf(Y[mo][r], 0.f);
+    for (int r = 0; r < 4; ++r) Y[mo][r] = ngm_relu(Y[mo][r]);
 }
 
 // dX = W^T dY: k-step (mo, r) uses A[i][k=q] = W[16mo + 4q + r][16mi + i] = block(mo,mi)[row 4(i&3)+(i>>2)][4q + r]

@@ -90,6 +90,11 @@ __device__ __forceinline__ float ngm_sinf(float x) {
 
 __device__ __forceinline__ float ngm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// relu on a matrix-core result in ONE instruction.  fmaxf(y, 0) on an MFMA output compiles to two v_max_f32 (the first
+// quiets a possible signalling NaN); v_med3_f32(y, 0, +inf) needs no canonicalisation and agrees with fmaxf for every
+// input, NaN included (both return 0).
+__device__ __forceinline__ float ngm_relu(float y) { return __builtin_amdgcn_fmed3f(y, 0.f, __builtin_inff()); }
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (used when the caller passes no explicit torch.rand draws)
 // ------------------------------------------------------------------------------------------------

@@ -315,7 +315,7 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const flo
 #pragma unroll
     for (int mo = 0; mo < MOUT; ++mo)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = fmaxf(Y[nt][mo][r], 0.f);
+      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = ngm_relu(Y[nt][mo][r]);
 }
 
 // Output layer (4 x H) on the VALU: each lane reduces over ITS 16*MH features; the two lane halves

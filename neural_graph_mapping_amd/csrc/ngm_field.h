@@ -372,8 +372,11 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
       for (int m = 0; m < MH; ++m)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
-          *reinterpret_cast<float4*>(p + (8 * m + 2 * g4) * 128) =
-              make_float4(H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]);
+        {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          const v4f val = {H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]};
+          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128));   // streamed: read once, by the backward
+        }
     }
   }
 }

@@ -219,7 +219,7 @@ __device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint3
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 nt\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_base)

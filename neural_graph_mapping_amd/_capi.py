@@ -163,7 +163,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays"]
+            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;
 # torch.optim.Adam skips grad-less parameters, so the sparse Adam must skip them too)

@@ -228,6 +228,12 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 
+static unsigned long long* g_debug_cycles_fwd = nullptr;
+int ngm_debug_fwd_phase_cycles(unsigned long long* out16) {
+  if (!g_debug_cycles_fwd || !out16) return NGM_E_INVALID;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(out16, g_debug_cycles_fwd, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
+}
 int ngm_debug_phase_cycles(unsigned long long* out16) {
   if (!g_debug_cycles || !out16) return NGM_E_INVALID;
   (void)hipDeviceSynchronize();
@@ -525,6 +531,11 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
     a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
     a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
     if (p.act_layer_stride) { a.act = reinterpret_cast<float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
+    static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
+    if (timing) {
+      if (!g_debug_cycles_fwd) { (void)hipMalloc(&g_debug_cycles_fwd, 128); (void)hipMemset(g_debug_cycles_fwd, 0, 128); }
+      a.debug_cycles = g_debug_cycles_fwd;
+    }
   }
   e = ngm_launch_render_fwd(a, p.blocks_fwd, (hipStream_t)stream);
   if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");

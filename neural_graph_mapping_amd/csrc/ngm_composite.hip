@@ -33,12 +33,13 @@ __global__ void k_sample_rays(SamplerArgs a) {
 #pragma clang fp contract(off)
   const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
   const int S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
+  const uint64_t poff = philox_launch_offset(a.rays);
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t ray = g / a.S;
     const int e = (int)(g - ray * a.S);
     const RayGeom rg = ray_geom(a.rc, a.rays, ray, S_g > 0);
     float t; int rank;
-    sample_rank(a.rc, a.rays, rg, ray, e, S_c, S_g, &t, &rank);
+    sample_rank(a.rc, a.rays, poff, rg, ray, e, S_c, S_g, &t, &rank);
     const int64_t o = ray * a.S + rank;
     if (a.distances) a.distances[o] = t;
     if (a.points_cam) {
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const float occ = act ? occ_at(a, rb + rl, k, S) : 0.f;
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
-      const float up = __shfl_up(q, 1, 64);
+      const float up = lane_prev(q, carry);
       const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
-      carry = __shfl(q, 63, 64);
+      carry = lane_value(q, 63);
       const float w = act ? occ * T_excl : 0.f;
       float c0 = 0, c1 = 0, c2 = 0, dp = 0;
       if (act) {
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       if (neus && valid) neus_partials(a, rb + rl, k, S, &dodg0, &dnext0, &disd0);
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
-      const float up = __shfl_up(q, 1, 64);
+      const float up = lane_prev(q, carry);
       const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
-      carry = __shfl(q, 63, 64);
+      carry = lane_value(q, 63);
       if (valid) {
         wl.tex[idx] = T_excl; wl.occ[idx] = occ; wl.doc[idx] = dodg0;
         if (neus) { wl.dnx[idx] = dnext0; wl.dis[idx] = disd0; }
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);
       const float Qk = (kr >= 1 && lane < 63) ? fmaf(nB, Qend, nA) : Qend;
       const float Qbefore = fmaf(B, Qend, A);
-      carryQ = __shfl(Qbefore, 0, 64);
+      carryQ = lane_value(Qbefore, 0);
       if (valid) {
         const float w = occ * T;
         if (a.d_colors) *reinterpret_cast<Rgb3*>(a.d_colors + 3 * g) = Rgb3{w * dC0, w * dC1, w * dC2};
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);
     const float Qk = (kr >= 1 && lane < 63) ? fmaf(nB, Qend, nA) : Qend;
     const float Qbefore = fmaf(B, Qend, A);
-    carryQ = __shfl(Qbefore, 0, 64);
+    carryQ = lane_value(Qbefore, 0);
     if (valid) {
       const float w = occ * T;
       float dg = T * (ak - Qk) * dodg;
@@ -446,7 +447,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
         dg += a.d_geom_samples[g];
       }
       if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;   // overwritten sample: no gradient reaches the MLP output
-      a.stashA[g] = make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg);
+      {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f dv = {cf * w * dC0, cf * w * dC1, cf * w * dC2, dg};
+        __builtin_nontemporal_store(dv, reinterpret_cast<v4f*>(a.stashA + g));     // read once, by the MLP backward
+      }
     }
   }
 }

@@ -191,17 +191,21 @@ __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm
 }
 
 // jitter draw for source element (stratum `which`, index i) of global ray `ray`
-__device__ __forceinline__ float jitter(const ngm_rays& rays, int which, int64_t ray, int n, int i) {
+// Philox stream offset of this launch: read ONCE per kernel (the device-side part is what a hipGraph replay advances);
+// re-reading it per draw put a global-load latency in front of every sample of the sampler.
+__device__ __forceinline__ uint64_t philox_launch_offset(const ngm_rays& rays) {
+  return rays.philox_offset + (rays.philox_offset_dev ? *rays.philox_offset_dev : 0ull);
+}
+__device__ __forceinline__ float jitter(const ngm_rays& rays, uint64_t poff, int which, int64_t ray, int n, int i) {
   const float* u = which ? rays.u_guided : rays.u_coarse;
   if (u) return u[ray * n + i];
-  const uint64_t off = rays.philox_offset + (rays.philox_offset_dev ? *rays.philox_offset_dev : 0ull);
-  return philox_uniform(rays.philox_seed, off, (uint64_t)(ray * n + i), (uint32_t)which);
+  return philox_uniform(rays.philox_seed, poff, (uint64_t)(ray * n + i), (uint32_t)which);
 }
 
 // number of elements of stratum (near,far,n) that are < x (strict=1) or <= x (strict=0).
 // Closed form from the stratified structure (element j lies in [near+j*d, near+(j+1)*d)), with the
 // three candidates around the boundary compared explicitly so fp32 rounding cannot mis-rank.
-__device__ __forceinline__ int strat_count_below(const ngm_rays& rays, int which, int64_t ray, float near, float far,
+__device__ __forceinline__ int strat_count_below(const ngm_rays& rays, uint64_t poff, int which, int64_t ray, float near, float far,
                                                  int n, const float* lin_tab, float x, bool strict) {
   const float span = far - near;
   int q;
@@ -216,48 +220,90 @@ __device__ __forceinline__ int strat_count_below(const ngm_rays& rays, int which
   const int lo = (span > 0.0f) ? max(q - 1, 0) : 0;
   const int hi = (span > 0.0f) ? min(q + 1, n - 1) : n - 1;
   for (int j = lo; j <= hi; ++j) {
-    const float tj = strat_t(near, far, n, j, jitter(rays, which, ray, n, j), lin_tab);
+    const float tj = strat_t(near, far, n, j, jitter(rays, poff, which, ray, n, j), lin_tab);
     cnt += strict ? (tj < x) : (tj <= x);
   }
   return min(cnt, n);
 }
 
 // sorted distance + rank of source element e (0..S_c-1 coarse, S_c.. guided) of a ray
-__device__ __forceinline__ void sample_rank(const ngm_render_cfg& cfg, const ngm_rays& rays, const RayGeom& g,
+__device__ __forceinline__ void sample_rank(const ngm_render_cfg& cfg, const ngm_rays& rays, uint64_t poff, const RayGeom& g,
                                             int64_t ray, int e, int S_c, int S_g, float* t_out, int* rank_out) {
   if (e < S_c) {
-    const float t = strat_t(g.near, g.far, S_c, e, jitter(rays, 0, ray, S_c, e), rays.lin_coarse);
+    const float t = strat_t(g.near, g.far, S_c, e, jitter(rays, poff, 0, ray, S_c, e), rays.lin_coarse);
     int rank = e;
-    if (S_g > 0) rank += strat_count_below(rays, 1, ray, g.gnear, g.gfar, S_g, rays.lin_guided, t, true);
+    if (S_g > 0) rank += strat_count_below(rays, poff, 1, ray, g.gnear, g.gfar, S_g, rays.lin_guided, t, true);
     *t_out = t; *rank_out = rank;
   } else {
     const int j = e - S_c;
-    const float t = strat_t(g.gnear, g.gfar, S_g, j, jitter(rays, 1, ray, S_g, j), rays.lin_guided);
-    const int rank = j + strat_count_below(rays, 0, ray, g.near, g.far, S_c, rays.lin_coarse, t, false);
+    const float t = strat_t(g.gnear, g.gfar, S_g, j, jitter(rays, poff, 1, ray, S_g, j), rays.lin_guided);
+    const int rank = j + strat_count_below(rays, poff, 0, ray, g.near, g.far, S_c, rays.lin_coarse, t, false);
     *t_out = t; *rank_out = rank;
   }
 }
+
+// phase timing of the fused forward (debug builds, -DNGM_PHASE_TIMING; compiled out otherwise): PTICK(pc, k) adds
+// the shader-clock cycles since the previous tick to slot k
+struct PhaseClock {
+  unsigned long long acc[14];
+  unsigned long long last, start, rstart;
+  __device__ __forceinline__ void begin() {
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = 0;
+    rstart = __builtin_amdgcn_s_memrealtime();
+    start = last = __builtin_readcyclecounter();
+  }
+  __device__ __forceinline__ void tick(int k) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[k] += now - last; last = __builtin_readcyclecounter();
+  }
+};
+#ifdef NGM_PHASE_TIMING
+#define PTICK(pc, k) do { if (pc) (pc)->tick(k); } while (0)
+#else
+#define PTICK(pc, k)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // wave-level segmented scans over 64 lanes = 64 consecutive flat samples.  A segment = one ray;
 // k = sample index inside the ray, so lane-d belongs to the same segment iff k >= d (&& lane >= d).
 // ------------------------------------------------------------------------------------------------
+// The lane exchange is DPP (row_shr inside the 16-lane rows, then row_bcast:15 / row_bcast:31 to carry the row
+// totals forward): 6 VALU-only steps, no LDS-pipe ds_bpermute and no wait.  Lanes the DPP source does not
+// reach keep `ident`, so the in-row bound check comes for free; `k >= d` is the segment condition.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float ident, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+#define NGM_DPP_ROW_SHR(d) (0x110 + (d))
+#define NGM_DPP_ROW_BCAST15 0x142
+#define NGM_DPP_ROW_BCAST31 0x143
+#define NGM_DPP_WAVE_SHR1 0x138
 __device__ __forceinline__ float seg_scan_add(float v, int k, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d && k >= d) v += o;
-  }
+  const int pr = lane & 15;
+  float o;
+  o = dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(0.f, v); v += (k >= 1) ? o : 0.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(2), 0xf>(0.f, v); v += (k >= 2) ? o : 0.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(4), 0xf>(0.f, v); v += (k >= 4) ? o : 0.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(8), 0xf>(0.f, v); v += (k >= 8) ? o : 0.f;
+  o = dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(0.f, v); v += (k > pr) ? o : 0.f;          // rows 1,3 += total of row 0,2
+  o = dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(0.f, v); v += (k > lane - 32) ? o : 0.f;   // rows 2,3 += total of lanes 0..31
   return v;
 }
 __device__ __forceinline__ float seg_scan_mul(float v, int k, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d && k >= d) v *= o;
-  }
+  const int pr = lane & 15;
+  float o;
+  o = dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(1.f, v); v *= (k >= 1) ? o : 1.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(2), 0xf>(1.f, v); v *= (k >= 2) ? o : 1.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(4), 0xf>(1.f, v); v *= (k >= 4) ? o : 1.f;
+  o = dpp_take<NGM_DPP_ROW_SHR(8), 0xf>(1.f, v); v *= (k >= 8) ? o : 1.f;
+  o = dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(1.f, v); v *= (k > pr) ? o : 1.f;
+  o = dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(1.f, v); v *= (k > lane - 32) ? o : 1.f;
   return v;
 }
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// value of lane-1 (lane 0 keeps `ident`)
+__device__ __forceinline__ float lane_prev(float v, float ident) { return dpp_take<NGM_DPP_WAVE_SHR1, 0xf>(ident, v); }
 // reverse affine scan: composes x -> A + B*x from the segment END towards lower lanes.
 // kr = number of samples after this one inside the ray (S-1-k); result maps Q_end to Q_before(lane).
 __device__ __forceinline__ void seg_rscan_affine(float& A, float& B, int kr, int lane) {

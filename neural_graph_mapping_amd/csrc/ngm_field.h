@@ -107,6 +107,120 @@ __device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg
   }
 }
 
+// Two-phase staging of one field's parameters for kernels that have other latency-bound work to do while the
+// weights travel: issue() only starts the global loads (straight-line code: everything is in flight at once;
+// 16-byte loads for the matrices when the rows allow it), commit() builds the same LDS image as load_field_to_lds.
+// Needs blockDim.x >= 256 (>= 32*MH threads for the small tables); caller must __syncthreads() after commit().
+template <int MI, int MH, int L>
+struct FieldStage {
+  static constexpr int NIT = (MH * 32 * MH * 32 / 4 + 255) / 256;   // 16-byte chunks per thread and layer (upper bound)
+  float4 v[L][NIT];
+  float4 enc0, enc1, wout;
+  float bias[L], bout;
+  __device__ __forceinline__ void issue(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int D = fc.dim_enc, H = fc.dim_hidden;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int MIN = (l == 0) ? MI : MH;
+      const int Din = (l == 0) ? D : H;
+      const float* W = pr.w[l] + row * pr.w_stride[l];
+      const int ncol4 = MIN * 8, total4 = MH * 32 * ncol4;
+      const bool vec = ((Din & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e4 = tid + it * nthr;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e4 < total4) {
+          const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
+          if (o < H && c < Din) {
+            const float* src = W + (int64_t)o * Din + c;
+            if (vec) x = *reinterpret_cast<const float4*>(src);
+            else {
+              x.x = src[0];
+              if (c + 1 < Din) x.y = src[1];
+              if (c + 2 < Din) x.z = src[2];
+              if (c + 3 < Din) x.w = src[3];
+            }
+          }
+        }
+        v[l][it] = x;
+      }
+      bias[l] = (tid < H) ? pr.b[l][row * pr.b_stride[l] + tid] : 0.f;
+    }
+    // output layer (4 x H) -> float4 per hidden feature
+    wout = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < H) {
+      const float* W = pr.w[L] + row * pr.w_stride[L];
+      wout = make_float4(W[tid], W[H + tid], W[2 * H + tid], W[3 * H + tid]);
+    }
+    bout = (tid < 4) ? pr.b[L][row * pr.b_stride[L] + tid] : 0.f;
+    // encoding table (same rows as load_field_to_lds)
+    enc0 = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
+    enc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fc.encoding == NGM_ENC_PERMUTO) {
+      enc0.w = 0.f;
+      if (tid < fc.nr_levels) {
+        const float* hs = pr.shift + row * pr.shift_stride + 3 * tid;
+        enc0 = make_float4(fc.level_scale[3 * tid], fc.level_scale[3 * tid + 1], fc.level_scale[3 * tid + 2], 0.f);
+        enc1 = make_float4(hs[0], hs[1], hs[2], 0.f);
+      }
+    } else if (tid < D) {
+      const int f = tid;
+      if (fc.encoding == NGM_ENC_FOURIER) {
+        const int n_raw = fc.raw_coords ? 3 : 0;
+        if (f < n_raw) {
+          enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+        } else {
+          const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
+          enc0 = make_float4(w[0], w[1], w[2], NGM_FK_SIN);
+        }
+      } else if (fc.encoding == NGM_ENC_NERF) {
+        const int half = 3 * fc.num_octaves;
+        const int g = (f < half) ? f : f - half;
+        const int d = g / fc.num_octaves, o = g % fc.num_octaves;
+        const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
+        enc0 = make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
+      } else {
+        enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(float* sm, const ngm_field_cfg& fc) const {
+    using LY = FieldLds<MI, MH, L>;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (fc.encoding == NGM_ENC_PERMUTO) {
+      if (tid < 16) {
+        reinterpret_cast<float4*>(sm + LY::ENCW)[2 * tid] = enc0;
+        reinterpret_cast<float4*>(sm + LY::ENCW)[2 * tid + 1] = enc1;
+      }
+    } else if (tid < MI * 32) {
+      reinterpret_cast<float4*>(sm + LY::ENCW)[tid] = enc0;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int MIN = (l == 0) ? MI : MH;
+      const int ncol4 = MIN * 8, total4 = MH * 32 * ncol4;
+      float* dst = sm + LY::w_off(l);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e4 = tid + it * nthr;
+        if (e4 < total4) {
+          const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
+          const int mo = o >> 5, io = o & 31, mi = c >> 5, ic = c & 31;
+          const float x[4] = {v[l][it].x, v[l][it].y, v[l][it].z, v[l][it].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            dst[((((mo * MIN + mi) * 16 + col_r(ic + j)) * 2 + col_hi(ic + j)) * NGM_WGS) + io] = x[j];
+        }
+      }
+      if (tid < MH * 32) sm[LY::b_off(l) + tid] = bias[l];
+    }
+    if (tid < MH * 32) reinterpret_cast<float4*>(sm + LY::WOUT)[tid] = wout;
+    if (tid < 4) sm[LY::BOUT + tid] = bout;
+  }
+};
+
 // Encoding of one sample position into the lane's B-operand registers.
 // Lane (j = lane&31, hi = lane>>5) holds features 32*mi + frow(r,hi) of sample j.
 // Feature kinds: RAW features can only sit in slots (mi = 0, r < 3, hi = 0) (features 0..2); every other
@@ -401,11 +515,13 @@ __device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[
 // layer of the default path as well and cost the fused forward 14 us.
 template <int MI, int MH, int L, int NT, bool ADD = false>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
-                                        const ActStash* st = nullptr) {
+                                        const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
   if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
+  PTICK(pc, 5);
   if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
+  PTICK(pc, 6);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
     f32x16 T[NT][MH];
@@ -415,7 +531,9 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
     if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
+    PTICK(pc, 5);
     if (st && st->base) act_store<MH, NT>(*st, l, lane, Hlast);
+    PTICK(pc, 6);
   }
 }
 
@@ -423,7 +541,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
 template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, bool ADD = false>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
-                                          const ActStash* st = nullptr) {
+                                          const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
   using LY = FieldLds<MI, MH, L>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
@@ -437,6 +555,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
     encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
   }
+  PTICK(pc, 4);
   f32x16 Hl[2][MH];
 #ifdef NGM_ABLF_NOMFMA   // timing ablation: encoding and output layer without the hidden layers
 #pragma unroll
@@ -444,7 +563,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, st);
+  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, st, pc);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
@@ -457,6 +576,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     // fixed summation order: low-feature half first
     o[c] = (hi ? (recv + own) : (own + recv)) + sm[LY::BOUT + c];
   }
+  PTICK(pc, 7);
   return make_float4(o[0], o[1], o[2], o[3]);
 }
 

@@ -450,13 +450,29 @@ struct GradReduceK {
   GradSeg seg[2 * (NGM_MAX_LAYERS + 1) + 1];
 };
 
-__global__ void k_grad_reduce(GradReduceK a) {
-  const int f = blockIdx.y;
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.ptot) return;
+// 64 parameters x 4 interleaved quarter-sums of the per-workgroup partials per block (the quarters are
+// combined in a fixed order -> deterministic); 4x the loads in flight of a one-thread-per-parameter loop.
+__global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
+  __shared__ float part[4][64];
+  const int f = blockIdx.y, q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 64 + l;
   float s = 0.f;
-  // workgroup b of the backward kernel handled field b % F
-  for (int c = 0; c < a.blocks_per_field; ++c) s += a.partials[((int64_t)c * a.F + f) * a.p_pad + p];
+  if (p < a.ptot) {
+    // workgroup b of the backward kernel handled field b % F
+    const float* src = a.partials + (int64_t)f * a.p_pad + p;
+    const int64_t cs = (int64_t)a.F * a.p_pad;
+    int c = q;
+#pragma unroll 1
+    for (; c + 12 < a.blocks_per_field; c += 16) {
+      const float v0 = src[c * cs], v1 = src[(c + 4) * cs], v2 = src[(c + 8) * cs], v3 = src[(c + 12) * cs];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; c < a.blocks_per_field; c += 4) s += src[c * cs];
+  }
+  part[q][l] = s;
+  __syncthreads();
+  if (q != 0 || p >= a.ptot) return;
+  s = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
   for (int k = 0; k < a.nseg; ++k) {
     if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) {
       if (a.seg[k].dst) a.seg[k].dst[(int64_t)f * a.seg[k].stride + (p - a.seg[k].off)] = s;
@@ -483,7 +499,7 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
     k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l]};
   }
   k.nseg = n;
-  dim3 grid((unsigned)((k.ptot + 255) / 256), (unsigned)g.F);
+  dim3 grid((unsigned)((k.ptot + 63) / 64), (unsigned)g.F);
   hipLaunchKernelGGL(k_grad_reduce, grid, dim3(256), 0, st, k);
   return 0;
 }

@@ -88,8 +88,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   const int F = a.rays.F, R = a.rays.R;
   const int f = blockIdx.x % F, chunk = blockIdx.x / F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
-  __syncthreads();
+#ifdef NGM_PHASE_TIMING
+  PhaseClock pclk; pclk.begin();
+  PhaseClock* const pc = a.debug_cycles ? &pclk : nullptr;
+#endif
+  // the field parameters travel while the first batch of rays is set up (both are latency chains, and every
+  // wave of the chip is in this phase at the same time, so there is no matrix work to hide them under)
+  FieldStage<MI, MH, L> fstage;
+  fstage.issue(a.fc, a.pr, row);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
   RenderWaveLds wl(sm + LY::TOTAL + wave * RenderWaveLds::floats(a.maxs), a.maxs);
@@ -114,12 +120,15 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   const int r_beg = min(blk_end, blk_beg + wave * per_wave), r_end = min(blk_end, r_beg + per_wave);
   const int BR = max(1, min(RF_BRMAX, a.maxs / S));
 
+  const uint64_t poff = philox_launch_offset(a.rays);
   float ls[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) ls[i] = 0.f;
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
 
-  for (int rb = r_beg; rb < r_end; rb += BR) {
+  // phases (1)+(2) of a batch; run for batch b+1 at the end of batch b's pass (and for the first batch while the
+  // weights are still in flight)
+  auto prepare = [&](int rb) __attribute__((always_inline)) {
     const int nb = min(BR, r_end - rb);
     const int nsamp = nb * S;
     // ---- (1) ray setup: one lane per ray
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       for (int c = 0; c < RF_RA; ++c) wl.ra[lane][c] = 0.f;
     }
     WAVE_SYNC();
+    PTICK(pc, 1);
     // ---- (2) sorted sample distances: closed-form rank of every source element (no sort)
     for (int idx = lane; idx < nsamp; idx += 64) {
       const int rl = fdiv_idx(idx, inv_s, S), e = idx - rl * S;
@@ -155,11 +165,20 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_ABLF_NOSAMPLER   // timing ablations of the fused forward (results meaningless when defined)
       t = g.near + (g.far - g.near) * (float)e / (float)S; rank = e;
 #else
-      sample_rank(a.rc, a.rays, g, ray, e, S_c, S_g, &t, &rank);
+      sample_rank(a.rc, a.rays, poff, g, ray, e, S_c, S_g, &t, &rank);
 #endif
       wl.tbuf[rl * S + rank] = t;
     }
     WAVE_SYNC();
+    PTICK(pc, 2);
+  };
+  if (r_beg < r_end) prepare(r_beg);
+  fstage.commit(sm, a.fc);
+  __syncthreads();
+  PTICK(pc, 0);
+  for (int rb = r_beg; rb < r_end; rb += BR) {
+    const int nb = min(BR, r_end - rb);
+    const int nsamp = nb * S;
     // ---- (3) MLP + compositing pass, 64 consecutive flat samples per step
     float carry = 1.0f;
     for (int base = 0; base < nsamp; base += 64) {
@@ -181,7 +200,12 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_ABLF_NOMLP
       const float4 o = make_float4(x, y, z, x * y);
 #else
+      PTICK(pc, 3);
+#ifdef NGM_PHASE_TIMING
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast, pc);
+#else
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast);
+#endif
 #endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
       const float depth = -(rt[6] * t);
@@ -195,16 +219,20 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       // transmittance: segmented inclusive product of (1-occ), carried across steps
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
-      const float up = __shfl_up(q, 1, 64);
+      const float up = lane_prev(q, carry);
       const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
-      carry = __shfl(q, 63, 64);
+      carry = lane_value(q, 63);
       const float w = valid ? occ * T_excl : 0.f;
       if (valid) {
         wl.wbuf[idx] = w; wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2;
         if (a.stashA) {
           const int64_t gs = ((int64_t)f * R + rb) * S + idx;
-          a.stashA[gs] = make_float4(c0, c1, c2, geom);
-          a.stashB[gs] = make_float2(t, T_excl);
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v4f sa = {c0, c1, c2, geom};
+          const v2f sb = {t, T_excl};
+          __builtin_nontemporal_store(sa, reinterpret_cast<v4f*>(a.stashA + gs));   // read once, by the next kernel
+          __builtin_nontemporal_store(sb, reinterpret_cast<v2f*>(a.stashB + gs));
         }
       }
       const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
@@ -225,6 +253,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         }
       }
       WAVE_SYNC();
+      PTICK(pc, 8);
     }
     // ---- (4) variance pass around the finished means (rm.py:781-790)
 #ifdef NGM_ABLF_NOVAR
@@ -252,6 +281,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       }
       WAVE_SYNC();
     }
+    PTICK(pc, 9);
     // ---- (5) per-ray outputs + loss partial sums
     if (lane < nb) {
       const int64_t ray = (int64_t)f * R + rb + lane;
@@ -278,6 +308,8 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       }
     }
     WAVE_SYNC();
+    PTICK(pc, 10);
+    if (rb + BR < r_end) prepare(rb + BR);
   }
   // ---- block reduction of the loss partial sums (deterministic order)
   if (a.has_targets && a.loss_partials) {
@@ -296,6 +328,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       a.loss_partials[(int64_t)blockIdx.x * NGM_NUM_LOSS_SUMS + threadIdx.x] = v;
     }
   }
+#ifdef NGM_PHASE_TIMING
+  PTICK(pc, 11);
+  if (pc && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+    for (int k = 0; k < 14; ++k) a.debug_cycles[k] = pclk.acc[k];
+    a.debug_cycles[14] = __builtin_readcyclecounter() - pclk.start;
+    a.debug_cycles[15] = __builtin_amdgcn_s_memrealtime() - pclk.rstart;   // 100 MHz ticks: gives the shader clock
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

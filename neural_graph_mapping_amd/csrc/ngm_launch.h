@@ -40,6 +40,7 @@ struct RenderFwdArgs {
   float* loss_partials;   // (blocks, 16)
   float* act;             // hidden-activation stash [L][F*R*S][64] (train, 64-wide hidden layers) or NULL
   int64_t act_layer_stride;  // floats
+  unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase shader-clock cycles of one wave
 };
 
 // backward of the field MLP for flat samples of each field

@@ -134,17 +134,31 @@ __device__ __forceinline__ void load_field16(float* sm, const ngm_field_cfg& fc,
 }
 
 // ---- tile helpers (lane (j = lane&15, q = lane>>4)) ---------------------------------------------------
-template <int T, bool NEED_COS, bool WITH_DERIV>
+// HW = true (backward with stashed activations): sine and cosine from v_sin_f32 / v_cos_f32.  Those take the
+// argument in revolutions and reduce it themselves, so the position is scaled by 1/(2 pi) once per sample and
+// the whole software reduction + two polynomials (28 VALU per value) become 3 FMAs + v_fract + 2 quarter-rate
+// instructions.  Max abs error ~4e-7 + 1.2e-7 |arg| (tools/micro/hwsin.hip) -- inside the gradient tolerance
+// (2e-3 relative), not inside the forward's, which keeps the polynomial.
+template <int T, bool NEED_COS, bool WITH_DERIV, bool HW = false>
 __device__ __forceinline__ void encode16(const float* sm_encw, int q, float x, float y, float z, f32x4 (&E)[T], f32x4 (&dE)[T]) {
   const float4* tab = reinterpret_cast<const float4*>(sm_encw);
+  const float inv2pi = 0.15915494309189535f;
+  const float xr = x * inv2pi, yr = y * inv2pi, zr = z * inv2pi;
 #pragma unroll
   for (int m = 0; m < T; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float4 w = tab[16 * m + 4 * q + r];
-      const float arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
-      float s, c;
-      ngm_sincosf(arg, &s, &c);
+      float s, c, arg;
+      if constexpr (HW) {
+        const float rev = __builtin_amdgcn_fractf(fmaf(w.z, zr, fmaf(w.y, yr, w.x * xr)));
+        s = __builtin_amdgcn_sinf(rev);
+        c = __builtin_amdgcn_cosf(rev);
+        arg = (r == 0) ? x : (r == 1) ? y : z;     // only read for raw-coordinate rows, whose w is the unit vector e_r
+      } else {
+        arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
+        ngm_sincosf(arg, &s, &c);
+      }
       float v = s, d = c;
       if (NEED_COS) { const bool is_cos = (w.w == NGM_FK_COS); v = is_cos ? c : s; d = is_cos ? -s : c; }
       if (m == 0 && r < 3) { const bool raw = (w.w == NGM_FK_RAW); v = raw ? arg : v; d = raw ? 0.f : d; }

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
     {
       const float4 pt = *reinterpret_cast<const float4*>(pbuf + 4 * j);
       f32x4 E[4];
-      encode16<4, NEED_COS, ENC_GRAD>(sm + LW::ENCW, q, pt.x, pt.y, pt.z, E, dEa);
+      encode16<4, NEED_COS, ENC_GRAD, true>(sm + LW::ENCW, q, pt.x, pt.y, pt.z, E, dEa);
       WAVE_SYNC();
       store16b(Etile, lane, E);
       WAVE_SYNC();

@@ -356,8 +356,8 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 int ngm_debug_phase_cycles(unsigned long long* out16);
 /* Same for the fused forward (library built with -DNGM_PHASE_TIMING): slots = prologue, ray setup, sampler, step head,
  * encoding, hidden layers, activation stash stores, output layer, compositing, variance pass, ray outputs, block
- * reduction, -, -, total shader cycles, total 100 MHz ticks. */
-int ngm_debug_fwd_phase_cycles(unsigned long long* out16);
+ * reduction, -, -, total shader cycles, total 100 MHz ticks; then the event timeline of the 8 waves of that workgroup. */
+int ngm_debug_fwd_phase_cycles(unsigned long long* out528);   /* 16 summary slots + 8 waves x 64 timeline entries ((slot << 48) | cycles) */
 
 /* Debug: which MLP backward kernel the last ngm_render_bwd* / ngm_field_eval_bwd call launched:
  * 0 = k_field_bwd (32-sample tiles, forward recompute), 1 = k_field_bwd16 (16-sample tiles, recompute),

@@ -228,11 +228,12 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 
+#define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)
 static unsigned long long* g_debug_cycles_fwd = nullptr;
-int ngm_debug_fwd_phase_cycles(unsigned long long* out16) {
-  if (!g_debug_cycles_fwd || !out16) return NGM_E_INVALID;
+int ngm_debug_fwd_phase_cycles(unsigned long long* out528) {
+  if (!g_debug_cycles_fwd || !out528) return NGM_E_INVALID;
   (void)hipDeviceSynchronize();
-  return hipMemcpy(out16, g_debug_cycles_fwd, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
+  return hipMemcpy(out528, g_debug_cycles_fwd, NGM_FWD_DEBUG_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
 }
 int ngm_debug_phase_cycles(unsigned long long* out16) {
   if (!g_debug_cycles || !out16) return NGM_E_INVALID;
@@ -533,7 +534,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
     if (p.act_layer_stride) { a.act = reinterpret_cast<float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
     static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
     if (timing) {
-      if (!g_debug_cycles_fwd) { (void)hipMalloc(&g_debug_cycles_fwd, 128); (void)hipMemset(g_debug_cycles_fwd, 0, 128); }
+      if (!g_debug_cycles_fwd) { (void)hipMalloc(&g_debug_cycles_fwd, NGM_FWD_DEBUG_WORDS * 8); (void)hipMemset(g_debug_cycles_fwd, 0, NGM_FWD_DEBUG_WORDS * 8); }
       a.debug_cycles = g_debug_cycles_fwd;
     }
   }

@@ -93,7 +93,39 @@ __device__ __forceinline__ float ngm_sigmoid(float x) { return 1.0f / (1.0f + ex
 // relu on a matrix-core result in ONE instruction.  fmaxf(y, 0) on an MFMA output compiles to two v_max_f32 (the first
 // quiets a possible signalling NaN); v_med3_f32(y, 0, +inf) needs no canonicalisation and agrees with fmaxf for every
 // input, NaN included (both return 0).
-__device__ __forceinline__ float ngm_relu(float y) { return __builtin_amdgcn_fmed3f(y, 0.f, __builtin_inff()); }
+// one v_max_f32 (the builtin max / med3 forms get a second, canonicalising v_max from the compiler: MFMA results
+// could be signalling NaNs as far as it knows)
+__device__ __forceinline__ float ngm_relu(float y) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(y));
+  return r;
+}
+
+// Two sines per instruction stream: the same routine as ngm_sinf on a float2, so that the 13 arithmetic steps
+// compile to packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per
+// issue slot on gfx950); only the sign flip stays per element.  Element-wise identical to ngm_sinf.
+typedef float ngm_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ngm_v2f ngm_splat2(float v) { return ngm_v2f{v, v}; }
+__device__ __forceinline__ ngm_v2f ngm_fma2(ngm_v2f a, ngm_v2f b, ngm_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ ngm_v2f ngm_sinf2(ngm_v2f x) {
+  const ngm_v2f magic = ngm_splat2(12582912.0f);
+  const ngm_v2f n = ngm_fma2(x, ngm_splat2(0.3183098861837907f), magic);
+  const ngm_v2f k = n - magic;
+  ngm_v2f r = ngm_fma2(k, ngm_splat2(-3.140625f), x);
+  r = ngm_fma2(k, ngm_splat2(-9.670257568359375e-4f), r);
+  r = ngm_fma2(k, ngm_splat2(-6.2771141529083251953e-7f), r);
+  const ngm_v2f z = r * r;
+  ngm_v2f p = ngm_splat2(-2.3846690373585197e-08f);
+  p = ngm_fma2(p, z, ngm_splat2(2.7522618610619714e-06f));
+  p = ngm_fma2(p, z, ngm_splat2(-1.9840804033395678e-04f));
+  p = ngm_fma2(p, z, ngm_splat2(8.33333049561397e-03f));
+  p = ngm_fma2(p, z, ngm_splat2(-1.6666666606465025e-01f));
+  const ngm_v2f s = ngm_fma2(r * z, p, r);
+  ngm_v2f o;
+  o.x = __uint_as_float(__float_as_uint(s.x) ^ (__float_as_uint(n.x) << 31));
+  o.y = __uint_as_float(__float_as_uint(s.y) ^ (__float_as_uint(n.y) << 31));
+  return o;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (used when the caller passes no explicit torch.rand draws)
@@ -170,6 +202,12 @@ __device__ __forceinline__ float strat_t(float near, float far, int n, int i, fl
 __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm_rays& rays, int64_t ray, bool guided) {
 #pragma clang fp contract(off)
   RayGeom g;
+  // optional per-ray arrays: every load is issued unconditionally (absent arrays read a valid dummy address) so
+  // that they travel together; behind null checks each one would be its own basic block and its own memory latency
+  const float* dummy = reinterpret_cast<const float*>(rays.ijs);
+  const float near_v = *(rays.near ? rays.near + ray : dummy);
+  const float far_v = *(rays.far ? rays.far + ray : dummy);
+  const float gt_v = *(rays.gt ? rays.gt + ray : dummy);
   const int64_t i = rays.ijs[2 * ray], j = rays.ijs[2 * ray + 1];
   const float vx = ((float)j - cfg.cx) / cfg.fx;
   const float vy = -(((float)i - cfg.cy) / cfg.fy);
@@ -179,9 +217,9 @@ __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm
   const float nrm = sqrtf(sxy + zz);
   const float den = fmaxf(nrm, 1e-12f);
   g.dx = vx / den; g.dy = vy / den; g.dz = vz / den;
-  g.near = rays.near ? rays.near[ray] : rays.near_const;
-  g.far = rays.far ? rays.far[ray] : rays.far_const;
-  g.gt = rays.gt ? rays.gt[ray] : 0.0f;
+  g.near = rays.near ? near_v : rays.near_const;
+  g.far = rays.far ? far_v : rays.far_const;
+  g.gt = rays.gt ? gt_v : 0.0f;
   g.gnear = g.near; g.gfar = g.far;
   if (guided) {
     const bool invalid = (g.gt == 0.0f) || (g.near > g.gt) || (g.far < g.gt);
@@ -205,8 +243,11 @@ __device__ __forceinline__ float jitter(const ngm_rays& rays, uint64_t poff, int
 // number of elements of stratum (near,far,n) that are < x (strict=1) or <= x (strict=0).
 // Closed form from the stratified structure (element j lies in [near+j*d, near+(j+1)*d)), with the
 // three candidates around the boundary compared explicitly so fp32 rounding cannot mis-rank.
+// ucache (optional): this ray's draws of stratum `which`, already made (LDS) -- each Philox draw is ~100 VALU
+// instructions and every element is looked at by up to three elements of the other stratum.
 __device__ __forceinline__ int strat_count_below(const ngm_rays& rays, uint64_t poff, int which, int64_t ray, float near, float far,
-                                                 int n, const float* lin_tab, float x, bool strict) {
+                                                 int n, const float* lin_tab, float x, bool strict,
+                                                 const float* ucache = nullptr) {
   const float span = far - near;
   int q;
   if (!(span > 0.0f)) q = 0;
@@ -220,24 +261,29 @@ __device__ __forceinline__ int strat_count_below(const ngm_rays& rays, uint64_t 
   const int lo = (span > 0.0f) ? max(q - 1, 0) : 0;
   const int hi = (span > 0.0f) ? min(q + 1, n - 1) : n - 1;
   for (int j = lo; j <= hi; ++j) {
-    const float tj = strat_t(near, far, n, j, jitter(rays, poff, which, ray, n, j), lin_tab);
+    const float tj = strat_t(near, far, n, j, ucache ? ucache[j] : jitter(rays, poff, which, ray, n, j), lin_tab);
     cnt += strict ? (tj < x) : (tj <= x);
   }
   return min(cnt, n);
 }
 
 // sorted distance + rank of source element e (0..S_c-1 coarse, S_c.. guided) of a ray
+// ucache (optional): the S_c coarse then S_g guided draws of this ray, in source order
 __device__ __forceinline__ void sample_rank(const ngm_render_cfg& cfg, const ngm_rays& rays, uint64_t poff, const RayGeom& g,
-                                            int64_t ray, int e, int S_c, int S_g, float* t_out, int* rank_out) {
+                                            int64_t ray, int e, int S_c, int S_g, float* t_out, int* rank_out,
+                                            const float* ucache = nullptr) {
   if (e < S_c) {
-    const float t = strat_t(g.near, g.far, S_c, e, jitter(rays, poff, 0, ray, S_c, e), rays.lin_coarse);
+    const float u = ucache ? ucache[e] : jitter(rays, poff, 0, ray, S_c, e);
+    const float t = strat_t(g.near, g.far, S_c, e, u, rays.lin_coarse);
     int rank = e;
-    if (S_g > 0) rank += strat_count_below(rays, poff, 1, ray, g.gnear, g.gfar, S_g, rays.lin_guided, t, true);
+    if (S_g > 0) rank += strat_count_below(rays, poff, 1, ray, g.gnear, g.gfar, S_g, rays.lin_guided, t, true,
+                                           ucache ? ucache + S_c : nullptr);
     *t_out = t; *rank_out = rank;
   } else {
     const int j = e - S_c;
-    const float t = strat_t(g.gnear, g.gfar, S_g, j, jitter(rays, poff, 1, ray, S_g, j), rays.lin_guided);
-    const int rank = j + strat_count_below(rays, poff, 0, ray, g.near, g.far, S_c, rays.lin_coarse, t, false);
+    const float u = ucache ? ucache[e] : jitter(rays, poff, 1, ray, S_g, j);
+    const float t = strat_t(g.gnear, g.gfar, S_g, j, u, rays.lin_guided);
+    const int rank = j + strat_count_below(rays, poff, 0, ray, g.near, g.far, S_c, rays.lin_coarse, t, false, ucache);
     *t_out = t; *rank_out = rank;
   }
 }
@@ -247,15 +293,21 @@ __device__ __forceinline__ void sample_rank(const ngm_render_cfg& cfg, const ngm
 struct PhaseClock {
   unsigned long long acc[14];
   unsigned long long last, start, rstart;
-  __device__ __forceinline__ void begin() {
+  unsigned long long* log;   // optional per-wave event log: (slot << 48) | cycles since begin(), 64 entries
+  int nlog;
+  __device__ __forceinline__ void begin(unsigned long long* wave_log = nullptr) {
 #pragma unroll
     for (int i = 0; i < 14; ++i) acc[i] = 0;
+    log = wave_log; nlog = 0;
     rstart = __builtin_amdgcn_s_memrealtime();
     start = last = __builtin_readcyclecounter();
   }
   __device__ __forceinline__ void tick(int k) {
     const unsigned long long now = __builtin_readcyclecounter();
-    acc[k] += now - last; last = __builtin_readcyclecounter();
+    acc[k] += now - last;
+    if (log && nlog < 64 && (threadIdx.x & 63) == 0) log[nlog] = ((unsigned long long)k << 48) | (now - start);
+    ++nlog;
+    last = __builtin_readcyclecounter();
   }
 };
 #ifdef NGM_PHASE_TIMING
@@ -315,10 +367,15 @@ __device__ __forceinline__ void seg_rscan_affine(float& A, float& B, int kr, int
   }
 }
 
+// sum over the 64 lanes (uniform result): DPP row scans, row totals carried by row_bcast, lane 63 read back
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v += dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_SHR(2), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_SHR(4), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_SHR(8), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return lane_value(v, 63);
 }
 
 // geometry value written over samples behind the camera (rm.py:614-622)

@@ -250,6 +250,26 @@ __device__ __forceinline__ void encode_sample(const float* sm_encw, int hi, floa
   }
 }
 
+// Sine-only encoding (Fourier features, forward) of the lane's TWO samples (one per 32-column tile) at once:
+// both use the same table rows, so every step is a packed-fp32 instruction over (tile 0, tile 1).
+template <int MI>
+__device__ __forceinline__ void encode_pair_sin(const float* sm_encw, int hi, ngm_v2f x, ngm_v2f y, ngm_v2f z,
+                                                f32x16 (&E0)[MI], f32x16 (&E1)[MI]) {
+  const float4* tab = reinterpret_cast<const float4*>(sm_encw);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w = tab[32 * mi + frow(r, 0) + 4 * hi];
+      const ngm_v2f arg = ngm_fma2(ngm_splat2(w.z), z, ngm_fma2(ngm_splat2(w.y), y, ngm_splat2(w.x) * x));
+      ngm_v2f v = ngm_sinf2(arg);
+      if (mi == 0 && r < 3) { const bool raw = (w.w == NGM_FK_RAW); v.x = raw ? arg.x : v.x; v.y = raw ? arg.y : v.y; }
+      E0[mi][r] = v.x; E1[mi][r] = v.y;
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Permutohedral-lattice hash encoding (positional_encodings.py:19-66).  PARITY UNPINNED: restates the
 // published algorithm exactly as oracle/ngm_oracle.py:encode_permuto (elevate -> nearest remainder-0
@@ -384,17 +404,14 @@ template <int MIN, int MOUT, int NT>
 __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const float* __restrict__ B, int lane,
                                           const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT]) {
   const int io = lane & 31, hi = lane >> 5;
+  // accumulators start at 0 (an inline constant of the first MFMA, no register initialisation); the bias is added
+  // after the contraction, packed, like the reference's addmm epilogue
 #pragma unroll
-  for (int mo = 0; mo < MOUT; ++mo) {
-    f32x16 bias;
+  for (int mo = 0; mo < MOUT; ++mo)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
-      bias[4 * q + 0] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
-    }
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = bias;
-  }
+      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = 0.f;
   // software-pipelined A-fragment fetch: the LDS reads of k-step group g+1 are issued before the MFMAs
   // of group g (4 k-steps per group), so their latency hides under the matrix pipe.
   constexpr int NG = MIN * 4;
@@ -425,11 +442,20 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const flo
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int mo = 0; mo < MOUT; ++mo) {
 #pragma unroll
-    for (int mo = 0; mo < MOUT; ++mo)
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
+      const ngm_v2f b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = ngm_relu(Y[nt][mo][r]);
+      for (int nt = 0; nt < NT; ++nt) {
+        const ngm_v2f y01 = ngm_v2f{Y[nt][mo][4 * q], Y[nt][mo][4 * q + 1]} + b01;
+        const ngm_v2f y23 = ngm_v2f{Y[nt][mo][4 * q + 2], Y[nt][mo][4 * q + 3]} + b23;
+        Y[nt][mo][4 * q] = ngm_relu(y01.x); Y[nt][mo][4 * q + 1] = ngm_relu(y01.y);
+        Y[nt][mo][4 * q + 2] = ngm_relu(y23.x); Y[nt][mo][4 * q + 3] = ngm_relu(y23.y);
+      }
+    }
+  }
 }
 
 // Output layer (4 x H) on the VALU: each lane reduces over ITS 16*MH features; the two lane halves
@@ -438,23 +464,26 @@ template <int MH, int NT>
 __device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, const f32x16 (&Hh)[NT][MH],
                                                   float (&part)[NT][4]) {
   const float4* w4 = reinterpret_cast<const float4*>(sm_wout);
+  // packed over the output channels: (w.x, w.y) and (w.z, w.w) are register pairs straight from the LDS read
+  ngm_v2f p01[NT], p23[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { part[nt][0] = part[nt][1] = part[nt][2] = part[nt][3] = 0.f; }
+  for (int nt = 0; nt < NT; ++nt) { p01[nt] = ngm_splat2(0.f); p23[nt] = ngm_splat2(0.f); }
 #pragma unroll
   for (int mi = 0; mi < MH; ++mi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float4 w = w4[32 * mi + frow(r, 0) + 4 * hi];
+      const ngm_v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float h = Hh[nt][mi][r];
-        part[nt][0] = fmaf(w.x, h, part[nt][0]);
-        part[nt][1] = fmaf(w.y, h, part[nt][1]);
-        part[nt][2] = fmaf(w.z, h, part[nt][2]);
-        part[nt][3] = fmaf(w.w, h, part[nt][3]);
+        const ngm_v2f h = ngm_splat2(Hh[nt][mi][r]);
+        p01[nt] = ngm_fma2(w01, h, p01[nt]);
+        p23[nt] = ngm_fma2(w23, h, p23[nt]);
       }
     }
   }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { part[nt][0] = p01[nt].x; part[nt][1] = p01[nt].y; part[nt][2] = p23[nt].x; part[nt][3] = p23[nt].y; }
 }
 
 // Hidden-activation stash written by the training forward and consumed by the backward kernel (which
@@ -552,8 +581,13 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0][0]);
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1][0]);
   } else {
-    encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
-    encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+    if constexpr (!NEED_COS) {
+      const ngm_v2f X = {hi ? ox : x, hi ? x : ox}, Y = {hi ? oy : y, hi ? y : oy}, Z = {hi ? oz : z, hi ? z : oz};
+      encode_pair_sin<MI>(sm + LY::ENCW, hi, X, Y, Z, E[0], E[1]);
+    } else {
+      encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0], dummy);
+      encode_sample<MI, NEED_COS, false>(sm + LY::ENCW, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1], dummy);
+    }
   }
   PTICK(pc, 4);
   f32x16 Hl[2][MH];

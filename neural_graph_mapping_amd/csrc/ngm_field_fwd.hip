@@ -89,7 +89,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   const int f = blockIdx.x % F, chunk = blockIdx.x / F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
 #ifdef NGM_PHASE_TIMING
-  PhaseClock pclk; pclk.begin();
+  // timeline of every wave of the middle block: 16 summary slots, then 64 log entries per wave
+  PhaseClock pclk;
+  pclk.begin((a.debug_cycles && blockIdx.x == gridDim.x / 2) ? a.debug_cycles + 16 + 64 * (threadIdx.x >> 6) : nullptr);
   PhaseClock* const pc = a.debug_cycles ? &pclk : nullptr;
 #endif
   // the field parameters travel while the first batch of rays is set up (both are latency chains, and every
@@ -134,11 +136,20 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     // ---- (1) ray setup: one lane per ray
     if (lane < nb) {
       const int64_t ray = (int64_t)f * R + rb + lane;
+      // pose rows first: three 16-byte loads that travel with the ray's scalars
+      const float* Tp = a.rays.c2w_per_ray ? a.rays.c2ws + ray * 16 : a.rays.c2ws;
+      float4 T0, T1, T2;
+      if ((reinterpret_cast<uintptr_t>(a.rays.c2ws) & 15) == 0) {
+        const float4* T4 = reinterpret_cast<const float4*>(Tp);
+        T0 = T4[0]; T1 = T4[1]; T2 = T4[2];
+      } else {
+        T0 = make_float4(Tp[0], Tp[1], Tp[2], Tp[3]); T1 = make_float4(Tp[4], Tp[5], Tp[6], Tp[7]);
+        T2 = make_float4(Tp[8], Tp[9], Tp[10], Tp[11]);
+      }
       const RayGeom g = ray_geom(a.rc, a.rays, ray, guided);
-      const float* T = a.rays.c2w_per_ray ? a.rays.c2ws + ray * 16 : a.rays.c2ws;
-      Vec3 dw{T[0] * g.dx + T[1] * g.dy + T[2] * g.dz, T[4] * g.dx + T[5] * g.dy + T[6] * g.dz,
-              T[8] * g.dx + T[9] * g.dy + T[10] * g.dz};
-      Vec3 ow{T[3] - px, T[7] - py, T[11] - pz};
+      Vec3 dw{T0.x * g.dx + T0.y * g.dy + T0.z * g.dz, T1.x * g.dx + T1.y * g.dy + T1.z * g.dz,
+              T2.x * g.dx + T2.y * g.dy + T2.z * g.dz};
+      Vec3 ow{T0.w - px, T1.w - py, T2.w - pz};
       dw = quat_rotate_inv(qw, qx, qy, qz, dw);
       ow = quat_rotate_inv(qw, qx, qy, qz, ow);
       float* rt = wl.rt[lane];
@@ -155,7 +166,16 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     }
     WAVE_SYNC();
     PTICK(pc, 1);
-    // ---- (2) sorted sample distances: closed-form rank of every source element (no sort)
+    // ---- (2) sorted sample distances: closed-form rank of every source element (no sort).  The draws are made once
+    // per element into the (still unused) weight plane; the ranking reads its neighbours' draws from there.
+#ifndef NGM_ABLF_NOSAMPLER
+    for (int idx = lane; idx < nsamp; idx += 64) {
+      const int rl = fdiv_idx(idx, inv_s, S), e = idx - rl * S;
+      const int64_t ray = (int64_t)f * R + rb + rl;
+      wl.wbuf[idx] = (e < S_c) ? jitter(a.rays, poff, 0, ray, S_c, e) : jitter(a.rays, poff, 1, ray, S_g, e - S_c);
+    }
+    WAVE_SYNC();
+#endif
     for (int idx = lane; idx < nsamp; idx += 64) {
       const int rl = fdiv_idx(idx, inv_s, S), e = idx - rl * S;
       const int64_t ray = (int64_t)f * R + rb + rl;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_ABLF_NOSAMPLER   // timing ablations of the fused forward (results meaningless when defined)
       t = g.near + (g.far - g.near) * (float)e / (float)S; rank = e;
 #else
-      sample_rank(a.rc, a.rays, poff, g, ray, e, S_c, S_g, &t, &rank);
+      sample_rank(a.rc, a.rays, poff, g, ray, e, S_c, S_g, &t, &rank, wl.wbuf + rl * S);
 #endif
       wl.tbuf[rl * S + rank] = t;
     }

@@ -336,13 +336,18 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
             tot = buf[12] or 1
             print("phase cycles (wave 0, block 0):", {n: (int(buf[i]), round(100 * buf[i] / tot, 1)) for i, n in enumerate(names)})
         L.ngm_debug_fwd_phase_cycles.argtypes = [C.c_void_p]
+        buf = (C.c_ulonglong * (16 + 8 * 64))()
         if L.ngm_debug_fwd_phase_cycles(buf) == 0:
             names = ["prologue", "raysetup", "sampler", "stephead", "encode", "layers", "actstore", "outlayer", "composite",
                      "variance", "rayout", "blockreduce", "-", "-", "TOTAL", "REALTIME_100MHz"]
             tot = buf[14] or 1
             print("forward phase cycles (wave 0, middle block):",
                   {n: (int(buf[i]), round(100 * buf[i] / tot, 1)) for i, n in enumerate(names)},
-                  "shader clock GHz:", round(buf[14] / max(1, buf[15]) * 0.1, 3))
+                  "counter GHz:", round(buf[14] / max(1, buf[15]) * 0.1, 3))
+            for w in range(8):
+                ev = [(int(buf[16 + 64 * w + i]) >> 48, int(buf[16 + 64 * w + i]) & ((1 << 48) - 1)) for i in range(64)]
+                ev = [(k, c) for k, c in ev if c]
+                print(f"  wave {w}: " + " ".join(f"{names[k][:4]}@{c // 100 / 10:.1f}k" for k, c in ev))
     gn = {k: float(np.abs(v.numpy()).max()) for k, v in gdev.items()}
     record(f"time_{'hash' if hash_enc else 'fourier'}_F{F}_R{R}_S{S_c + S_g}", fwd_ms=round(tf, 4), bwd_ms=round(tb, 4),
            Msamples_per_s=round(n / (tf + tb) / 1e3, 1), loss=float(lout.numpy()[0]),

@@ -163,6 +163,20 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < RF_RA; ++c) wl.ra[lane][c] = 0.f;
+      if (a.has_targets) {
+        // the ray's targets ride along in the free table slots: the output phase at the end of the batch then
+        // has no global load (and no memory latency) left in it
+        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
+        const unsigned char dm = a.tg.depth_mask[ray];
+        const unsigned char* tmp = a.tg.term_mask ? a.tg.term_mask + ray : a.tg.depth_mask + ray;
+        const float* tpp = (a.tg.term_mask && a.tg.term_probs) ? a.tg.term_probs + ray : a.tg.rgbds;
+        const unsigned char tm = *tmp;
+        const float tp = *tpp;
+        rt[12] = tg.x; rt[13] = tg.y; rt[14] = tg.z; rt[15] = tg.w;
+        wl.ra[lane][9] = dm ? 1.f : 0.f;
+        wl.ra[lane][10] = (a.tg.term_mask && tm) ? 1.f : 0.f;
+        wl.ra[lane][11] = tp;
+      }
     }
     WAVE_SYNC();
     PTICK(pc, 1);
@@ -204,12 +218,15 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     for (int base = 0; base < nsamp; base += 64) {
       const int idx = base + lane;
       const bool valid = idx < nsamp;
-      const int rl = valid ? fdiv_idx(idx, inv_s, S) : 0;
-      const int k = valid ? idx - rl * S : 0;
+      // lanes past the end work on a clamped index (selects, not branches: every LDS read below is issued at once)
+      const int ci = min(idx, nsamp - 1);
+      const int rl = fdiv_idx(ci, inv_s, S);
+      const int k = valid ? ci - rl * S : 0;
       const float* rt = wl.rt[rl];
-      const float t = valid ? wl.tbuf[idx] : 0.f;
-      float x = 0, y = 0, z = 0;
-      if (valid) { x = fmaf(t, rt[3], rt[0]); y = fmaf(t, rt[4], rt[1]); z = fmaf(t, rt[5], rt[2]); }
+      const float t_raw = wl.tbuf[ci];
+      const float t = valid ? t_raw : 0.f;
+      const float x = valid ? fmaf(t, rt[3], rt[0]) : 0.f, y = valid ? fmaf(t, rt[4], rt[1]) : 0.f,
+                  z = valid ? fmaf(t, rt[5], rt[2]) : 0.f;
       ActStash ast;
 #ifdef NGM_ABLF_NOACT
       ast.base = nullptr; ast.layer_stride = 0;
@@ -231,11 +248,12 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float depth = -(rt[6] * t);
       // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622
       const float geom = (a.rc.overwrite_behind_camera && rt[6] * t > 0.f) ? behind_camera_geometry(mode) : o.w;
-      float occ = 0.f;
-      if (valid) {
-        if (mode == NGM_GEO_DENSITY) { if (k < S - 1) occ = occ_density(geom, wl.tbuf[idx + 1] - t, nullptr); }   // rm.py:746-749, last sample dropped
-        else occ = occ_pointwise(mode, gamma, geom, nullptr);
-      }
+      float occ;
+      if (mode == NGM_GEO_DENSITY) {                                       // rm.py:746-749, last sample dropped
+        const float o_d = occ_density(geom, wl.tbuf[min(ci + 1, nsamp - 1)] - t, nullptr);
+        occ = (k < S - 1) ? o_d : 0.f;
+      } else occ = occ_pointwise(mode, gamma, geom, nullptr);
+      occ = valid ? occ : 0.f;
       // transmittance: segmented inclusive product of (1-occ), carried across steps
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
@@ -283,14 +301,17 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #endif
       const int idx = base + lane;
       const bool valid = idx < nsamp;
-      const int rl = valid ? fdiv_idx(idx, inv_s, S) : 0;
-      const int k = valid ? idx - rl * S : 0;
+      const int ci = min(idx, nsamp - 1);
+      const int rl = fdiv_idx(ci, inv_s, S);
+      const int k = valid ? ci - rl * S : 0;
       const float* ra = wl.ra[rl];
-      const float w = valid ? wl.wbuf[idx] : 0.f;
-      const float t = valid ? wl.tbuf[idx] : 0.f;
+      const float w_raw = wl.wbuf[ci], t_raw = wl.tbuf[ci];
+      const float q0 = wl.cbuf[0][ci], q1 = wl.cbuf[1][ci], q2 = wl.cbuf[2][ci];
+      const float w = valid ? w_raw : 0.f;
+      const float t = valid ? t_raw : 0.f;
       const float depth = -(wl.rt[rl][6] * t);
-      float e0 = ra[0] - (valid ? wl.cbuf[0][idx] : 0.f), e1 = ra[1] - (valid ? wl.cbuf[1][idx] : 0.f),
-            e2 = ra[2] - (valid ? wl.cbuf[2][idx] : 0.f), e3 = ra[3] - depth;
+      float e0 = ra[0] - (valid ? q0 : 0.f), e1 = ra[1] - (valid ? q1 : 0.f),
+            e2 = ra[2] - (valid ? q2 : 0.f), e3 = ra[3] - depth;
       const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
                   v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
       const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
@@ -312,8 +333,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       if (a.pred.depth_vars) a.pred.depth_vars[ray] = ra[8];
       if (a.pred.term_probs) a.pred.term_probs[ray] = term;
       if (a.has_targets) {
-        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
-        const bool m = a.tg.depth_mask[ray] && (term > a.rc.term_threshold);  // rm.py:1787
+        const float* rt = wl.rt[lane];
+        const float4 tg = make_float4(rt[12], rt[13], rt[14], rt[15]);
+        const bool m = (ra[9] != 0.f) && (term > a.rc.term_threshold);  // rm.py:1787
         if (m) {
           ls[NGM_LS_PHOTO_SUM] += fabsf(tg.x - ra[0]) + fabsf(tg.y - ra[1]) + fabsf(tg.z - ra[2]);
           ls[NGM_LS_PHOTO_CNT] += 1.f;
@@ -321,8 +343,8 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
           ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);
           ls[NGM_LS_DEPTH_CNT] += 1.f;
         }
-        if (a.tg.term_mask && a.tg.term_mask[ray]) {
-          const float e = term - a.tg.term_probs[ray];
+        if (ra[10] != 0.f) {
+          const float e = term - ra[11];
           ls[NGM_LS_TERM_SUM] += e * e; ls[NGM_LS_TERM_CNT] += 1.f;
         }
       }

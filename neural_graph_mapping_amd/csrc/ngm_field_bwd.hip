@@ -581,8 +581,17 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
       const int64_t g = (int64_t)f * a.P + s;
       const float4 p = a.xyz[g];
       d = a.dE[level * NP + g];
+#ifdef NGM_ABLH_NOSIMPLEX   // timing ablations of k_hash_grad (results meaningless when defined)
+      idx[0] = (uint32_t)(p.x * 1000.f) & mask; idx[1] = (idx[0] + 1) & mask; idx[2] = (idx[0] + 2) & mask; idx[3] = (idx[0] + 3) & mask;
+      bw[0] = p.x; bw[1] = p.y; bw[2] = p.z; bw[3] = 1.f - p.x;
+#else
       permuto_simplex(p.x, p.y, p.z, lp, mask, idx, bw);
+#endif
     }
+#ifdef NGM_ABLH_NOSCATTER
+    if (valid) { tab[threadIdx.x] += (unsigned long long)(idx[0] + idx[1] + idx[2] + idx[3]) + to_fix(d.x * bw[0] + d.y * bw[1] + bw[2] + bw[3]); }
+    continue;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       // consecutive lanes = consecutive samples of a ray: at coarse levels they hit the same vertex in long

@@ -571,8 +571,35 @@ __global__ void k_adam_multi(AdamMultiK a) {
   const int f = blockIdx.y;
   const int64_t row = a.field_index ? a.field_index[f] : f;
   const double step = (double)(a.step_dev ? *a.step_dev : a.step);
-  const float lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+  float lr_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
+  if ((int64_t)blockIdx.x * blockDim.x < t.numel) {     // the grid is sized for the largest tensor
+    lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+  }
+  const bool vec = ((t.numel | t.stride | t.grad_stride) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.grad) |
+                     reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0;
+  if (vec) {                                   // 16-byte accesses (the hash tables: 128 Ki floats per field)
+    const int64_t n4 = t.numel >> 2;
+    float4* P4 = reinterpret_cast<float4*>(t.param + row * t.stride);
+    float4* M4 = reinterpret_cast<float4*>(t.exp_avg + row * t.stride);
+    float4* V4 = reinterpret_cast<float4*>(t.exp_avg_sq + row * t.stride);
+    const float4* G4 = reinterpret_cast<const float4*>(t.grad + (int64_t)f * t.grad_stride);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 p = P4[i], m = M4[i], v = V4[i];
+      const float4 g4 = G4[i];
+      float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &g4.x;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float g = pg[c] + a.wd * pp[c];
+        const float mn = a.beta1 * pm[c] + (1.0f - a.beta1) * g;
+        const float vn = a.beta2 * pv[c] + (1.0f - a.beta2) * g * g;
+        pm[c] = mn; pv[c] = vn;
+        pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+      }
+      M4[i] = m; V4[i] = v; P4[i] = p;
+    }
+  } else
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.numel; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t o = row * t.stride + i;
     const float p = t.param[o];
@@ -607,7 +634,9 @@ int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* 
   a.n = n; a.field_index = field_index; a.step_dev = step_dev; a.step = step;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
   a.advance_step = advance_step; a.advance_offset = advance_offset;
-  dim3 grid((unsigned)std::min<int64_t>((mx + 255) / 256, 16), (unsigned)F, (unsigned)n);
+  // blocks per (field, tensor): enough to put the large tensors (hash tables) on every CU
+  const int64_t want = std::max<int64_t>(1, (4 * 256 + (int64_t)F - 1) / F);
+  dim3 grid((unsigned)std::min<int64_t>((mx / 4 + 255) / 256 + 1, std::max<int64_t>(16, want)), (unsigned)F, (unsigned)n);
   hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, st, a);
   return 0;
 }

@@ -136,7 +136,10 @@ typedef struct ngm_rays {
   const int64_t* ijs;      /* (F,R,2) [row, col]                                            */
   const float* c2ws;       /* (F,R,4,4) when c2w_per_ray != 0 else (4,4) shared              */
   int32_t c2w_per_ray;
-  int32_t reserved0;
+  int32_t philox_offset_autoinc; /* != 0 (training forward with targets only): *philox_offset_dev is incremented once
+                                  * after every workgroup of the forward has read it (the loss-reduction kernel does
+                                  * it), i.e. the counter counts iterations; ngm_adam_sparse_multi can read the same
+                                  * counter as its device-side step.  The pointer is then written through.         */
   const float* near;       /* (F,R) or NULL -> near_const                                    */
   const float* far;        /* (F,R) or NULL -> far_const                                     */
   const float* gt;         /* (F,R) or NULL; 0.0 = no depth                                  */

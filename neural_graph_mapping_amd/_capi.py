@@ -61,7 +61,7 @@ class RenderCfg(C.Structure):
 
 class Rays(C.Structure):
     _fields_ = [("F", C.c_int32), ("R", C.c_int32), ("ijs", C.c_void_p), ("c2ws", f32p),
-                ("c2w_per_ray", C.c_int32), ("reserved0", C.c_int32), ("near", f32p), ("far", f32p),
+                ("c2w_per_ray", C.c_int32), ("philox_offset_autoinc", C.c_int32), ("near", f32p), ("far", f32p),
                 ("gt", f32p), ("near_const", C.c_float), ("far_const", C.c_float),
                 ("field_pos", f32p), ("field_quat", f32p), ("u_coarse", f32p), ("u_guided", f32p),
                 ("lin_coarse", f32p), ("lin_guided", f32p), ("philox_seed", C.c_uint64),

@@ -11,7 +11,7 @@
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
                        float* dirs, float* points_world, hipStream_t st);
 int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st);
-int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st);
+int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, uint64_t* counter, hipStream_t st);
 int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists, hipStream_t st);
 int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
                     const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
@@ -543,7 +543,9 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   e = check_launch("ngm_render_fwd");
   if (e) return e;
   if (has_tg) {
-    ngm_launch_loss_reduce(a.loss_partials, p.blocks_fwd, loss_sums, (hipStream_t)stream);
+    ngm_launch_loss_reduce(a.loss_partials, p.blocks_fwd, loss_sums,
+                           (rays->philox_offset_autoinc && rays->philox_offset_dev) ? const_cast<uint64_t*>(rays->philox_offset_dev) : nullptr,
+                           (hipStream_t)stream);
     e = check_launch("ngm_loss_reduce");
   }
   return e;

@@ -491,7 +491,9 @@ int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* o
 }
 
 // sum of per-workgroup loss partials: 16 slots x 16 strided lanes, then a fixed-order tree
-__global__ void k_loss_reduce(const float* partials, int nblocks, float* sums) {
+// counter (optional): the iteration counter behind the Philox offset / Adam step, advanced here -- the forward that
+// read it has finished (stream order) and the Adam kernel that reads it next has not started
+__global__ void k_loss_reduce(const float* partials, int nblocks, float* sums, unsigned long long* counter) {
   __shared__ float red[16][17];
   const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;   // 256 threads
   float s = 0.f;
@@ -504,9 +506,10 @@ __global__ void k_loss_reduce(const float* partials, int nblocks, float* sums) {
     for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
     sums[threadIdx.x] = t;
   }
+  if (counter && threadIdx.x == 0) *counter += 1ull;
 }
-int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, hipStream_t st) {
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, partials, nblocks, sums);
+int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, uint64_t* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, partials, nblocks, sums, reinterpret_cast<unsigned long long*>(counter));
   return 0;
 }
 

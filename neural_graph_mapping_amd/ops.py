@@ -154,7 +154,7 @@ def linspace_table(n: int, device):
 
 
 def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=None, u_guided=None, seed=0, offset=0,
-              near_const=0.0, far_const=8.0, keep=None, pose_index=None, philox_offset_dev=None):
+              near_const=0.0, far_const=8.0, keep=None, pose_index=None, philox_offset_dev=None, philox_autoinc=False):
     """Build an ngm_rays record; `keep` (list) receives every temporary that must outlive the launch."""
     keep = keep if keep is not None else []
     _require_gpu(ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided)
@@ -175,7 +175,7 @@ def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=Non
         pose_index = pose_index.contiguous()
         _require_gpu(pose_index)
     keep.extend(ts + [pose_index, philox_offset_dev])
-    return K.Rays(F, R, _ptr(ts[0]), _ptr(ts[1]), per_ray, 0, _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]),
+    return K.Rays(F, R, _ptr(ts[0]), _ptr(ts[1]), per_ray, 1 if (philox_autoinc and philox_offset_dev is not None) else 0, _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]),
                   float(near_const), float(far_const), _ptr(ts[5]), _ptr(ts[6]), _ptr(ts[7]), _ptr(ts[8]),
                   _ptr(ts[9]), _ptr(ts[10]), int(seed), int(offset), _ptr(pose_index), _ptr(philox_offset_dev))
 

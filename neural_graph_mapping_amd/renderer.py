@@ -379,14 +379,16 @@ class NeuralGraphRenderer:
         update=False, also the gradients.  Every launch is asynchronous on the current stream and the
         sequence is hipGraph-capturable (device-side step / jitter counters, no allocation after the
         first call with a given batch shape)."""
-        ctx = self._iteration_forward(target, u_coarse, u_guided, seed)
+        ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=update)
         if self.process_group is not None:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
             torch.distributed.all_reduce(ctx["w"]["sums"], group=self.process_group)
         return self._iteration_backward(ctx, update)
 
-    def _iteration_forward(self, target: Target, u_coarse=None, u_guided=None, seed=0) -> dict:
-        """First half of the iteration: fused forward + local loss sums (everything before the all-reduce)."""
+    def _iteration_forward(self, target: Target, u_coarse=None, u_guided=None, seed=0, advance=True) -> dict:
+        """First half of the iteration: fused forward + local loss sums (everything before the all-reduce).
+        One device counter counts the iterations: the forward adds it to the Philox offset, the loss-reduction kernel
+        advances it (advance=True) and Adam then reads it as its step -- no launch of its own for the bookkeeping."""
         L = K.lib()
         fc, rc = self._fc, self._rc_train
         fids = target.field_ids
@@ -396,10 +398,12 @@ class NeuralGraphRenderer:
         ps = ops.params_struct(fc, allp, fids)           # kernels read rows field_ids[f] in place: no gather
         w = self._workspace(F, R)
         keep = []
+        if self._step_dev is None:
+            self._step_dev = torch.full((1,), self._step, device=self._device, dtype=torch.int64)
         rays = ops.make_rays(rc, target.ijs, target.c2ws, target.near_distances, target.far_distances,
                              target.gt_distances, self._global_map_dict["positions"],
                              self._global_map_dict["orientations"], u_coarse, u_guided, seed, keep=keep,
-                             pose_index=fids, philox_offset_dev=w["philox"])
+                             pose_index=fids, philox_offset_dev=self._step_dev, philox_autoinc=advance)
         dm = target.depth_mask.view(torch.uint8) if target.depth_mask.dtype == torch.bool else target.depth_mask
         tm = target.term_mask
         if tm is not None and tm.dtype == torch.bool:
@@ -431,13 +435,9 @@ class NeuralGraphRenderer:
                 "freespace": lv[4], "tsdf": lv[5]}
         if update:
             self._step += 1                                  # one counter for all fields (rm.py:380-385)
-            if self._step_dev is None:
-                self._step_dev = torch.full((1,), self._step, device=self._device, dtype=torch.int64)
+            # the device counter already holds the new step: the forward's loss reduction advanced it
             ops.adam_sparse_multi_(fc, allp, self._optim_state, grads, fids, self._step, self._step_dev,
                                    lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
-            # separate 1-thread launch: folding the advance into the Adam kernel (last block done -> ++) was
-            # measured 17 us SLOWER, every block then fences its parameter stores before the atomic
-            K.check(L.ngm_step_advance(self._step_dev.data_ptr(), w["philox"].data_ptr(), st), "ngm_step_advance")
         else:
             loss["grads"] = grads
         loss["prediction"] = Prediction(w["rgbds"], w["color_vars"], w["depth_vars"], w["term_probs"], None, None)
@@ -471,7 +471,7 @@ class NeuralGraphRenderer:
         try:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                ctx = self._iteration_forward(target, None, None, seed)
+                ctx = self._iteration_forward(target, None, None, seed, advance=True)
             with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 out = self._iteration_backward(ctx, True)
         except RuntimeError:

@@ -419,12 +419,15 @@ struct RenderPlan {
 // has a kernel that consumes them: 49..64-wide hidden layers, 1-2 layers, non-hash encoding.  The
 // backward then skips its forward recompute.  NGM_NO_ACT_STASH=1 turns it off (recompute; saves
 // 256 B * L per sample of workspace).
-static bool act_stash_ok(const ngm_field_cfg* fc) {
+// 0: none; 1: post-ReLU hidden activations of 64-wide layers (k_field_bwd16s); 2: the hash encoding itself
+// (<= 32 features; k_field_bwd16 then skips the simplex search and the table gathers, the hidden layers are recomputed)
+static int act_stash_kind(const ngm_field_cfg* fc) {
   static const bool off = getenv("NGM_NO_ACT_STASH") != nullptr;
-  if (off) return false;
+  if (off) return 0;
   const int th = (fc->dim_hidden + 15) / 16, ti = (fc->dim_enc + 15) / 16;
-  return fc->encoding != NGM_ENC_PERMUTO && fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 &&
-         fc->num_layers <= 2;   // with a skip connection the stashed activation no longer tells the ReLU mask
+  if (fc->encoding == NGM_ENC_PERMUTO) return (ti == 2 && fc->dim_hidden <= 32) ? 2 : 0;
+  // with a skip connection the stashed activation no longer tells the ReLU mask
+  return (fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2) ? 1 : 0;
 }
 
 static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {
@@ -463,9 +466,13 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
-    if (act_stash_ok(fc)) {
+    const int kind = act_stash_kind(fc);
+    if (kind == 1) {
       p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
       p.off_act = o; o = align_up(o + fc->num_layers * p.act_layer_stride * 4 + 64, 256);
+    } else if (kind == 2) {
+      p.act_layer_stride = align_up(NS, 32) * 32 + 1024;      // one "layer": the 32-feature encoding
+      p.off_act = o; o = align_up(o + p.act_layer_stride * 4 + 64, 256);
     }
   }
   p.total = o + 256;

@@ -585,6 +585,9 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     static_assert(!HASH || MI == 1, "hash encoding: 2*levels <= 32 features");
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0][0]);
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1][0]);
+    // training: the encoding itself is what the backward cannot cheaply recompute (simplex search + 64 table
+    // gathers per sample) -> stash it (128 B per sample); the one hidden layer is recomputed there
+    if (st && st->base) act_store<MI, 2>(*st, 0, lane, E);
   } else {
     if constexpr (!NEED_COS) {
       const ngm_v2f X = {hi ? ox : x, hi ? x : ox}, Y = {hi ? oy : y, hi ? y : oy}, Z = {hi ? oz : z, hi ? z : oz};
@@ -602,7 +605,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, st, pc);
+  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, HASH ? nullptr : st, pc);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);

@@ -20,18 +20,32 @@
 // 70% slower: hipcc then guards every later ds_read with vmcnt(0) and stops interleaving them.)
 struct RawIn16 {
   float4 r0, r1, dout;
+  float4 e[2];     // hash encoding of the sample from the forward's stash (HASH with a.act only)
   float t;
   bool valid;
 };
 
+// E_STASH: the lane's two 16-byte chunks (features 16m + 4q + {0..3}) of the stashed hash encoding,
+// layout act[tile = g >> 5][chunk = feature >> 2][g & 31][4 floats] with 8 chunks per sample
+template <bool E_STASH = false>
 __device__ __forceinline__ RawIn16 fetch_inputs16(const FieldBwdArgs& a, int f, int64_t n, int64_t end, bool ray_mode,
-                                                  uint32_t rays_per_field) {
+                                                  uint32_t rays_per_field, int q = 0) {
   RawIn16 in;
   in.valid = n < end;
   in.r0 = in.r1 = in.dout = make_float4(0.f, 0.f, 0.f, 0.f);
+  in.e[0] = in.e[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   in.t = 0.f;
   if (in.valid) {
     const int64_t g = (int64_t)f * a.P + n;
+    if constexpr (E_STASH) {
+      if (a.act) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* tile = reinterpret_cast<const v4f*>(a.act) + (g >> 5) * (8 * 32) + (g & 31);
+        const v4f e0 = __builtin_nontemporal_load(tile + q * 32), e1 = __builtin_nontemporal_load(tile + (4 + q) * 32);
+        in.e[0] = make_float4(e0.x, e0.y, e0.z, e0.w);
+        in.e[1] = make_float4(e1.x, e1.y, e1.z, e1.w);
+      }
+    }
     if (ray_mode) {
       const int64_t ray = (int64_t)f * rays_per_field + (uint32_t)n / (uint32_t)a.S;
       in.r0 = reinterpret_cast<const float4*>(a.raytab)[2 * ray];
@@ -95,13 +109,13 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
   TICK(0);   // prologue (weights -> LDS)
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   const uint32_t rays_per_field = ray_mode ? (uint32_t)(a.P / a.S) : 0u;
-  RawIn16 nxt = fetch_inputs16(a, f, beg + wave * 16 + j, end, ray_mode, rays_per_field);
+  RawIn16 nxt = fetch_inputs16<HASH && TI == 2>(a, f, beg + wave * 16 + j, end, ray_mode, rays_per_field, q);
   for (int64_t base = beg + wave * 16; base < end; base += 16 * B16_WAVES) {
     // software pipeline: this tile's raw inputs were fetched one iteration ago; issue the next tile's
     // loads now so that their HBM latency hides behind this tile's arithmetic
     const RawIn16 cur = nxt;
     const int64_t n = base + j;
-    nxt = fetch_inputs16(a, f, n + 16 * B16_WAVES, end, ray_mode, rays_per_field);
+    nxt = fetch_inputs16<HASH && TI == 2>(a, f, n + 16 * B16_WAVES, end, ray_mode, rays_per_field, q);
     const bool valid = cur.valid;
     float x = 0, y = 0, z = 0;
     float4 dout = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -119,7 +133,14 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
     TICK(1);   // sample inputs (global loads)
     // ---- forward recompute
     f32x4 E[TI], dEa[TI];
-    if constexpr (HASH) encode_hash16<TI>(sm + LY::ENCW, hc, q, x, y, z, E);
+    if constexpr (HASH) {
+      // ray mode after a training forward: the encoding comes from the forward's stash (no simplex search, no
+      // table gathers here); point mode / no stash: recompute
+      if (TI == 2 && a.act) {
+#pragma unroll
+        for (int m = 0; m < TI; ++m) E[m] = f32x4{cur.e[m & 1].x, cur.e[m & 1].y, cur.e[m & 1].z, cur.e[m & 1].w};
+      } else encode_hash16<TI>(sm + LY::ENCW, hc, q, x, y, z, E);
+    }
 #ifdef NGM_ABL_NOVALU
     else {
 #pragma unroll

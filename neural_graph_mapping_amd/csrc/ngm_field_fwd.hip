@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_ABLF_NOACT
       ast.base = nullptr; ast.layer_stride = 0;
 #else
-      ast.base = (MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
+      ast.base = (HASH ? MI == 1 : MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
 #endif
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
 #ifdef NGM_ABLF_NOMLP

@@ -542,7 +542,17 @@ int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 // is then flushed once with global float atomics (chunks <= 8 adds per entry instead of one global
 // atomic per sample-vertex).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long to_fix(float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); }
+// float -> Q23.40 two's complement with fp32 / integer instructions only (the double-precision route was 10 f64
+// instructions per value): |v| * 2^9 = hi + rem, hi = floor, rem in [0,1), both exact for a non-negative operand;
+// magnitude = hi * 2^31 + trunc(rem * 2^31), then the sign.  |v| < 2^22; error < 2^-40 (truncation toward zero).
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+  const float s = fabsf(v) * 512.0f;
+  const float fl = floorf(s);
+  const unsigned int hi = (unsigned int)fl;
+  const unsigned int lo = (unsigned int)((s - fl) * 2147483648.0f);     // < 2^31
+  const unsigned long long mag = ((unsigned long long)(hi >> 1) << 32) | ((hi << 31) | lo);
+  return (v < 0.f) ? (0ull - mag) : mag;
+}
 
 struct HashGradArgs {
   ngm_field_cfg fc;
@@ -592,27 +602,32 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
     if (valid) { tab[threadIdx.x] += (unsigned long long)(idx[0] + idx[1] + idx[2] + idx[3]) + to_fix(d.x * bw[0] + d.y * bw[1] + bw[2] + bw[3]); }
     continue;
 #endif
+    // consecutive lanes = consecutive samples of a ray: at coarse levels they sit in the same simplex in long
+    // runs, which would serialise the LDS atomic unit (measured 163 LDS cycles per ds_add_f32).  Reduce each run
+    // inside the wave first (segmented scans; a run = lanes whose four vertices all repeat the previous lane's, so
+    // one run structure serves the 8 sums) and let its last lane issue the atomics.
+    bool same = valid && lane > 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      // consecutive lanes = consecutive samples of a ray: at coarse levels they hit the same vertex in long
-      // runs, which would serialise the LDS atomic unit (measured 163 LDS cycles per ds_add_f32).  Reduce
-      // each run inside the wave first (segmented scan) and let its last lane issue ONE atomic.
-      const uint32_t key = valid ? idx[r] : (0x80000000u | (uint32_t)lane);
-      const uint32_t prev = __shfl_up(key, 1, 64);
-      const bool head = (lane == 0) || (key != prev);
-      const unsigned long long hm = __ballot(head);
-      float v0 = d.x * bw[r], v1 = d.y * bw[r];
-      if (__popcll(hm) <= 40) {                                   // wave-uniform
-        const unsigned long long below = hm & ((2ull << lane) - 1ull);
-        const int k = lane - (63 - __clzll(below));
-        v0 = seg_scan_add(v0, k, lane);
-        v1 = seg_scan_add(v1, k, lane);
-        const bool tail = (lane == 63) || ((hm >> (lane + 1)) & 1ull);
-        if (tail && valid) { atomicAdd(&tab[2 * idx[r]], to_fix(v0)); atomicAdd(&tab[2 * idx[r] + 1], to_fix(v1)); }
-      } else if (valid) {
-        atomicAdd(&tab[2 * idx[r]], to_fix(v0));
-        atomicAdd(&tab[2 * idx[r] + 1], to_fix(v1));
-      }
+      const uint32_t key = valid ? idx[r] : 0xffffffffu;
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)key, NGM_DPP_WAVE_SHR1, 0xf, 0xf, false);
+      same = same && (key == prev);
+    }
+    const unsigned long long hm = __ballot(!same);
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[2 * r] = d.x * bw[r]; v[2 * r + 1] = d.y * bw[r]; }
+    bool issue = valid;
+    if (__popcll(hm) <= 40) {                                   // wave-uniform
+      const unsigned long long below = hm & ((2ull << lane) - 1ull);
+      const int k = lane - (63 - __clzll(below));
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = seg_scan_add(v[c], k, lane);
+      issue = valid && ((lane == 63) || ((hm >> (lane + 1)) & 1ull));
+    }
+    if (issue) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { atomicAdd(&tab[2 * idx[r]], to_fix(v[2 * r])); atomicAdd(&tab[2 * idx[r] + 1], to_fix(v[2 * r + 1])); }
     }
   }
   __syncthreads();

@@ -500,6 +500,36 @@ def test_full_size_properties_m1():
         grad_close(d["grads"][k], 2 * pa[k], 1e-5, k)
 
 
+def test_iteration_counter_drives_jitter_and_adam_step():
+    """One device counter counts the iterations (ngm_rays.philox_offset_autoinc): the forward adds it to the Philox
+    offset, the loss reduction advances it, Adam reads it as its step.  update=False must leave it alone; a captured
+    iteration must advance it at every replay (fresh jitter, growing step)."""
+    F, R = 2, 16
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=8)
+    pos, quat, t = synth_target(F, R, seed=3)
+    r = make_renderer(fkw, ckw, F)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    a = r.optimization_iteration(tgt, seed=5, update=False)["prediction"].rgbds.clone()
+    b = r.optimization_iteration(tgt, seed=5, update=False)["prediction"].rgbds.clone()
+    assert torch.equal(a, b) and int(r._step_dev.item()) == 0                   # nothing advanced
+    p0 = {k: v.clone() for k, v in r._model.all_fields_params.items()}
+    r.optimization_iteration(tgt, seed=5, update=True)
+    assert int(r._step_dev.item()) == 1 == r._step
+    c = r.optimization_iteration(tgt, seed=5, update=False)["prediction"].rgbds.clone()
+    assert not torch.equal(a, c)                                                 # new jitter offset (and new parameters)
+    # first Adam step with zero moments moves every parameter with a non-zero gradient by ~lr (bias correction of step 1)
+    moved = max(float((r._model.all_fields_params[k] - p0[k]).abs().max()) for k in p0)
+    assert 0.2 * r._learning_rate < moved < 1.5 * r._learning_rate, moved
+    replay = r.capture_iteration(tgt, seed=5)
+    s0 = int(r._step_dev.item())
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    assert int(r._step_dev.item()) == s0 + 3 == r._step
+
+
 @pytest.mark.parametrize("F,R,n_c,n_g", [(1, 5, 3, 0), (2, 33, 1, 1), (5, 7, 8, 16), (1, 1, 128, 0), (3, 130, 20, 4)])
 def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
     _ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=32, num_layers=1))

@@ -2,7 +2,7 @@
 //
 // The reference finds the K nearest field centres of every query point, evaluates each touched field
 // in a Python loop over boolean masks and blends with softmax(-distance_factor * dist).  Here:
-//   k_knn_assign  : brute-force K-nearest (K <= 4, all centres in LDS), radius test, softmax weights;
+//   k_knn_assign  : exact K-nearest (K <= 4, all centres in LDS, per-wave candidate list), radius test, softmax weights;
 //                   per-workgroup LDS histogram -> one global atomic per field per workgroup
 //   k_knn_offsets : exclusive scans over fields (segment offsets, tile offsets)
 //   k_knn_scatter : (point,k) pairs bucketed by field (counting sort)
@@ -13,6 +13,13 @@
 #include "ngm_launch.h"
 
 #include <algorithm>
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 
 #define KNN_TILE 4096
 #define KNN_MAXK 4
@@ -36,21 +43,93 @@ struct KnnArgs {
   float4* pair_out;     // (P*K)
 };
 
+// wave-wide min / max (uniform result): DPP row scans + row broadcasts, lane 63 read back (no LDS-pipe shuffles)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_src(float ident, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+  const float id = INFINITY;
+  v = fminf(v, dpp_src<0x111, 0xf>(id, v)); v = fminf(v, dpp_src<0x112, 0xf>(id, v));
+  v = fminf(v, dpp_src<0x114, 0xf>(id, v)); v = fminf(v, dpp_src<0x118, 0xf>(id, v));
+  v = fminf(v, dpp_src<0x142, 0xa>(id, v)); v = fminf(v, dpp_src<0x143, 0xc>(id, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
+
+// K nearest centres, exact, with a per-wave candidate list.  The 64 points of a wave are consecutive samples of a
+// ray (or neighbours of a dense grid): they sit in a ball (c0, rho).  If D bounds the K-th nearest distance of c0
+// from above, the K nearest centres of EVERY point of the wave lie within D + 2 rho of c0 (triangle inequality), so
+// only those centres -- typically a handful of a few hundred -- are compared per point.  D = the K-th smallest of the
+// 64 lanes' minima over disjoint subsets of the centres (K distinct centres, hence an upper bound).  The list keeps
+// the field order, so distances, tie-breaking and results are bit-identical to the brute-force loop; incoherent
+// points only make the list long.
 __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   float4* cpos = reinterpret_cast<float4*>(smf);       // NF centres, one 16-byte broadcast read each
   int* hist = reinterpret_cast<int*>(smf + 4 * a.NF);  // NF
+  int* cand_all = hist + a.NF;                         // 4 waves x NF candidate indices
   for (int i = threadIdx.x; i < a.NF; i += blockDim.x) cpos[i] = make_float4(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2], 0.f);
   for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   const int K = a.K;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * blockDim.x) {
-    const float x = a.points[3 * p], y = a.points[3 * p + 1], z = a.points[3 * p + 2];
+  const int lane = threadIdx.x & 63;
+  int* cand = cand_all + (threadIdx.x >> 6) * a.NF;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < a.P; p0 += stride) {   // uniform trip count per wave
+    const int64_t p = p0 + threadIdx.x;
+    const bool live = p < a.P;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) { x = a.points[3 * p]; y = a.points[3 * p + 1]; z = a.points[3 * p + 2]; }
+    // ---- bounding ball of the wave's points
+    const float big = 3.0e38f;
+    const float lx = wave_min_f(live ? x : big), hx = wave_max_f(live ? x : -big);
+    const float ly = wave_min_f(live ? y : big), hy = wave_max_f(live ? y : -big);
+    const float lz = wave_min_f(live ? z : big), hz = wave_max_f(live ? z : -big);
+    int ncand = 0;
+    if (lx <= hx) {                                            // at least one live lane (wave-uniform)
+      const float cx = 0.5f * (lx + hx), cy = 0.5f * (ly + hy), cz = 0.5f * (lz + hz);
+      const float ex = x - cx, ey = y - cy, ez = z - cz;
+      const float rho = sqrtf(wave_max_f(live ? ex * ex + ey * ey + ez * ez : 0.f)) * 1.0001f + 1e-12f;
+      // ---- upper bound D of the K-th nearest distance of c0
+      float dmin = INFINITY;
+      for (int f = lane; f < a.NF; f += 64) {
+        const float4 c = cpos[f];
+        const float dx = cx - c.x, dy = cy - c.y, dz = cz - c.z;
+        dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
+      }
+      float D2 = INFINITY;
+      for (int k = 0; k < K; ++k) {
+        D2 = wave_min_f(dmin);
+        const unsigned long long who = __ballot(dmin == D2);
+        if (who && lane == __ffsll((long long)who) - 1) dmin = INFINITY;   // pop one lane's minimum per round
+      }
+      // fewer than K centres: D2 is inf and every centre stays a candidate.  Slack: the bound is compared in squared
+      // distances computed in fp32 -> widen by a relative 1e-4 (costs nothing, keeps the list a superset).
+      const float reach = (sqrtf(D2) + 2.0f * rho) * 1.0001f;
+      const float reach2 = reach * reach;
+      // ---- candidate list in field order
+      for (int f0 = 0; f0 < a.NF; f0 += 64) {
+        const int f = f0 + lane;
+        bool keep = false;
+        if (f < a.NF) {
+          const float4 c = cpos[f];
+          const float dx = cx - c.x, dy = cy - c.y, dz = cz - c.z;
+          keep = !(dx * dx + dy * dy + dz * dz > reach2);      // NaN-safe: keeps the centre
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) cand[ncand + __popcll(m & ((1ull << lane) - 1ull))] = f;
+        ncand += __popcll(m);
+      }
+    }
+    WAVE_SYNC();
+    if (live) {
     float bd[KNN_MAXK]; int bi[KNN_MAXK];
 #pragma unroll
     for (int k = 0; k < KNN_MAXK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
     float worst = INFINITY;                                   // bd[K-1]: most centres are farther and skip the insertion
-    for (int f = 0; f < a.NF; ++f) {
+    for (int ci = 0; ci < ncand; ++ci) {
+      const int f = cand[ci];
       const float4 c = cpos[f];
       const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
       float d = dx * dx + dy * dy + dz * dz;
@@ -82,23 +161,32 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
         if (inside) atomicAdd(&hist[bi[k]], 1);
       }
     }
+    }
+    WAVE_SYNC();     // the next round overwrites the candidate list
   }
   __syncthreads();
   for (int i = threadIdx.x; i < a.NF; i += blockDim.x)
     if (hist[i]) atomicAdd(&a.counts[i], hist[i]);
 }
 
+// exclusive scans over the fields (segment offsets, tile offsets): one wave, 64 fields per round
 __global__ void k_knn_offsets(KnnArgs a) {
-  // single workgroup; NF is a few hundred at most
-  if (threadIdx.x == 0) {
-    int so = 0, to = 0;
-    for (int f = 0; f < a.NF; ++f) {
-      a.seg_off[f] = so; a.tile_off[f] = to;
-      so += a.counts[f]; to += (a.counts[f] + KNN_TILE - 1) / KNN_TILE;
-      a.cursor[f] = 0;
+  const int lane = threadIdx.x;          // launched with 64 threads
+  int so = 0, to = 0;
+  for (int f0 = 0; f0 < a.NF; f0 += 64) {
+    const int f = f0 + lane;
+    const int c = (f < a.NF) ? a.counts[f] : 0;
+    const int t = (c + KNN_TILE - 1) / KNN_TILE;
+    int sc = c, st = t;                  // inclusive wave scans
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int oc = __shfl_up(sc, d, 64), ot = __shfl_up(st, d, 64);
+      if (lane >= d) { sc += oc; st += ot; }
     }
-    a.seg_off[a.NF] = so; a.tile_off[a.NF] = to;
+    if (f < a.NF) { a.seg_off[f] = so + sc - c; a.tile_off[f] = to + st - t; a.cursor[f] = 0; }
+    so += __shfl(sc, 63, 64); to += __shfl(st, 63, 64);
   }
+  if (lane == 0) { a.seg_off[a.NF] = so; a.tile_off[a.NF] = to; }
 }
 
 // Counting-sort scatter in two levels: every workgroup ranks its SC_ITEMS * 256 pairs per field with LDS atomics,
@@ -225,7 +313,7 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   a.pair_out = reinterpret_cast<float4*>(carve(16 * n));
   (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
   const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
-  const size_t lds_a = (size_t)num_fields * 20;
+  const size_t lds_a = (size_t)num_fields * (20 + 4 * 4);    // centres, histogram, 4 waves of candidate lists
   hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));

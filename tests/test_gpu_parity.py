@@ -599,6 +599,29 @@ def test_knn_blend_vs_oracle(NF, K_, P):
     close(out, ref, rtol=3e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("NF,K_", [(150, 2), (150, 4), (3, 4), (70, 1)])
+def test_knn_blend_ray_ordered_points_vs_oracle(NF, K_):
+    """points in ray order (what render_image feeds): the assignment kernel culls the field list per wave from the
+    wave's bounding ball -- the result must still be the exact K nearest (ragged tail, segments that leave every
+    field, fewer centres than K)."""
+    torch.manual_seed(100 + NF)
+    fs = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)
+    fc = K.field_cfg(encoding="fourier", dim_enc=32, num_layers=1)
+    params = O.init_params(fs, NF, seed=NF, sigma=3.0)
+    g = torch.arange(0.0, 3.01, 0.6)
+    grid = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pos = grid[torch.randperm(grid.shape[0])[:NF] % grid.shape[0]] if NF <= grid.shape[0] else grid
+    pos = pos.clone() + 1e-3 * torch.randn(pos.shape[0], 3)   # no exact distance ties (their order is unpinned in the reference)
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
+    o = torch.rand(37, 1, 3) * 3
+    d = torch.nn.functional.normalize(torch.randn(37, 1, 3), dim=-1)
+    t = torch.linspace(-1.0, 5.0, 333)[None, :, None]
+    pts = (o + t * d).reshape(-1, 3)[:-11]                    # 37 rays x 333 samples, ragged tail
+    ref = O.field_set_forward_knn(pts, pos, quat, params, fs, num_knn=K_, distance_factor=10.0, outside_value=1.0)
+    out = ops.field_eval_knn(fc, cu(params), pts.to(DEV), pos.to(DEV), quat.to(DEV), K_, 10.0, 1.0)
+    close(out, ref, rtol=3e-4, atol=3e-5)
+
+
 def test_render_image_and_psnr_golden():
     g = load_golden("g9_render_image")
     w, h, fx, fy, cx, cy = [float(x) for x in g["cam"]]

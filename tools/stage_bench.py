@@ -105,6 +105,30 @@ def main():
         torch.autograd.grad(out, list(params.values()), go, retain_graph=True)
     add("field_eval_bwd", timeit(fbwd, iters=10), flops=nsamp * 33792, bytes_=nsamp * 28,
         note="point-mode backward (k_field_bwd16, recomputes the forward), 33 792 algorithmic flop/sample")
+    # ---- M2: render only, no_grad, 4096 rays x 128 samples, eval-style single stratum (ngm_render_fwd
+    # without targets / stash), through the reference-shaped render_ijs
+    from neural_graph_mapping_amd import models as M
+    from neural_graph_mapping_amd import renderer as Rr
+    F2, R2, S2 = 8, 512, 128
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
+        num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(dev)
+    cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, dict(geometry_mode="nrgbd", geometry_factor=20.0, truncation_distance=0.1,
+                                                field_radius=1.0, num_samples_coarse=S2, num_samples_depth_guided=0), device=dev)
+    r.add_fields(F2)
+    r.set_field_poses(torch.zeros(F2, 3, device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(F2, 1))
+    ijs2 = torch.stack([torch.randint(0, 480, (F2, R2), device=dev), torch.randint(0, 640, (F2, R2), device=dev)], -1)
+    c2w = torch.eye(4, device=dev)
+    c2w[2, 3] = 2.5
+    near2, far2 = torch.full((F2, R2), 1.5, device=dev), torch.full((F2, R2), 3.5, device=dev)
+    ids = torch.arange(F2, device=dev)
+    with torch.no_grad():
+        secs = timeit(lambda: r.render_ijs(ijs2, c2w, field_ids=ids, near_distances=near2, far_distances=far2, seed=3))
+    add("M2_render_ijs_nograd", secs, flops=F2 * R2 * S2 * 16896,
+        note="8 fields x 512 rays x 128 samples, render only (k_render_fwd without stash), incl. the Python layer of render_ijs")
+    res["stages"]["M2_render_ijs_nograd"]["ray_samples_per_s"] = round(F2 * R2 * S2 / secs / 1e6, 1) * 1e6
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -274,8 +274,6 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   constexpr int BLK = LW::BLK;
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field16<4, 4, L, S16_RS>(sm, a.fc, a.pr, row);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   float* wl = sm + LW::WTOTAL + wave * LY::WAVE_TOTAL;
@@ -330,6 +328,9 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
     issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INBUF * 4);
     issue_act(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::act(L) * 4);
   }
+  // the weights are staged while the first tile's transfers are in flight (their LDS regions are disjoint)
+  load_field16<4, 4, L, S16_RS>(sm, a.fc, a.pr, row);
+  __syncthreads();
   TICK_DECL;
   TICK(0);
   for (uint32_t base = first; base < end; base += 16 * B16_WAVES) {

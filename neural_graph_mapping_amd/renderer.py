@@ -210,6 +210,10 @@ class NeuralGraphRenderer:
                        pos=pos, quat=quat, u_coarse=u_coarse, u_guided=u_guided if guided else None, seed=seed,
                        near_const=self._config.get("near_distance", 0.0), far_const=self._config.get("far_distance", 8.0))
         params = self._model.vmap_fields_params
+        if rc.geometry_mode == K.GEO["neus"]:
+            return self._render_ijs_staged(rc, ijs, c2ws, field_ids, near_distances, far_distances,
+                                           gt_distances if guided else None, gt_distances, u_coarse,
+                                           u_guided if guided else None, seed, overwrite_samples_behind_camera)
         rgbds, cvars, dvars, term, geoms, dists = _RenderIjs.apply(self._fc, rc, names, rays_kw,
                                                                    *[params[n] for n in names])
         fs = ts = None
@@ -223,6 +227,70 @@ class NeuralGraphRenderer:
                 m = (deltas.abs() < tau) & (gt != 0.0)
                 ts = geoms[m] * tau - deltas[m]                                         # rm.py:632-639
         return Prediction(rgbds, cvars, dvars, term, fs, ts)
+
+    def _render_ijs_staged(self, rc, ijs, c2ws, field_ids, near, far, gt_sampler, gt, u_coarse, u_guided, seed,
+                           overwrite_behind) -> Prediction:
+        """_render_ijs as a chain of the standalone stages (sampler -> per-field evaluation -> quadrature), every stage
+        an autograd function over its HIP kernels.  Serves the geometry mode the fused kernels do not: neus, whose
+        occupancy couples neighbouring samples through the per-field learnable `_neus_sd` (rm.py:641-644, 753-758)."""
+        params = self._model.vmap_fields_params
+        pos = self._global_map_dict["positions"][field_ids]
+        quat = self._global_map_dict["orientations"][field_ids]
+        pc, pw, dists = ops.sample_rays_world(rc, ijs, c2ws, near, far, gt_sampler, u_coarse, u_guided, seed,
+                                              near_const=self._config.get("near_distance", 0.0),
+                                              far_const=self._config.get("far_distance", 8.0))
+        F, R, S = dists.shape
+        out = ops.field_eval(self._fc, {k: v for k, v in params.items() if k != "_neus_sd"}, pw.reshape(F, R * S, 3),
+                             pos, quat).view(F, R, S, 4)
+        colors = rc.color_factor * out[..., :3]                                              # rm.py:610
+        geoms = out[..., 3]
+        depths = -pc[..., 2]                                                                  # rm.py:612
+        if overwrite_behind and near is not None and not bool((near >= 0).all()):             # rm.py:494-495
+            const = -100.0 if rc.geometry_mode in (K.GEO["occupancy"], K.GEO["density"]) else 1.0   # rm.py:614-622
+            geoms = torch.where(pc[..., 2] > 0, torch.full_like(geoms, const), geoms)
+        isds = None
+        if rc.geometry_mode == K.GEO["neus"]:
+            isds = 1.0 / torch.abs(params["_neus_sd"].view(-1, 1, 1))                         # rm.py:641-644
+        C, D, Cv, Dv, term, _ = ops.quadrature(rc, colors, geoms, dists, depths, isds)
+        fs = ts = None
+        tau = rc.truncation_distance
+        if gt is not None:
+            g = gt[..., None]
+            if rc.w_freespace != 0.0:
+                fs = geoms[dists < (g - tau) * (g != 0.0)] * tau                              # rm.py:624-630
+            if rc.w_tsdf != 0.0:
+                deltas = g - dists
+                m = (deltas.abs() < tau) & (g != 0.0)
+                ts = geoms[m] * tau - deltas[m]                                               # rm.py:632-639
+        return Prediction(torch.cat([C, D[..., None]], -1), Cv, Dv, term, fs, ts)
+
+    def optimization_iteration_staged(self, target: Target, u_coarse=None, u_guided=None, seed=0, update=True) -> dict:
+        """The training iteration for configurations outside the fused kernels (geometry mode neus): staged render,
+        torch loss, autograd through the stage kernels, the same sparse Adam (incl. `_neus_sd`)."""
+        fids = target.field_ids
+        pred = self.render_ijs(target.ijs, target.c2ws, field_ids=fids, near_distances=target.near_distances,
+                               far_distances=target.far_distances, gt_distances=target.gt_distances,
+                               u_coarse=u_coarse, u_guided=u_guided, seed=seed)
+        loss = self.compute_losses(target, pred)
+        params = self._model.vmap_fields_params
+        names = [n for n, v in params.items() if v.requires_grad]
+        grads = torch.autograd.grad(loss["combined"], [params[n] for n in names], allow_unused=True)
+        gd = {n: (g if g is not None else torch.zeros_like(params[n])) for n, g in zip(names, grads)}
+        out = {k: v.detach() for k, v in loss.items()}
+        out["prediction"] = pred
+        if not update:
+            out["grads"] = gd
+            return out
+        self._step += 1
+        with torch.no_grad():
+            for n in names:
+                allp = self._model.all_fields_params[n]
+                st = self._optim_state[n]
+                ops.adam_sparse_(allp, st["exp_avg"], st["exp_avg_sq"], gd[n].contiguous(), fids, self._step,
+                                 lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step)
+        return out
 
     def compute_losses(self, target: Target, prediction: Prediction) -> dict:
         """_compute_losses (rm.py:1769-1872) on torch tensors (l1 photometric, huber depth)."""
@@ -379,6 +447,8 @@ class NeuralGraphRenderer:
         update=False, also the gradients.  Every launch is asynchronous on the current stream and the
         sequence is hipGraph-capturable (device-side step / jitter counters, no allocation after the
         first call with a given batch shape)."""
+        if self._rc_train.geometry_mode == K.GEO["neus"]:
+            return self.optimization_iteration_staged(target, u_coarse, u_guided, seed, update)
         ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=update)
         if self.process_group is not None:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
@@ -448,6 +518,9 @@ class NeuralGraphRenderer:
         replays it.  Tensors of `target` are read in place at every replay; the Adam step counter and the Philox
         jitter offset live on the device and advance inside the graph.  With a process group the iteration becomes
         two graphs (before / after the loss all-reduce) and the 64-byte collective is issued between the replays."""
+        if self._rc_train.geometry_mode == K.GEO["neus"]:
+            raise NotImplementedError("capture_iteration: the staged (neus) iteration allocates under autograd; call "
+                                      "optimization_iteration directly")
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--fields-total", type=int, default=0,
+                    help="strong scaling (SURVEY 8d): this many fields in total, split field-per-GPU over the ranks "
+                         "(default 0 = weak scaling, 8 fields per GPU)")
     ap.add_argument("--variant", choices=["fourier", "hash"], default="fourier",
                     help="field network: fourier = the headline M1 workload (default); hash = the reference's default "
                          "permutohedral-hash network on the same batch (auxiliary measurement)")
@@ -161,7 +164,10 @@ def main():
     L = K.lib()
 
     # field-per-GPU sharding: rank r owns global fields r, r+world, ... ; local slot = id // world
-    nf_global = F_PER_GPU * world
+    strong = args.fields_total > 0
+    if strong and args.fields_total % world:
+        raise SystemExit("--fields-total must be a multiple of the number of GPUs")
+    F_PER_GPU = args.fields_total // world if strong else globals()["F_PER_GPU"]
     r = build_renderer(dev, F_PER_GPU, args.variant)
     pos, quat, tgt_cpu = synth_target(F_PER_GPU, R, seed=1000 + rank)
     r.set_field_poses(pos.to(dev), quat.to(dev))
@@ -170,7 +176,7 @@ def main():
     if world > 1 or torch.distributed.is_initialized():
         r.process_group = torch.distributed.group.WORLD
 
-    # the whole iteration (7 kernels) is captured once into a hipGraph and replayed;
+    # the whole iteration (6 kernels) is captured once into a hipGraph and replayed;
     # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
     # multi-GPU: two graphs around the loss all-reduce (renderer.capture_iteration); --eager launches every kernel
     use_graph = not args.eager
@@ -220,9 +226,9 @@ def main():
         value = world * n_local * args.steps / dt
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
                    value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
-                   config=dict(workload="M1: 8 fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
+                   config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
                                            "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
                                         + ", nrgbd compositing, NRGBD intrinsics",

@@ -356,7 +356,7 @@ int ngm_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 /* Debug: with NGM_PHASE_TIMING set in the environment the backward kernel's first wave records its
  * s_memtime cycles per phase (prologue, inputs, encode, forward, output layer, staging, wgrad, dgrad,
  * encoding grads, relu mask, -, epilogue, total); this copies the 16 counters of the last launch. */
-int ngm_debug_phase_cycles(unsigned long long* out16);
+int ngm_debug_phase_cycles(unsigned long long* out528);   /* 16 slots (-DNGM_PHASE_TIMING) + 8 x 64 timeline entries (-DNGM_BWD_TIMELINE) */
 /* Same for the fused forward (library built with -DNGM_PHASE_TIMING): slots = prologue, ray setup, sampler, step head,
  * encoding, hidden layers, activation stash stores, output layer, compositing, variance pass, ray outputs, block
  * reduction, -, -, total shader cycles, total 100 MHz ticks; then the event timeline of the 8 waves of that workgroup. */

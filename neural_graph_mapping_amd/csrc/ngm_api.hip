@@ -81,6 +81,7 @@ static int fail(int code, const char* msg) {
   return code;
 }
 // prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
+#define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
@@ -88,7 +89,7 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
   a.debug_cycles = nullptr;
   if (timing) {
-    if (!g_debug_cycles) { (void)hipMalloc(&g_debug_cycles, 16 * sizeof(unsigned long long)); (void)hipMemset(g_debug_cycles, 0, 128); }
+    if (!g_debug_cycles) { (void)hipMalloc(&g_debug_cycles, NGM_FWD_DEBUG_WORDS * 8); (void)hipMemset(g_debug_cycles, 0, NGM_FWD_DEBUG_WORDS * 8); }
     a.debug_cycles = g_debug_cycles;
   }
   // order of preference: stashed activations (no forward recompute) -> 16-sample-tile recompute ->
@@ -228,17 +229,16 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 
-#define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)
 static unsigned long long* g_debug_cycles_fwd = nullptr;
 int ngm_debug_fwd_phase_cycles(unsigned long long* out528) {
   if (!g_debug_cycles_fwd || !out528) return NGM_E_INVALID;
   (void)hipDeviceSynchronize();
   return hipMemcpy(out528, g_debug_cycles_fwd, NGM_FWD_DEBUG_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
 }
-int ngm_debug_phase_cycles(unsigned long long* out16) {
-  if (!g_debug_cycles || !out16) return NGM_E_INVALID;
+int ngm_debug_phase_cycles(unsigned long long* out528) {
+  if (!g_debug_cycles || !out528) return NGM_E_INVALID;
   (void)hipDeviceSynchronize();
-  return hipMemcpy(out16, g_debug_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
+  return hipMemcpy(out528, g_debug_cycles, NGM_FWD_DEBUG_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess ? NGM_OK : NGM_E_HIP;
 }
 
 int ngm_device_info(int* ncu, char* name, int name_len) {

@@ -133,6 +133,107 @@ __device__ __forceinline__ void load_field16(float* sm, const ngm_field_cfg& fc,
   }
 }
 
+// Two-phase variant of load_field16 for B16_THREADS-thread workgroups: issue() starts every global load as
+// straight-line code (16-byte loads for the matrices when the rows allow it), commit() writes the same LDS image.
+// The serial loops of load_field16 cost the stash backward ~13 k clocks before its first MFMA; caller must
+// __syncthreads() after commit().
+template <int TI, int TH, int L, int RS = B16_RS>
+struct FieldStage16 {
+  static constexpr int NIT = (TH * 16 * TH * 4 + B16_THREADS - 1) / B16_THREADS;   // 16-byte chunks per thread and layer
+  float4 v[L][NIT];
+  float4 enc0, enc1, wout;
+  float bias[L];
+  __device__ __forceinline__ void issue(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
+    const int tid = threadIdx.x;
+    const int D = fc.dim_enc, H = fc.dim_hidden;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int TIN = (l == 0) ? TI : TH, Din = (l == 0) ? D : H;
+      const float* W = pr.w[l] + row * pr.w_stride[l];
+      const int ncol4 = TIN * 4, total4 = TH * 16 * ncol4;
+      const bool vec = ((Din & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e4 = tid + it * B16_THREADS;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e4 < total4) {
+          const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
+          if (o < H && c < Din) {
+            const float* src = W + (int64_t)o * Din + c;
+            if (vec) x = *reinterpret_cast<const float4*>(src);
+            else {
+              x.x = src[0];
+              if (c + 1 < Din) x.y = src[1];
+              if (c + 2 < Din) x.z = src[2];
+              if (c + 3 < Din) x.w = src[3];
+            }
+          }
+        }
+        v[l][it] = x;
+      }
+      bias[l] = (tid < H) ? pr.b[l][row * pr.b_stride[l] + tid] : 0.f;
+    }
+    wout = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < H) {
+      const float* W = pr.w[L] + row * pr.w_stride[L];
+      wout = make_float4(W[tid], W[H + tid], W[2 * H + tid], W[3 * H + tid]);
+    }
+    enc0 = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
+    enc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fc.encoding == NGM_ENC_PERMUTO) {
+      enc0.w = 0.f;
+      if (tid < fc.nr_levels) {
+        const float* hs = pr.shift + row * pr.shift_stride + 3 * tid;
+        enc0 = make_float4(fc.level_scale[3 * tid], fc.level_scale[3 * tid + 1], fc.level_scale[3 * tid + 2], 0.f);
+        enc1 = make_float4(hs[0], hs[1], hs[2], 0.f);
+      }
+    } else if (tid < D) {
+      const int f = tid;
+      if (fc.encoding == NGM_ENC_FOURIER) {
+        const int n_raw = fc.raw_coords ? 3 : 0;
+        if (f < n_raw) enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+        else { const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3; enc0 = make_float4(w[0], w[1], w[2], NGM_FK_SIN); }
+      } else if (fc.encoding == NGM_ENC_NERF) {
+        const int half = 3 * fc.num_octaves;
+        const int g = (f < half) ? f : f - half;
+        const int d = g / fc.num_octaves, o = g % fc.num_octaves;
+        const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
+        enc0 = make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
+      } else enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+    }
+  }
+  __device__ __forceinline__ void commit(float* sm, const ngm_field_cfg& fc) const {
+    using LY = Lds16<TI, TH, L, RS>;
+    const int tid = threadIdx.x;
+    if (fc.encoding == NGM_ENC_PERMUTO) {
+      if (tid < 16) {
+        reinterpret_cast<float4*>(sm + LY::ENCW)[2 * tid] = enc0;
+        reinterpret_cast<float4*>(sm + LY::ENCW)[2 * tid + 1] = enc1;
+      }
+    } else if (tid < TI * 16) {
+      reinterpret_cast<float4*>(sm + LY::ENCW)[tid] = enc0;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int TIN = (l == 0) ? TI : TH;
+      const int ncol4 = TIN * 4, total4 = TH * 16 * ncol4;
+      float* dst = sm + LY::w_off(l);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e4 = tid + it * B16_THREADS;
+        if (e4 < total4) {
+          const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
+          const int mo = o >> 4, ol = o & 15, mi = c >> 4, cl = c & 15;
+          float* blk = dst + (mo * TIN + mi) * LY::BLK + (cl >> 2) * RS + ol;     // row 4*j + (cl >> 2) for column cl + j
+          blk[0] = v[l][it].x; blk[4 * RS] = v[l][it].y; blk[8 * RS] = v[l][it].z; blk[12 * RS] = v[l][it].w;
+        }
+      }
+      if (tid < TH * 16) sm[LY::b_off(l) + tid] = bias[l];
+    }
+    if (tid < TH * 16) reinterpret_cast<float4*>(sm + LY::WOUT)[tid] = wout;
+  }
+};
+
 // ---- tile helpers (lane (j = lane&15, q = lane>>4)) ---------------------------------------------------
 // HW = true (backward with stashed activations): sine and cosine from v_sin_f32 / v_cos_f32.  Those take the
 // argument in revolutions and reduce it themselves, so the position is scaled by 1/(2 pi) once per sample and
@@ -351,7 +452,9 @@ __device__ __forceinline__ float fold_parts(float v) {
 // ([wave][tile][reg][lane], conflict-free), then the 512 threads each add the 8 copies of two elements
 // and write the result to the workgroup's partial vector in HBM.  `stage` = LDS scratch of at least
 // 8 * 1024 floats; the caller has passed a __syncthreads() after its last use of that memory.
-template <int TI, int TH, int L, bool ENC_GRAD>
+// EPI_CH: C tiles parked per wave and round (stage must hold 8 * EPI_CH * 256 floats); more tiles per round = fewer
+// barrier pairs (4 -> 16 took the epilogue of k_field_bwd16s from 8 rounds to 2).
+template <int TI, int TH, int L, bool ENC_GRAD, int EPI_CH = 4>
 __device__ __forceinline__ void bwd16_epilogue(const FieldBwdArgs& a, float* stage, f32x4 (&acc0)[TH][TI],
                                                f32x4 (&accH)[(L > 1) ? (L - 1) : 1][TH][TH], float (&dbh)[L],
                                                float (&dwo)[4], float (&dwf)[3], float (&dbo)[4]) {
@@ -362,7 +465,7 @@ __device__ __forceinline__ void bwd16_epilogue(const FieldBwdArgs& a, float* sta
   float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
   const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
   constexpr int NT0 = TH * TI, NTH = TH * TH, NT = NT0 + (L - 1) * NTH;
-  constexpr int EPI_CH = 4, EPI_W = EPI_CH * 4 * 64;       // floats parked per wave and round
+  constexpr int EPI_W = EPI_CH * 4 * 64;                   // floats parked per wave and round
 #pragma unroll
   for (int t0 = 0; t0 < NT; t0 += EPI_CH) {
 #pragma unroll

@@ -265,10 +265,33 @@ __device__ __forceinline__ void issue_act(const char* sbase, uint32_t gb, uint32
   }
 }
 
+#ifndef NGM_OLDER_SHARE
+#define NGM_OLDER_SHARE 18u     // 32nds of a workgroup's tiles that go to its four older waves (see the tile lists below)
+#endif
+
+// per-wave event timeline of the middle workgroup (debug builds, -DNGM_BWD_TIMELINE; a.debug_cycles must hold
+// 16 + 8 * 64 words): entry, after the prologue barrier, every tile start, loop end, kernel end
+#ifdef NGM_BWD_TIMELINE
+#define BTL_DECL                                                                                                    \
+  unsigned long long* btl = (a.debug_cycles && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0)              \
+                                ? a.debug_cycles + 16 + 64 * (threadIdx.x >> 6) : nullptr;                        \
+  int btl_n = 0;                                                                                                    \
+  const unsigned long long btl_t0 = __builtin_readcyclecounter()
+#define BTL(k)                                                                                                      \
+  do {                                                                                                              \
+    if (btl && btl_n < 64) btl[btl_n] = ((unsigned long long)(k) << 48) | (__builtin_readcyclecounter() - btl_t0);  \
+    ++btl_n;                                                                                                        \
+  } while (0)
+#else
+#define BTL_DECL
+#define BTL(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <int L, bool NEED_COS, bool ENC_GRAD>
 __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  BTL_DECL;
   using LY = Lds16s<L>;
   using LW = typename LY::W;
   constexpr int BLK = LW::BLK;
@@ -302,7 +325,17 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   dwf[0] = dwf[1] = dwf[2] = 0.f;
 
   const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
-  const uint32_t first = beg + wave * 16;
+  // Tile lists.  The SIMD's arbiter favours its older wave (waves 0-3 of the workgroup): with an even split those
+  // finished ~2 of 16 tiles ahead of waves 4-7, which then ran their last tiles alone, without a partner to hide
+  // LDS / DMA latency behind (wave timeline, -DNGM_BWD_TIMELINE).  So the older waves take NGM_OLDER_SHARE/32 = 18/32 of the tiles (17: 180.6 us, 18: 178.6, 19: 180.5):
+  // tiles [0, nA) go round-robin to waves 0-3, tiles [nA, T) to waves 4-7.  Static, hence deterministic.
+  const uint32_t T = (end - beg + 15u) >> 4;
+  uint32_t nA = ((T * NGM_OLDER_SHARE + 31u) / 32u + 3u) & ~3u;
+  if (nA > T) nA = T;
+  const bool older = wave < 4;
+  const uint32_t first = beg + 16u * (older ? (uint32_t)wave : nA + (uint32_t)(wave - 4));
+  const uint32_t lend = older ? min(end, beg + 16u * nA) : end;       // end of this wave's list (samples)
+  constexpr uint32_t TSTRIDE = 16 * (B16_WAVES / 2);                  // 4 waves share a list
   FieldStreams fs;
   {
     const int64_t g0 = (int64_t)f * a.P;
@@ -324,19 +357,25 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   float* R0 = wl + LY::XE;
   float* A1 = wl + LY::act(1);
   float* AL = wl + LY::act(L);
-  if (first < end) {
+  if (first < lend) {
     issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INBUF * 4);
     issue_act(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::act(L) * 4);
   }
   // the weights are staged while the first tile's transfers are in flight (their LDS regions are disjoint)
-  load_field16<4, 4, L, S16_RS>(sm, a.fc, a.pr, row);
+  {
+    FieldStage16<4, 4, L, S16_RS> stage;
+    stage.issue(a.fc, a.pr, row);
+    stage.commit(sm, a.fc);
+  }
   __syncthreads();
+  BTL(1);
   TICK_DECL;
   TICK(0);
-  for (uint32_t base = first; base < end; base += 16 * B16_WAVES) {
-    const uint32_t n = base + j, nxt = base + 16 * B16_WAVES;
-    const bool valid = n < end, more = nxt < end;
+  for (uint32_t base = first; base < lend; base += TSTRIDE) {
+    const uint32_t n = base + j, nxt = base + TSTRIDE;
+    const bool valid = n < end, more = nxt < lend;
     // ---- inputs and the last hidden activation tile (landed while the previous tile was differentiated)
+    BTL(2);
     TICK(10);   // loop back-edge
     DMA_WAIT(0);
     TICK(3);    // wait for inputs + last hidden tile
@@ -447,7 +486,9 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   }
   DMA_WAIT(0);
   TICK(10);
+  BTL(3);
   __syncthreads();
+  BTL(4);
 #ifdef NGM_ABLS_NOEPI   // timing ablation: keep the accumulators alive with one store, skip the reduction
   {
     float keep = dbh[0] + dwo[0] + dwo[1] + dwo[2] + dwo[3] + dwf[0] + dwf[1] + dwf[2] + dbo[0] + dbo[1] + dbo[2] + dbo[3];
@@ -461,7 +502,11 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   }
   return;
 #endif
-  bwd16_epilogue<4, 4, L, ENC_GRAD>(a, sm + LW::WTOTAL, acc0, accH, dbh, dwo, dwf, dbo);
+  // all of LDS is free now (the barrier above was the last use of weights and tiles): all C tiles in two rounds
+  constexpr int EPI = (L == 2) ? 16 : 8;                     // 2 rounds for either depth
+  static_assert(LW::WTOTAL + B16_WAVES * LY::WAVE_TOTAL >= B16_WAVES * EPI * 256, "epilogue staging does not fit");
+  bwd16_epilogue<4, 4, L, ENC_GRAD, EPI>(a, sm, acc0, accH, dbh, dwo, dwf, dbo);
+  BTL(5);
   TICK(11);
   TICK_REPORT
 }

@@ -328,13 +328,19 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
     n = F * R * (S_c + S_g)
     tf /= iters; tb /= iters
     if os.environ.get("NGM_PHASE_TIMING"):
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * (16 + 8 * 64))()
         L.ngm_debug_phase_cycles.argtypes = [C.c_void_p]
         if L.ngm_debug_phase_cycles(buf) == 0:
             names = ["prologue", "inputs", "encode", "fwd", "outlayer", "stage+colsum", "wgrad", "dgrad", "encgrad",
                      "relumask", "-", "epilogue", "TOTAL"]
             tot = buf[12] or 1
             print("phase cycles (wave 0, block 0):", {n: (int(buf[i]), round(100 * buf[i] / tot, 1)) for i, n in enumerate(names)})
+            tl = ["entry", "prologue", "tile", "loopend", "barrier", "end"]
+            for w in range(8):
+                ev = [(int(buf[16 + 64 * w + i]) >> 48, int(buf[16 + 64 * w + i]) & ((1 << 48) - 1)) for i in range(64)]
+                ev = [(k, c) for k, c in ev if c]
+                if ev:
+                    print(f"  bwd wave {w}: " + " ".join(f"{tl[k][:4]}@{c // 100 / 10:.1f}k" for k, c in ev))
         L.ngm_debug_fwd_phase_cycles.argtypes = [C.c_void_p]
         buf = (C.c_ulonglong * (16 + 8 * 64))()
         if L.ngm_debug_fwd_phase_cycles(buf) == 0:

@@ -67,7 +67,11 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
   constexpr int BLK = LY::BLK;
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field16<TI, TH, L>(sm, a.fc, a.pr, row);
+  {
+    FieldStage16<TI, TH, L> stage;      // every parameter load in flight at once, then the permuting LDS writes
+    stage.issue(a.fc, a.pr, row);
+    stage.commit(sm, a.fc);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
@@ -109,13 +113,22 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
   TICK(0);   // prologue (weights -> LDS)
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   const uint32_t rays_per_field = ray_mode ? (uint32_t)(a.P / a.S) : 0u;
-  RawIn16 nxt = fetch_inputs16<HASH && TI == 2>(a, f, beg + wave * 16 + j, end, ray_mode, rays_per_field, q);
-  for (int64_t base = beg + wave * 16; base < end; base += 16 * B16_WAVES) {
+  // tile lists as in k_field_bwd16s: the SIMD's older wave (waves 0-3) runs ahead of its partner, so it takes 18/32
+  // of the workgroup's tiles ([0, nA) round-robin over waves 0-3, [nA, T) over waves 4-7); static -> deterministic
+  const int64_t T = (end - beg + 15) >> 4;
+  int64_t nA = ((T * 18 + 31) / 32 + 3) & ~(int64_t)3;
+  if (nA > T) nA = T;
+  const bool older = wave < 4;
+  const int64_t first = beg + 16 * (older ? (int64_t)wave : nA + (wave - 4));
+  const int64_t lend = older ? min(end, beg + 16 * nA) : end;
+  constexpr int TSTRIDE = 16 * (B16_WAVES / 2);
+  RawIn16 nxt = fetch_inputs16<HASH && TI == 2>(a, f, first + j, lend, ray_mode, rays_per_field, q);
+  for (int64_t base = first; base < lend; base += TSTRIDE) {
     // software pipeline: this tile's raw inputs were fetched one iteration ago; issue the next tile's
     // loads now so that their HBM latency hides behind this tile's arithmetic
     const RawIn16 cur = nxt;
     const int64_t n = base + j;
-    nxt = fetch_inputs16<HASH && TI == 2>(a, f, n + 16 * B16_WAVES, end, ray_mode, rays_per_field, q);
+    nxt = fetch_inputs16<HASH && TI == 2>(a, f, n + TSTRIDE, lend, ray_mode, rays_per_field, q);
     const bool valid = cur.valid;
     float x = 0, y = 0, z = 0;
     float4 dout = make_float4(0.f, 0.f, 0.f, 0.f);

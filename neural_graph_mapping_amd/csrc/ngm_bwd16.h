@@ -72,71 +72,10 @@ struct Lds16 {
   static constexpr int TOTAL = WTOTAL + B16_WAVES * WAVE_TOTAL;
 };
 
-// weights -> LDS: block (mo, mi) holds W[16mo + o][16mi + c] at row krow(c) = 4*(c&3) + (c>>2), col o
-template <int TI, int TH, int L, int RS = B16_RS>
-__device__ __forceinline__ void load_field16(float* sm, const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
-  using LY = Lds16<TI, TH, L, RS>;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int D = fc.dim_enc, H = fc.dim_hidden;
-  if (fc.encoding == NGM_ENC_PERMUTO) {
-    for (int l = tid; l < 16; l += nthr) {
-      float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l < fc.nr_levels) {
-        const float* hs = pr.shift + row * pr.shift_stride + 3 * l;
-        sc = make_float4(fc.level_scale[3 * l], fc.level_scale[3 * l + 1], fc.level_scale[3 * l + 2], 0.f);
-        sh = make_float4(hs[0], hs[1], hs[2], 0.f);
-      }
-      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l] = sc;
-      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l + 1] = sh;
-    }
-  } else {
-    for (int f = tid; f < TI * 16; f += nthr) {
-      float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
-      if (f < D) {
-        if (fc.encoding == NGM_ENC_FOURIER) {
-          const int n_raw = fc.raw_coords ? 3 : 0;
-          if (f < n_raw) e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-          else { const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3; e = make_float4(w[0], w[1], w[2], NGM_FK_SIN); }
-        } else if (fc.encoding == NGM_ENC_NERF) {
-          const int half = 3 * fc.num_octaves;
-          const int g = (f < half) ? f : f - half;
-          const int d = g / fc.num_octaves, o = g % fc.num_octaves;
-          const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
-          e = make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
-        } else e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-      }
-      reinterpret_cast<float4*>(sm + LY::ENCW)[f] = e;
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int TIN = (l == 0) ? TI : TH, Din = (l == 0) ? D : H;
-    const float* W = pr.w[l] + row * pr.w_stride[l];
-    const float* B = pr.b[l] + row * pr.b_stride[l];
-    float* dst = sm + LY::w_off(l);
-    const int ncol = TIN * 16, total = TH * 16 * ncol;
-    for (int e = tid; e < total; e += nthr) {
-      const int o = e / ncol, c = e - o * ncol;
-      const float v = (o < H && c < Din) ? W[(int64_t)o * Din + c] : 0.f;
-      const int mo = o >> 4, ol = o & 15, mi = c >> 4, cl = c & 15;
-      dst[(mo * TIN + mi) * LY::BLK + (4 * (cl & 3) + (cl >> 2)) * RS + ol] = v;
-    }
-    for (int o = tid; o < TH * 16; o += nthr) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
-  }
-  {
-    const float* W = pr.w[L] + row * pr.w_stride[L];
-    for (int f = tid; f < TH * 16; f += nthr) {
-      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < H) w4 = make_float4(W[f], W[H + f], W[2 * H + f], W[3 * H + f]);
-      reinterpret_cast<float4*>(sm + LY::WOUT)[f] = w4;
-    }
-  }
-}
-
-// Two-phase variant of load_field16 for B16_THREADS-thread workgroups: issue() starts every global load as
-// straight-line code (16-byte loads for the matrices when the rows allow it), commit() writes the same LDS image.
-// The serial loops of load_field16 cost the stash backward ~13 k clocks before its first MFMA; caller must
-// __syncthreads() after commit().
+// weights -> LDS in two phases (B16_THREADS-thread workgroups): issue() starts every global load as straight-line
+// code (16-byte loads for the matrices when the rows allow it), commit() writes the LDS image: block (mo, mi) holds
+// W[16mo + o][16mi + c] at row krow(c) = 4*(c&3) + (c>>2), col o.  (Loops that loaded and stored element by element
+// cost the stash backward ~13 k clocks before its first MFMA.)  Caller must __syncthreads() after commit().
 template <int TI, int TH, int L, int RS = B16_RS>
 struct FieldStage16 {
   static constexpr int NIT = (TH * 16 * TH * 4 + B16_THREADS - 1) / B16_THREADS;   // 16-byte chunks per thread and layer

@@ -31,85 +31,10 @@ struct FieldDims {
   int D, H, L, n_raw, n_feat;  // logical sizes; Fourier: n_raw = 3 if raw_coords, n_feat rows of enc_w
 };
 
-// Build the per-feature encoding table and copy + permute one field's weights into LDS.
-// All threads of the workgroup participate; caller must __syncthreads() afterwards.
-template <int MI, int MH, int L>
-__device__ __forceinline__ void load_field_to_lds(float* sm, const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
-  using LY = FieldLds<MI, MH, L>;
-  const int tid = threadIdx.x;
-  const int D = fc.dim_enc, H = fc.dim_hidden;
-  // ---- encoding table
-  const int nthr = blockDim.x;
-  if (fc.encoding == NGM_ENC_PERMUTO) {
-    // per level: {sx, sy, sz, 0, shift_x, shift_y, shift_z, 0}  (16 levels x 8 floats = the MI==1 table)
-    for (int l = tid; l < 16; l += nthr) {
-      float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l < fc.nr_levels) {
-        const float* hs = pr.shift + row * pr.shift_stride + 3 * l;
-        sc = make_float4(fc.level_scale[3 * l], fc.level_scale[3 * l + 1], fc.level_scale[3 * l + 2], 0.f);
-        sh = make_float4(hs[0], hs[1], hs[2], 0.f);
-      }
-      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l] = sc;
-      reinterpret_cast<float4*>(sm + LY::ENCW)[2 * l + 1] = sh;
-    }
-  } else
-  for (int f = tid; f < MI * 32; f += nthr) {
-    float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
-    if (f < D) {
-      if (fc.encoding == NGM_ENC_FOURIER) {
-        const int n_raw = fc.raw_coords ? 3 : 0;
-        if (f < n_raw) {
-          e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-        } else {
-          const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
-          e = make_float4(w[0], w[1], w[2], NGM_FK_SIN);
-        }
-      } else if (fc.encoding == NGM_ENC_NERF) {
-        // layout: sines (dim-major, octave-minor) then cosines (positional_encodings.py:268-271)
-        const int half = 3 * fc.num_octaves;
-        const int g = (f < half) ? f : f - half;
-        const int d = g / fc.num_octaves, o = g % fc.num_octaves;
-        const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
-        e = make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
-      } else {  // NGM_ENC_NONE: raw coordinates
-        e = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-      }
-    }
-    reinterpret_cast<float4*>(sm + LY::ENCW)[f] = e;
-  }
-  // ---- hidden layers: W_l (H x Din) row-major in HBM -> A-fragment order
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int MIN = (l == 0) ? MI : MH;
-    const int Din = (l == 0) ? D : H;
-    const float* W = pr.w[l] + row * pr.w_stride[l];
-    const float* B = pr.b[l] + row * pr.b_stride[l];
-    float* dst = sm + LY::w_off(l);
-    const int ncol = MIN * 32, total = MH * 32 * ncol;
-    for (int e = tid; e < total; e += nthr) {
-      const int o = e / ncol, c = e - o * ncol;
-      const float v = (o < H && c < Din) ? W[(int64_t)o * Din + c] : 0.f;
-      const int mo = o >> 5, io = o & 31, mi = c >> 5, ic = c & 31;
-      dst[((((mo * MIN + mi) * 16 + col_r(ic)) * 2 + col_hi(ic)) * NGM_WGS) + io] = v;
-    }
-    for (int o = tid; o < MH * 32; o += nthr) sm[LY::b_off(l) + o] = (o < H) ? B[o] : 0.f;
-  }
-  // ---- output layer (4 x H) -> float4 per hidden feature
-  {
-    const float* W = pr.w[L] + row * pr.w_stride[L];
-    const float* B = pr.b[L] + row * pr.b_stride[L];
-    for (int f = tid; f < MH * 32; f += nthr) {
-      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < H) w4 = make_float4(W[f], W[H + f], W[2 * H + f], W[3 * H + f]);
-      reinterpret_cast<float4*>(sm + LY::WOUT)[f] = w4;
-    }
-    if (tid < 4) sm[LY::BOUT + tid] = B[tid];
-  }
-}
-
 // Two-phase staging of one field's parameters for kernels that have other latency-bound work to do while the
 // weights travel: issue() only starts the global loads (straight-line code: everything is in flight at once;
-// 16-byte loads for the matrices when the rows allow it), commit() builds the same LDS image as load_field_to_lds.
+// 16-byte loads for the matrices when the rows allow it), commit() permutes them into the A-fragment order of the
+// forward kernels (FieldLds) and builds the per-feature encoding table.
 // Needs blockDim.x >= 256 (>= 32*MH threads for the small tables); caller must __syncthreads() after commit().
 template <int MI, int MH, int L>
 struct FieldStage {
@@ -155,7 +80,7 @@ struct FieldStage {
       wout = make_float4(W[tid], W[H + tid], W[2 * H + tid], W[3 * H + tid]);
     }
     bout = (tid < 4) ? pr.b[L][row * pr.b_stride[L] + tid] : 0.f;
-    // encoding table (same rows as load_field_to_lds)
+    // encoding table: one float4 per feature (weights of the argument, kind)
     enc0 = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
     enc1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (fc.encoding == NGM_ENC_PERMUTO) {

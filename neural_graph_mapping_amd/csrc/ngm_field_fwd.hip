@@ -23,7 +23,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  {
+    FieldStage<MI, MH, L> fstage;       // every parameter load in flight at once, then the permuting LDS writes
+    fstage.issue(a.fc, a.pr, row);
+    fstage.commit(sm, a.fc);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float div, off;

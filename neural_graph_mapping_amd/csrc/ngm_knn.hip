@@ -230,7 +230,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   const int tile = blockIdx.x - a.tile_off[f];
   const int beg = a.seg_off[f] + tile * KNN_TILE, end = min(a.seg_off[f + 1], beg + KNN_TILE);
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  load_field_to_lds<MI, MH, L>(sm, a.fc, a.pr, row);
+  {
+    FieldStage<MI, MH, L> fstage;       // every parameter load in flight at once, then the permuting LDS writes
+    fstage.issue(a.fc, a.pr, row);
+    fstage.commit(sm, a.fc);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float div, off;

@@ -285,6 +285,17 @@ int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, c
                           int32_t F, int64_t step, int64_t* step_dev, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int32_t advance_step_dev,
                           uint64_t* advance_philox_offset_dev, void* stream);
+/* ngm_render_bwd + the sparse Adam update of the active fields (rm.py:1183-1221) with the MLP tensors updated by the
+ * gradient-reduction kernel itself (no Adam launch, no gradient round trip; the gradients are still written to `grads`).
+ * mlp_tensors: one entry per gradient segment, in the order enc_w (Fourier encoding only), w_0, b_0, ..., w_L, b_L
+ * (their `grad` members are ignored); lattice_tensor: the hash tables (permutohedral encoding only, NULL otherwise),
+ * updated from grads->lattice by a regular Adam launch.  step / step_dev as in ngm_adam_sparse_multi. */
+int ngm_render_bwd_adam(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
+                        const ngm_rays* rays, const ngm_targets* targets, const ngm_prediction* pred,
+                        const float* loss_sums, const ngm_grads* grads, const ngm_adam_tensor* mlp_tensors,
+                        int32_t num_mlp_tensors, const ngm_adam_tensor* lattice_tensor, const int64_t* field_index,
+                        int64_t step, int64_t* step_dev, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float* loss_values, void* workspace, int64_t workspace_bytes, void* stream);
 /* ++*step_dev, ++*philox_offset_dev on the stream (either may be NULL): end-of-iteration bookkeeping
  * for graph-captured training loops. */
 int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* stream);

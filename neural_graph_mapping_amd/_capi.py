@@ -132,6 +132,10 @@ def lib():
                                  P(Prediction), vp, P(Grads), vp, vp, i64, vp]
     L.ngm_render_bwd_seeded.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), vp, vp, vp,
                                         P(Grads), vp, i64, vp]
+    L.ngm_render_bwd_adam.argtypes = [P(FieldCfg), P(RenderCfg), P(Params), P(Rays), P(Targets), P(Prediction), vp,
+                                      P(Grads), P(AdamTensor), i32, P(AdamTensor), vp, i64, vp, f32, f32, f32, f32, f32,
+                                      vp, vp, i64, vp]
+    L.ngm_render_bwd_adam.restype = C.c_int
     L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
     L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, i32, vp, vp]
@@ -161,7 +165,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd_packed",
             "ngm_field_eval_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
-            "ngm_render_bwd", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
+            "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
             "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays"]
 

@@ -359,6 +359,7 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
     if (rc) return rc;
   }
   GradReduceArgs g;
+  memset(&g.adam, 0, sizeof(g.adam));
   g.fc = *fcfg; g.gr = *grads; g.F = F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
   ngm_launch_grad_reduce(g, (hipStream_t)stream);
   return check_launch("ngm_grad_reduce");
@@ -560,7 +561,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
 
 static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
                              const ngm_rays* rays, StashBwdArgs& sb, const ngm_grads* grads, void* workspace,
-                             int64_t workspace_bytes, hipStream_t st) {
+                             int64_t workspace_bytes, hipStream_t st, const GradAdam* adam = nullptr) {
   const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, true);
   if (!workspace || workspace_bytes < p.total) return fail(NGM_E_WORKSPACE, "render_bwd: workspace too small");
   char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
@@ -593,8 +594,10 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
     if (e) return e;
   }
   GradReduceArgs g;
+  memset(&g.adam, 0, sizeof(g.adam));
+  if (adam) g.adam = *adam;
   g.fc = *fcfg; g.gr = *grads; g.F = rays->F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
-  ngm_launch_grad_reduce(g, st);
+  if (ngm_launch_grad_reduce(g, st)) return fail(NGM_E_INVALID, "render_bwd_adam: adam tensors do not match the parameter segments");
   return check_launch("ngm_grad_reduce");
 }
 
@@ -610,6 +613,37 @@ int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   sb.seed_mode = 0; sb.tg = *targets; sb.pred = *pred; sb.loss_sums = loss_sums;
   sb.loss_out = loss_out;      // written by the compositing-backward kernel (no separate launch)
   return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ngm_render_bwd_adam(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params, const ngm_rays* rays,
+                        const ngm_targets* targets, const ngm_prediction* pred, const float* loss_sums, const ngm_grads* grads,
+                        const ngm_adam_tensor* mlp_tensors, int32_t num_mlp_tensors, const ngm_adam_tensor* lattice_tensor,
+                        const int64_t* field_index, int64_t step, int64_t* step_dev, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  int e = check_render(fcfg, rcfg, params, rays);
+  if (e) return e;
+  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !loss_sums || !grads ||
+      !mlp_tensors || num_mlp_tensors < 1 || (step < 1 && !step_dev))
+    return fail(NGM_E_INVALID, "render_bwd_adam: bad argument");
+  if ((fcfg->encoding == NGM_ENC_PERMUTO) != (lattice_tensor != nullptr))
+    return fail(NGM_E_INVALID, "render_bwd_adam: lattice_tensor goes with the permutohedral encoding");
+  StashBwdArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.seed_mode = 0; sb.tg = *targets; sb.pred = *pred; sb.loss_sums = loss_sums;
+  sb.loss_out = loss_out;
+  GradAdam ad;
+  ad.tensors = mlp_tensors; ad.num = num_mlp_tensors; ad.field_index = field_index; ad.step = step; ad.step_dev = step_dev;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay;
+  e = render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream, &ad);
+  if (e) return e;
+  if (lattice_tensor) {        // the hash tables: their gradient comes out of k_hash_reduce, plain Adam launch
+    if (!lattice_tensor->param || !lattice_tensor->exp_avg || !lattice_tensor->exp_avg_sq || !lattice_tensor->grad)
+      return fail(NGM_E_INVALID, "render_bwd_adam: NULL lattice tensor");
+    ngm_launch_adam_multi(lattice_tensor, 1, field_index, rays->F, step, step_dev, lr, beta1, beta2, eps, weight_decay,
+                          nullptr, nullptr, (hipStream_t)stream);
+    e = check_launch("ngm_adam_sparse_multi");
+  }
+  return e;
 }
 
 int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,

@@ -446,12 +446,15 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // deterministic reduction of the per-workgroup partial gradient vectors into the caller's tensors
 // ------------------------------------------------------------------------------------------------
-struct GradSeg { int64_t off, size; float* dst; int64_t stride; };
+struct GradSeg { int64_t off, size; float* dst; int64_t stride; float* param; float* m; float* v; int64_t pstride; };
 struct GradReduceK {
   int F, blocks_per_field, nseg;
   const float* partials;
   int64_t p_pad, ptot;
   GradSeg seg[2 * (NGM_MAX_LAYERS + 1) + 1];
+  // fused sparse Adam (seg[k].param != NULL): torch.optim.Adam with L2-coupled weight decay, as k_adam_multi
+  const int64_t* field_index; const int64_t* step_dev; int64_t step;
+  float lr, beta1, beta2, eps, wd;
 };
 
 // 64 parameters x 4 interleaved quarter-sums of the per-workgroup partials per block (the quarters are
@@ -479,7 +482,23 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
   s = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
   for (int k = 0; k < a.nseg; ++k) {
     if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) {
-      if (a.seg[k].dst) a.seg[k].dst[(int64_t)f * a.seg[k].stride + (p - a.seg[k].off)] = s;
+      const int64_t i = p - a.seg[k].off;
+      if (a.seg[k].dst) a.seg[k].dst[(int64_t)f * a.seg[k].stride + i] = s;
+      if (a.seg[k].param) {
+        // the update of rm.py:1183-1221 on row field_index[f], straight from the reduced gradient (no second
+        // launch, no gradient round trip); same arithmetic as k_adam_multi
+        const double step = (double)(a.step_dev ? *a.step_dev : a.step);
+        const float lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+        const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+        const int64_t row = a.field_index ? a.field_index[f] : f;
+        const int64_t o = row * a.seg[k].pstride + i;
+        const float pv = a.seg[k].param[o];
+        const float g = s + a.wd * pv;
+        const float mn = a.beta1 * a.seg[k].m[o] + (1.0f - a.beta1) * g;
+        const float vn = a.beta2 * a.seg[k].v[o] + (1.0f - a.beta2) * g * g;
+        a.seg[k].m[o] = mn; a.seg[k].v[o] = vn;
+        a.seg[k].param[o] = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+      }
       break;
     }
   }
@@ -494,15 +513,26 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
   int n = 0;
   if (g.fc.encoding == NGM_ENC_FOURIER) {
     const int64_t sz = (int64_t)(g.fc.raw_coords ? g.fc.dim_enc - 3 : g.fc.dim_enc) * 3;
-    k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride};
+    k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride, nullptr, nullptr, nullptr, 0};
   }
   for (int l = 0; l <= g.fc.num_layers; ++l) {
     const int din = (l == 0) ? g.fc.dim_enc : g.fc.dim_hidden;
     const int dout = (l == g.fc.num_layers) ? g.fc.dim_out : g.fc.dim_hidden;
-    k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l]};
-    k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l]};
+    k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l], nullptr, nullptr, nullptr, 0};
+    k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l], nullptr, nullptr, nullptr, 0};
   }
   k.nseg = n;
+  k.field_index = nullptr; k.step_dev = nullptr; k.step = 1; k.lr = k.beta1 = k.beta2 = k.eps = k.wd = 0.f;
+  if (g.adam.tensors) {
+    if (g.adam.num != n) return NGM_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+      const ngm_adam_tensor& t = g.adam.tensors[i];
+      if (t.numel != k.seg[i].size || !t.param || !t.exp_avg || !t.exp_avg_sq) return NGM_E_INVALID;
+      k.seg[i].param = t.param; k.seg[i].m = t.exp_avg; k.seg[i].v = t.exp_avg_sq; k.seg[i].pstride = t.stride;
+    }
+    k.field_index = g.adam.field_index; k.step_dev = g.adam.step_dev; k.step = g.adam.step;
+    k.lr = g.adam.lr; k.beta1 = g.adam.beta1; k.beta2 = g.adam.beta2; k.eps = g.adam.eps; k.wd = g.adam.wd;
+  }
   dim3 grid((unsigned)((k.ptot + 63) / 64), (unsigned)g.F);
   hipLaunchKernelGGL(k_grad_reduce, grid, dim3(256), 0, st, k);
   return 0;

@@ -72,6 +72,15 @@ struct FieldBwdArgs {
 };
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st);
 
+// optional: apply sparse Adam to the reduced gradient in the same kernel (one adam tensor per gradient segment,
+// in the segment order enc_w (Fourier only), w_0, b_0, ..., w_L, b_L)
+struct GradAdam {
+  const ngm_adam_tensor* tensors;    // host array, num == number of segments; NULL: reduction only
+  int num;
+  const int64_t* field_index;
+  int64_t step; const int64_t* step_dev;
+  float lr, beta1, beta2, eps, wd;
+};
 struct GradReduceArgs {
   ngm_field_cfg fc;
   ngm_grads gr;
@@ -79,6 +88,7 @@ struct GradReduceArgs {
   int blocks_per_field;
   const float* partials;
   int64_t p_pad;
+  GradAdam adam;
 };
 
 // composite (quadrature) standalone + stash variants

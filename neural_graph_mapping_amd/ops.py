@@ -300,6 +300,24 @@ def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, b
                                     weight_decay, _stream()), "ngm_adam_sparse")
 
 
+def adam_tensor_arrays(fc, params, state, grads):
+    """(mlp AdamTensor array in gradient-segment order, lattice AdamTensor or None) for ngm_render_bwd_adam."""
+    names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
+    mlp = [n for n in names if n != "_encoding.lattice_values"]
+    arr = (K.AdamTensor * len(mlp))()
+    for i, n in enumerate(mlp):
+        p, g = params[n], grads[n]
+        arr[i] = K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
+                              g.data_ptr(), p.stride(0), g.stride(0), g[0].numel())
+    lat = None
+    if "_encoding.lattice_values" in names:
+        n = "_encoding.lattice_values"
+        p, g = params[n], grads[n]
+        lat = (K.AdamTensor * 1)(K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
+                                             g.data_ptr(), p.stride(0), g.stride(0), g[0].numel()))
+    return arr, len(mlp), lat
+
+
 def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=None, lr=1e-3, betas=(0.9, 0.999),
                        eps=1e-15, weight_decay=1e-5, advance=False, philox_offset_dev=None):
     """One launch for every parameter tensor of the field set (rows `field_index` updated in place)."""

@@ -497,18 +497,24 @@ class NeuralGraphRenderer:
         if "grads" not in w:
             w["grads"], w["gs"], w["gflat"] = ops.alloc_grads(fc, F, self._device)
         grads, gs = w["grads"], w["gs"]
-        K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
-                                 w["sums"].data_ptr(), C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
-                                 st), "ngm_render_bwd")
+        if update:
+            # backward + sparse Adam in one call: the gradient-reduction kernel applies the update of the MLP tensors
+            # itself (rm.py:1183-1221); the device counter already holds the new step (the loss reduction advanced it)
+            self._step += 1                                  # one counter for all fields (rm.py:380-385)
+            arr, n_mlp, lat = ops.adam_tensor_arrays(fc, allp, self._optim_state, grads)
+            K.check(L.ngm_render_bwd_adam(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
+                                          w["sums"].data_ptr(), C.byref(gs), arr, n_mlp, lat, ops._ptr(fids), int(self._step),
+                                          ops._ptr(self._step_dev), self._learning_rate, 0.9, 0.999, self._adam_eps,
+                                          self._adam_weight_decay, w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st),
+                    "ngm_render_bwd_adam")
+        else:
+            K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
+                                     w["sums"].data_ptr(), C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
+                                     st), "ngm_render_bwd")
         lv = w["loss"]
         loss = {"combined": lv[0], "termination": lv[1], "photometric_l1": lv[2], "depth_huber": lv[3],
                 "freespace": lv[4], "tsdf": lv[5]}
-        if update:
-            self._step += 1                                  # one counter for all fields (rm.py:380-385)
-            # the device counter already holds the new step: the forward's loss reduction advanced it
-            ops.adam_sparse_multi_(fc, allp, self._optim_state, grads, fids, self._step, self._step_dev,
-                                   lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
-        else:
+        if not update:
             loss["grads"] = grads
         loss["prediction"] = Prediction(w["rgbds"], w["color_vars"], w["depth_vars"], w["term_probs"], None, None)
         return loss

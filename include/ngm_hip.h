@@ -289,7 +289,7 @@ int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, c
  * gradient-reduction kernel itself (no Adam launch, no gradient round trip; the gradients are still written to `grads`).
  * mlp_tensors: one entry per gradient segment, in the order enc_w (Fourier encoding only), w_0, b_0, ..., w_L, b_L
  * (their `grad` members are ignored); lattice_tensor: the hash tables (permutohedral encoding only, NULL otherwise),
- * updated from grads->lattice by a regular Adam launch.  step / step_dev as in ngm_adam_sparse_multi. */
+ * updated by the table-gradient reduction kernel.  step / step_dev as in ngm_adam_sparse_multi. */
 int ngm_render_bwd_adam(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
                         const ngm_rays* rays, const ngm_targets* targets, const ngm_prediction* pred,
                         const float* loss_sums, const ngm_grads* grads, const ngm_adam_tensor* mlp_tensors,

@@ -561,7 +561,8 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
 
 static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
                              const ngm_rays* rays, StashBwdArgs& sb, const ngm_grads* grads, void* workspace,
-                             int64_t workspace_bytes, hipStream_t st, const GradAdam* adam = nullptr) {
+                             int64_t workspace_bytes, hipStream_t st, const GradAdam* adam = nullptr,
+                             const GradAdam* lattice_adam = nullptr, bool* lattice_adam_applied = nullptr) {
   const RenderPlan p = plan_render(fcfg, rcfg, rays->F, rays->R, rays->gt != nullptr, true);
   if (!workspace || workspace_bytes < p.total) return fail(NGM_E_WORKSPACE, "render_bwd: workspace too small");
   char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
@@ -588,7 +589,8 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   e = check_launch("ngm_field_bwd");
   if (e) return e;
   if (fcfg->encoding == NGM_ENC_PERMUTO) {
-    e = ngm_launch_hash_grad(a, st);
+    if (lattice_adam) a.lattice_adam = *lattice_adam;
+    e = ngm_launch_hash_grad(a, st, lattice_adam_applied);
     if (e) return fail(e, "permutohedral backward: hash table too large for the LDS-staged scatter");
     e = check_launch("ngm_hash_grad");
     if (e) return e;
@@ -634,11 +636,15 @@ int ngm_render_bwd_adam(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, c
   GradAdam ad;
   ad.tensors = mlp_tensors; ad.num = num_mlp_tensors; ad.field_index = field_index; ad.step = step; ad.step_dev = step_dev;
   ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay;
-  e = render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream, &ad);
+  if (lattice_tensor && (!lattice_tensor->param || !lattice_tensor->exp_avg || !lattice_tensor->exp_avg_sq || !lattice_tensor->grad))
+    return fail(NGM_E_INVALID, "render_bwd_adam: NULL lattice tensor");
+  GradAdam lad = ad;
+  lad.tensors = lattice_tensor; lad.num = lattice_tensor ? 1 : 0;
+  bool lattice_done = false;
+  e = render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream, &ad,
+                        lattice_tensor ? &lad : nullptr, &lattice_done);
   if (e) return e;
-  if (lattice_tensor) {        // the hash tables: their gradient comes out of k_hash_reduce, plain Adam launch
-    if (!lattice_tensor->param || !lattice_tensor->exp_avg || !lattice_tensor->exp_avg_sq || !lattice_tensor->grad)
-      return fail(NGM_E_INVALID, "render_bwd_adam: NULL lattice tensor");
+  if (lattice_tensor && !lattice_done) {   // unaligned tables: k_hash_reduce left the update to a plain Adam launch
     ngm_launch_adam_multi(lattice_tensor, 1, field_index, rays->F, step, step_dev, lr, beta1, beta2, eps, weight_decay,
                           nullptr, nullptr, (hipStream_t)stream);
     e = check_launch("ngm_adam_sparse_multi");

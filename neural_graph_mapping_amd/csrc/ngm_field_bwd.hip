@@ -595,6 +595,10 @@ struct HashGradArgs {
   const float2* dE; const float4* xyz;
   float* gtab; int64_t gstride;
   float* part;     // [F][L][chunks][2T] per-workgroup partial tables (plain stores, reduced in fixed order)
+  // optional fused sparse Adam on the tables (ad_param != NULL), as k_adam_multi
+  float* ad_param; float* ad_m; float* ad_v; int64_t ad_stride;
+  const int64_t* ad_field_index; const int64_t* ad_step_dev; int64_t ad_step;
+  float ad_lr, ad_beta1, ad_beta2, ad_eps, ad_wd;
 };
 
 __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
@@ -682,9 +686,29 @@ __global__ void k_hash_reduce(HashGradArgs a) {
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   reinterpret_cast<float4*>(a.gtab + (int64_t)f * a.gstride + (int64_t)level * T * 2)[i] = s;
+  if (a.ad_param) {
+    const double step = (double)(a.ad_step_dev ? *a.ad_step_dev : a.ad_step);
+    const float lr_bc1 = (float)((double)a.ad_lr / (1.0 - pow((double)a.ad_beta1, step)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.ad_beta2, step)));
+    const int64_t row = a.ad_field_index ? a.ad_field_index[f] : f;
+    const int64_t o4 = (row * a.ad_stride + (int64_t)level * T * 2) / 4 + i;       // tables are 16-byte aligned rows
+    float4 p = reinterpret_cast<float4*>(a.ad_param)[o4], m = reinterpret_cast<float4*>(a.ad_m)[o4],
+           v = reinterpret_cast<float4*>(a.ad_v)[o4];
+    float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &s.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float g = pg[c] + a.ad_wd * pp[c];
+      const float mn = a.ad_beta1 * pm[c] + (1.0f - a.ad_beta1) * g;
+      const float vn = a.ad_beta2 * pv[c] + (1.0f - a.ad_beta2) * g * g;
+      pm[c] = mn; pv[c] = vn;
+      pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.ad_eps));
+    }
+    reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
+    reinterpret_cast<float4*>(a.ad_param)[o4] = p;
+  }
 }
 
-int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st) {
+int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_applied) {
   HashGradArgs a;
   a.fc = fb.fc; a.pr = fb.pr; a.F = fb.F; a.P = fb.P; a.dE = fb.hash_dE; a.xyz = fb.hash_xyz;
   a.gtab = fb.lattice_grad; a.gstride = fb.lattice_grad_stride;
@@ -698,8 +722,22 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st) {
   if (chunks > 8) chunks = 8;
   a.chunks = chunks; a.per_chunk = (fb.P + chunks - 1) / chunks;
   a.part = fb.hash_part;
+  a.ad_param = nullptr;
+  if (fb.lattice_adam.tensors) {
+    const ngm_adam_tensor& t = fb.lattice_adam.tensors[0];
+    const int64_t per = (int64_t)fb.fc.nr_levels * T * 2;
+    // vector path only: rows and pointers 16-byte aligned (else the caller's separate Adam launch does it)
+    if (t.numel == per && (t.stride & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0) {
+      a.ad_param = t.param; a.ad_m = t.exp_avg; a.ad_v = t.exp_avg_sq; a.ad_stride = t.stride;
+      a.ad_field_index = fb.lattice_adam.field_index; a.ad_step_dev = fb.lattice_adam.step_dev; a.ad_step = fb.lattice_adam.step;
+      a.ad_lr = fb.lattice_adam.lr; a.ad_beta1 = fb.lattice_adam.beta1; a.ad_beta2 = fb.lattice_adam.beta2;
+      a.ad_eps = fb.lattice_adam.eps; a.ad_wd = fb.lattice_adam.wd;
+    }
+  }
   (void)hipFuncSetAttribute((const void*)k_hash_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_hash_grad, dim3(chunks, fb.fc.nr_levels, fb.F), dim3(512), lds, st, a);
   hipLaunchKernelGGL(k_hash_reduce, dim3((T / 2 + 255) / 256, fb.fc.nr_levels, fb.F), dim3(256), 0, st, a);
+  if (adam_applied) *adam_applied = a.ad_param != nullptr;
   return 0;
 }

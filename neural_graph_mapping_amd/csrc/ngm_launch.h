@@ -44,6 +44,15 @@ struct RenderFwdArgs {
 };
 
 // backward of the field MLP for flat samples of each field
+// optional: apply sparse Adam to the reduced gradient in the same kernel (one adam tensor per gradient segment,
+// in the segment order enc_w (Fourier only), w_0, b_0, ..., w_L, b_L)
+struct GradAdam {
+  const ngm_adam_tensor* tensors;    // host array, num == number of segments; NULL: reduction only
+  int num;
+  const int64_t* field_index;
+  int64_t step; const int64_t* step_dev;
+  float lr, beta1, beta2, eps, wd;
+};
 struct FieldBwdArgs {
   ngm_field_cfg fc;
   ngm_params pr;
@@ -69,18 +78,10 @@ struct FieldBwdArgs {
   const float* act;       // hidden-activation stash written by the forward (ray mode) or NULL = recompute
   int64_t act_layer_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
+  GradAdam lattice_adam;              // optional (tensors != NULL, num == 1): k_hash_reduce applies Adam to the hash tables
 };
-int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st);
+int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr);
 
-// optional: apply sparse Adam to the reduced gradient in the same kernel (one adam tensor per gradient segment,
-// in the segment order enc_w (Fourier only), w_0, b_0, ..., w_L, b_L)
-struct GradAdam {
-  const ngm_adam_tensor* tensors;    // host array, num == number of segments; NULL: reduction only
-  int num;
-  const int64_t* field_index;
-  int64_t step; const int64_t* step_dev;
-  float lr, beta1, beta2, eps, wd;
-};
 struct GradReduceArgs {
   ngm_field_cfg fc;
   ngm_grads gr;

@@ -755,6 +755,15 @@ def test_permuto_fused_train_step_vs_oracle():
     before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
     r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
     assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched
+    # the update itself (fused into the reduction kernels: MLP tensors in k_grad_reduce, hash tables in k_hash_reduce):
+    # first Adam step from zero moments on the oracle's gradients
+    for k in ("_encoding.lattice_values", "_linears.0.weight", "_linears.1.bias"):
+        exp, _, _ = O.adam_step(params[k], po[k].grad, torch.zeros_like(params[k]), torch.zeros_like(params[k]), 1,
+                                lr=1e-3, eps=1e-15, weight_decay=1e-5)
+        got = model.all_fields_params[k].cpu()
+        big = po[k].grad.abs() > 1e-3 * po[k].grad.abs().max()     # |update| = lr there, whatever the rounding of g
+        close(got[big], exp[big], rtol=1e-5, atol=2e-6)
+        assert float((got - params[k]).abs().max()) <= 1.001e-3     # nothing moves by more than lr on step 1
 
 
 # ------------------------------------------------------------------ training-target sampler (G11)

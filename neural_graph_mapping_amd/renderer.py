@@ -449,11 +449,33 @@ class NeuralGraphRenderer:
         first call with a given batch shape)."""
         if self._rc_train.geometry_mode == K.GEO["neus"]:
             return self.optimization_iteration_staged(target, u_coarse, u_guided, seed, update)
+        if target.ijs.shape[0] == 0:
+            return self._idle_iteration(update)
         ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=update)
         if self.process_group is not None:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
             torch.distributed.all_reduce(ctx["w"]["sums"], group=self.process_group)
         return self._iteration_backward(ctx, update)
+
+    def _idle_iteration(self, update=True) -> dict:
+        """A rank none of whose fields is active in this iteration: it contributes zeros to the loss
+        all-reduce (which it must still enter), launches nothing else, and keeps the shared counters in step."""
+        from . import distributed as D
+        sums = torch.zeros(16, device=self._device)
+        if self.process_group is not None:
+            torch.distributed.all_reduce(sums, group=self.process_group)
+        rc = self._rc_train
+        loss = D.loss_values_from_sums(sums, rc.w_termination, rc.w_photometric, rc.w_depth, rc.w_freespace, rc.w_tsdf)
+        if update:
+            self._step += 1
+            if self._step_dev is None:
+                self._step_dev = torch.full((1,), self._step, device=self._device, dtype=torch.int64)
+            else:
+                self._step_dev += 1
+        else:
+            loss["grads"] = {}
+        loss["prediction"] = None
+        return loss
 
     def _iteration_forward(self, target: Target, u_coarse=None, u_guided=None, seed=0, advance=True) -> dict:
         """First half of the iteration: fused forward + local loss sums (everything before the all-reduce).

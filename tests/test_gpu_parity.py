@@ -546,6 +546,25 @@ def test_full_size_properties_m1():
         grad_close(d["grads"][k], 2 * pa[k], 1e-5, k)
 
 
+def test_idle_rank_iteration():
+    """a rank with no active field in an iteration still enters the loss all-reduce with zeros and keeps the shared
+    step counter moving; without a process group that is just the bookkeeping."""
+    F, R = 2, 8
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=4, num_samples_depth_guided=4)
+    pos, quat, t = synth_target(F, R, seed=3)
+    r = make_renderer(fkw, ckw, F)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    empty = make_target({k: v[:0] for k, v in t.items()}, torch.arange(0))
+    p0 = {k: v.clone() for k, v in r._model.all_fields_params.items()}
+    out = r.optimization_iteration(empty, update=True)
+    assert float(out["combined"]) == 0.0 and r._step == 1 and int(r._step_dev.item()) == 1
+    for k, v in r._model.all_fields_params.items():
+        assert torch.equal(v, p0[k])
+    r.optimization_iteration(make_target(t, torch.arange(F)), seed=1, update=True)      # a normal iteration follows
+    assert r._step == 2 and int(r._step_dev.item()) == 2
+
+
 def test_iteration_counter_drives_jitter_and_adam_step():
     """One device counter counts the iterations (ngm_rays.philox_offset_autoinc): the forward adds it to the Philox
     offset, the loss reduction advances it, Adam reads it as its step.  update=False must leave it alone; a captured

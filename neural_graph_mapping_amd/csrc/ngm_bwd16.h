@@ -76,7 +76,9 @@ struct Lds16 {
 // code (16-byte loads for the matrices when the rows allow it), commit() writes the LDS image: block (mo, mi) holds
 // W[16mo + o][16mi + c] at row krow(c) = 4*(c&3) + (c>>2), col o.  (Loops that loaded and stored element by element
 // cost the stash backward ~13 k clocks before its first MFMA.)  Caller must __syncthreads() after commit().
-template <int TI, int TH, int L, int RS = B16_RS>
+// SWZ: the four 16-byte column groups of LDS row r sit at positions (group ^ (r >> 2)) -- with RS = 16 that makes the
+// 16-byte reads of dgrad16v (k_field_bwd16s) bank-conflict free (they were 2-way with the padded rows).
+template <int TI, int TH, int L, int RS = B16_RS, bool SWZ = false>
 struct FieldStage16 {
   static constexpr int NIT = (TH * 16 * TH * 4 + B16_THREADS - 1) / B16_THREADS;   // 16-byte chunks per thread and layer
   float4 v[L][NIT];
@@ -163,8 +165,13 @@ struct FieldStage16 {
         if (e4 < total4) {
           const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
           const int mo = o >> 4, ol = o & 15, mi = c >> 4, cl = c & 15;
-          float* blk = dst + (mo * TIN + mi) * LY::BLK + (cl >> 2) * RS + ol;     // row 4*j + (cl >> 2) for column cl + j
-          blk[0] = v[l][it].x; blk[4 * RS] = v[l][it].y; blk[8 * RS] = v[l][it].z; blk[12 * RS] = v[l][it].w;
+          float* blk = dst + (mo * TIN + mi) * LY::BLK + (cl >> 2) * RS;          // row 4*j + (cl >> 2) for column cl + j
+          const float x[4] = {v[l][it].x, v[l][it].y, v[l][it].z, v[l][it].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = SWZ ? ((((ol >> 2) ^ j) << 2) | (ol & 3)) : ol;       // row >> 2 == j
+            blk[4 * j * RS + col] = x[j];
+          }
         }
       }
       if (tid < TH * 16) sm[LY::b_off(l) + tid] = bias[l];

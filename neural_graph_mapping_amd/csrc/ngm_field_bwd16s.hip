@@ -37,10 +37,11 @@ __device__ __forceinline__ int bk_idx(int n, int ft) {
 }
 
 // Row stride of the 16x16 weight blocks in this kernel: only the data-gradient MFMAs read them, four consecutive
-// outputs at a time.  20 floats = 16-byte aligned rows -> one ds_read_b128 serves four k-steps and the 64 lanes spread
-// evenly over the eight 4-bank groups ((5 p + q) mod 8); with the 17 of the recompute kernel the same reads compile to
-// unaligned b96/b32 mixes and some banks are hit four times.
-#define S16_RS 20
+// outputs at a time (one ds_read_b128 = four k-steps).  Unpadded rows of 16 floats with the four 16-byte groups of row r
+// stored at (group ^ (r >> 2)): each of the instruction's four 16-lane service groups then touches 16 distinct 16-byte
+// slots (simulated with the lane groups of MI355X_MICROARCH.md, LDS) -- padded rows of 20 floats were 2-way
+// conflicted (SQ_LDS_BANK_CONFLICT 24 % of the LDS cycles of the kernel came from this and the tile stores).
+#define S16_RS 16
 
 template <int L>
 struct Lds16s {
@@ -105,7 +106,7 @@ __device__ __forceinline__ void mfma_results_ready(f32x4 (&d)[4]) {
 template <int BLK>
 __device__ __forceinline__ void dgrad16v(const float* __restrict__ W, int lane, const f32x4 (&dY)[4], f32x4 (&dX)[4]) {
   const int i = lane & 15, q = lane >> 4;
-  const float* Wl = W + (4 * (i & 3) + (i >> 2)) * S16_RS + 4 * q;
+  const float* Wl = W + (4 * (i & 3) + (i >> 2)) * S16_RS + 4 * (q ^ (i & 3));   // row = 4 (i & 3) + (i >> 2): swizzle by row >> 2
   // one 16-byte read = the A operands of the four k-steps (mo, r = 0..3) of tile mi; double buffered over mo
   float4 abuf[2][4];
 #pragma unroll
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16s(FieldBwdArgs a) {
   }
   // the weights are staged while the first tile's transfers are in flight (their LDS regions are disjoint)
   {
-    FieldStage16<4, 4, L, S16_RS> stage;
+    FieldStage16<4, 4, L, S16_RS, true> stage;
     stage.issue(a.fc, a.pr, row);
     stage.commit(sm, a.fc);
   }

@@ -736,10 +736,11 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
 
 
-def test_permuto_fused_train_step_vs_oracle():
-    """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP."""
+@pytest.mark.parametrize("F,R,n_c,n_g", [(3, 40, 8, 16), (1, 9, 4, 4), (2, 33, 3, 2), (5, 7, 8, 16), (3, 130, 20, 4)])
+def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
+    """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP; ragged shapes put
+    field starts in the middle of the 32-sample tiles of the encoding stash and leave partial 16-sample tiles."""
     torch.manual_seed(5)
-    F, R, n_c, n_g = 3, 40, 8, 16
     fs = O.FieldSpec(num_layers=1, **PERMUTO)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
     pos, quat, t = synth_target(F, R, seed=17)
@@ -767,6 +768,9 @@ def test_permuto_fused_train_step_vs_oracle():
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
     close(res["prediction"].rgbds, pred["rgbds"].detach(), rtol=2e-3, atol=2e-4)
+    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
+    if min(n_m, pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())) == 0:
+        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
     close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         if po[k].grad is not None:

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
       for (int m = 0; m < TI; ++m) { E[m] = f32x4{x, y, z, x}; dEa[m] = E[m]; }
     }
 #else
-    else encode16<TI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, q, x, y, z, E, dEa);
+    else encode16<TI, NEED_COS, ENC_GRAD, true>(sm + LY::ENCW, q, x, y, z, E, dEa);   // hardware sine / cosine, as the forward kernels
 #endif
     TICK(2);   // encode (sincos)
     WAVE_SYNC();

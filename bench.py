@@ -137,6 +137,20 @@ def cpu_baseline(budget_s=15.0):
                        f"oracle/ngm_oracle.py on torch CPU fp32, {dt:.1f} s")
 
 
+def launch_ranks(n):
+    """Re-exec this script under torch.distributed.run with n ranks on this node; returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,15 +166,35 @@ def main():
                          "permutohedral-hash network on the same batch (auxiliary measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torchrun rendezvous on
+        # 127.0.0.1) and pass their output through; the rank-0 child prints the JSON line
+        raise SystemExit(launch_ranks(args.gpus))
+
     from neural_graph_mapping_amd import _capi as K
     from neural_graph_mapping_amd import distributed as D
-    rank, local, world = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    share = os.environ.get("NGM_BENCH_SHARE_GPU", "0") == "1"       # test rigs with fewer GPUs than ranks (gloo only)
+    backend = os.environ.get("NGM_DIST_BACKEND") or None
+    world_env, local_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a line for the wrong job size")
+    ndev = torch.cuda.device_count()
+    if local_env >= ndev and not share:
+        raise SystemExit(f"rank with LOCAL_RANK={local_env} has no GPU of its own ({ndev} visible); one process per GPU")
+    dev_index = local_env % ndev
+    torch.cuda.set_device(dev_index)                                 # rank -> GPU binding before any collective
+    os.environ["LOCAL_RANK"] = str(dev_index)
+    rank, local, world = D.init_from_env(backend)
+    dev = torch.device("cuda", dev_index)
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the all-reduce saw {ranks_seen} ranks")
     L = K.lib()
 
     # field-per-GPU sharding: rank r owns global fields r, r+world, ... ; local slot = id // world
@@ -221,11 +255,17 @@ def main():
         if n.value:
             kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
 
+    devs = [dev_index]
+    if world > 1:                                    # which GPU every rank really ran on (rank -> GPU binding evidence)
+        dv = torch.zeros(world, device=dev, dtype=torch.int64)
+        dv[rank] = dev_index
+        torch.distributed.all_reduce(dv)
+        devs = dv.tolist()
     if rank == 0:
         n_local = F_PER_GPU * R * (S_C + S_G)
         value = world * n_local * args.steps / dt
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
-                   value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   value=value, unit="ray-samples/s", n_gpus=ranks_seen, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
                    config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
@@ -233,7 +273,8 @@ def main():
                                            "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
                                         + ", nrgbd compositing, NRGBD intrinsics",
                                fields_per_gpu=F_PER_GPU, rays_per_field=R, samples_per_ray=S_C + S_G,
-                               sharding=f"field-per-GPU x{world}", jitter="in-kernel Philox",
+                               sharding=f"field-per-GPU x{world}", ranks_seen=ranks_seen,
+                               devices=sorted(set(devs)), jitter="in-kernel Philox",
                                launch=("eager" if (not use_graph or getattr(replay, "graph", None) is None) else
                                        "hipGraph replay" if r.process_group is None else "2 hipGraphs + all-reduce"), final_loss=loss))
         fb = kern.get("field_bwd")

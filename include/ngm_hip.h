@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 1
+#define NGM_ABI_VERSION 2
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -241,7 +241,9 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
                    int64_t workspace_bytes, void* stream);
 /* Backward of loss["combined"] (rm.py:1871) w.r.t. every field parameter.  loss_sums are the
  * GLOBAL sums/counts (after the caller's cross-GPU all-reduce of ngm_render_fwd's output);
- * workspace must be the one filled by the matching ngm_render_fwd call.  loss_out (optional,
+ * workspace must be the one filled by the matching ngm_render_fwd call.  The workspace is
+ * SINGLE-USE: every ngm_render_bwd* call overwrites the saved forward values with the per-sample
+ * gradients in place, so a second backward needs a new ngm_render_fwd.  loss_out (optional,
  * device float[8]): combined, termination, photometric, depth, freespace, tsdf. */
 int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
                    const ngm_params* params, const ngm_rays* rays, const ngm_targets* targets,
@@ -256,9 +258,10 @@ int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
                           void* stream);
 /* read access to the per-sample values saved by ngm_render_fwd(train): copies geometry (F,R,S)
  * and sorted distances (F,R,S) out of the workspace (for Prediction.freespace_geometry /
- * tsdf_residuals, rm.py:624-639). */
+ * tsdf_residuals, rm.py:624-639).  S = the samples per ray the forward ran with: S_c + S_g when
+ * its rays carried gt, S_c otherwise (anything else: NGM_E_INVALID); geoms / dists hold F*R*S floats. */
 int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F,
-                            int32_t R, const void* workspace, float* geoms, float* dists,
+                            int32_t R, int32_t S, const void* workspace, float* geoms, float* dists,
                             void* stream);
 
 /* ---- sparse per-field Adam (rm.py:347-389, 668-707, 1183-1221) ---------------
@@ -302,7 +305,8 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
- * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4. */
+ * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4; N_f <= 4096 (the assignment kernel
+ * keeps 36 B per field in the 160 KiB LDS; more: NGM_E_UNSUPPORTED). */
 int64_t ngm_field_eval_knn_workspace(int32_t num_fields, int64_t P, int32_t num_knn);
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields,
                        int64_t P, const float* points, const float* field_pos,
@@ -345,6 +349,29 @@ int ngm_target_visibility(const ngm_keyframes* kf, int32_t F, const float* field
 int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* field_pos, float radius,
                     const float* bbox, const int64_t* frame_cids, const float* u_xy,
                     const ngm_target_out* out, void* stream);
+
+/* ---- mesh extraction -------------------------------------------------------------------
+ * Marching cubes on a dense grid of field values: replaces the pytorch3d.ops.marching_cubes call of
+ * NeuralGraphMap._extract_mesh (rm.py:2255-2298; the grid itself is filled by ngm_field_eval_knn, rm.py:2255-2261).
+ * volume (nx,ny,nz) fp32 row-major (z fastest), "inside" = value > isolevel (the caller negates nrgbd / neus volumes,
+ * rm.py:2277-2289).  Two passes over the same volume / workspace:
+ *   _count: classifies edges and cells, scans; counts (device int64[2]) = number of vertices, number of faces;
+ *   _emit : verts (V,3) fp32 in GRID-INDEX coordinates (x in [0,nx-1], ...; the caller maps them to world
+ *           coordinates as rm.py:2304-2317 does), faces (T,3) int64 vertex indices, outward normals
+ *           (inside -> outside).  Entries beyond max_verts / max_faces are dropped.
+ * Output order is deterministic: vertices by (grid point ((x*ny)+y)*nz+z, axis x<y<z) of the crossed edge's lower end,
+ * faces by cell index ((x*(ny-1))+y)*(nz-1)+z.  One vertex per crossed edge (indexed, watertight mesh).
+ * PARITY UNPINNED against pytorch3d (un-vendored): the triangulation table is derived from the cube topology
+ * (oracle/mesh_oracle.py restates it); vertex positions are the same linear interpolation.
+ * ngm_marching_cubes_tables copies the derived table (host call, no device): tri_table[256*15] edge ids (-1 padded),
+ * tri_count[256]. */
+int64_t ngm_marching_cubes_workspace(int32_t nx, int32_t ny, int32_t nz);
+int ngm_marching_cubes_count(const float* volume, int32_t nx, int32_t ny, int32_t nz, float isolevel,
+                             int64_t* counts, void* workspace, int64_t workspace_bytes, void* stream);
+int ngm_marching_cubes_emit(const float* volume, int32_t nx, int32_t ny, int32_t nz, float isolevel, float* verts,
+                            int64_t max_verts, int64_t* faces, int64_t max_faces, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int ngm_marching_cubes_tables(int8_t* tri_table, int32_t* tri_count);
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------
  * When enabled, every launch of the listed kernels is bracketed by hipEvents recorded on the launch

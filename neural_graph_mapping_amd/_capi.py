@@ -136,7 +136,7 @@ def lib():
                                       P(Grads), P(AdamTensor), i32, P(AdamTensor), vp, i64, vp, f32, f32, f32, f32, f32,
                                       vp, vp, i64, vp]
     L.ngm_render_bwd_adam.restype = C.c_int
-    L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, vp, vp, vp, vp]
+    L.ngm_render_read_samples.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, i32, vp, vp, vp, vp]
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
     L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, i32, vp, vp]
     L.ngm_step_advance.argtypes = [vp, vp, vp]
@@ -149,6 +149,13 @@ def lib():
     L.ngm_target_rays.argtypes = [P(Keyframes), i32, i32, vp, f32, vp, vp, vp, P(TargetOut), vp]
     L.ngm_target_visibility.restype = C.c_int
     L.ngm_target_rays.restype = C.c_int
+    L.ngm_marching_cubes_workspace.argtypes = [i32, i32, i32]
+    L.ngm_marching_cubes_workspace.restype = i64
+    L.ngm_marching_cubes_count.argtypes = [vp, i32, i32, i32, f32, vp, vp, i64, vp]
+    L.ngm_marching_cubes_emit.argtypes = [vp, i32, i32, i32, f32, vp, i64, vp, i64, vp, i64, vp]
+    L.ngm_marching_cubes_tables.argtypes = [vp, vp]
+    for name in ("ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"):
+        getattr(L, name).restype = C.c_int
     L.ngm_profile_enable.argtypes = [i32]
     L.ngm_profile_read.argtypes = [i32, P(C.c_double), P(i64)]
     for name in ("ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read"):
@@ -167,7 +174,8 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays"]
+            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_target_visibility", "ngm_target_rays",
+            "ngm_marching_cubes_workspace", "ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;
 # torch.optim.Adam skips grad-less parameters, so the sparse Adam must skip them too)

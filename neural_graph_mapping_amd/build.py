@@ -18,8 +18,11 @@ OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libngm_hip.so")
 SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_field_bwd16.hip", "ngm_field_bwd16s.hip", "ngm_target.hip", "ngm_composite.hip",
-           "ngm_knn.hip"]
-HEADERS = ["ngm_device.h", "ngm_field.h", "ngm_launch.h", "../../include/ngm_hip.h"]
+           "ngm_knn.hip", "ngm_mesh.hip"]
+def _headers():
+    """Every header any source may include: all of csrc/*.h + the public C ABI header (the digest of an
+    object covers all of them, so editing any header invalidates the cached objects)."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/ngm_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -32,7 +35,7 @@ def _hipcc():
 
 def _digest(src, flags):
     h = hashlib.sha256()
-    for f in [src] + HEADERS:
+    for f in [src] + _headers():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(flags).encode())

@@ -20,6 +20,12 @@ int ngm_launch_adam_multi(const ngm_adam_tensor* tensors, int n, const int64_t* 
                           const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd,
                           int64_t* advance_step, uint64_t* advance_offset, hipStream_t st);
 int ngm_launch_step_advance(int64_t* step_dev, uint64_t* off_dev, hipStream_t st);
+int64_t ngm_mc_workspace_bytes(int nx, int ny, int nz);
+int ngm_launch_mc_count(const float* vol, int nx, int ny, int nz, float iso, int64_t* counts, void* workspace,
+                        int64_t workspace_bytes, hipStream_t st);
+int ngm_launch_mc_emit(const float* vol, int nx, int ny, int nz, float iso, float* verts, int64_t max_verts,
+                       int64_t* faces, int64_t max_faces, void* workspace, int64_t workspace_bytes, hipStream_t st);
+int ngm_mc_copy_tables(int8_t* tri_table, int32_t* tri_count);
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
                    void* workspace, int64_t workspace_bytes, hipStream_t st);
@@ -664,11 +670,14 @@ int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
   return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F, int32_t R,
+int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F, int32_t R, int32_t S,
                             const void* workspace, float* geoms, float* dists, void* stream) {
   if (check_field_cfg(fcfg) || !rcfg || !workspace) return fail(NGM_E_INVALID, "render_read_samples: bad argument");
-  // the stash of a guided (training) render
-  const RenderPlan p = plan_render(fcfg, rcfg, F, R, true, true);
+  // S tells which plan the forward ran with (it plans from rays->gt): the stash offsets and the copy size depend on it
+  const bool guided = S != rcfg->num_samples_coarse;
+  if (S != rcfg->num_samples_coarse + (guided ? rcfg->num_samples_guided : 0))
+    return fail(NGM_E_INVALID, "render_read_samples: S is neither S_c nor S_c + S_g of this render cfg");
+  const RenderPlan p = plan_render(fcfg, rcfg, F, R, guided, true);
   const char* ws = reinterpret_cast<const char*>(align_up((int64_t)workspace, 256));
   ngm_launch_read_stash(reinterpret_cast<const float4*>(ws + p.off_stashA), reinterpret_cast<const float2*>(ws + p.off_stashB),
                         (int64_t)F * R * p.S, geoms, dists, (hipStream_t)stream);
@@ -727,6 +736,36 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   if (e == NGM_E_WORKSPACE) return fail(e, "ngm_field_eval_knn: workspace too small");
   if (e) return fail(e, "ngm_field_eval_knn: not available for this configuration");
   return check_launch("ngm_field_eval_knn");
+}
+
+// ------------------------------------------------------------------------------------------------
+// mesh extraction
+// ------------------------------------------------------------------------------------------------
+int64_t ngm_marching_cubes_workspace(int32_t nx, int32_t ny, int32_t nz) {
+  if (nx < 2 || ny < 2 || nz < 2 || 3 * (int64_t)nx * ny * nz + 1 > 0x7fffffff) return NGM_E_INVALID;
+  return ngm_mc_workspace_bytes(nx, ny, nz);
+}
+static int mc_fail(int e, const char* what) {
+  if (e == NGM_E_WORKSPACE) return fail(e, "marching cubes: workspace too small");
+  if (e == NGM_E_UNSUPPORTED) return fail(e, "marching cubes: grid too large (3 * nx * ny * nz must fit 31 bits)");
+  if (e == NGM_E_HIP) return fail(e, "marching cubes: HIP error");
+  if (e) return fail(e, what);
+  return check_launch(what);
+}
+int ngm_marching_cubes_count(const float* volume, int32_t nx, int32_t ny, int32_t nz, float isolevel, int64_t* counts,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+  return mc_fail(ngm_launch_mc_count(volume, nx, ny, nz, isolevel, counts, workspace, workspace_bytes, (hipStream_t)stream),
+                 "ngm_marching_cubes_count: bad argument");
+}
+int ngm_marching_cubes_emit(const float* volume, int32_t nx, int32_t ny, int32_t nz, float isolevel, float* verts,
+                            int64_t max_verts, int64_t* faces, int64_t max_faces, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+  return mc_fail(ngm_launch_mc_emit(volume, nx, ny, nz, isolevel, verts, max_verts, faces, max_faces, workspace,
+                                    workspace_bytes, (hipStream_t)stream), "ngm_marching_cubes_emit: bad argument");
+}
+int ngm_marching_cubes_tables(int8_t* tri_table, int32_t* tri_count) {
+  const int e = ngm_mc_copy_tables(tri_table, tri_count);
+  return e ? fail(e, "marching cubes: table derivation failed") : NGM_OK;
 }
 
 }  // extern "C"

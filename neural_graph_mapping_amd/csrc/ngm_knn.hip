@@ -300,7 +300,8 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
                    void* workspace, int64_t workspace_bytes, hipStream_t st) {
   if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
-  if (num_fields > 8192 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
+  // k_knn_assign keeps centres + histogram + 4 candidate lists of every field in LDS: 36 B per field of the 160 KiB
+  if (num_fields > 4096 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
   KnnArgs a;
   a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.P = P; a.points = points; a.pos = pos; a.quat = quat;
   a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = fc->field_radius; a.out = out;
@@ -318,7 +319,13 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
   const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
   const size_t lds_a = (size_t)num_fields * (20 + 4 * 4);    // centres, histogram, 4 waves of candidate lists
+  if (lds_a > 48 * 1024) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_assign),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36);
+    if (attr != hipSuccess) return NGM_E_HIP;
+  }
   hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
+  if (hipGetLastError() != hipSuccess) return NGM_E_HIP;      // an over-sized LDS request fails here, not four launches later
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
   hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), (size_t)num_fields * 4, st, a);

@@ -118,14 +118,16 @@ def gather_image(local_rows: torch.Tensor, num_pixels: int, group=None, dst: int
     per = (num_pixels + world - 1) // world
     pad = torch.zeros((per,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     pad[: local_rows.shape[0]] = local_rows
-    blocks = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(blocks, pad, group=group)
-    if dist.get_rank(group) != dst:
+    # gather to ONE rank: only `dst` allocates the image (an all_gather would hand every rank a copy it drops)
+    me = dist.get_rank(group)
+    blocks = [torch.empty_like(pad) for _ in range(world)] if me == dst else None
+    dist.gather(pad, blocks, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+    if me != dst:
         return None
     return torch.cat(blocks)[:num_pixels]
 
 
-def render_image_sharded(renderer, c2w, num_fields: int, camera=None, group=None, dst: int = 0):
+def render_image_sharded(renderer, c2w, num_fields: int, camera=None, group=None, dst: int = 0, u=None, seed: int = 0):
     """render_image (rm.py:402-437) on a field-per-GPU sharded map: all-gather the field parameters once, every
     rank renders its slice of the pixels with the kNN-blended evaluation kernels, rank `dst` receives the image."""
     cam = camera or renderer._camera
@@ -133,7 +135,7 @@ def render_image_sharded(renderer, c2w, num_fields: int, camera=None, group=None
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     full = gather_field_params(renderer._model.all_fields_params, num_fields, group)
     b, e = pixel_shard(cam.height * cam.width, rank, world)
-    rgbd, dvar = renderer.render_pixels(c2w, b, e, params=full, camera=cam)
+    rgbd, dvar = renderer.render_pixels(c2w, b, e, params=full, camera=cam, u=u, seed=seed)
     img = gather_image(torch.cat([rgbd, dvar[:, None]], -1), cam.height * cam.width, group, dst)
     if img is None:
         return None, None

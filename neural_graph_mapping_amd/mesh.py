@@ -1,0 +1,200 @@
+"""Mesh extraction: dense-grid field evaluation -> marching cubes -> vertex colours -> PLY.
+
+Host-side mirror of ``NeuralGraphMap._extract_mesh`` (run_mapping.py:2186-2384).  The grid is filled by the
+kNN-blended evaluation kernels (``ops.field_eval_knn``), the iso-surface is extracted by the HIP marching-cubes
+kernels (``ngm_marching_cubes_*``; the reference calls the un-vendored ``pytorch3d.ops.marching_cubes``), the file
+is the binary little-endian PLY layout ``pytorch3d.io.save_ply`` writes for (verts, faces, verts_colors).
+No CPU fallback: device tensors in, device tensors out.
+"""
+import ctypes as C
+import itertools
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi as K
+from . import ops
+
+
+def marching_cubes(volume: torch.Tensor, isolevel: float):
+    """volume (nx, ny, nz) fp32 on the GPU, inside = value > isolevel -> (verts (V,3) fp32 in grid-index
+    coordinates (x, y, z), faces (T,3) int64).  Deterministic order, one vertex per crossed grid edge."""
+    ops._require_gpu(volume)
+    if volume.dim() != 3 or volume.dtype != torch.float32:
+        raise ValueError("marching_cubes expects a (nx, ny, nz) float32 volume")
+    volume = volume.contiguous()
+    nx, ny, nz = volume.shape
+    L = K.lib()
+    wsb = L.ngm_marching_cubes_workspace(nx, ny, nz)
+    if wsb < 0:
+        raise ValueError(f"marching_cubes: grid {nx}x{ny}x{nz} not supported (every side >= 2, 3*nx*ny*nz < 2^31)")
+    dev = volume.device
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    counts = torch.zeros(2, device=dev, dtype=torch.int64)
+    st = ops._stream()
+    K.check(L.ngm_marching_cubes_count(volume.data_ptr(), nx, ny, nz, float(isolevel), counts.data_ptr(), ws.data_ptr(), wsb,
+                                       st), "ngm_marching_cubes_count")
+    nv, nf = (int(v) for v in counts.tolist())                  # the only host sync: output sizes
+    verts = torch.empty(nv, 3, device=dev, dtype=torch.float32)
+    faces = torch.empty(nf, 3, device=dev, dtype=torch.int64)
+    if nv or nf:
+        K.check(L.ngm_marching_cubes_emit(volume.data_ptr(), nx, ny, nz, float(isolevel), verts.data_ptr(), nv,
+                                          faces.data_ptr(), nf, ws.data_ptr(), wsb, st), "ngm_marching_cubes_emit")
+    return verts, faces
+
+
+def save_ply(path_or_file, verts: torch.Tensor, faces: torch.Tensor, verts_colors: Optional[torch.Tensor] = None) -> None:
+    """Binary little-endian PLY as pytorch3d.io.save_ply(f, verts, faces, verts_colors, ascii=False,
+    colors_as_uint8=False) lays it out (the call of rm.py:2375-2384): float x y z [red green blue] per vertex,
+    `list uchar int vertex_indices` per face."""
+    v = verts.detach().cpu().numpy().astype("<f4")
+    f = faces.detach().cpu().numpy().astype("<i4")
+    header = ["ply", "format binary_little_endian 1.0", f"element vertex {len(v)}", "property float x", "property float y",
+              "property float z"]
+    if verts_colors is not None:
+        c = verts_colors.detach().cpu().numpy().astype("<f4")
+        header += ["property float red", "property float green", "property float blue"]
+        v = np.concatenate([v, c], 1)
+    header += [f"element face {len(f)}", "property list uchar int vertex_indices", "end_header"]
+    rec = np.empty(len(f), dtype=[("n", "u1"), ("idx", "<i4", (3,))])
+    rec["n"] = 3
+    rec["idx"] = f
+    own = isinstance(path_or_file, (str, os.PathLike))
+    fp = open(path_or_file, "wb") if own else path_or_file
+    try:
+        fp.write(("\n".join(header) + "\n").encode("ascii"))
+        fp.write(np.ascontiguousarray(v).tobytes())
+        fp.write(rec.tobytes())
+    finally:
+        if own:
+            fp.close()
+
+
+def load_ply(path):
+    """Reader for the files save_ply writes (tests / round trips): (verts (V,3), faces (T,3), colors (V,3) | None)."""
+    with open(path, "rb") as fp:
+        props, nv, nf = [], 0, 0
+        while True:
+            line = fp.readline().decode("ascii").strip()
+            if line.startswith("element vertex"):
+                nv = int(line.split()[-1])
+            elif line.startswith("element face"):
+                nf = int(line.split()[-1])
+            elif line.startswith("property float"):
+                props.append(line.split()[-1])
+            elif line == "end_header":
+                break
+        v = np.frombuffer(fp.read(4 * len(props) * nv), dtype="<f4").reshape(nv, len(props))
+        rec = np.frombuffer(fp.read(13 * nf), dtype=[("n", "u1"), ("idx", "<i4", (3,))])
+    cols = torch.from_numpy(v[:, 3:6].copy()) if len(props) >= 6 else None
+    return torch.from_numpy(v[:, :3].copy()), torch.from_numpy(rec["idx"].astype(np.int64)), cols
+
+
+def _matrix_to_quaternion(R: torch.Tensor) -> torch.Tensor:
+    """real-first unit quaternion of a rotation matrix (the sign is irrelevant for rotating points)"""
+    m = R.double()
+    t = m.trace()
+    if t > 0:
+        s = torch.sqrt(t + 1.0) * 2
+        q = torch.stack([0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s])
+    else:
+        i = int(torch.argmax(torch.diagonal(m)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = torch.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+        q = torch.zeros(4, dtype=torch.float64)
+        q[0] = (m[k, j] - m[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (m[j, i] + m[i, j]) / s
+        q[1 + k] = (m[k, i] + m[i, k]) / s
+    return (q / q.norm()).float()
+
+
+def _quat_mul(a, b):
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+@torch.no_grad()
+def extract_mesh(renderer, mesh_file_path=None, resolution: Optional[float] = None, threshold: Optional[float] = None,
+                 transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200):
+    """NeuralGraphMap._extract_mesh (rm.py:2186-2384): bounding box of the field centres +- 2 r, grid of spacing
+    `resolution` (default: the training sample spacing, rm.py:199-207), blocks of `block`^3 cells evaluated with the
+    kNN-blended fields, marching cubes per block, vertex colours from a second evaluation with radius + 0.1
+    (rm.py:2320-2340), one PLY + `<stem>_fields.txt`.  Returns (verts (V,3) world, faces (T,3), colours (V,3) in
+    [0,255] as the reference stores them) or None when no block crosses the iso-surface."""
+    m = renderer._model
+    dev = renderer._device
+    gmd = renderer._global_map_dict
+    num = gmd["num"]
+    pos = gmd["positions"][:num]
+    quat = gmd["orientations"][:num]
+    if transform is not None:
+        transform = transform.to(dev)
+        pos = pos @ transform[:3, :3].T + transform[:3, 3]                     # utils.transform_points
+        quat = _quat_mul(_matrix_to_quaternion(transform[:3, :3].cpu()).to(dev), quat)   # utils.transform_quaternions
+    params = {k: v for k, v in m.all_fields_params.items() if k != "_neus_sd"}
+    fidx = None
+    if field_ids is not None:
+        field_ids = field_ids[field_ids < num].to(dev)
+        if len(field_ids) == 0:
+            return None
+        pos, quat, fidx = pos[field_ids].contiguous(), quat[field_ids].contiguous(), field_ids.contiguous()
+    r = renderer._field_radius
+    lo = pos.min(0)[0] - 2 * r
+    hi = pos.max(0)[0] + 2 * r
+    if resolution is None:
+        cfg = renderer._config
+        n_g = cfg.get("num_samples_depth_guided", 0)
+        rho = cfg.get("range_depth_guided") or cfg.get("truncation_distance", 0.1)
+        resolution = 2 * rho / n_g if n_g > 0 else 2 * r / cfg["num_samples_coarse"]
+    axes = [torch.arange(float(lo[i]), float(hi[i]), step=resolution, device=dev) for i in range(3)]
+    mode = renderer._rc_train.geometry_mode
+    isolevel, low_is_inside = {K.GEO["occupancy"]: (0.5, False), K.GEO["density"]: (30.0, False),
+                               K.GEO["neus"]: (0.0, True), K.GEO["nrgbd"]: (0.0, True)}[mode]     # rm.py:2268-2289
+    if threshold is not None:
+        isolevel = threshold
+    gfac, cfac = renderer._rc_train.geometry_factor, renderer._rc_train.color_factor
+    fc_color = m.field_cfg(r + 0.1)                                  # "avoid black colors on field boundaries"
+    big = int(renderer._config.get("block_size", 3000000))
+
+    def evaluate(fc, pts):
+        outs = [ops.field_eval_knn(fc, params, pts[s:s + big], pos, quat, m._num_knn, m._distance_factor, m._outside_value,
+                                   fidx) for s in range(0, pts.shape[0], big)]
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    all_v, all_f, all_c, offset = [], [], [], 0
+    starts = [range(0, len(a) - 1, block) for a in axes]               # blocks overlap by one grid plane (rm.py:2236-2240)
+    for xs, ys, zs in itertools.product(*starts):
+        bx, by, bz = axes[0][xs:xs + block + 1], axes[1][ys:ys + block + 1], axes[2][zs:zs + block + 1]
+        xyz = torch.cartesian_prod(bx, by, bz)
+        vol = evaluate(renderer._fc, xyz)[:, 3].reshape(len(bx), len(by), len(bz))
+        if mode == K.GEO["occupancy"]:
+            vol = torch.sigmoid(gfac * vol)
+        if low_is_inside:
+            vol = -vol
+        v, f = marching_cubes(vol.contiguous(), isolevel)
+        if len(v) == 0:
+            continue
+        # grid-index coordinates -> world: the block's axes are uniform, so this is the reference's affine map of the
+        # normalised coordinates (rm.py:2304-2317) without the detour through [-1, 1]
+        org = torch.stack([bx[0], by[0], bz[0]])
+        span = torch.stack([bx[-1] - bx[0], by[-1] - by[0], bz[-1] - bz[0]])
+        n1 = torch.tensor([len(bx) - 1, len(by) - 1, len(bz) - 1], device=dev, dtype=torch.float32)
+        vw = v / n1 * span + org
+        col = torch.clamp(cfac * evaluate(fc_color, vw)[:, :3], 0, 1) * 255
+        all_v.append(vw)
+        all_f.append(f + offset)
+        all_c.append(col)
+        offset += len(vw)
+    if not all_v:
+        return None
+    verts, faces, cols = torch.cat(all_v), torch.cat(all_f), torch.cat(all_c)
+    if mesh_file_path is not None:
+        stem, _ = os.path.splitext(str(mesh_file_path))
+        np.savetxt(stem + "_fields.txt", pos.cpu().numpy())
+        save_ply(mesh_file_path, verts, faces, cols)
+    return verts, faces, cols

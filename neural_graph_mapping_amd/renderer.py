@@ -88,7 +88,7 @@ class _RenderIjs(torch.autograd.Function):
         geoms = dists = None
         if ws is not None:
             geoms, dists = torch.empty(F, R, S, device=dev), torch.empty(F, R, S, device=dev)
-            K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, ws.data_ptr(), geoms.data_ptr(),
+            K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, S, ws.data_ptr(), geoms.data_ptr(),
                                               dists.data_ptr(), ops._stream()), "ngm_render_read_samples")
         ctx.fc, ctx.rc, ctx.names, ctx.rays_kw, ctx.ws, ctx.wsb = fc, rc, names, rays_kw, ws, wsb
         ctx.save_for_backward(*param_tensors)
@@ -99,6 +99,10 @@ class _RenderIjs(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_rgbds, d_cv, d_dv, d_term, d_geoms, d_dists):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("render_ijs: second backward through the same render -- the backward kernels overwrite the "
+                               "saved per-sample values in place (single-use workspace, include/ngm_hip.h); render again")
+        ctx.consumed = True
         fc, rc, names = ctx.fc, ctx.rc, ctx.names
         params = dict(zip(names, ctx.saved_tensors))
         keep = []
@@ -183,6 +187,12 @@ class NeuralGraphRenderer:
                                    m._outside_value) for s in range(0, pts.shape[0], block)]
         return torch.cat(outs).reshape(*lead, 4)
 
+    def extract_mesh(self, mesh_file_path=None, resolution: Optional[float] = None, threshold: Optional[float] = None,
+                     transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200):
+        """_extract_mesh (rm.py:2186-2384): dense grid -> HIP marching cubes -> vertex colours -> PLY (see mesh.py)."""
+        from . import mesh
+        return mesh.extract_mesh(self, mesh_file_path, resolution, threshold, transform, field_ids, block)
+
     # -- reference-compatible API --------------------------------------------------------------
     def quadrature(self, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):
         return ops.quadrature(self._rc_train, sample_colors, sample_geometries, sample_distances, sample_depths,
@@ -196,8 +206,9 @@ class NeuralGraphRenderer:
             raise NotImplementedError("render_ijs: only the training path (use_vmap=True, field_ids given) is fused; "
                                       "use render_image for the kNN evaluation path")
         self._model.set_vmap_fields(field_ids)
-        for v in self._model.vmap_fields_params.values():
-            v.requires_grad_()
+        for n, v in self._model.vmap_fields_params.items():
+            if n not in K.NO_GRAD_PARAMS:                 # constants (hash shifts): no gradient, no Adam, no weight decay
+                v.requires_grad_()
         guided = gt_distances is not None and self._rc_train.num_samples_guided > 0
         rc = self._rc_train if guided else self._rc_plain
         if not overwrite_samples_behind_camera:                      # default True (rm.py:450); checked per sample
@@ -273,7 +284,7 @@ class NeuralGraphRenderer:
                                u_coarse=u_coarse, u_guided=u_guided, seed=seed)
         loss = self.compute_losses(target, pred)
         params = self._model.vmap_fields_params
-        names = [n for n, v in params.items() if v.requires_grad]
+        names = [n for n, v in params.items() if v.requires_grad and n not in K.NO_GRAD_PARAMS]
         grads = torch.autograd.grad(loss["combined"], [params[n] for n in names], allow_unused=True)
         gd = {n: (g if g is not None else torch.zeros_like(params[n])) for n, g in zip(names, grads)}
         out = {k: v.detach() for k, v in loss.items()}
@@ -541,7 +552,7 @@ class NeuralGraphRenderer:
         loss["prediction"] = Prediction(w["rgbds"], w["color_vars"], w["depth_vars"], w["term_probs"], None, None)
         return loss
 
-    def capture_iteration(self, target: Target, seed=0):
+    def capture_iteration(self, target: Target, seed=0, u_coarse=None, u_guided=None):
         """Capture optimization_iteration(target) into hipGraphs (torch.cuda.CUDAGraph); the returned callable
         replays it.  Tensors of `target` are read in place at every replay; the Adam step counter and the Philox
         jitter offset live on the device and advance inside the graph.  With a process group the iteration becomes
@@ -553,12 +564,12 @@ class NeuralGraphRenderer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):                                # warm-up on a side stream (allocations, lazy init)
-                out = self.optimization_iteration(target, seed=seed)
+                out = self.optimization_iteration(target, u_coarse, u_guided, seed=seed)
         torch.cuda.current_stream().wait_stream(s)
         if self.process_group is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.optimization_iteration(target, seed=seed)
+                out = self.optimization_iteration(target, u_coarse, u_guided, seed=seed)
             self._step -= 1                                   # the capture pass records, it does not execute
 
             def replay():
@@ -572,7 +583,7 @@ class NeuralGraphRenderer:
         try:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                ctx = self._iteration_forward(target, None, None, seed, advance=True)
+                ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=True)
             with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 out = self._iteration_backward(ctx, True)
         except RuntimeError:
@@ -581,7 +592,7 @@ class NeuralGraphRenderer:
             torch.cuda.synchronize()
 
             def eager():
-                return self.optimization_iteration(target, seed=seed)
+                return self.optimization_iteration(target, u_coarse, u_guided, seed=seed)
             eager.graph = None
             return eager
         self._step -= 1

@@ -149,7 +149,7 @@ def stratified_distances(near, far, n: int, u):
 
 
 def sample_rays(ijs, cam: CameraSpec, near, far, gt, spec: RenderSpec, u_coarse, u_guided=None,
-                num_samples=None):
+                num_samples=None, return_order=False):
     """Coarse stratum + depth-guided stratum, merged ascending (rm.py:513-545).
 
     Returns points_cam (...,S,3), distances (...,S) sorted, dirs (...,3)."""
@@ -162,8 +162,12 @@ def sample_rays(ijs, cam: CameraSpec, near, far, gt, spec: RenderSpec, u_coarse,
         g_near = torch.where(invalid, near, gt - spec.range_depth_guided)
         g_far = torch.where(invalid, far, gt + spec.range_depth_guided)
         t_g = stratified_distances(g_near, g_far, n_g, u_guided)
-        t = torch.sort(torch.cat([t, t_g], -1), dim=-1)[0]          # rm.py:538-545
+        t, order = torch.sort(torch.cat([t, t_g], -1), dim=-1)      # rm.py:538-545
+    else:
+        order = torch.arange(t.shape[-1]).expand(t.shape)
     pts = dirs.unsqueeze(-2) * t.unsqueeze(-1)                      # camera.py:291
+    if return_order:       # test aid: sorted slot -> source element (< n_c: coarse draw, else guided draw - n_c)
+        return pts, t, dirs, order
     return pts, t, dirs
 
 
@@ -306,10 +310,11 @@ def encode_permuto(x, lattice, shift, fs: FieldSpec):
     return out.reshape(F, P, L * lattice.shape[-1])
 
 
-def field_mlp(h, params, fs: FieldSpec):
+def field_mlp(h, params, fs: FieldSpec, pre_out: Optional[list] = None):
     """NeuralField.forward (models.py:143-182): relu on all but the last layer, then the skip connection:
     concat appends the encoding, add adds it to the first D units, rezero scales by a learnt per-layer scalar and
-    adds the layer's own input (the encoding for layer 0)."""
+    adds the layer's own input (the encoding for layer 0).  `pre_out` (test aid) collects the hidden layers'
+    pre-activations, i.e. the arguments of the ReLUs."""
     n = fs.num_layers
     D = fs.dim_enc
     enc = h
@@ -320,6 +325,8 @@ def field_mlp(h, params, fs: FieldSpec):
         h = torch.einsum("fpi,foi->fpo", h, W) + b.unsqueeze(-2)
         if i == n:
             break
+        if pre_out is not None:
+            pre_out.append(h)
         h = torch.relu(h)
         if fs.skip_mode == "concat":
             h = torch.cat((h, enc), -1)

@@ -1,0 +1,204 @@
+"""-m gpu tests named after the BASELINE.json configurations whose shapes the parity suite did not reach:
+
+  cfg2  Replica office0: the reference's default network (permutohedral hash, 1x32 MLP) at full batch size
+  cfg3  ScanNet, ~200 pose-graph fields, a random active set of <= 32 per iteration (rm.py:1280-1319)
+  cfg4  8192 rays x 256 samples per batch
+  eval  the derived evaluation sample count S = 640 (rm.py:199-207) through the fused render
+
+Each shape gets (a) a comparison with the CPU oracle at a size the oracle finishes in seconds (ragged on purpose) and
+(b) size-independent properties at the full size: finiteness, term in [0,1], non-negative variances, bitwise run-to-run
+determinism, untouched inactive fields.  Tolerances as in test_gpu_parity.py (forward 2e-4 / 2e-5, gradients 2e-3 of
+max |grad|; hash: forward 2e-3 / 2e-4 -- parity of the hash encoding with the reference's CUDA package is unpinned)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import (DEV, NRGBD, close, grad_close, kink_free_draws, make_renderer, make_target,  # noqa: E402
+                        ragged_case, synth_target)
+from neural_graph_mapping_amd import _capi as K  # noqa: E402
+from oracle import ngm_oracle as O  # noqa: E402
+
+FOURIER = dict(encoding="fourier", dim_enc=64, num_layers=2)
+HASH = dict(encoding="permuto", num_layers=1, nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4)
+
+
+def _perturb(r, scale=0.05, lattice=0.1):
+    """random-init fields that differ from each other (add_fields clones the prototype)"""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    with torch.no_grad():
+        for k, v in r._model.all_fields_params.items():
+            if k == "_encoding.lattice_values":
+                v.add_(lattice * torch.randn(v.shape, device=DEV, generator=g))
+            elif v.dim() > 1 and k != "_encoding.random_shift_per_level":
+                v.add_(scale * torch.randn(v.shape, device=DEV, generator=g))
+
+
+def _properties(r, tgt, seed=11):
+    a = r.optimization_iteration(tgt, seed=seed, update=False)
+    ga = {k: v.clone() for k, v in a["grads"].items()}
+    p = a["prediction"]
+    rgbds, term = p.rgbds.clone(), p.term_probs.clone()
+    assert torch.isfinite(rgbds).all() and torch.isfinite(a["combined"]) and float(a["combined"]) > 0
+    for k, v in ga.items():
+        assert torch.isfinite(v).all(), k
+        assert k in K.NO_GRAD_PARAMS or float(v.abs().max()) > 0, k
+    assert float(term.min()) >= -1e-6 and float(term.max()) <= 1 + 1e-5            # sum w + background = 1
+    assert (p.color_vars >= -1e-7).all() and (p.depth_vars >= -1e-7).all()
+    b = r.optimization_iteration(tgt, seed=seed, update=False)                     # fixed reduction orders everywhere
+    assert torch.equal(b["prediction"].rgbds, rgbds) and torch.equal(b["prediction"].term_probs, term)
+    for k in ga:
+        assert torch.equal(b["grads"][k], ga[k]), k
+    c = r.optimization_iteration(tgt, seed=seed + 1, update=False)                 # other jitter, other numbers
+    assert not torch.equal(c["prediction"].rgbds, rgbds)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ cfg2
+def test_cfg2_hash_network_full_m1_batch_properties():
+    F, R = 8, 512
+    r = make_renderer(HASH, dict(num_samples_coarse=64, num_samples_depth_guided=64), F)
+    _perturb(r)
+    pos, quat, t = synth_target(F, R)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    _properties(r, tgt)
+    shifts = r._model.all_fields_params["_encoding.random_shift_per_level"].clone()
+    replay = r.capture_iteration(tgt, seed=3)
+    losses = [float(replay()["combined"]) for _ in range(30)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]                  # it trains
+    assert torch.equal(shifts, r._model.all_fields_params["_encoding.random_shift_per_level"])
+
+
+@pytest.mark.parametrize("F,R,n_c,n_g", [(2, 24, 64, 64), (1, 5, 128, 128)])
+def test_cfg2_hash_network_vs_oracle_many_samples_per_ray(F, R, n_c, n_g):
+    torch.manual_seed(F * 7 + R)
+    fkw = dict(HASH)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
+    pos, quat, t = synth_target(F, R, seed=R)
+    params = O.init_params(fs, F, seed=R)
+    params["_encoding.lattice_values"] += 0.1 * torch.randn_like(params["_encoding.lattice_values"])
+    params["_linears.1.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    loss["combined"].backward()
+    r = make_renderer(fkw, dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g), F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach(), rtol=2e-3, atol=2e-4)
+    close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
+    for k in po:
+        if po[k].grad is not None:
+            grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+
+
+# ------------------------------------------------------------------------------------------------ cfg3
+def test_cfg3_200_fields_random_active_sets():
+    """200 fields in the store, the reference's default network and batch (hash 1x32, 512 rays, 8+16 samples), 32 random
+    active fields per iteration addressed in place through field_ids (no gather / scatter, rm.py:668-707)."""
+    NF, FA, R = 200, 32, 512
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16)
+    r = make_renderer(HASH, ckw, NF)
+    _perturb(r)
+    gen = torch.Generator().manual_seed(5)
+    pos_all = 3.0 * torch.rand(NF, 3, generator=gen)
+    quat_all = torch.nn.functional.normalize(torch.randn(NF, 4, generator=gen), dim=-1)
+    r.set_field_poses(pos_all.to(DEV), quat_all.to(DEV))
+    touched = torch.zeros(NF, dtype=torch.bool)
+    p0 = {k: v.clone() for k, v in r._model.all_fields_params.items()}
+    for it in range(3):
+        ids = torch.randperm(NF, generator=gen)[:FA].sort().values
+        _, _, t = synth_target(FA, R, seed=100 + it)
+        # synth_target draws its own field centres: move the rays to the store's centres for these ids
+        shift = (pos_all[ids] - synth_target(FA, 1, seed=100 + it)[0])[:, None]
+        t["c2ws"] = t["c2ws"].clone()
+        t["c2ws"][..., :3, 3] += shift
+        tgt = make_target(t, ids)
+        if it == 0:
+            # same numbers as a renderer that holds ONLY the active fields (rows gathered up front)
+            u_c, u_g = torch.rand(FA, R, 8, generator=gen).to(DEV), torch.rand(FA, R, 16, generator=gen).to(DEV)
+            a = r.optimization_iteration(tgt, u_c, u_g, update=False)
+            r2 = make_renderer(HASH, ckw, FA, {k: v[ids.to(DEV)] for k, v in r._model.all_fields_params.items()})
+            r2.set_field_poses(pos_all[ids].to(DEV), quat_all[ids].to(DEV))
+            b = r2.optimization_iteration(make_target(t, torch.arange(FA)), u_c, u_g, update=False)
+            assert torch.equal(a["prediction"].rgbds, b["prediction"].rgbds)
+            for k in b["grads"]:
+                assert torch.equal(a["grads"][k], b["grads"][k]), k
+        out = r.optimization_iteration(tgt, seed=it, update=True)
+        assert torch.isfinite(out["combined"])
+        touched[ids] = True
+    assert r._step == 3
+    for k, v in r._model.all_fields_params.items():
+        same = (v == p0[k]).flatten(1).all(1).cpu()
+        if k in ("_encoding.random_shift_per_level", "_neus_sd"):       # no gradient in this mode: never touched
+            assert bool(same.all()), k
+            continue
+        assert bool(same[~touched].all()), k                       # inactive fields: bitwise untouched
+        assert not bool(same[touched].any()), k                    # active fields: all moved
+        m = r._optim_state[k]["exp_avg"]
+        assert bool((m[(~touched).to(DEV)] == 0).all())
+
+
+# ------------------------------------------------------------------------------------------------ cfg4
+def test_cfg4_8192_rays_x_256_samples_properties():
+    F, R = 16, 512
+    r = make_renderer(FOURIER, dict(num_samples_coarse=128, num_samples_depth_guided=128), F)
+    _perturb(r)
+    pos, quat, t = synth_target(F, R, seed=2)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    _properties(r, tgt)
+    assert K.lib().ngm_debug_last_bwd_variant() == 2               # activation-stash backward at this size too
+    replay = r.capture_iteration(tgt, seed=3)
+    losses = [float(replay()["combined"]) for _ in range(20)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("F,R", [(2, 19), (1, 3)])
+def test_cfg4_256_samples_per_ray_vs_oracle(F, R):
+    ragged_case(F, R, 128, 128, dict(FOURIER))
+    assert K.lib().ngm_debug_last_bwd_variant() == 2
+
+
+# ------------------------------------------------------------------------------------------------ eval S = 640
+def test_eval_style_fused_render_640_samples_vs_oracle():
+    """_render_ijs(use_vmap=True) without depth guidance at the evaluation sample count of rm.py:199-207."""
+    F, R, S = 2, 33, 640
+    torch.manual_seed(3)
+    fs = O.FieldSpec(**FOURIER)
+    rs = O.RenderSpec(num_samples_coarse=S, num_samples_depth_guided=0)
+    pos, quat, t = synth_target(F, R, seed=9)
+    params = O.init_params(fs, F, seed=4, sigma=3.0)
+    params["_linears.2.weight"] *= 2.0
+    u = torch.rand(F, R, S)
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, params, fs, rs, t["near"], t["far"], None, u, None)
+    r = make_renderer(FOURIER, dict(num_samples_coarse=S, num_samples_depth_guided=0), F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    ids = torch.arange(F, device=DEV)
+    with torch.no_grad():
+        p = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, field_ids=ids, near_distances=t["near"].to(DEV),
+                         far_distances=t["far"].to(DEV), gt_distances=None, u_coarse=u.to(DEV))
+    close(p.rgbds, pred["rgbds"])
+    close(p.term_probs, pred["term_probs"])
+    close(p.depth_vars, pred["depth_vars"], rtol=1e-3, atol=1e-5)
+    close(p.color_vars, pred["color_vars"], rtol=1e-3, atol=1e-5)
+
+
+def test_eval_style_fused_render_4096_rays_x_640_samples_properties():
+    F, R, S = 8, 512, 640
+    r = make_renderer(FOURIER, dict(num_samples_coarse=S, num_samples_depth_guided=0), F)
+    _perturb(r)
+    pos, quat, t = synth_target(F, R, seed=6)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    ids = torch.arange(F, device=DEV)
+    kw = dict(field_ids=ids, near_distances=t["near"].to(DEV), far_distances=t["far"].to(DEV), gt_distances=None)
+    with torch.no_grad():
+        a = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, seed=5, **kw)
+        b = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, seed=5, **kw)
+    assert torch.isfinite(a.rgbds).all() and torch.equal(a.rgbds, b.rgbds)
+    assert float(a.term_probs.min()) >= -1e-6 and float(a.term_probs.max()) <= 1 + 1e-5
+    assert (a.depth_vars >= -1e-7).all()

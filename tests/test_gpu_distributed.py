@@ -1,0 +1,196 @@
+"""Multi-rank runs of the PRODUCT renderer on the GPU (-m gpu): two processes share GPU 0 (the test boxes have one
+GPU; gloo moves the device tensors of the 64-byte loss all-reduce and of the evaluation gathers), fields sharded
+`owner = id % world` (rm.py:1383-1427).  Checked against the reference fixtures and against the
+one-process run of the same renderer:
+  * eager `optimization_iteration` with `process_group` set on `shard_target` slices: loss, prediction, union of grads;
+  * `capture_iteration` (two hipGraphs around the all-reduce): trained parameters after 5 updates;
+  * a rank none of whose fields is active (idle rank) still completes the collective;
+  * `render_image_sharded` vs `render_image` / G9.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, split_prefix
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import CASES, DEV, close, grad_close, make_renderer, make_target  # noqa: E402
+from neural_graph_mapping_amd import distributed as D  # noqa: E402
+from neural_graph_mapping_amd import renderer as Rr  # noqa: E402
+
+NAME = "g6_train_3field"
+N_REPLAY = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    D.init_from_env(backend="gloo")
+
+
+def _local_renderer(g, rank, world, active=None):
+    """Renderer holding only this rank's fields (local slot = id // world) + its slice of the fixture's Target."""
+    fkw, ckw = CASES[NAME]
+    F = g["pos"].shape[0]
+    ids = torch.arange(F)
+    own = D.owned_mask(ids, rank, world)
+    r = make_renderer(fkw, ckw, int(own.sum()), {k: v[own] for k, v in split_prefix(g, "p::").items()})
+    r.set_field_poses(g["pos"][own].to(DEV), g["quat"][own].to(DEV))
+    r.process_group = dist.group.WORLD
+    t = dict(split_prefix(g, "t::"))
+    t["field_ids"] = ids
+    t["u_coarse"], t["u_guided"] = g["u_coarse"], g["u_guided"]
+    if active is not None:
+        t = {k: v[active] for k, v in t.items()}
+    tgt_all = make_target(t, t["field_ids"])
+    tgt = D.shard_target(tgt_all, rank, world)                     # the rows (fields) this rank owns
+    keep = D.owned_mask(t["field_ids"], rank, world)
+    tgt = tgt._replace(field_ids=D.global_to_local(tgt.field_ids, world))
+    return r, tgt, t["u_coarse"][keep].to(DEV), t["u_guided"][keep].to(DEV), t["field_ids"][keep]
+
+
+def _train_worker(rank, world, port, out):
+    _init(rank, world, port)
+    g = load_golden(NAME)
+    r, tgt, uc, ug, gids = _local_renderer(g, rank, world)
+    res = r.optimization_iteration(tgt, uc, ug, update=False)
+    rec = dict(ids=gids, loss={k: v.cpu() for k, v in res.items() if k not in ("grads", "prediction")},
+               grads={k: v.cpu().clone() for k, v in res["grads"].items()}, rgbds=res["prediction"].rgbds.cpu().clone())
+    # captured iteration: 2 warm-up updates + N_REPLAY replays, explicit draws so that the trajectory is comparable
+    replay = r.capture_iteration(tgt, u_coarse=uc, u_guided=ug)
+    for _ in range(N_REPLAY):
+        last = replay()
+    torch.cuda.synchronize()
+    rec.update(graphs=replay.graph is not None, step=r._step, step_dev=int(r._step_dev.item()),
+               last_loss=last["combined"].cpu(), params={k: v.cpu().clone() for k, v in r._model.all_fields_params.items()})
+    torch.save(rec, os.path.join(out, f"train{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process(g, n_updates, active=None):
+    fkw, ckw = CASES[NAME]
+    F = g["pos"].shape[0]
+    r = make_renderer(fkw, ckw, F, split_prefix(g, "p::"))
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    t = dict(split_prefix(g, "t::"))
+    ids = torch.arange(F)
+    uc, ug = g["u_coarse"], g["u_guided"]
+    if active is not None:
+        t, ids, uc, ug = {k: v[active] for k, v in t.items()}, ids[active], uc[active], ug[active]
+    tgt = make_target(t, ids)
+    first = r.optimization_iteration(tgt, uc.to(DEV), ug.to(DEV), update=False)
+    first = dict(loss=first["combined"].cpu(), grads={k: v.cpu().clone() for k, v in first["grads"].items()},
+                 rgbds=first["prediction"].rgbds.cpu().clone())
+    last = None
+    for _ in range(n_updates):
+        last = r.optimization_iteration(tgt, uc.to(DEV), ug.to(DEV), update=True)
+    return first, last, {k: v.cpu().clone() for k, v in r._model.all_fields_params.items()}
+
+
+def test_two_ranks_product_renderer_eager_and_captured(tmp_path):
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(NAME)
+    ref_g, ref_loss = split_prefix(g, "g::"), split_prefix(g, "loss::")
+    first, last, params1 = _single_process(g, 2 + N_REPLAY)
+    seen = []
+    for rank in range(world):
+        res = torch.load(os.path.join(tmp_path, f"train{rank}.pt"))
+        ids = res["ids"]
+        seen += ids.tolist()
+        # eager, against the reference fixture (global loss on every rank, this rank's rows of every gradient) ...
+        for k, v in ref_loss.items():
+            close(res["loss"][k], v, rtol=2e-4, atol=1e-5)
+        close(res["rgbds"], g["pred_rgbds"][ids])
+        for k, v in ref_g.items():
+            scale = v.abs().max().clamp_min(1e-12)
+            assert float((res["grads"][k] - v[ids]).abs().max() / scale) < 2e-3, k
+            # ... and against the one-process run of the same kernels (same arithmetic, only the loss sums are
+            # accumulated in a different order: per rank, then across ranks)
+            assert float((res["grads"][k] - first["grads"][k][ids]).abs().max() / scale) < 1e-5, k
+        assert res["graphs"], "the sharded iteration was not captured into hipGraphs (fell back to eager launches)"
+        assert res["step"] == 2 + N_REPLAY == res["step_dev"]
+        close(res["last_loss"], last["combined"], rtol=1e-4, atol=1e-6)
+        for k, v in res["params"].items():
+            close(v, params1[k][ids], rtol=1e-4, atol=1e-6)
+    assert sorted(seen) == list(range(g["pos"].shape[0]))
+
+
+def _idle_worker(rank, world, port, out):
+    _init(rank, world, port)
+    g = load_golden(NAME)
+    active = torch.tensor([0, 2])                                   # both owned by rank 0: rank 1 has nothing to do
+    r, tgt, uc, ug, gids = _local_renderer(g, rank, world, active)
+    assert tgt.ijs.shape[0] == (2 if rank == 0 else 0)
+    res = r.optimization_iteration(tgt, uc, ug, update=True)
+    torch.cuda.synchronize()
+    torch.save(dict(loss=res["combined"].cpu(), step=r._step, step_dev=int(r._step_dev.item())),
+               os.path.join(out, f"idle{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_idle_rank_completes_the_collective(tmp_path):
+    world = 2
+    mp.spawn(_idle_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(NAME)
+    first, _, _ = _single_process(g, 0, active=torch.tensor([0, 2]))
+    for rank in range(world):
+        res = torch.load(os.path.join(tmp_path, f"idle{rank}.pt"))
+        close(res["loss"], first["loss"], rtol=1e-5, atol=1e-6)       # the idle rank reports the same global loss
+        assert res["step"] == 1 == res["step_dev"]                    # and keeps the shared Adam step counter
+
+
+# ------------------------------------------------------------------------------------------ evaluation path
+def _g9_renderer(g, own=None):
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, eval_far_distance=float(g["eval_far"]),
+               eval_num_samples=int(g["eval_num_samples"]))
+    p = split_prefix(g, "p::")
+    if own is not None:
+        p = {k: v[own] for k, v in p.items()}
+    NF = next(iter(p.values())).shape[0]
+    r = make_renderer(fkw, ckw, NF, p)
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))          # poses are replicated on every rank
+    w, h, fx, fy, cx, cy = [float(x) for x in g["cam"]]
+    return r, Rr.Camera(int(w), int(h), fx, fy, cx, cy, pixel_center=0.0)
+
+
+def _eval_worker(rank, world, port, out):
+    _init(rank, world, port)
+    g = load_golden("g9_render_image")
+    NF = g["pos"].shape[0]
+    r, cam = _g9_renderer(g, D.local_field_slots(NF, rank, world))
+    rgbd, dvar = D.render_image_sharded(r, g["c2w"].to(DEV), NF, camera=cam, u=g["u"].to(DEV))
+    assert (rgbd is None) == (rank != 0)
+    if rank == 0:
+        torch.save(dict(rgbd=rgbd.cpu(), dvar=dvar.cpu()), os.path.join(out, "image.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_render_image_sharded(tmp_path):
+    world = 2
+    mp.spawn(_eval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("g9_render_image")
+    res = torch.load(os.path.join(tmp_path, "image.pt"))
+    close(res["rgbd"], g["rgbd"], rtol=5e-4, atol=5e-5)               # the reference's render_image
+    close(res["dvar"], g["dvar"], rtol=5e-4, atol=5e-5)
+    r, cam = _g9_renderer(g)
+    rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
+    assert torch.equal(res["rgbd"], rgbd.cpu()) and torch.equal(res["dvar"], dvar.cpu())   # pixels are independent

@@ -19,52 +19,8 @@ from neural_graph_mapping_amd import models as M  # noqa: E402
 from neural_graph_mapping_amd import ops  # noqa: E402
 from neural_graph_mapping_amd import renderer as Rr  # noqa: E402
 from oracle import ngm_oracle as O  # noqa: E402
-
-DEV = "cuda"
-NRGBD_KW = dict(fx=554.2562584220408, fy=554.2562584220408, cx=319.5, cy=239.5)
-NRGBD = O.CameraSpec(640, 480, **NRGBD_KW)
-
-
-def cu(d):
-    return {k: v.to(DEV) for k, v in d.items()}
-
-
-def close(a, b, rtol=2e-4, atol=2e-5):
-    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol)
-
-
-def grad_close(a, b, tol=2e-3, name=""):
-    scale = b.abs().max().clamp_min(1e-12)
-    err = float((a.cpu() - b.cpu()).abs().max() / scale)
-    assert err < tol, (name, err)
-
-
-def loose_grad_close(a, b, name=""):
-    """robust to a single ReLU-boundary flip (|pre-activation| ~ 1e-8 flips sign in fp32): L2 + loose max"""
-    a, b = a.cpu(), b.cpu()
-    assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 5e-3, name
-    assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) < 3e-2, name
-
-
-def away_from_relu_boundaries(q, pos, quat, params, fs, margin=1e-5, tries=20):
-    """Resample query points whose fp64 pre-activations come within `margin` of a ReLU kink, where the
-    derivative is discontinuous and fp32 implementations may legitimately disagree."""
-    p64 = {k: v.double() for k, v in params.items()}
-    g = torch.Generator().manual_seed(99)
-    for _ in range(tries):
-        x = O.world_to_field(q.double(), pos.double(), quat.double(), 1.0, "unit_cube")
-        h = O.encode(x, p64, fs)
-        bad = torch.zeros(q.shape[:2], dtype=torch.bool)
-        for i in range(fs.num_layers):
-            pre = torch.einsum("fpi,foi->fpo", h, p64[f"_linears.{i}.weight"]) + p64[f"_linears.{i}.bias"].unsqueeze(-2)
-            bad |= (pre.abs() < margin).any(-1)
-            h = torch.relu(pre)
-        if not bad.any():
-            return q
-        q = q.clone()
-        q[bad] = (pos[:, None] + 0.5 * torch.randn(q.shape, generator=g))[bad]
-    return q
-
+from gpu_common import (CASES, DEV, NRGBD, NRGBD_KW, away_from_relu_boundaries, close, cu, grad_close,  # noqa: E402
+                        kink_free_draws, make_renderer, make_target, ragged_case, synth_target)
 
 def test_device_is_gfx950_and_library_loaded():
     n = C.c_int(0)
@@ -169,6 +125,7 @@ def test_skip_add_fused_train_step_vs_oracle():
     params = O.init_params(fs, F, seed=11, sigma=3.0)
     params["_linears.2.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
     r = make_renderer(fkw, ckw, F, params)
@@ -179,7 +136,7 @@ def test_skip_add_fused_train_step_vs_oracle():
     close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
     loss["combined"].backward()
     for k in po:
-        loose_grad_close(res["grads"][k], po[k].grad, k)
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
 
 
 FIELD_CASES = [dict(encoding="fourier", dim_enc=64, num_layers=2), dict(encoding="fourier", dim_enc=32, num_layers=2),
@@ -309,6 +266,7 @@ def test_fused_train_step_density_mode_vs_oracle():
     params["_linears.2.weight"] *= 4.0
     params["_linears.2.bias"][:, 3] += 1.0           # positive densities on a good share of the samples
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
     r = make_renderer(fkw, ckw, F, params)
@@ -321,7 +279,7 @@ def test_fused_train_step_density_mode_vs_oracle():
     close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
     loss["combined"].backward()
     for k in po:
-        loose_grad_close(res["grads"][k], po[k].grad, k)
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
 
 
 def test_neus_staged_train_step_vs_oracle():
@@ -341,6 +299,7 @@ def test_neus_staged_train_step_vs_oracle():
     params["_linears.2.weight"] *= 3.0
     sd = torch.tensor([0.4, 0.8, 1.5])
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     sdo = sd.clone().requires_grad_()
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g,
@@ -359,7 +318,7 @@ def test_neus_staged_train_step_vs_oracle():
     close(res["prediction"].term_probs, pred["term_probs"].detach())
     close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
     for k in po:
-        loose_grad_close(res["grads"][k], po[k].grad, k)
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
     close(res["grads"]["_neus_sd"].view(-1), sdo.grad, rtol=5e-3, atol=1e-6)
     before = r._model.all_fields_params["_neus_sd"].clone()
     r.optimization_iteration_staged(tgt, u_c.to(DEV), u_g.to(DEV), update=True)
@@ -371,48 +330,6 @@ def test_neus_staged_train_step_vs_oracle():
 
 
 # ------------------------------------------------------------------------- train step (G6, G7)
-CASES = {
-    "g6_train_cfg0": (dict(encoding="fourier", dim_enc=64, num_layers=2), dict(num_samples_coarse=16, num_samples_depth_guided=16)),
-    "g6_train_3field": (dict(encoding="fourier", dim_enc=64, num_layers=2),
-                        dict(num_samples_coarse=8, num_samples_depth_guided=16, termination_weight=0.5)),
-    "g6_train_nerf_l1": (dict(encoding="nerf", num_octaves=8, num_layers=1), dict(num_samples_coarse=8, num_samples_depth_guided=8)),
-    # cameras inside the field, near < 0: geometry of samples behind the camera overwritten (rm.py:614-622)
-    "g10_train_behind_camera": (dict(encoding="fourier", dim_enc=64, num_layers=2),
-                                dict(num_samples_coarse=12, num_samples_depth_guided=8, termination_weight=0.5)),
-}
-
-
-def make_renderer(fkw, ckw, num_fields, params=None):
-    if fkw["encoding"] == "fourier":
-        et = "neural_graph_mapping.positional_encodings.PositionalEncodingFourier"
-        ek = dict(dim_in=3, dim_out=fkw["dim_enc"], mu=0.0, sigma=4.0, raw_coords=True)
-    else:
-        et = "neural_graph_mapping.positional_encodings.PositionalEncodingNeRF"
-        ek = dict(dim_in=3, num_octaves=fkw["num_octaves"], start_octave=0)
-    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
-        encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0,
-        skip_mode=fkw.get("skip_mode", "no")), num_knn=2,
-        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
-    cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
-               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
-               learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0)
-    cfg.update(ckw)
-    cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5, pixel_center=0.0)
-    r = Rr.NeuralGraphRenderer(model, cam, cfg, device=DEV)
-    r.add_fields(num_fields)
-    if params is not None:
-        for k, v in params.items():
-            model.all_fields_params[k].copy_(v.to(DEV))
-    return r
-
-
-def make_target(t, ids):
-    t = cu(t)
-    return Rr.Target(ijs=t["ijs"], c2ws=t["c2ws"], near_distances=t["near"], far_distances=t["far"], gt_distances=t["gt"],
-                     field_ids=ids.to(DEV), rgbds=t["rgbds"], rgb_mask=t["depth_mask"], depth_mask=t["depth_mask"],
-                     term_probs=t["term_probs"], term_mask=t["term_mask"])
-
-
 @pytest.mark.parametrize("name", list(CASES))
 def test_fused_train_step_golden(name):
     g = load_golden(name)
@@ -484,28 +401,6 @@ def test_sparse_adam_ten_iterations_golden():
 
 
 # ---------------------------------------------------------------- full-size properties (M1 shape)
-def synth_target(F, R, seed=0):
-    gen = torch.Generator().manual_seed(seed)
-    pos = 0.5 * torch.randn(F, 3, generator=gen)
-    quat = torch.nn.functional.normalize(torch.randn(F, 4, generator=gen), dim=-1)
-    ijs = torch.stack([torch.randint(0, 480, (F, R), generator=gen), torch.randint(0, 640, (F, R), generator=gen)], -1)
-    eye = pos[:, None] + torch.nn.functional.normalize(torch.randn(F, R, 3, generator=gen), dim=-1) * (2 + torch.rand(F, R, 1, generator=gen))
-    fwd = torch.nn.functional.normalize(pos[:, None] + 0.3 * torch.randn(F, R, 3, generator=gen) - eye, dim=-1)
-    right = torch.nn.functional.normalize(torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]).expand_as(fwd)), dim=-1)
-    c2w = torch.eye(4).repeat(F, R, 1, 1)
-    c2w[..., :3, 0], c2w[..., :3, 1], c2w[..., :3, 2], c2w[..., :3, 3] = right, torch.linalg.cross(right, fwd), -fwd, eye
-    d = O.ijs_to_directions(ijs, NRGBD)
-    pos_c = torch.einsum("...kd,...k->...d", c2w[..., :3, :3], pos[:, None] - c2w[..., :3, 3])
-    center = (pos_c * d).sum(-1)
-    near, far = (center - 1).clamp_min(0), (center + 1).clamp_min(0)
-    gt = near + (far - near) * (0.1 + 0.8 * torch.rand(F, R, generator=gen))
-    gt[torch.rand(F, R, generator=gen) < 0.1] = 0.0
-    rgbds = torch.cat([torch.rand(F, R, 3, generator=gen), (gt * d[..., 2].abs())[..., None]], -1)
-    dm = (gt > near) & (gt < far) & (gt != 0)
-    return pos, quat, dict(ijs=ijs, c2ws=c2w, near=near, far=far, gt=gt, rgbds=rgbds, depth_mask=dm,
-                           term_probs=(gt < far).float(), term_mask=(gt > near) & (gt != 0))
-
-
 def test_full_size_properties_m1():
     F, R = 8, 512
     fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
@@ -597,7 +492,7 @@ def test_iteration_counter_drives_jitter_and_adam_step():
 
 @pytest.mark.parametrize("F,R,n_c,n_g", [(1, 5, 3, 0), (2, 33, 1, 1), (5, 7, 8, 16), (1, 1, 128, 0), (3, 130, 20, 4)])
 def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
-    _ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=32, num_layers=1))
+    ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=32, num_layers=1))
 
 
 @pytest.mark.parametrize("F,R,n_c,n_g,layers", [(2, 33, 1, 1, 2), (5, 7, 8, 16, 2), (3, 130, 20, 4, 2), (3, 37, 5, 2, 1),
@@ -605,39 +500,9 @@ def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
 def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers):
     """64-wide layers: the training forward stashes the hidden activations and k_field_bwd16s consumes them
     (partial 16-sample tiles, fields that start in the middle of a 32-sample stash tile)."""
-    _ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers))
+    ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers))
     from neural_graph_mapping_amd import _capi
     assert _capi.lib().ngm_debug_last_bwd_variant() == 2
-
-
-def _ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0):
-    torch.manual_seed(F * 1000 + R)
-    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geometry_mode,
-               geometry_factor=geometry_factor)
-    pos, quat, t = synth_target(F, R, seed=R)
-    fs = O.FieldSpec(**fkw)
-    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,
-                      geometry_mode=geometry_mode, geometry_factor=geometry_factor)
-    params = O.init_params(fs, F, seed=R, sigma=3.0)
-    params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
-    u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
-    po = {k: v.clone().requires_grad_() for k, v in params.items()}
-    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
-    r = make_renderer(fkw, ckw, F, params)
-    r.set_field_poses(pos.to(DEV), quat.to(DEV))
-    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV) if n_g else None,
-                                   update=False)
-    close(res["prediction"].rgbds, pred["rgbds"].detach())
-    close(res["prediction"].term_probs, pred["term_probs"].detach())
-    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
-    n_fs, n_ts, n_t = pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())
-    if min(n_m, n_fs, n_ts, n_t) == 0:
-        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
-    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
-    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
-    loss["combined"].backward()
-    for k in po:
-        loose_grad_close(res["grads"][k], po[k].grad, k)
 
 
 # ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)
@@ -719,6 +584,15 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     fc = K.field_cfg(num_layers=L_, **PERMUTO)
     params = O.init_params(fs, F, seed=3)
     x = torch.rand(F, P, 3)                                          # already in the unit-cube field frame
+    p64 = {k: v.double() for k, v in params.items()}
+    for _ in range(20):                                              # keep the points off the ReLU kinks (fp64 check)
+        pres = []
+        O.field_mlp(O.encode(x.double(), p64, fs), p64, fs, pre_out=pres)
+        bad = torch.stack([(pre.abs() < 5e-5).any(-1) for pre in pres]).any(0)
+        if not bad.any():
+            break
+        x[bad] = torch.rand(int(bad.sum()), 3)
+    assert not bad.any()
     d_out = torch.randn(F, P, 4)
     po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
     out_o = O.field_forward_local(x, po, fs)
@@ -730,7 +604,7 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     (out * d_out.to(DEV)).sum().backward()
     for k in po:
         if po[k].grad is not None:
-            loose_grad_close(pg[k].grad, po[k].grad, k)
+            grad_close(pg[k].grad, po[k].grad, 2e-3, k)
     # table gradient: every touched entry matches, untouched entries are exactly zero
     gl, rl = pg["_encoding.lattice_values"].grad.cpu(), po["_encoding.lattice_values"].grad
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
@@ -747,6 +621,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
     params = O.init_params(fs, F, seed=9)
     params["_linears.1.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
     po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
     loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
@@ -774,7 +649,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
     close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         if po[k].grad is not None:
-            loose_grad_close(res["grads"][k], po[k].grad, k)
+            grad_close(res["grads"][k], po[k].grad, 2e-3, k)
     before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
     r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
     assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched
@@ -932,4 +807,4 @@ def test_fused_train_random_shapes_vs_oracle(seed):
     mode = ["nrgbd", "occupancy", "density"][seed % 3]
     if n_c + n_g < 2 and mode == "density":
         n_c += 1                                                   # density drops the last sample
-    _ragged_case(F, R, n_c, n_g, fkw, geometry_mode=mode, geometry_factor=20.0 if mode != "density" else 1.0)
+    ragged_case(F, R, n_c, n_g, fkw, geometry_mode=mode, geometry_factor=20.0 if mode != "density" else 1.0)

@@ -189,7 +189,7 @@ def run_train_case(name, fckw, rckw, g=None, check=True):
                              ws.ptr, wsb, None), "render_fwd")
     H.synchronize()
     geo, dis = H.DeviceArray((F, R, S)), H.DeviceArray((F, R, S))
-    K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, ws.ptr, geo.ptr, dis.ptr, None), "read_samples")
+    K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, rc.num_samples_coarse + rc.num_samples_guided, ws.ptr, geo.ptr, dis.ptr, None), "read_samples")
     geo_np, dis_np = geo.numpy(), dis.numpy()
     K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred), sums.ptr,
                              C.byref(gs), lout.ptr, ws.ptr, wsb, None), "render_bwd")

@@ -32,6 +32,7 @@ D_ENC, N_LAYERS = 64, 2
 FLOP_FWD = 2 * (64 * 64 + 64 * 64 + 64 * 4)      # 16 896 flop / sample
 FLOP_BWD = 2 * FLOP_FWD                          # wgrad + dgrad: 33 792 flop / sample
 PEAK_F32_MFMA_TF = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def synth_target(F, Rn, seed, field_offset=0):
@@ -277,23 +278,45 @@ def main():
                                devices=sorted(set(devs)), jitter="in-kernel Philox",
                                launch=("eager" if (not use_graph or getattr(replay, "graph", None) is None) else
                                        "hipGraph replay" if r.process_group is None else "2 hipGraphs + all-reduce"), final_loss=loss))
-        fb = kern.get("field_bwd")
+        fb, ff = kern.get("field_bwd"), kern.get("render_fwd")
         if fb and args.variant == "fourier":
             achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12
-            traffic = None
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_field_bwd.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            from neural_graph_mapping_amd import _capi
-            variant = _capi.lib().ngm_debug_last_bwd_variant()
+                traffic_src = "profiles/pmc_field_bwd.json: separate rocprofv3 --pmc pass of this workload, NOT this run"
+            variant = K.lib().ngm_debug_last_bwd_variant()
             kname = {0: "k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32, forward recompute)",
                      1: "k_field_bwd16<4,4,2> (v_mfma_f32_16x16x4_f32, forward recompute)",
                      2: "k_field_bwd16s<2> (v_mfma_f32_16x16x4_f32, activations from the forward's stash)"}.get(variant, "?")
             res["roofline"] = dict(bound="mfma", kernel=kname, achieved=achieved,
                                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
-                                   traffic=traffic, avg_launch_us=fb["avg_us"], launches_timed=fb["launches"],
+                                   traffic=traffic, traffic_source=traffic_src, avg_launch_us=fb["avg_us"],
+                                   launches_timed=fb["launches"],
                                    timing="HIP events on the launch stream, instrumented pass of the same steps",
                                    algorithmic_flop_per_launch=FLOP_BWD * n_local)
+            if ff:      # the second MFMA kernel and the whole step against the same peak (algorithmic MLP flops only)
+                a_f = FLOP_FWD * n_local / (ff["avg_us"] * 1e-6) / 1e12
+                res["roofline_fwd"] = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=a_f,
+                                           peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=a_f / PEAK_F32_MFMA_TF,
+                                           avg_launch_us=ff["avg_us"], algorithmic_flop_per_launch=FLOP_FWD * n_local)
+            a_s = (FLOP_FWD + FLOP_BWD) * n_local / (dt / args.steps) / 1e12
+            res["roofline_step"] = dict(bound="mfma", achieved=a_s, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                                        frac=a_s / PEAK_F32_MFMA_TF, note="whole timed step (all kernels + launch gaps), "
+                                        "algorithmic MLP flops fwd 16 896 + bwd 33 792 per sample")
+        hg = kern.get("hash_grad")
+        if hg and args.variant == "hash":
+            # the table-gradient scatter is 16 levels x 4 vertices x 2 features x 4 B = 512 B per sample
+            algo = 512 * n_local
+            ach = algo / (hg["avg_us"] * 1e-6) / 1e9
+            res["roofline"] = dict(bound="hbm", kernel="k_hash_grad (simplex search + per-level table in LDS, Q23.40 integer atomics)",
+                                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                                   avg_launch_us=hg["avg_us"], launches_timed=hg["launches"],
+                                   algorithmic_bytes_per_launch=algo,
+                                   timing="HIP events on the launch stream, instrumented pass of the same steps",
+                                   note="priced against the HBM scatter it replaces (512 B/sample, SURVEY 8d); the kernel "
+                                        "itself accumulates in LDS and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
         res["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in kern.items()}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

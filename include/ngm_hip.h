@@ -385,7 +385,10 @@ enum ngm_kernel_id {
   NGM_K_POINTS_FWD = 5,
   NGM_K_COMPOSITE_FWD = 6,
   NGM_K_COMPOSITE_BWD = 7,
-  NGM_K_COUNT = 8
+  NGM_K_HASH_GRAD = 8,   /* hash-table gradient: simplex search + LDS fixed-point scatter (one level per workgroup) */
+  NGM_K_HASH_REDUCE = 9, /* sum of the per-workgroup partial tables (+ fused sparse Adam on the tables)             */
+  NGM_K_LOSS_REDUCE = 10,
+  NGM_K_COUNT = 11
 };
 int ngm_profile_enable(int32_t on);
 int ngm_profile_reset(void);

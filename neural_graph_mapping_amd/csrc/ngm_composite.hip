@@ -509,6 +509,7 @@ __global__ void k_loss_reduce(const float* partials, int nblocks, float* sums, u
   if (counter && threadIdx.x == 0) *counter += 1ull;
 }
 int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, uint64_t* counter, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_LOSS_REDUCE, st);
   hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, partials, nblocks, sums, reinterpret_cast<unsigned long long*>(counter));
   return 0;
 }

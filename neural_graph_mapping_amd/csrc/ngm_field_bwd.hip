@@ -742,8 +742,14 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
     }
   }
   (void)hipFuncSetAttribute((const void*)k_hash_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_hash_grad, dim3(chunks, fb.fc.nr_levels, fb.F), dim3(512), lds, st, a);
-  hipLaunchKernelGGL(k_hash_reduce, dim3((T / 2 + 255) / 256, fb.fc.nr_levels, fb.F), dim3(256), 0, st, a);
+  {
+    NgmProfScope prof_(NGM_K_HASH_GRAD, st);
+    hipLaunchKernelGGL(k_hash_grad, dim3(chunks, fb.fc.nr_levels, fb.F), dim3(512), lds, st, a);
+  }
+  {
+    NgmProfScope prof_(NGM_K_HASH_REDUCE, st);
+    hipLaunchKernelGGL(k_hash_reduce, dim3((T / 2 + 255) / 256, fb.fc.nr_levels, fb.F), dim3(256), 0, st, a);
+  }
   if (adam_applied) *adam_applied = a.ad_param != nullptr;
   return 0;
 }

@@ -9,7 +9,7 @@ No CPU fallback: device tensors in, device tensors out.
 import ctypes as C
 import itertools
 import os
-from typing import Optional
+from typing import List, Optional
 
 import numpy as np
 import torch
@@ -18,13 +18,9 @@ from . import _capi as K
 from . import ops
 
 
-def marching_cubes(volume: torch.Tensor, isolevel: float):
-    """volume (nx, ny, nz) fp32 on the GPU, inside = value > isolevel -> (verts (V,3) fp32 in grid-index
-    coordinates (x, y, z), faces (T,3) int64).  Deterministic order, one vertex per crossed grid edge."""
-    ops._require_gpu(volume)
-    if volume.dim() != 3 or volume.dtype != torch.float32:
-        raise ValueError("marching_cubes expects a (nx, ny, nz) float32 volume")
-    volume = volume.contiguous()
+@torch.library.custom_op("ngm355::marching_cubes", mutates_args=(), device_types="cuda")
+def _marching_cubes_op(volume: torch.Tensor, isolevel: float) -> List[torch.Tensor]:
+    """[verts (V,3) fp32 grid-index coordinates, faces (T,3) int64]; data-dependent sizes (no fake kernel)"""
     nx, ny, nz = volume.shape
     L = K.lib()
     wsb = L.ngm_marching_cubes_workspace(nx, ny, nz)
@@ -42,6 +38,17 @@ def marching_cubes(volume: torch.Tensor, isolevel: float):
     if nv or nf:
         K.check(L.ngm_marching_cubes_emit(volume.data_ptr(), nx, ny, nz, float(isolevel), verts.data_ptr(), nv,
                                           faces.data_ptr(), nf, ws.data_ptr(), wsb, st), "ngm_marching_cubes_emit")
+    return [verts, faces]
+
+
+def marching_cubes(volume: torch.Tensor, isolevel: float):
+    """volume (nx, ny, nz) fp32 on the GPU, inside = value > isolevel -> (verts (V,3) fp32 in grid-index
+    coordinates (x, y, z), faces (T,3) int64).  Deterministic order, one vertex per crossed grid edge.
+    Dispatches through torch.ops.ngm355.marching_cubes."""
+    ops._require_gpu(volume)
+    if volume.dim() != 3 or volume.dtype != torch.float32:
+        raise ValueError("marching_cubes expects a (nx, ny, nz) float32 volume")
+    verts, faces = torch.ops.ngm355.marching_cubes(volume.contiguous(), float(isolevel))
     return verts, faces
 
 

@@ -5,11 +5,36 @@ gfx950 kernel reached through ``_capi``.  There is NO CPU / eager fallback: tens
 ROCm device ("cuda" under PyTorch-ROCm) and the HIP library must be built, otherwise the call raises.
 """
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
 from . import _capi as K
+
+
+# ------------------------------------------------------------------------------------------------
+# torch.library registration: every op below is visible to the dispatcher as torch.ops.ngm355.<name>
+# (schema, fake/meta shapes, autograd formula) and calls the C ABI underneath.  "cuda" (= ROCm) kernels only:
+# there is no CPU registration on purpose.  Configuration structs travel as small uint8 CPU tensors (the bytes
+# of ngm_field_cfg / ngm_render_cfg), stacked parameter dictionaries as Tensor[] in K.param_names() order.
+# ------------------------------------------------------------------------------------------------
+NS = "ngm355"
+
+
+def cfg_blob(struct) -> torch.Tensor:
+    return torch.frombuffer(bytearray(bytes(struct)), dtype=torch.uint8)
+
+
+def _field_cfg(blob: torch.Tensor) -> "K.FieldCfg":
+    return K.FieldCfg.from_buffer_copy(blob.numpy().tobytes())
+
+
+def _render_cfg(blob: torch.Tensor) -> "K.RenderCfg":
+    return K.RenderCfg.from_buffer_copy(blob.numpy().tobytes())
+
+
+def _op(name, mutates_args=()):
+    return torch.library.custom_op(f"{NS}::{name}", mutates_args=mutates_args, device_types="cuda")
 
 
 def _require_gpu(*tensors):
@@ -80,54 +105,82 @@ def alloc_grads(fc: K.FieldCfg, F: int, device, flat: Optional[torch.Tensor] = N
 # ------------------------------------------------------------------------------------------------
 # K2+K3: NeuralFieldSet.forward(use_vmap=True) with autograd
 # ------------------------------------------------------------------------------------------------
-class _FieldEval(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, fc, names, points, pos, quat, *param_tensors):
-        params = dict(zip(names, param_tensors))
-        _require_gpu(points, pos, quat, *param_tensors)
-        points = _f32c(points, "points")
-        F, P, _ = points.shape
-        out = torch.empty(F, P, 4, device=points.device, dtype=torch.float32)
-        ps = params_struct(fc, params)
-        K.check(K.lib().ngm_field_eval_fwd(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)),
-                                           _ptr(_f32c(quat)), _ptr(out), _stream()), "ngm_field_eval_fwd")
-        ctx.fc, ctx.names = fc, names
-        ctx.save_for_backward(points, pos, quat, *param_tensors)
-        return out
+@_op("field_eval")
+def _field_eval_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[torch.Tensor], quat: Optional[torch.Tensor],
+                   params: List[torch.Tensor]) -> torch.Tensor:
+    fc = _field_cfg(fcfg)
+    pd = dict(zip(K.param_names(fc), params))
+    F, P, _ = points.shape
+    out = torch.empty(F, P, 4, device=points.device, dtype=torch.float32)
+    ps = params_struct(fc, pd)
+    K.check(K.lib().ngm_field_eval_fwd(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)),
+                                       _ptr(_f32c(quat)), _ptr(out), _stream()), "ngm_field_eval_fwd")
+    return out
 
-    @staticmethod
-    def backward(ctx, d_out):
-        points, pos, quat, *param_tensors = ctx.saved_tensors
-        fc, names = ctx.fc, ctx.names
-        params = dict(zip(names, param_tensors))
-        F, P, _ = points.shape
-        d_out = _f32c(d_out, "d_out")
-        grads, gs, _ = alloc_grads(fc, F, points.device)
-        ps = params_struct(fc, params)
-        L = K.lib()
-        wsb = L.ngm_field_eval_bwd_workspace(C.byref(fc), F, P)
-        ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
-        K.check(L.ngm_field_eval_bwd(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)),
-                                     _ptr(d_out), C.byref(gs), _ptr(ws), wsb, _stream()), "ngm_field_eval_bwd")
-        return (None, None, None, None, None) + tuple(grads[n] for n in names)
+
+@_field_eval_op.register_fake
+def _(fcfg, points, pos, quat, params):
+    return points.new_empty(points.shape[0], points.shape[1], 4)
+
+
+@_op("field_eval_bwd")
+def _field_eval_bwd_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[torch.Tensor], quat: Optional[torch.Tensor],
+                       d_out: torch.Tensor, params: List[torch.Tensor]) -> List[torch.Tensor]:
+    fc = _field_cfg(fcfg)
+    names = K.param_names(fc)
+    pd = dict(zip(names, params))
+    F, P, _ = points.shape
+    grads, gs, _ = alloc_grads(fc, F, points.device)
+    ps = params_struct(fc, pd)
+    L = K.lib()
+    wsb = L.ngm_field_eval_bwd_workspace(C.byref(fc), F, P)
+    ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
+    K.check(L.ngm_field_eval_bwd(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)),
+                                 _ptr(_f32c(d_out, "d_out")), C.byref(gs), _ptr(ws), wsb, _stream()), "ngm_field_eval_bwd")
+    return [grads[n] for n in names]
+
+
+@_field_eval_bwd_op.register_fake
+def _(fcfg, points, pos, quat, d_out, params):
+    return [torch.empty_like(p) for p in params]
+
+
+def _field_eval_setup(ctx, inputs, output):
+    fcfg, points, pos, quat, params = inputs
+    ctx.fcfg, ctx.has_pose, ctx.n = fcfg, pos is not None, len(params)
+    ctx.save_for_backward(points, *([pos, quat] if pos is not None else []), *params)
+
+
+def _field_eval_backward(ctx, d_out):
+    points, *rest = ctx.saved_tensors
+    pos, quat = (rest[0], rest[1]) if ctx.has_pose else (None, None)
+    params = rest[2:] if ctx.has_pose else rest
+    grads = torch.ops.ngm355.field_eval_bwd(ctx.fcfg, points, pos, quat, d_out.contiguous(), list(params))
+    return None, None, None, None, grads
+
+
+_field_eval_op.register_autograd(_field_eval_backward, setup_context=_field_eval_setup)
 
 
 def field_eval(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None, quat=None):
-    """(F,P,3) points -> (F,P,4); differentiable w.r.t. the parameters (not the points/poses)."""
-    names = tuple(K.param_names(fc))
-    return _FieldEval.apply(fc, names, points, pos, quat, *[params[n] for n in names])
+    """(F,P,3) points -> (F,P,4); differentiable w.r.t. the parameters (not the points/poses).
+    Dispatches through torch.ops.ngm355.field_eval."""
+    names = K.param_names(fc)
+    plist = [params[n] for n in names]
+    _require_gpu(points, pos, quat, *plist)
+    return torch.ops.ngm355.field_eval(cfg_blob(fc), _f32c(points, "points"), pos, quat, plist)
 
 
-def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.0, outside_value=1.0,
-                   field_index=None):
-    """models.py:347-405: kNN-blended evaluation of world points (P,3) over all fields -> (P,4)."""
-    _require_gpu(points, pos, quat)
-    points = _f32c(points.reshape(-1, 3))
+@_op("field_eval_knn")
+def _field_eval_knn_op(fcfg: torch.Tensor, points: torch.Tensor, pos: torch.Tensor, quat: torch.Tensor,
+                       params: List[torch.Tensor], num_knn: int, distance_factor: float, outside_value: float,
+                       field_index: Optional[torch.Tensor]) -> torch.Tensor:
+    fc = _field_cfg(fcfg)
     P, NF = points.shape[0], pos.shape[0]
     out = torch.empty(P, 4, device=points.device, dtype=torch.float32)
     if P == 0:
         return out
-    ps = params_struct(fc, params, field_index)
+    ps = params_struct(fc, dict(zip(K.param_names(fc), params)), field_index)
     L = K.lib()
     wsb = L.ngm_field_eval_knn_workspace(NF, P, num_knn)
     ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
@@ -135,6 +188,21 @@ def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.
                                  num_knn, distance_factor, outside_value, _ptr(out), _ptr(ws), wsb, _stream()),
             "ngm_field_eval_knn")
     return out
+
+
+@_field_eval_knn_op.register_fake
+def _(fcfg, points, pos, quat, params, num_knn, distance_factor, outside_value, field_index):
+    return points.new_empty(points.shape[0], 4)
+
+
+def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.0, outside_value=1.0,
+                   field_index=None):
+    """models.py:347-405: kNN-blended evaluation of world points (P,3) over all fields -> (P,4).
+    Dispatches through torch.ops.ngm355.field_eval_knn."""
+    plist = [params[n] for n in K.param_names(fc)]
+    _require_gpu(points, pos, quat, *plist)
+    return torch.ops.ngm355.field_eval_knn(cfg_blob(fc), _f32c(points.reshape(-1, 3)), pos, quat, plist, int(num_knn),
+                                           float(distance_factor), float(outside_value), field_index)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,43 +248,76 @@ def make_rays(rc: K.RenderCfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse=Non
                   _ptr(ts[9]), _ptr(ts[10]), int(seed), int(offset), _ptr(pose_index), _ptr(philox_offset_dev))
 
 
-def sample_rays(rc: K.RenderCfg, ijs, near, far, gt=None, u_coarse=None, u_guided=None, seed=0):
-    """camera.py:215-292 + rm.py:521-545 -> (points_cam (F,R,S,3), distances (F,R,S), dirs (F,R,3))."""
-    keep = []
+@_op("sample_rays")
+def _sample_rays_op(rcfg: torch.Tensor, ijs: torch.Tensor, c2ws: Optional[torch.Tensor], near: Optional[torch.Tensor],
+                    far: Optional[torch.Tensor], gt: Optional[torch.Tensor], u_coarse: Optional[torch.Tensor],
+                    u_guided: Optional[torch.Tensor], seed: int, near_const: float, far_const: float,
+                    num_samples: int) -> List[torch.Tensor]:
+    """[points_cam (F,R,S,3), points_world (F,R,S,3) or empty (no c2ws), distances (F,R,S), dirs (F,R,3)]"""
+    rc = _render_cfg(rcfg)
     dev = ijs.device
     F, R = ijs.shape[0], ijs.shape[1]
-    eye = torch.eye(4, device=dev)
-    pos = torch.zeros(F, 3, device=dev)
-    quat = torch.zeros(F, 4, device=dev)
-    rays = make_rays(rc, ijs, eye, near, far, gt, pos, quat, u_coarse, u_guided, seed, keep=keep)
+    world = c2ws is not None
+    pos, quat = torch.zeros(F, 3, device=dev), torch.zeros(F, 4, device=dev)
+    keep = []
+    rays = make_rays(rc, ijs, c2ws if world else torch.eye(4, device=dev), near, far, gt, pos, quat, u_coarse, u_guided,
+                     seed, near_const=near_const, far_const=far_const, keep=keep)
     S = rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0)
-    pts = torch.empty(F, R, S, 3, device=dev)
+    assert S == num_samples
+    pc = torch.empty(F, R, S, 3, device=dev)
+    pw = torch.empty((F, R, S, 3) if world else (0,), device=dev)
     dist = torch.empty(F, R, S, device=dev)
     dirs = torch.empty(F, R, 3, device=dev)
-    K.check(K.lib().ngm_sample_rays(C.byref(rc), C.byref(rays), _ptr(pts), _ptr(dist), _ptr(dirs), _stream()),
-            "ngm_sample_rays")
-    return pts, dist, dirs
+    K.check(K.lib().ngm_sample_rays_world(C.byref(rc), C.byref(rays), _ptr(pc), _ptr(pw) if world else None, _ptr(dist),
+                                          _ptr(dirs), _stream()), "ngm_sample_rays_world")
+    return [pc, pw, dist, dirs]
+
+
+@_sample_rays_op.register_fake
+def _(rcfg, ijs, c2ws, near, far, gt, u_coarse, u_guided, seed, near_const, far_const, num_samples):
+    F, R, S = ijs.shape[0], ijs.shape[1], num_samples
+    f = lambda *shape: torch.empty(*shape, device=ijs.device, dtype=torch.float32)
+    return [f(F, R, S, 3), f(F, R, S, 3) if c2ws is not None else f(0), f(F, R, S), f(F, R, 3)]
+
+
+def sample_rays(rc: K.RenderCfg, ijs, near, far, gt=None, u_coarse=None, u_guided=None, seed=0):
+    """camera.py:215-292 + rm.py:521-545 -> (points_cam (F,R,S,3), distances (F,R,S), dirs (F,R,3))."""
+    _require_gpu(ijs, near, far, gt, u_coarse, u_guided)
+    S = rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0)
+    pc, _, dist, dirs = torch.ops.ngm355.sample_rays(cfg_blob(rc), ijs, None, near, far, gt, u_coarse, u_guided, int(seed),
+                                                     0.0, 8.0, S)
+    return pc, dist, dirs
 
 
 def sample_rays_world(rc: K.RenderCfg, ijs, c2ws, near=None, far=None, gt=None, u_coarse=None, u_guided=None, seed=0,
                       near_const=0.0, far_const=8.0):
-    """sampler + utils.transform_points (rm.py:513-547): (points_cam, points_world, distances), each (F,R,S,·)."""
-    keep = []
-    dev = ijs.device
+    """sampler + utils.transform_points (rm.py:513-547): (points_cam, points_world, distances), each (F,R,S,.)."""
+    _require_gpu(ijs, c2ws, near, far, gt, u_coarse, u_guided)
     if ijs.dim() == 2:
         ijs = ijs[None]
-    F, R = ijs.shape[0], ijs.shape[1]
-    pos = torch.zeros(F, 3, device=dev)
-    quat = torch.zeros(F, 4, device=dev)
-    rays = make_rays(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const=near_const,
-                     far_const=far_const, keep=keep)
     S = rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0)
-    pc = torch.empty(F, R, S, 3, device=dev)
-    pw = torch.empty(F, R, S, 3, device=dev)
-    dist = torch.empty(F, R, S, device=dev)
-    K.check(K.lib().ngm_sample_rays_world(C.byref(rc), C.byref(rays), _ptr(pc), _ptr(pw), _ptr(dist), None, _stream()),
-            "ngm_sample_rays_world")
+    pc, pw, dist, _ = torch.ops.ngm355.sample_rays(cfg_blob(rc), ijs, c2ws, near, far, gt, u_coarse, u_guided, int(seed),
+                                                   float(near_const), float(far_const), S)
     return pc, pw, dist
+
+
+@_op("composite_packed")
+def _composite_packed_op(rcfg: torch.Tensor, field_out4: torch.Tensor, dists: torch.Tensor,
+                         points_cam: torch.Tensor) -> List[torch.Tensor]:
+    rc = _render_cfg(rcfg)
+    N, S = dists.shape
+    dev = dists.device
+    rgbd, cv, dv, term = (torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
+                          torch.empty(N, device=dev))
+    K.check(K.lib().ngm_composite_fwd_packed(C.byref(rc), N, S, _ptr(field_out4), _ptr(dists), _ptr(points_cam), _ptr(rgbd),
+                                             _ptr(cv), _ptr(dv), _ptr(term), _stream()), "ngm_composite_fwd_packed")
+    return [rgbd, cv, dv, term]
+
+
+@_composite_packed_op.register_fake
+def _(rcfg, field_out4, dists, points_cam):
+    N = dists.shape[0]
+    return [dists.new_empty(N, 4), dists.new_empty(N, 3), dists.new_empty(N), dists.new_empty(N)]
 
 
 def composite_packed(rc: K.RenderCfg, field_out4, dists, points_cam):
@@ -224,80 +325,245 @@ def composite_packed(rc: K.RenderCfg, field_out4, dists, points_cam):
     _require_gpu(field_out4, dists, points_cam)
     S = dists.shape[-1]
     N = dists.numel() // S
-    dev = dists.device
-    rgbd, cv, dv, term = (torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
-                          torch.empty(N, device=dev))
-    K.check(K.lib().ngm_composite_fwd_packed(C.byref(rc), N, S, _ptr(_f32c(field_out4)), _ptr(_f32c(dists)),
-                                             _ptr(_f32c(points_cam)), _ptr(rgbd), _ptr(cv), _ptr(dv), _ptr(term),
-                                             _stream()), "ngm_composite_fwd_packed")
-    return rgbd, cv, dv, term
+    return tuple(torch.ops.ngm355.composite_packed(cfg_blob(rc), _f32c(field_out4).reshape(N, S, 4), _f32c(dists).reshape(N, S),
+                                                   _f32c(points_cam).reshape(N, S, 3)))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused render (NeuralGraphMap._render_ijs(use_vmap=True), rm.py:439-666) with autograd
+# ------------------------------------------------------------------------------------------------
+def _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, keep):
+    return make_rays(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const=near_const,
+                     far_const=far_const, keep=keep)
+
+
+@_op("render_ijs")
+def _render_ijs_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2ws: torch.Tensor, near: Optional[torch.Tensor],
+                   far: Optional[torch.Tensor], gt: Optional[torch.Tensor], pos: torch.Tensor, quat: torch.Tensor,
+                   u_coarse: Optional[torch.Tensor], u_guided: Optional[torch.Tensor], seed: int, near_const: float,
+                   far_const: float, save: bool, num_samples: int, params: List[torch.Tensor]) -> List[torch.Tensor]:
+    """[rgbds (F,R,4), color_vars (F,R,3), depth_vars (F,R), term_probs (F,R), geoms (F,R,S) | empty, dists (F,R,S) | empty,
+    workspace (bytes) | empty]; geoms / dists / workspace are filled when `save` (needed for a backward or for the
+    free-space / TSDF vectors of the Prediction)."""
+    fc, rc = _field_cfg(fcfg), _render_cfg(rcfg)
+    keep = []
+    rays = _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, keep)
+    F, R = rays.F, rays.R
+    dev = ijs.device
+    S = rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0)
+    assert S == num_samples
+    rgbds, cvars, dvars, term = (torch.empty(F, R, 4, device=dev), torch.empty(F, R, 3, device=dev),
+                                 torch.empty(F, R, device=dev), torch.empty(F, R, device=dev))
+    pred = K.Prediction(rgbds.data_ptr(), cvars.data_ptr(), dvars.data_ptr(), term.data_ptr())
+    L = K.lib()
+    ps = params_struct(fc, dict(zip(K.param_names(fc), params)))
+    wsb = L.ngm_render_workspace(C.byref(fc), C.byref(rc), F, R, 1) if save else 0
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), None, C.byref(pred), None,
+                             _ptr(ws) if save else None, wsb, _stream()), "ngm_render_fwd")
+    geoms = torch.empty((F, R, S) if save else (0,), device=dev)
+    dists = torch.empty((F, R, S) if save else (0,), device=dev)
+    if save:
+        K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, S, ws.data_ptr(), geoms.data_ptr(),
+                                          dists.data_ptr(), _stream()), "ngm_render_read_samples")
+    return [rgbds, cvars, dvars, term, geoms, dists, ws]
+
+
+@_render_ijs_op.register_fake
+def _(fcfg, rcfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, save, num_samples,
+      params):
+    F, R, S = ijs.shape[0], ijs.shape[1], num_samples
+    f = lambda *shape: torch.empty(*shape, device=ijs.device, dtype=torch.float32)
+    n = (F, R, S) if save else (0,)
+    return [f(F, R, 4), f(F, R, 3), f(F, R), f(F, R), f(*n), f(*n), torch.empty(0, device=ijs.device, dtype=torch.uint8)]
+
+
+@_op("render_ijs_bwd", mutates_args=("workspace",))
+def _render_ijs_bwd_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2ws: torch.Tensor,
+                       near: Optional[torch.Tensor], far: Optional[torch.Tensor], gt: Optional[torch.Tensor],
+                       pos: torch.Tensor, quat: torch.Tensor, u_coarse: Optional[torch.Tensor],
+                       u_guided: Optional[torch.Tensor], seed: int, near_const: float, far_const: float,
+                       d_rgbds: torch.Tensor, d_term: torch.Tensor, d_geoms: Optional[torch.Tensor],
+                       workspace: torch.Tensor, params: List[torch.Tensor]) -> List[torch.Tensor]:
+    """gradients w.r.t. `params`; the backward kernels overwrite the saved forward values in `workspace` (single use)"""
+    fc, rc = _field_cfg(fcfg), _render_cfg(rcfg)
+    keep = []
+    rays = _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, keep)
+    names = K.param_names(fc)
+    grads, gs, _ = alloc_grads(fc, rays.F, ijs.device)
+    ps = params_struct(fc, dict(zip(names, params)))
+    K.check(K.lib().ngm_render_bwd_seeded(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), _ptr(d_rgbds), _ptr(d_term),
+                                          _ptr(d_geoms), C.byref(gs), workspace.data_ptr(), workspace.numel(), _stream()),
+            "ngm_render_bwd_seeded")
+    return [grads[n] for n in names]
+
+
+@_render_ijs_bwd_op.register_fake
+def _(fcfg, rcfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, d_rgbds, d_term,
+      d_geoms, workspace, params):
+    return [torch.empty_like(p) for p in params]
+
+
+_RAY_SLOTS = ("ijs", "c2ws", "near", "far", "gt", "pos", "quat", "u_coarse", "u_guided")
+
+
+def _render_ijs_setup(ctx, inputs, output):
+    fcfg, rcfg, *rest = inputs
+    ray_t, (seed, near_const, far_const, save, _), params = rest[:9], rest[9:14], rest[14]
+    ctx.fcfg, ctx.rcfg, ctx.scalars, ctx.save = fcfg, rcfg, (seed, near_const, far_const), save
+    ctx.present = [t is not None for t in ray_t]
+    ctx.consumed = False
+    ctx.save_for_backward(*[t for t in ray_t if t is not None], output[6], *params)
+    ctx.n_params = len(params)
+
+
+def _render_ijs_backward(ctx, grads):
+    if not ctx.save:
+        raise RuntimeError("render_ijs: backward through a render that saved nothing (call with requires_grad parameters)")
+    if ctx.consumed:
+        raise RuntimeError("render_ijs: second backward through the same render -- the backward kernels overwrite the "
+                           "saved per-sample values in place (single-use workspace, include/ngm_hip.h); render again")
+    ctx.consumed = True
+    saved = list(ctx.saved_tensors)
+    params = saved[len(saved) - ctx.n_params:]
+    ws = saved[len(saved) - ctx.n_params - 1]
+    it = iter(saved)
+    ray_t = [next(it) if p else None for p in ctx.present]
+    d_rgbds, _, _, d_term, d_geoms, _, _ = grads
+    seed, near_const, far_const = ctx.scalars
+    g = torch.ops.ngm355.render_ijs_bwd(ctx.fcfg, ctx.rcfg, *ray_t, seed, near_const, far_const, d_rgbds.contiguous(),
+                                        d_term.contiguous(), d_geoms.contiguous() if d_geoms.numel() else None, ws, params)
+    return (None,) * 16 + (g,)
+
+
+_render_ijs_op.register_autograd(_render_ijs_backward, setup_context=_render_ijs_setup)
+
+
+def render_ijs_fused(fc: K.FieldCfg, rc: K.RenderCfg, params: Dict[str, torch.Tensor], ijs, c2ws, near, far, gt, pos, quat,
+                     u_coarse=None, u_guided=None, seed=0, near_const=0.0, far_const=8.0):
+    """-> (rgbds, color_vars, depth_vars, term_probs, geoms | None, dists | None); differentiable w.r.t. `params` through
+    rgbds / term_probs / geoms.  Dispatches through torch.ops.ngm355.render_ijs."""
+    plist = [params[n] for n in K.param_names(fc)]
+    _require_gpu(ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, *plist)
+    save = bool(gt is not None or (torch.is_grad_enabled() and any(t.requires_grad for t in plist)))
+    if c2ws.dim() != 2 and c2ws.numel() != ijs.shape[0] * ijs.shape[1] * 16:
+        c2ws = c2ws.expand(ijs.shape[0], ijs.shape[1], 4, 4)
+    out = torch.ops.ngm355.render_ijs(cfg_blob(fc), cfg_blob(rc), ijs.contiguous(), _f32c(c2ws), _f32c(near), _f32c(far),
+                                      _f32c(gt), _f32c(pos), _f32c(quat), _f32c(u_coarse), _f32c(u_guided), int(seed),
+                                      float(near_const), float(far_const), save,
+                                      rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0), plist)
+    rgbds, cvars, dvars, term, geoms, dists, _ = out
+    return (rgbds, cvars.detach(), dvars.detach(), term, geoms if save else None, dists.detach() if save else None)
 
 
 # ------------------------------------------------------------------------------------------------
 # K4: quadrature with autograd (rm.py:709-799)
 # ------------------------------------------------------------------------------------------------
-class _Quadrature(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, rc, colors, geoms, dists, depths, isds):
-        _require_gpu(colors, geoms, dists, depths, isds)
-        lead = geoms.shape[:-1]
-        S = geoms.shape[-1]
-        N = geoms.numel() // S
-        colors, geoms, dists, depths = (_f32c(colors), _f32c(geoms), _f32c(dists), _f32c(depths))
-        isd_flat = None
-        if isds is not None:
-            isd_flat = isds.expand(*lead, 1).reshape(N).contiguous().float()
-        dev = geoms.device
-        S_eff = S - 1 if rc.geometry_mode in (K.GEO["density"], K.GEO["neus"]) else S
-        Cc, D, Cv, Dv, T = (torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev),
-                            torch.empty(N, device=dev), torch.empty(N, device=dev))
-        W = torch.empty(N, S_eff, device=dev)
-        K.check(K.lib().ngm_composite_fwd(C.byref(rc), N, S, _ptr(colors), _ptr(geoms), _ptr(dists), _ptr(depths),
-                                          _ptr(isd_flat), _ptr(Cc), _ptr(D), _ptr(Cv), _ptr(Dv), _ptr(T), _ptr(W),
-                                          _stream()), "ngm_composite_fwd")
-        ctx.rc = rc
-        ctx.isd_shape = None if isds is None else tuple(isds.shape)
-        ctx.lead = tuple(lead)
-        ctx.save_for_backward(colors, geoms, dists, depths, isd_flat)
-        ctx.mark_non_differentiable(Cv, Dv, W)
-        return (Cc.view(*lead, 3), D.view(*lead), Cv.view(*lead, 3), Dv.view(*lead), T.view(*lead),
-                W.view(*lead, S_eff))
+def _s_eff(rc, S):
+    return S - 1 if rc.geometry_mode in (K.GEO["density"], K.GEO["neus"]) else S
 
-    @staticmethod
-    def backward(ctx, dC, dD, dCv, dDv, dT, dW):
-        colors, geoms, dists, depths, isd_flat = ctx.saved_tensors
-        S = geoms.shape[-1]
-        N = geoms.numel() // S
-        d_colors = torch.empty_like(colors)
-        d_geoms = torch.empty_like(geoms)
-        want_isd = isd_flat is not None and ctx.needs_input_grad[5] and ctx.rc.geometry_mode == K.GEO["neus"]
-        d_isd = torch.empty(N, device=geoms.device) if want_isd else None
-        K.check(K.lib().ngm_composite_bwd(C.byref(ctx.rc), N, S, _ptr(colors), _ptr(geoms), _ptr(dists), _ptr(depths),
-                                          _ptr(isd_flat), _ptr(_f32c(dC)), _ptr(_f32c(dD)), _ptr(_f32c(dT)),
-                                          _ptr(d_colors), _ptr(d_geoms), _ptr(d_isd), _stream()), "ngm_composite_bwd")
-        g_isd = None
-        if want_isd:   # undo the broadcast of neus_isds to one value per ray
-            g_isd = d_isd.view(*ctx.lead, 1).sum_to_size(ctx.isd_shape)
-        return None, d_colors, d_geoms, None, None, g_isd
+
+@_op("quadrature")
+def _quadrature_op(rcfg: torch.Tensor, colors: torch.Tensor, geoms: torch.Tensor, dists: torch.Tensor, depths: torch.Tensor,
+                   isds: Optional[torch.Tensor], num_weights: int) -> List[torch.Tensor]:
+    rc = _render_cfg(rcfg)
+    N, S = geoms.shape
+    assert num_weights == _s_eff(rc, S)
+    dev = geoms.device
+    Cc, D, Cv, Dv, T = (torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev),
+                        torch.empty(N, device=dev), torch.empty(N, device=dev))
+    W = torch.empty(N, _s_eff(rc, S), device=dev)
+    K.check(K.lib().ngm_composite_fwd(C.byref(rc), N, S, _ptr(colors), _ptr(geoms), _ptr(dists), _ptr(depths),
+                                      _ptr(isds), _ptr(Cc), _ptr(D), _ptr(Cv), _ptr(Dv), _ptr(T), _ptr(W),
+                                      _stream()), "ngm_composite_fwd")
+    return [Cc, D, Cv, Dv, T, W]
+
+
+@_quadrature_op.register_fake
+def _(rcfg, colors, geoms, dists, depths, isds, num_weights):
+    N = geoms.shape[0]          # shapes from tensor sizes and ints only: the cfg bytes are not readable under fake mode
+    return [geoms.new_empty(N, 3), geoms.new_empty(N), geoms.new_empty(N, 3), geoms.new_empty(N), geoms.new_empty(N),
+            geoms.new_empty(N, num_weights)]
+
+
+@_op("quadrature_bwd")
+def _quadrature_bwd_op(rcfg: torch.Tensor, colors: torch.Tensor, geoms: torch.Tensor, dists: torch.Tensor,
+                       depths: torch.Tensor, isds: Optional[torch.Tensor], dC: torch.Tensor, dD: torch.Tensor,
+                       dT: torch.Tensor, want_isd: bool) -> List[torch.Tensor]:
+    rc = _render_cfg(rcfg)
+    N, S = geoms.shape
+    d_colors, d_geoms = torch.empty_like(colors), torch.empty_like(geoms)
+    d_isd = torch.empty(N if want_isd else 0, device=geoms.device)
+    K.check(K.lib().ngm_composite_bwd(C.byref(rc), N, S, _ptr(colors), _ptr(geoms), _ptr(dists), _ptr(depths),
+                                      _ptr(isds), _ptr(dC), _ptr(dD), _ptr(dT), _ptr(d_colors), _ptr(d_geoms),
+                                      _ptr(d_isd) if want_isd else None, _stream()), "ngm_composite_bwd")
+    return [d_colors, d_geoms, d_isd]
+
+
+@_quadrature_bwd_op.register_fake
+def _(rcfg, colors, geoms, dists, depths, isds, dC, dD, dT, want_isd):
+    return [torch.empty_like(colors), torch.empty_like(geoms), geoms.new_empty(geoms.shape[0] if want_isd else 0)]
+
+
+def _quadrature_setup(ctx, inputs, output):
+    rcfg, colors, geoms, dists, depths, isds, _ = inputs
+    ctx.rcfg, ctx.has_isd = rcfg, isds is not None
+    ctx.save_for_backward(colors, geoms, dists, depths, *([isds] if isds is not None else []))
+
+
+def _quadrature_backward(ctx, grads):
+    dC, dD, _, _, dT, _ = grads
+    colors, geoms, dists, depths, *rest = ctx.saved_tensors
+    isds = rest[0] if ctx.has_isd else None
+    N = geoms.shape[0]
+    z = lambda g, *shape: torch.zeros(*shape, device=geoms.device) if g is None else g.contiguous()
+    want = ctx.has_isd and ctx.needs_input_grad[5] and _render_cfg(ctx.rcfg).geometry_mode == K.GEO["neus"]
+    d_colors, d_geoms, d_isd = torch.ops.ngm355.quadrature_bwd(ctx.rcfg, colors, geoms, dists, depths, isds, z(dC, N, 3),
+                                                               z(dD, N), z(dT, N), bool(want))
+    return None, d_colors, d_geoms, None, None, (d_isd if want else None), None
+
+
+_quadrature_op.register_autograd(_quadrature_backward, setup_context=_quadrature_setup)
 
 
 def quadrature(rc: K.RenderCfg, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):
-    """Returns (ray_colors, ray_depths, ray_color_vars, ray_depth_vars, ray_term_probs, sample_weights)."""
-    return _Quadrature.apply(rc, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds)
+    """Returns (ray_colors, ray_depths, ray_color_vars, ray_depth_vars, ray_term_probs, sample_weights).
+    NeuralGraphMap._quadrature (rm.py:709-799) with autograd; dispatches through torch.ops.ngm355.quadrature."""
+    _require_gpu(sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds)
+    lead = sample_geometries.shape[:-1]
+    S = sample_geometries.shape[-1]
+    N = sample_geometries.numel() // S
+    isd_flat = None
+    if neus_isds is not None:                        # one value per ray (autograd undoes the broadcast)
+        isd_flat = neus_isds.expand(*lead, 1).reshape(N).contiguous().float()
+    Cc, D, Cv, Dv, T, W = torch.ops.ngm355.quadrature(
+        cfg_blob(rc), _f32c(sample_colors).reshape(N, S, 3), _f32c(sample_geometries).reshape(N, S),
+        _f32c(sample_distances).reshape(N, S), _f32c(sample_depths).reshape(N, S), isd_flat, _s_eff(rc, S))
+    return (Cc.view(*lead, 3), D.view(*lead), Cv.detach().view(*lead, 3), Dv.detach().view(*lead), T.view(*lead),
+            W.detach().view(*lead, W.shape[-1]))
 
 
 # ------------------------------------------------------------------------------------------------
 # sparse Adam (SURVEY 8f.1)
 # ------------------------------------------------------------------------------------------------
-def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-15,
-                 weight_decay=1e-5):
-    """In-place Adam on rows `field_index` of stacked tensors (N, ...); grad is (F, ...)."""
-    _require_gpu(param, exp_avg, exp_avg_sq, grad, field_index)
+@_op("adam_sparse_", mutates_args=("param", "exp_avg", "exp_avg_sq"))
+def _adam_sparse_op(param: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, grad: torch.Tensor,
+                    field_index: torch.Tensor, step: int, lr: float, beta1: float, beta2: float, eps: float,
+                    weight_decay: float) -> None:
     F = grad.shape[0]
     numel = grad[0].numel()
     K.check(K.lib().ngm_adam_sparse(_ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), param.stride(0), _ptr(grad),
-                                    grad.stride(0), _ptr(field_index), F, numel, int(step), lr, betas[0], betas[1], eps,
+                                    grad.stride(0), _ptr(field_index), F, numel, int(step), lr, beta1, beta2, eps,
                                     weight_decay, _stream()), "ngm_adam_sparse")
+
+
+def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-15,
+                 weight_decay=1e-5):
+    """In-place Adam on rows `field_index` of stacked tensors (N, ...); grad is (F, ...).
+    torch.ops.ngm355.adam_sparse_ (declared as mutating param / exp_avg / exp_avg_sq)."""
+    _require_gpu(param, exp_avg, exp_avg_sq, grad, field_index)
+    torch.ops.ngm355.adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, int(step), float(lr), float(betas[0]),
+                                  float(betas[1]), float(eps), float(weight_decay))
 
 
 def adam_tensor_arrays(fc, params, state, grads):

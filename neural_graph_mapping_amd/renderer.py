@@ -61,65 +61,6 @@ def make_render_cfg(camera: Camera, config: dict, guided: bool = True) -> K.Rend
         w_tsdf=config.get("tsdf_weight", 0.0))
 
 
-# ------------------------------------------------------------------------------------------------
-# generic (autograd) render: Prediction with the compacted free-space / TSDF vectors
-# ------------------------------------------------------------------------------------------------
-class _RenderIjs(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, fc, rc, names, rays_kw, *param_tensors):
-        params = dict(zip(names, param_tensors))
-        keep = []
-        rays = ops.make_rays(rc, keep=keep, **rays_kw)
-        F, R = rays.F, rays.R
-        dev = param_tensors[0].device
-        S = rc.num_samples_coarse + (rc.num_samples_guided if rays_kw.get("gt") is not None else 0)
-        pr = dict(rgbds=torch.empty(F, R, 4, device=dev), color_vars=torch.empty(F, R, 3, device=dev),
-                  depth_vars=torch.empty(F, R, device=dev), term_probs=torch.empty(F, R, device=dev))
-        pred = K.Prediction(*[t.data_ptr() for t in pr.values()])
-        L = K.lib()
-        ps = ops.params_struct(fc, params)
-        need_grad = any(t.requires_grad for t in param_tensors)
-        ws, wsb = None, 0
-        if need_grad or rays_kw.get("gt") is not None:
-            wsb = L.ngm_render_workspace(C.byref(fc), C.byref(rc), F, R, 1)
-            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-        K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), None, C.byref(pred), None,
-                                 ops._ptr(ws), wsb, ops._stream()), "ngm_render_fwd")
-        geoms = dists = None
-        if ws is not None:
-            geoms, dists = torch.empty(F, R, S, device=dev), torch.empty(F, R, S, device=dev)
-            K.check(L.ngm_render_read_samples(C.byref(fc), C.byref(rc), F, R, S, ws.data_ptr(), geoms.data_ptr(),
-                                              dists.data_ptr(), ops._stream()), "ngm_render_read_samples")
-        ctx.fc, ctx.rc, ctx.names, ctx.rays_kw, ctx.ws, ctx.wsb = fc, rc, names, rays_kw, ws, wsb
-        ctx.save_for_backward(*param_tensors)
-        ctx.mark_non_differentiable(pr["color_vars"], pr["depth_vars"])
-        if dists is not None:
-            ctx.mark_non_differentiable(dists)
-        return pr["rgbds"], pr["color_vars"], pr["depth_vars"], pr["term_probs"], geoms, dists
-
-    @staticmethod
-    def backward(ctx, d_rgbds, d_cv, d_dv, d_term, d_geoms, d_dists):
-        if getattr(ctx, "consumed", False):
-            raise RuntimeError("render_ijs: second backward through the same render -- the backward kernels overwrite the "
-                               "saved per-sample values in place (single-use workspace, include/ngm_hip.h); render again")
-        ctx.consumed = True
-        fc, rc, names = ctx.fc, ctx.rc, ctx.names
-        params = dict(zip(names, ctx.saved_tensors))
-        keep = []
-        rays = ops.make_rays(rc, keep=keep, **ctx.rays_kw)
-        dev = ctx.saved_tensors[0].device
-        F, R = rays.F, rays.R
-        d_rgbds = torch.zeros(F, R, 4, device=dev) if d_rgbds is None else ops._f32c(d_rgbds)
-        d_term = None if d_term is None else ops._f32c(d_term)
-        d_geoms = None if d_geoms is None else ops._f32c(d_geoms)
-        grads, gs, _ = ops.alloc_grads(fc, F, dev)
-        ps = ops.params_struct(fc, params)
-        K.check(K.lib().ngm_render_bwd_seeded(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), ops._ptr(d_rgbds),
-                                              ops._ptr(d_term), ops._ptr(d_geoms), C.byref(gs), ctx.ws.data_ptr(),
-                                              ctx.wsb, ops._stream()), "ngm_render_bwd_seeded")
-        return (None, None, None, None) + tuple(grads[n] for n in names)
-
-
 class NeuralGraphRenderer:
     """Renderer + per-field optimiser state for a ``NeuralFieldSet`` (hot-path half of NeuralGraphMap)."""
 
@@ -216,17 +157,15 @@ class NeuralGraphRenderer:
             rc.overwrite_behind_camera = 0
         pos = self._global_map_dict["positions"][field_ids]
         quat = self._global_map_dict["orientations"][field_ids]
-        names = tuple(K.param_names(self._fc))
-        rays_kw = dict(ijs=ijs, c2ws=c2ws, near=near_distances, far=far_distances, gt=gt_distances if guided else None,
-                       pos=pos, quat=quat, u_coarse=u_coarse, u_guided=u_guided if guided else None, seed=seed,
-                       near_const=self._config.get("near_distance", 0.0), far_const=self._config.get("far_distance", 8.0))
         params = self._model.vmap_fields_params
         if rc.geometry_mode == K.GEO["neus"]:
             return self._render_ijs_staged(rc, ijs, c2ws, field_ids, near_distances, far_distances,
                                            gt_distances if guided else None, gt_distances, u_coarse,
                                            u_guided if guided else None, seed, overwrite_samples_behind_camera)
-        rgbds, cvars, dvars, term, geoms, dists = _RenderIjs.apply(self._fc, rc, names, rays_kw,
-                                                                   *[params[n] for n in names])
+        rgbds, cvars, dvars, term, geoms, dists = ops.render_ijs_fused(
+            self._fc, rc, params, ijs, c2ws, near_distances, far_distances, gt_distances if guided else None, pos, quat,
+            u_coarse, u_guided if guided else None, seed, self._config.get("near_distance", 0.0),
+            self._config.get("far_distance", 8.0))
         fs = ts = None
         tau = rc.truncation_distance
         if gt_distances is not None and geoms is not None:

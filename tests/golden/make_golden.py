@@ -17,6 +17,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from _ref_import import NRGBD_CAMERA, build_map, import_reference, make_config  # noqa: E402
+import scene  # noqa: E402
 
 rm, models, camera, pe, losses, utils = import_reference()
 
@@ -384,6 +385,106 @@ def g7_adam():
          **p0, **p1, **m1, **v1, **steps)
 
 
+def _reference_trainer(F, pos, quat, n_c, n_g, seed, perturb_seed=None, scale=1.0):
+    """A reference NeuralGraphMap with F fields and the optimizer plumbing of g7 (rm.py:347-362)."""
+    cfg = make_config(num_samples_coarse=n_c, num_samples_depth_guided=n_g, dim_enc=64)
+    torch.manual_seed(seed)
+    ngm = rm.NeuralGraphMap(cfg)
+    ngm._camera = camera.Camera(**NRGBD_CAMERA)
+    ngm._optimizer = torch.optim.Adam([torch.zeros((), requires_grad=True)], lr=cfg["learning_rate"], eps=cfg["adam_eps"],
+                                      weight_decay=cfg["adam_weight_decay"])
+    ngm._global_map_dict["num"] = F
+    if ngm._global_map_dict["positions"].shape[0] < F:
+        ngm._extend_map_dict(F)
+    ngm._global_map_dict["positions"][:F] = pos
+    ngm._global_map_dict["orientations"][:F] = quat
+    ngm._add_fields(F)
+    proto = {k: v[0].clone() for k, v in ngm._model.all_fields_params.items()}
+    with torch.no_grad():
+        if perturb_seed is not None:                       # fields that differ: the recipe the tests replay (scene.py)
+            for k, v in ngm._model.all_fields_params.items():
+                v.copy_(scene.perturbed_init(proto[k], F, k, perturb_seed))
+        if scale != 1.0:
+            for v in ngm._model.all_fields_params.values():
+                v.mul_(scale)
+    return ngm, proto
+
+
+def _reference_iteration(ngm, t, fids, seed_u):
+    target = make_target(t, fids)
+    torch.manual_seed(seed_u)                               # the torch.rand draws of camera.py:274: coarse, then guided
+    pred = ngm._render_ijs(t["ijs"], t["c2ws"], ngm._camera, field_ids=fids, use_vmap=True, near_distances=t["near"],
+                           far_distances=t["far"], gt_distances=t["gt"])
+    loss = ngm._compute_losses(target, pred)
+    ngm._update_step(loss, fids)
+    return float(loss["combined"].detach())
+
+
+def g13_training_run():
+    """Long training runs of the REAL reference on the learnable sphere scene (tests/golden/scene.py regenerates every
+    batch from its seed, so the fixture holds no per-iteration data).
+      A  cfg0 (1 field, 256 rays x (16+16) samples, Fourier 2x64): 100 iterations; parameters after 10 / 30 / 100
+         iterations, moments after 100, every loss -- and the SAME run started from parameters scaled by (1 + 1e-7):
+         the reference's own sensitivity to a one-ulp change, which is the yardstick for "same trajectory".
+      B  an ensemble of fields trained together (one batch, rm.py:1164-1186): held-out PSNR of every field at
+         checkpoints over the second half of the run -> the ensemble-mean PSNR the kernels must reach within 0.1 dB.
+    """
+    n_c = n_g = 16
+    R = 256
+    # ---------------------------------------------------------------- A
+    gen = torch.Generator().manual_seed(13)
+    pos = 0.5 * torch.randn(1, 3, generator=gen)
+    quat = rand_quats(1, gen)
+    fids = torch.arange(1)
+    out = {}
+    for tag, scale in (("a", 1.0), ("b", 1.0 + 1e-7)):
+        ngm, proto = _reference_trainer(1, pos, quat, n_c, n_g, seed=130, perturb_seed=131, scale=scale)
+        if tag == "a":
+            out.update({"A::p0::" + k: v.clone() for k, v in ngm._model.all_fields_params.items()})
+        losses = []
+        for it in range(scene.A_ITERS):
+            t = scene.sphere_scene_batch(1, R, pos, scene.A_BATCH_SEED + it)
+            losses.append(_reference_iteration(ngm, t, fids, scene.A_U_SEED + it))
+            if it + 1 in scene.A_CHECKPOINTS:
+                out.update({f"A::{tag}{it + 1}::" + k: v.clone() for k, v in ngm._model.all_fields_params.items()})
+        out[f"A::{tag}::losses"] = np.array(losses, dtype=np.float32)
+        if tag == "a":
+            out.update({"A::m::" + k: ngm._optim_state[k]["exp_avg"].clone() for k in ngm._optim_state})
+            out.update({"A::v::" + k: ngm._optim_state[k]["exp_avg_sq"].clone() for k in ngm._optim_state})
+    save("g13_train_cfg0", pos=pos, quat=quat, **out)
+    # ---------------------------------------------------------------- B
+    F, iters = scene.B_FIELDS, scene.B_ITERS
+    gen = torch.Generator().manual_seed(14)
+    pos = 3.0 * torch.randn(F, 3, generator=gen)
+    quat = rand_quats(F, gen)
+    phase = 6.28 * torch.rand(F, 3, generator=gen)
+    fids = torch.arange(F)
+    ngm, proto = _reference_trainer(F, pos, quat, n_c, n_g, seed=140, perturb_seed=141)
+    init_chk = scene.checksum(ngm._model.all_fields_params)
+    th = scene.sphere_scene_batch(F, scene.B_HELD_OUT_RAYS, pos, scene.B_HELD_OUT_SEED, phase=phase)
+    losses, psnrs, derrs = [], [], []
+    import time
+    t0 = time.time()
+    for it in range(iters):
+        t = scene.sphere_scene_batch(F, R, pos, scene.B_BATCH_SEED + it, phase=phase)
+        losses.append(_reference_iteration(ngm, t, fids, scene.B_U_SEED + it))
+        if it + 1 >= scene.B_EVAL_FROM and (it + 1) % scene.B_EVAL_EVERY == 0:
+            with torch.no_grad():
+                torch.manual_seed(scene.B_HELD_OUT_U_SEED)
+                pred = ngm._render_ijs(th["ijs"], th["c2ws"], ngm._camera, field_ids=fids, use_vmap=True,
+                                       near_distances=th["near"], far_distances=th["far"], gt_distances=th["gt"])
+            ps, de = scene.held_out_scores(pred.rgbds, th)
+            psnrs.append(ps)
+            derrs.append(de)
+        if (it + 1) % 50 == 0:
+            print(f"  g13 B: {it + 1}/{iters}  {time.time() - t0:.0f} s  loss {losses[-1]:.4f}"
+                  + (f"  psnr {torch.stack(psnrs).mean():.3f}" if psnrs else ""), flush=True)
+    final = {"B::p1::" + k: v[:2].clone() for k, v in ngm._model.all_fields_params.items()}      # two fields, for the record
+    save("g13_train_ensemble", pos=pos, quat=quat, phase=phase, losses=np.array(losses, dtype=np.float32),
+         psnr=torch.stack(psnrs), depth_err=torch.stack(derrs), init_checksum=np.float64(init_chk),
+         **{"proto::" + k: v for k, v in proto.items()}, **final)
+
+
 def g8_knn():
     gen = torch.Generator().manual_seed(8)
     NF, P = 3, 200
@@ -419,6 +520,10 @@ def g9_render_image():
     model.all_fields_params["_linears.2.weight"].mul_(3.0)
     c2w = torch.eye(4)
     ngm.eval()
+    # G14: the same map as a checkpoint in the reference's own layout -- the dict NeuralGraphMap.save_model hands to
+    # torch.save (rm.py:2147-2156; its yoco config dump is control plane and not part of the interchange)
+    torch.save({"map_dict": ngm._global_map_dict, "all_fields_params": ngm._model.all_fields_params,
+                "state_dict": ngm._model.state_dict()}, os.path.join(HERE, "g14_checkpoint_reference_layout.pt"))
     torch.manual_seed(900)
     rgbd, dvar = ngm.render_image(c2w, cam)
     torch.manual_seed(900)
@@ -434,7 +539,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -37,3 +37,36 @@ def sphere_scene_batch(F, R, pos, seed, radius=0.6, phase=None):
     rgb = torch.where(hit_ok[..., None], 0.5 + 0.4 * torch.sin(3.0 * hit + ph), torch.zeros_like(hit))
     return dict(ijs=ijs, c2ws=c2w, near=near, far=far, gt=gt, rgbds=torch.cat([rgb, (gt * d[..., 2].abs())[..., None]], -1),
                 depth_mask=hit_ok, term_probs=hit_ok.float(), term_mask=torch.ones(F, R, dtype=torch.bool))
+
+
+# ---- the long training runs of fixture G13 (make_golden.g13_training_run <-> tests/test_gpu_training_run.py) --------
+A_ITERS, A_CHECKPOINTS, A_BATCH_SEED, A_U_SEED = 100, (10, 30, 100), 20000, 30000
+B_FIELDS, B_ITERS, B_BATCH_SEED, B_U_SEED = 96, 1200, 40000, 50000
+B_EVAL_FROM, B_EVAL_EVERY = 400, 20
+B_HELD_OUT_RAYS, B_HELD_OUT_SEED, B_HELD_OUT_U_SEED = 512, 99, 77
+
+
+def perturbed_init(proto: torch.Tensor, F: int, name: str, seed: int) -> torch.Tensor:
+    """F copies of the prototype tensor (models.py:254-257 clones it for every new field) + 0.05 N(0,1) on weights and
+    biases so that the fields differ; seeded per tensor name, regenerated identically by the tests."""
+    import zlib
+    out = proto.unsqueeze(0).repeat(F, *([1] * proto.dim())).clone()
+    if proto.dim() >= 1:
+        g = torch.Generator().manual_seed(seed + zlib.crc32(name.encode()) % 100000)
+        out += 0.05 * torch.randn(out.shape, generator=g)
+    return out
+
+
+def checksum(params: dict) -> float:
+    return float(sum(v.double().abs().sum() for v in params.values()))
+
+
+def held_out_scores(rgbds: torch.Tensor, th: dict):
+    """per field: PSNR of the colours (evaluation.py:46-56: clamp to [0,1], data range 1) and mean |depth error| over
+    the held-out rays that hit the sphere"""
+    m = th["depth_mask"].to(rgbds.device)
+    tgt = th["rgbds"].to(rgbds.device)
+    n = m.sum(-1).clamp_min(1)
+    mse = (((rgbds[..., :3].clamp(0, 1) - tgt[..., :3]) ** 2).mean(-1) * m).sum(-1) / n
+    derr = ((rgbds[..., 3] - tgt[..., 3]).abs() * m).sum(-1) / n
+    return (10.0 * torch.log10(1.0 / mse)).cpu(), derr.cpu()

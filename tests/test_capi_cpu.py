@@ -95,3 +95,31 @@ def test_missing_library_fails_loudly(capi, monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libngm_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         capi.lib()
+
+
+def test_ops_are_registered_with_the_dispatcher(capi):
+    """north_star: "a thin C-ABI exposed as PyTorch-ROCm custom ops" -- every op is a torch.library op of namespace
+    ngm355 (schema + fake shapes + autograd formula) with a ROCm ("cuda") kernel only: no CPU registration."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from neural_graph_mapping_amd import mesh, ops  # noqa: F401
+    names = {"sample_rays", "field_eval", "field_eval_bwd", "field_eval_knn", "quadrature", "quadrature_bwd",
+             "composite_packed", "render_ijs", "render_ijs_bwd", "adam_sparse_", "marching_cubes"}
+    for n in names:
+        assert hasattr(torch.ops.ngm355, n), n
+    assert "Tensor(a0!) param" in str(torch.ops.ngm355.adam_sparse_.default._schema)        # declared as mutating
+    assert "!) workspace" in str(torch.ops.ngm355.render_ijs_bwd.default._schema)
+    fc, rc = capi.field_cfg(), capi.render_cfg(num_samples_coarse=4, num_samples_guided=0)
+    params = [torch.zeros(1, *s) for s in capi.param_shapes(fc).values()]
+    with pytest.raises(NotImplementedError):                                                # dispatcher: no CPU kernel
+        torch.ops.ngm355.field_eval(ops.cfg_blob(fc), torch.zeros(1, 8, 3), None, None, params)
+    # shape inference without a device (what torch.compile / export see)
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        g = torch.empty(6, 4, device="cuda")
+        out = torch.ops.ngm355.quadrature(ops.cfg_blob(rc), torch.empty(6, 4, 3, device="cuda"), g, g, g, None, 4)
+        assert [tuple(o.shape) for o in out] == [(6, 3), (6,), (6, 3), (6,), (6,), (6, 4)]
+        ij = torch.empty(2, 5, 2, dtype=torch.int64, device="cuda")
+        out = torch.ops.ngm355.sample_rays(ops.cfg_blob(rc), ij, None, None, None, None, None, None, 0, 0.0, 8.0, 4)
+        assert [tuple(o.shape) for o in out] == [(2, 5, 4, 3), (0,), (2, 5, 4), (2, 5, 3)]
+        o = torch.ops.ngm355.field_eval(ops.cfg_blob(fc), torch.empty(1, 8, 3, device="cuda"), None, None,
+                                        [torch.empty(p.shape, device="cuda") for p in params])
+        assert tuple(o.shape) == (1, 8, 4)

@@ -19,6 +19,10 @@ from gpu_common import (DEV, NRGBD, close, grad_close, kink_free_draws, make_ren
 from neural_graph_mapping_amd import _capi as K  # noqa: E402
 from oracle import ngm_oracle as O  # noqa: E402
 
+# hash encoding: the finest level scales positions by 1 / sigma = 1e4, so the fp32 position error of ~1e-7 becomes
+# ~1e-3 ABSOLUTE in lattice coordinates, i.e. in the barycentric weights (in the oracle just as in the kernels and in the
+# reference's CUDA package); gradients of entries that few samples touch inherit it -> 1e-2 of max |grad| instead of 2e-3
+HASH_GRAD_TOL = 1e-2
 FOURIER = dict(encoding="fourier", dim_enc=64, num_layers=2)
 HASH = dict(encoding="permuto", num_layers=1, nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4)
 
@@ -93,7 +97,7 @@ def test_cfg2_hash_network_vs_oracle_many_samples_per_ray(F, R, n_c, n_g):
     close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         if po[k].grad is not None:
-            grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+            grad_close(res["grads"][k], po[k].grad, HASH_GRAD_TOL, k)
 
 
 # ------------------------------------------------------------------------------------------------ cfg3
@@ -133,7 +137,7 @@ def test_cfg3_200_fields_random_active_sets():
         touched[ids] = True
     assert r._step == 3
     for k, v in r._model.all_fields_params.items():
-        same = (v == p0[k]).flatten(1).all(1).cpu()
+        same = (v == p0[k]).reshape(v.shape[0], -1).all(1).cpu()
         if k in ("_encoding.random_shift_per_level", "_neus_sd"):       # no gradient in this mode: never touched
             assert bool(same.all()), k
             continue

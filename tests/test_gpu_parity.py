@@ -398,6 +398,7 @@ def test_sparse_adam_ten_iterations_golden():
             continue
         close(r._model.all_fields_params[k], v, rtol=2e-3, atol=5e-5)
         close(r._optim_state[k]["exp_avg"], g["m1::" + k], rtol=5e-3, atol=1e-6)
+        grad_close(r._optim_state[k]["exp_avg_sq"], g["v1::" + k], 5e-3, "exp_avg_sq " + k)   # sums of g^2: 2x the gradient bar
 
 
 # ---------------------------------------------------------------- full-size properties (M1 shape)
@@ -604,7 +605,7 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     (out * d_out.to(DEV)).sum().backward()
     for k in po:
         if po[k].grad is not None:
-            grad_close(pg[k].grad, po[k].grad, 2e-3, k)
+            grad_close(pg[k].grad, po[k].grad, 1e-2, k)              # hash: fp32 lattice coordinates at sigma = 1e-4
     # table gradient: every touched entry matches, untouched entries are exactly zero
     gl, rl = pg["_encoding.lattice_values"].grad.cpu(), po["_encoding.lattice_values"].grad
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
@@ -649,7 +650,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
     close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         if po[k].grad is not None:
-            grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+            grad_close(res["grads"][k], po[k].grad, 1e-2, k)          # hash: fp32 lattice coordinates at sigma = 1e-4
     before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
     r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
     assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched
@@ -808,3 +809,33 @@ def test_fused_train_random_shapes_vs_oracle(seed):
     if n_c + n_g < 2 and mode == "density":
         n_c += 1                                                   # density drops the last sample
     ragged_case(F, R, n_c, n_g, fkw, geometry_mode=mode, geometry_factor=20.0 if mode != "density" else 1.0)
+
+
+# ------------------------------------------------------------------ checkpoint interchange (rm.py:2147-2173)
+def test_checkpoint_in_reference_layout_renders_the_reference_image(tmp_path):
+    """G14: a .pt written by the real reference (the dict of save_model, rm.py:2149-2156) for the map of G9.  A renderer
+    with an EMPTY field set loads it and must render the reference's image; saving and re-loading changes nothing."""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g9_render_image")
+    w, h, fx, fy, cx, cy = [float(x) for x in g["cam"]]
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, eval_far_distance=float(g["eval_far"]),
+               eval_num_samples=int(g["eval_num_samples"]))
+    cam = Rr.Camera(int(w), int(h), fx, fy, cx, cy, pixel_center=0.0)
+    r = make_renderer(dict(encoding="fourier", dim_enc=64, num_layers=2), ckw, 1)     # holds one unrelated field
+    r.load_model(os.path.join(GOLDEN, "g14_checkpoint_reference_layout.pt"))
+    assert r._global_map_dict["num"] == 3 and r._model.all_fields_params["_linears.0.weight"].is_cuda
+    rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
+    close(rgbd, g["rgbd"], rtol=5e-4, atol=5e-5)
+    close(dvar, g["dvar"], rtol=5e-4, atol=5e-5)
+    r.save_model(str(tmp_path / "again.pt"))
+    r2 = make_renderer(dict(encoding="fourier", dim_enc=64, num_layers=2), ckw, 0)
+    r2.load_model(str(tmp_path / "again.pt"))
+    rgbd2, _ = r2.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
+    assert torch.equal(rgbd, rgbd2)
+    # a loaded map trains: moments start from zero (the reference does not checkpoint them either)
+    _, _, t = synth_target(3, 16, seed=2)
+    t["c2ws"] = t["c2ws"].clone()
+    t["c2ws"][..., :3, 3] += (g["pos"] - synth_target(3, 1, seed=2)[0])[:, None]
+    out = r2.optimization_iteration(make_target(t, torch.arange(3)), seed=1, update=True)
+    assert torch.isfinite(out["combined"]) and r2._step == 1

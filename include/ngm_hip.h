@@ -231,7 +231,11 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
  * world->local -> encoding -> MLP -> compositing in ONE kernel.  When `targets` is non-NULL it
  * also accumulates the loss partial sums of _compute_losses (rm.py:1769-1872) into
  * loss_sums[NGM_NUM_LOSS_SUMS] (device, overwritten) and fills the saved-for-backward part of
- * the workspace.  sample_stash (optional, (F,R,S,6): r,g,b,geometry,t,T) exposes the per-sample
+ * the workspace.  loss_sums == NULL with targets = DEFERRED reduction: the per-workgroup partial sums
+ * stay in the workspace and the matching ngm_render_bwd / ngm_render_bwd_adam call (also with
+ * loss_sums == NULL) sums them itself -- one launch less per step on a single GPU, where nothing
+ * (no all-reduce) happens between forward and backward; the philox_offset_autoinc counter is then
+ * advanced by the backward.  sample_stash (optional, (F,R,S,6): r,g,b,geometry,t,T) exposes the per-sample
  * values for callers that need the compacted free-space / TSDF vectors of the Prediction. */
 int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F,
                              int32_t R, int32_t train);

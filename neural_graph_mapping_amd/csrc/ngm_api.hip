@@ -527,7 +527,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   if (!pred) return fail(NGM_E_INVALID, "render_fwd: pred is NULL");
   const bool has_tg = targets != nullptr;
   const bool save = workspace != nullptr;   // keep the per-sample stash for a later backward
-  if (has_tg && (!targets->rgbds || !targets->depth_mask || !loss_sums)) return fail(NGM_E_INVALID, "render_fwd: incomplete targets");
+  if (has_tg && (!targets->rgbds || !targets->depth_mask)) return fail(NGM_E_INVALID, "render_fwd: incomplete targets");
   if (has_tg && targets->term_mask && !targets->term_probs) return fail(NGM_E_INVALID, "render_fwd: term_mask without term_probs");
   if (has_tg && !save) return fail(NGM_E_WORKSPACE, "render_fwd: targets need a workspace");
   if (save && (!pred->rgbds || !pred->term_probs)) return fail(NGM_E_INVALID, "render_fwd(save): pred.rgbds/term_probs required");
@@ -556,7 +556,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_render_fwd");
   if (e) return e;
-  if (has_tg) {
+  if (has_tg && loss_sums) {      // loss_sums == NULL: deferred -- ngm_render_bwd* (loss_sums == NULL) reduces the partials itself
     ngm_launch_loss_reduce(a.loss_partials, p.blocks_fwd, loss_sums,
                            (rays->philox_offset_autoinc && rays->philox_offset_dev) ? const_cast<uint64_t*>(rays->philox_offset_dev) : nullptr,
                            (hipStream_t)stream);
@@ -576,6 +576,12 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   sb.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
   sb.stashB = reinterpret_cast<const float2*>(ws + p.off_stashB);
   sb.raytab = reinterpret_cast<const float*>(ws + p.off_raytab);
+  if (sb.seed_mode == 0 && !sb.loss_sums) {      // deferred loss reduction: the forward left its partials in the workspace
+    sb.loss_partials = reinterpret_cast<const float*>(ws + p.off_losspart);
+    sb.n_partials = p.blocks_fwd;
+    sb.counter = (rays->philox_offset_autoinc && rays->philox_offset_dev)
+                     ? reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(rays->philox_offset_dev)) : nullptr;
+  }
   int e = ngm_launch_stash_bwd(sb, st);
   if (e) return fail(e, "render_bwd: unsupported geometry mode");
   e = check_launch("ngm_stash_bwd");
@@ -614,7 +620,7 @@ int ngm_render_bwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
                    float* loss_out, void* workspace, int64_t workspace_bytes, void* stream) {
   int e = check_render(fcfg, rcfg, params, rays);
   if (e) return e;
-  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !loss_sums || !grads)
+  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !grads)
     return fail(NGM_E_INVALID, "render_bwd: NULL argument");
   StashBwdArgs sb;
   memset(&sb, 0, sizeof(sb));
@@ -630,7 +636,7 @@ int ngm_render_bwd_adam(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, c
                         float eps, float weight_decay, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream) {
   int e = check_render(fcfg, rcfg, params, rays);
   if (e) return e;
-  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !loss_sums || !grads ||
+  if (!targets || !targets->rgbds || !targets->depth_mask || !pred || !pred->rgbds || !pred->term_probs || !grads ||
       !mlp_tensors || num_mlp_tensors < 1 || (step < 1 && !step_dev))
     return fail(NGM_E_INVALID, "render_bwd_adam: bad argument");
   if ((fcfg->encoding == NGM_ENC_PERMUTO) != (lattice_tensor != nullptr))

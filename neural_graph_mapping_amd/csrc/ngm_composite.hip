@@ -369,11 +369,32 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   const float inv_s = 1.0f / (float)S;
   const float tau = a.rc.truncation_distance, gamma = a.rc.geometry_factor, cf = a.rc.color_factor;
   const int mode = a.rc.geometry_mode;
-  // global loss normalisers (after the caller's all-reduce)
+  // global loss normalisers (after the caller's all-reduce, or -- deferred reduction -- summed here by every workgroup
+  // from the forward's partials in k_loss_reduce's fixed order: identical in all workgroups, deterministic)
+  __shared__ float s_red[16][17];
+  __shared__ float s_sums[NGM_NUM_LOSS_SUMS];
+  const float* sums = a.loss_sums;
+  if (a.seed_mode == 0 && a.loss_partials) {             // kernel-uniform branch
+    const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
+    float s = 0.f;
+    for (int b = part; b < a.n_partials; b += 16) s += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
+    s_red[part][slot] = s;
+    __syncthreads();
+    if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) t += s_red[p][threadIdx.x];
+      s_sums[threadIdx.x] = t;
+      if (blockIdx.x == 0 && a.sums_out) a.sums_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+    sums = s_sums;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.counter) *a.counter += 1ull;
+  }
   float k_photo = 0, k_depth = 0, k_term = 0, k_fs = 0, k_ts = 0;
   if (a.seed_mode == 0) {
-    const float n_m = a.loss_sums[NGM_LS_PHOTO_CNT], n_d = a.loss_sums[NGM_LS_DEPTH_CNT], n_t = a.loss_sums[NGM_LS_TERM_CNT],
-                n_fs = a.loss_sums[NGM_LS_FS_CNT], n_ts = a.loss_sums[NGM_LS_TSDF_CNT];
+    const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
+                n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
     k_photo = n_m > 0 ? a.rc.w_photometric / (3.0f * n_m) : 0.f;
     k_depth = n_d > 0 ? a.rc.w_depth / n_d : 0.f;
     k_term = n_t > 0 ? a.rc.w_termination * 2.0f / n_t : 0.f;
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     k_ts = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
   }
   // the loss scalars ride along (one thread; saves a launch in the training step)
-  if (a.loss_out && a.seed_mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) loss_values_from_sums(a.rc, a.loss_sums, a.loss_out);
+  if (a.loss_out && a.seed_mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) loss_values_from_sums(a.rc, sums, a.loss_out);
   const int64_t nsamp_all = (r_end - r_beg) * S;
   float carryQ = 0.f;
   const int64_t nsteps = (nsamp_all + 63) / 64;

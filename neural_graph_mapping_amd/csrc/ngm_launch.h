@@ -125,6 +125,12 @@ struct StashBwdArgs {
   const float* d_term;        // (F,R)
   const float* d_geom_samples;// (F,R,S) or NULL
   float* loss_out;            // (8) loss scalars from loss_sums (seed mode 0) or NULL
+  // deferred loss reduction (single GPU: nothing happens between forward and backward): every workgroup sums the
+  // forward's per-workgroup partials itself, in the fixed order of k_loss_reduce -> one launch less per step
+  const float* loss_partials; // (n_partials, 16) or NULL -> loss_sums holds the (all-reduced) sums
+  int n_partials;
+  float* sums_out;            // (16) optional copy of the reduced sums
+  unsigned long long* counter;// optional iteration counter to advance (what k_loss_reduce does otherwise)
 };
 
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);

@@ -455,9 +455,12 @@ class NeuralGraphRenderer:
         pred = K.Prediction(w["rgbds"].data_ptr(), w["color_vars"].data_ptr(), w["depth_vars"].data_ptr(),
                             w["term_probs"].data_ptr())
         st = ops._stream()
+        # single GPU: nothing happens between forward and backward, so the loss partials are reduced by the backward
+        # itself (deferred reduction, one launch less); with a process group the sums are needed here for the all-reduce
+        defer = self.process_group is None
         K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
-                                 w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
-        return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp,
+                                 None if defer else w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
+        return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp, defer=defer,
                     keep=(keep, dm, tm, rgbds_t, target))
 
     def _iteration_backward(self, ctx: dict, update=True) -> dict:
@@ -469,19 +472,20 @@ class NeuralGraphRenderer:
         if "grads" not in w:
             w["grads"], w["gs"], w["gflat"] = ops.alloc_grads(fc, F, self._device)
         grads, gs = w["grads"], w["gs"]
+        sums_ptr = None if ctx.get("defer") else w["sums"].data_ptr()
         if update:
             # backward + sparse Adam in one call: the gradient-reduction kernel applies the update of the MLP tensors
             # itself (rm.py:1183-1221); the device counter already holds the new step (the loss reduction advanced it)
             self._step += 1                                  # one counter for all fields (rm.py:380-385)
             arr, n_mlp, lat = ops.adam_tensor_arrays(fc, allp, self._optim_state, grads)
             K.check(L.ngm_render_bwd_adam(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
-                                          w["sums"].data_ptr(), C.byref(gs), arr, n_mlp, lat, ops._ptr(fids), int(self._step),
+                                          sums_ptr, C.byref(gs), arr, n_mlp, lat, ops._ptr(fids), int(self._step),
                                           ops._ptr(self._step_dev), self._learning_rate, 0.9, 0.999, self._adam_eps,
                                           self._adam_weight_decay, w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st),
                     "ngm_render_bwd_adam")
         else:
             K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
-                                     w["sums"].data_ptr(), C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
+                                     sums_ptr, C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
                                      st), "ngm_render_bwd")
         lv = w["loss"]
         loss = {"combined": lv[0], "termination": lv[1], "photometric_l1": lv[2], "depth_huber": lv[3],

@@ -37,7 +37,7 @@ enum ngm_status {
 };
 
 enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3 };
-enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1 }; /* models.py:159-180; concat: not built, rezero: the reference's constructor raises */
+enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /* models.py:159-180; rezero: the reference's constructor raises */
 enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
 enum ngm_geometry_mode { NGM_GEO_NRGBD = 0, NGM_GEO_OCCUPANCY = 1, NGM_GEO_DENSITY = 2, NGM_GEO_NEUS = 3 };
 
@@ -77,7 +77,9 @@ typedef struct ngm_field_cfg {
   float level_scale[16 * 3];  /* per level, per axis i: 1 / (sqrt((i+1)(i+2)) * sigma_l); fill with    */
                               /* ngm_permuto_fill_scales() (or from numpy.geomspace, as _capi.py does)  */
   int32_t skip_mode;          /* ngm_skip_mode: "add" adds the encoding to the first D units after every       */
-                              /* hidden layer (models.py:162-169); needs dim_hidden >= dim_enc                  */
+                              /* hidden layer (models.py:162-169); needs dim_hidden >= dim_enc.  "concat"       */
+                              /* appends it (models.py:159-161): layers 1..L (incl. the output layer) then have */
+                              /* H + D inputs, "_linears.{i}.weight" is (out_i, H + D) for i >= 1               */
 } ngm_field_cfg;
 
 /* fills cfg->level_scale from nr_levels / coarsest_scale / finest_scale (double precision) */

@@ -198,7 +198,7 @@ def check(rc, what=""):
 # ------------------------------------------------------------------------------------------------
 # struct builders from plain python values / raw device addresses
 # ------------------------------------------------------------------------------------------------
-SKIP = {"no": 0, "add": 1}
+SKIP = {"no": 0, "add": 1, "concat": 2}
 
 
 def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,
@@ -206,8 +206,8 @@ def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, st
               nr_levels=16, nr_feat_per_level=2, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4,
               skip_mode="no"):
     if skip_mode not in SKIP:
-        raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no' and 'add' have kernels; 'concat' is not built, and the "
-                                  "reference's own constructor raises for 'rezero' (models.py:131-132)")
+        raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no', 'add' and 'concat' have kernels; the reference's own "
+                                  "constructor raises for 'rezero' (models.py:131-132)")
     if encoding == "nerf":
         dim_enc = 6 * num_octaves
     if encoding == "none":
@@ -249,7 +249,7 @@ def param_shapes(fc: FieldCfg):
         shapes["_encoding.lattice_values"] = (fc.nr_levels, 2 ** fc.log2_hashmap_size, fc.nr_feat_per_level)
         shapes["_encoding.random_shift_per_level"] = (fc.nr_levels, 3)
     for i in range(fc.num_layers + 1):
-        din = fc.dim_enc if i == 0 else fc.dim_hidden
+        din = fc.dim_enc if i == 0 else fc.dim_hidden + (fc.dim_enc if fc.skip_mode == SKIP["concat"] else 0)   # models.py:115-119
         dout = fc.dim_out if i == fc.num_layers else fc.dim_hidden
         shapes[f"_linears.{i}.weight"] = (dout, din)
         shapes[f"_linears.{i}.bias"] = (dout,)

@@ -130,9 +130,10 @@ static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * 
 // floats of LDS taken by one field's weights (mirrors FieldLds<MI,MH,L>::TOTAL in ngm_field.h)
 static int64_t field_lds_floats(const ngm_field_cfg* fc) {
   const int64_t MI = (fc->dim_enc + 31) / 32, MH = (fc->dim_hidden + 31) / 32;
+  const int64_t MC = MH + (fc->skip_mode == NGM_SKIP_CONCAT ? MI : 0);      // input tiles of layers >= 1 and of the output layer
   int64_t t = MI * 32 * 4;
-  for (int l = 0; l < fc->num_layers; ++l) t += MH * (l == 0 ? MI : MH) * 16 * 2 * 33 + MH * 32;
-  return t + MH * 32 * 4 + 8;
+  for (int l = 0; l < fc->num_layers; ++l) t += MH * (l == 0 ? MI : MC) * 16 * 2 * 33 + MH * 32;
+  return t + MC * 32 * 4 + 8;
 }
 
 static int check_field_cfg(const ngm_field_cfg* fc) {
@@ -151,7 +152,10 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
     return fail(NGM_E_UNSUPPORTED, "dim_enc / dim_hidden must be <= 64");
   if (((fc->dim_enc + 31) / 32) != ((fc->dim_hidden + 31) / 32) && !(fc->dim_enc <= 32 && fc->dim_hidden <= 32))
     return fail(NGM_E_UNSUPPORTED, "dim_enc and dim_hidden must pad to the same multiple of 32");
-  if (fc->skip_mode != NGM_SKIP_NO && fc->skip_mode != NGM_SKIP_ADD) return fail(NGM_E_UNSUPPORTED, "skip_mode: only no / add");
+  if (fc->skip_mode != NGM_SKIP_NO && fc->skip_mode != NGM_SKIP_ADD && fc->skip_mode != NGM_SKIP_CONCAT)
+    return fail(NGM_E_UNSUPPORTED, "skip_mode: no / add / concat");
+  if (fc->skip_mode == NGM_SKIP_CONCAT && fc->encoding != NGM_ENC_FOURIER && fc->encoding != NGM_ENC_NONE)
+    return fail(NGM_E_UNSUPPORTED, "skip_mode concat: compiled for the Fourier encoding and for no encoding");
   if (fc->skip_mode == NGM_SKIP_ADD && (fc->dim_hidden < fc->dim_enc || fc->encoding == NGM_ENC_PERMUTO))
     return fail(NGM_E_UNSUPPORTED, "skip_mode add: needs dim_hidden >= dim_enc and a non-hash encoding");
   return NGM_OK;

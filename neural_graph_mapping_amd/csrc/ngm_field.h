@@ -12,18 +12,22 @@
 #define NGM_FK_SIN 2.0f   // value = sin(w . x)
 #define NGM_FK_COS 3.0f   // value = cos(w . x)
 
-template <int MI, int MH, int L>
+// CAT: skip_mode "concat" (models.py:159-161): every layer after the first (and the output layer) reads
+// cat(hidden, encoding): MH + MI input tiles, the encoding part starting at tile column 32 * MH.
+template <int MI, int MH, int L, bool CAT = false>
 struct FieldLds {
+  static constexpr int MIN(int l) { return l == 0 ? MI : (CAT ? MH + MI : MH); }   // input tiles of hidden layer l
+  static constexpr int MOUT_IN = CAT ? MH + MI : MH;                                // input tiles of the output layer
   static constexpr int ENCW = 0;                             // float4[MI*32]
   static constexpr int ENCW_SIZE = MI * 32 * 4;
   static constexpr int w_off(int l) {                        // hidden layer l weights
     int o = ENCW + ENCW_SIZE;
-    for (int i = 0; i < l; ++i) o += wfrag_size(MH, i == 0 ? MI : MH) + MH * 32;
+    for (int i = 0; i < l; ++i) o += wfrag_size(MH, MIN(i)) + MH * 32;
     return o;
   }
-  static constexpr int b_off(int l) { return w_off(l) + wfrag_size(MH, l == 0 ? MI : MH); }
-  static constexpr int WOUT = b_off(L - 1) + MH * 32;         // float4[MH*32]: the 4 output weights per feature
-  static constexpr int BOUT = WOUT + MH * 32 * 4;             // float[4]
+  static constexpr int b_off(int l) { return w_off(l) + wfrag_size(MH, MIN(l)); }
+  static constexpr int WOUT = b_off(L - 1) + MH * 32;         // float4[MOUT_IN*32]: the 4 output weights per input feature
+  static constexpr int BOUT = WOUT + MOUT_IN * 32 * 4;        // float[4]
   static constexpr int TOTAL = (BOUT + 4 + 3) & ~3;           // floats, 16-byte multiple
 };
 
@@ -36,36 +40,43 @@ struct FieldDims {
 // 16-byte loads for the matrices when the rows allow it), commit() permutes them into the A-fragment order of the
 // forward kernels (FieldLds) and builds the per-feature encoding table.
 // Needs blockDim.x >= 256 (>= 32*MH threads for the small tables); caller must __syncthreads() after commit().
-template <int MI, int MH, int L>
+template <int MI, int MH, int L, bool CAT = false>
 struct FieldStage {
-  static constexpr int NIT = (MH * 32 * MH * 32 / 4 + 255) / 256;   // 16-byte chunks per thread and layer (upper bound)
+  using LYS = FieldLds<MI, MH, L, CAT>;
+  static constexpr int NIT = (MH * 32 * (CAT ? MH + MI : MH) * 32 / 4 + 255) / 256;   // 16-byte chunks per thread and layer (upper bound)
   float4 v[L][NIT];
-  float4 enc0, enc1, wout;
+  float4 enc0, enc1, wout, wout_e;
   float bias[L], bout;
   __device__ __forceinline__ void issue(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int D = fc.dim_enc, H = fc.dim_hidden;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      const int MIN = (l == 0) ? MI : MH;
-      const int Din = (l == 0) ? D : H;
+      constexpr int MIN = LYS::MIN(1);           // l >= 1 (l == 0 handled through the ternaries below)
+      const int min_l = (l == 0) ? MI : MIN;
+      const bool cat_l = CAT && l > 0;           // input = cat(hidden (H), encoding (D)): logical row length H + D
+      const int Din = (l == 0) ? D : (cat_l ? H + D : H);
       const float* W = pr.w[l] + row * pr.w_stride[l];
-      const int ncol4 = MIN * 8, total4 = MH * 32 * ncol4;
-      const bool vec = ((Din & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+      const int ncol4 = min_l * 8, total4 = MH * 32 * ncol4;
+      const bool vec = ((Din & 3) == 0) && (!cat_l || (H & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int e4 = tid + it * nthr;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e4 < total4) {
-          const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
-          if (o < H && c < Din) {
+          const int o = e4 / ncol4, ct = 4 * (e4 - o * ncol4);      // tile column
+          // concat: tile columns [0, 32 MH) = hidden features, [32 MH, ...) = encoding features (logical column H + .)
+          const bool enc_part = cat_l && ct >= 32 * MH;
+          const int c = enc_part ? H + (ct - 32 * MH) : ct;          // logical column
+          const int lim = enc_part ? H + D : (cat_l ? H : Din);      // end of this part's logical columns
+          if (o < H && c < lim) {
             const float* src = W + (int64_t)o * Din + c;
             if (vec) x = *reinterpret_cast<const float4*>(src);
             else {
               x.x = src[0];
-              if (c + 1 < Din) x.y = src[1];
-              if (c + 2 < Din) x.z = src[2];
-              if (c + 3 < Din) x.w = src[3];
+              if (c + 1 < lim) x.y = src[1];
+              if (c + 2 < lim) x.z = src[2];
+              if (c + 3 < lim) x.w = src[3];
             }
           }
         }
@@ -75,9 +86,12 @@ struct FieldStage {
     }
     // output layer (4 x H) -> float4 per hidden feature
     wout = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < H) {
+    wout_e = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const int Dout_in = CAT ? H + D : H;                 // row length of the (4, .) output matrix
       const float* W = pr.w[L] + row * pr.w_stride[L];
-      wout = make_float4(W[tid], W[H + tid], W[2 * H + tid], W[3 * H + tid]);
+      if (tid < H) wout = make_float4(W[tid], W[Dout_in + tid], W[2 * Dout_in + tid], W[3 * Dout_in + tid]);
+      if (CAT && tid < D) wout_e = make_float4(W[H + tid], W[Dout_in + H + tid], W[2 * Dout_in + H + tid], W[3 * Dout_in + H + tid]);
     }
     bout = (tid < 4) ? pr.b[L][row * pr.b_stride[L] + tid] : 0.f;
     // encoding table: one float4 per feature (weights of the argument, kind)
@@ -112,7 +126,7 @@ struct FieldStage {
     }
   }
   __device__ __forceinline__ void commit(float* sm, const ngm_field_cfg& fc) const {
-    using LY = FieldLds<MI, MH, L>;
+    using LY = LYS;
     const int tid = threadIdx.x, nthr = blockDim.x;
     if (fc.encoding == NGM_ENC_PERMUTO) {
       if (tid < 16) {
@@ -124,7 +138,7 @@ struct FieldStage {
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      const int MIN = (l == 0) ? MI : MH;
+      const int MIN = (l == 0) ? MI : LYS::MIN(1);
       const int ncol4 = MIN * 8, total4 = MH * 32 * ncol4;
       float* dst = sm + LY::w_off(l);
 #pragma unroll
@@ -142,6 +156,7 @@ struct FieldStage {
       if (tid < MH * 32) sm[LY::b_off(l) + tid] = bias[l];
     }
     if (tid < MH * 32) reinterpret_cast<float4*>(sm + LY::WOUT)[tid] = wout;
+    if (CAT && tid < MI * 32) reinterpret_cast<float4*>(sm + LY::WOUT)[MH * 32 + tid] = wout_e;
     if (tid < 4) sm[LY::BOUT + tid] = bout;
   }
 };
@@ -483,26 +498,39 @@ __device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[
   }
 }
 
-// ADD is a template parameter on purpose: as a run-time flag it kept the encoding registers alive through every
-// layer of the default path as well and cost the fused forward 14 us.
-template <int MI, int MH, int L, int NT, bool ADD = false>
+// SKIP (0 no, 1 add, 2 concat) is a template parameter on purpose: as a run-time flag it kept the encoding registers
+// alive through every layer of the default path as well and cost the fused forward 14 us.
+template <int MI, int MH, int L, int NT, int SKIP = 0>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
                                         const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
-  using LY = FieldLds<MI, MH, L>;
+  using LY = FieldLds<MI, MH, L, SKIP == 2>;
   layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
-  if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
+  if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
   PTICK(pc, 5);
   if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
   PTICK(pc, 6);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
     f32x16 T[NT][MH];
-    layer_fwd<MH, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hlast, T);
+    if constexpr (SKIP == 2) {
+      // concat (models.py:159-161): the layer reads cat(hidden, encoding) -- MH + MI input tiles, all in registers
+      f32x16 Xc[NT][MH + MI];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m) Xc[nt][m] = Hlast[nt][m];
+#pragma unroll
+        for (int m = 0; m < MI; ++m) Xc[nt][MH + m] = E[nt][m];
+      }
+      layer_fwd<MH + MI, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Xc, T);
+    } else {
+      layer_fwd<MH, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hlast, T);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
-    if constexpr (ADD) skip_add<MI, MH, NT>(Hlast, E);
+    if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
     PTICK(pc, 5);
     if (st && st->base) act_store<MH, NT>(*st, l, lane, Hlast);
     PTICK(pc, 6);
@@ -511,10 +539,10 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
-template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, bool ADD = false>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, int SKIP = 0>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
                                           const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
-  using LY = FieldLds<MI, MH, L>;
+  using LY = FieldLds<MI, MH, L, SKIP == 2>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
   const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
@@ -543,10 +571,18 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, ADD>(sm, lane, E, Hl, HASH ? nullptr : st, pc);
+  mlp_fwd<MI, MH, L, 2, SKIP>(sm, lane, E, Hl, HASH ? nullptr : st, pc);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);
+  if constexpr (SKIP == 2) {          // the output layer reads cat(hidden, encoding) as well
+    float pe[2][4];
+    out_layer_partial<MI, 2>(sm + LY::WOUT + MH * 32 * 4, hi, E, pe);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) part[nt][c] += pe[nt][c];
+  }
   float o[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {

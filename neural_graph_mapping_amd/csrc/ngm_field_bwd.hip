@@ -19,9 +19,9 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-template <int MI, int MH, int L>
+template <int MI, int MH, int L, bool CAT = false>
 struct BwdLds {
-  using LY = FieldLds<MI, MH, L>;
+  using LY = FieldLds<MI, MH, L, CAT>;
   static constexpr int STR_E = 32 * MI + 4;
   static constexpr int STR_H = 32 * MH + 4;
   static constexpr int STR_D = (STR_E > STR_H) ? STR_E : STR_H;
@@ -185,15 +185,16 @@ __device__ __forceinline__ void outer_accum(const float* colbuf, int stride, con
   }
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD, bool HASH>
+template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD, bool HASH, bool CAT = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  using LY = FieldLds<MI, MH, L>;
-  using BL = BwdLds<MI, MH, L>;
+  using LY = FieldLds<MI, MH, L, CAT>;
+  using BL = BwdLds<MI, MH, L, CAT>;
+  constexpr int MC = CAT ? MH + MI : MH;       // input tiles of the layers after the first (concat: hidden ++ encoding)
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   {
-    FieldStage<MI, MH, L> fstage;       // every parameter load in flight at once, then the permuting LDS writes
+    FieldStage<MI, MH, L, CAT> fstage;       // every parameter load in flight at once, then the permuting LDS writes
     fstage.issue(a.fc, a.pr, row);
     fstage.commit(sm, a.fc);
   }
@@ -230,6 +231,19 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
       for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accH[l][mo][mi][r] = 0.f;
+  }
+  // concat: d(W_l[:, H:]) of the layers after the first (their encoding columns), and of the output layer
+  f32x16 accE[(CAT && L > 1) ? (L - 1) : 1][MH][MI];
+  float dwoE[4] = {0.f, 0.f, 0.f, 0.f};      // lane = encoding feature
+  if constexpr (CAT) {
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+      for (int mo = 0; mo < MH; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accE[l][mo][mi][r] = 0.f;
   }
   float dbh[L];            // lane = hidden feature
   float dwo[4], dbo[4];    // output layer: dwo lane = hidden feature; dbo per sample lane
@@ -286,7 +300,16 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     for (int l = 1; l < L; ++l) {
       store_tile<MH>(wl + BL::x_off(l), BL::STR_H, lane, Hc[0]);
       f32x16 Hn[1][MH];
-      layer_fwd<MH, MH, 1>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hc, Hn);
+      if constexpr (CAT) {
+        f32x16 Xc[1][MC];
+#pragma unroll
+        for (int m = 0; m < MH; ++m) Xc[0][m] = Hc[0][m];
+#pragma unroll
+        for (int m = 0; m < MI; ++m) Xc[0][MH + m] = E[0][m];
+        layer_fwd<MC, MH, 1>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Xc, Hn);
+      } else {
+        layer_fwd<MH, MH, 1>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hc, Hn);
+      }
 #pragma unroll
       for (int m = 0; m < MH; ++m) Hc[0][m] = Hn[0][m];
       rmask[l] = relu_bits<MH>(Hc[0]);
@@ -301,6 +324,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     store_tile<MH>(bufD, BL::STR_D, lane, Hc[0]);
     WAVE_SYNC();
     outer_accum<MH, 4>(bufD, BL::STR_D, obuf, lane, dwo);
+    if constexpr (CAT) outer_accum<MI, 4>(wl + BL::x_off(0), BL::STR_E, obuf, lane, dwoE);   // encoding columns of W_out
     if (hi == 0) { dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w; }
     // dH_L = W_out^T dout, masked by the ReLU of the last hidden layer
     f32x16 dY[MH];
@@ -315,6 +339,15 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
           if (add_enc && mi < MI) dEsum[mi < MI ? mi : 0][r] += dh;
           dY[mi][r] = ((rmask[L - 1] >> (16 * mi + r)) & 1u) ? dh : 0.f;
         }
+      if constexpr (CAT) {       // d(enc) through the output layer's encoding columns
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float4 w = w4[32 * (MH + mi) + frow(r, 0) + 4 * hi];
+            dEsum[mi][r] += fmaf(w.w, dout.w, fmaf(w.z, dout.z, fmaf(w.y, dout.y, w.x * dout.x)));
+          }
+      }
     }
     // ---- hidden layers, last to first
 #pragma unroll
@@ -356,7 +389,21 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
       } else {
         layer_wgrad<MH, MH>(bufD, BL::STR_D, wl + BL::x_off(l), BL::STR_H, lane, accH[l - 1]);
         f32x16 dX[MH], Xl[MH];
-        layer_dgrad<MH, MH>(sm + LY::w_off(l), lane, dY, dX);
+        if constexpr (CAT) {
+          // the layer's input is cat(hidden, encoding): weight gradient of the encoding columns from the staged
+          // encoding tile, data gradient over all MH + MI input tiles, the encoding part joins dEsum
+          layer_wgrad<MH, MI>(bufD, BL::STR_D, wl + BL::x_off(0), BL::STR_E, lane, accE[l - 1]);
+          f32x16 dXc[MC];
+          layer_dgrad<MC, MH>(sm + LY::w_off(l), lane, dY, dXc);
+#pragma unroll
+          for (int mi = 0; mi < MH; ++mi) dX[mi] = dXc[mi];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dEsum[mi][r] += dXc[MH + mi][r];
+        } else {
+          layer_dgrad<MH, MH>(sm + LY::w_off(l), lane, dY, dX);
+        }
         if (add_enc) {
           // dX = gradient w.r.t. in_l = relu(z_{l-1}) + [enc; 0]
 #pragma unroll
@@ -395,7 +442,12 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   if (MI == 1) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) dwf[c] += __shfl_down(dwf[c], 32, 64);
+    if constexpr (CAT) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dwoE[c] += __shfl_down(dwoE[c], 32, 64);
+    }
   }
+  const int DC = CAT ? H + D : H;          // row length of W_l (l >= 1) and of W_out
 #pragma unroll
   for (int c = 0; c < 4; ++c) dbo[c] = wave_sum(dbo[c]);
   for (int w = 0; w < NGM_WAVES_PER_BLOCK; ++w) {
@@ -413,12 +465,20 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
               if (i < D) red[w_off[0] + (int64_t)o * D + i] += acc0[mo][mi][r];
             }
 #pragma unroll
-            for (int l = 1; l < L; ++l)
+            for (int l = 1; l < L; ++l) {
 #pragma unroll
               for (int mi = 0; mi < MH; ++mi) {
                 const int i = 32 * mi + j;
-                if (i < H) red[w_off[l] + (int64_t)o * H + i] += accH[l - 1][mo][mi][r];
+                if (i < H) red[w_off[l] + (int64_t)o * DC + i] += accH[l - 1][mo][mi][r];
               }
+              if constexpr (CAT) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                  const int i = 32 * mi + j;
+                  if (i < D) red[w_off[l] + (int64_t)o * DC + H + i] += accE[l - 1][mo][mi][r];
+                }
+              }
+            }
           }
         }
       }
@@ -427,7 +487,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
 #pragma unroll
         for (int l = 0; l < L; ++l) red[b_off[l] + lane] += dbh[l];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) red[w_off[L] + (int64_t)c * H + lane] += dwo[c];
+        for (int c = 0; c < 4; ++c) red[w_off[L] + (int64_t)c * DC + lane] += dwo[c];
+      }
+      if (CAT && lane < 32 * MI && lane < D) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[w_off[L] + (int64_t)c * DC + H + lane] += dwoE[c];
       }
       if (lane < 4) red[b_off[L] + lane] += (lane == 0 ? dbo[0] : lane == 1 ? dbo[1] : lane == 2 ? dbo[2] : dbo[3]);
       if (ENC_GRAD && a.fc.encoding == NGM_ENC_FOURIER) {
@@ -517,7 +581,7 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
     k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride, nullptr, nullptr, nullptr, 0};
   }
   for (int l = 0; l <= g.fc.num_layers; ++l) {
-    const int din = (l == 0) ? g.fc.dim_enc : g.fc.dim_hidden;
+    const int din = (l == 0) ? g.fc.dim_enc : g.fc.dim_hidden + (g.fc.skip_mode == NGM_SKIP_CONCAT ? g.fc.dim_enc : 0);
     const int dout = (l == g.fc.num_layers) ? g.fc.dim_out : g.fc.dim_hidden;
     k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l], nullptr, nullptr, nullptr, 0};
     k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l], nullptr, nullptr, nullptr, 0};
@@ -542,19 +606,22 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 template <int MI, int MH, int L>
 static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
-  const size_t lds = BwdLds<MI, MH, L>::TOTAL * sizeof(float);
-#define NGM_LB(NC, EG, HS)                                                                                              \
+#define NGM_LB(NC, EG, HS, CT)                                                                                          \
   do {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)k_field_bwd<MI, MH, L, NC, EG, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    const size_t lds = BwdLds<MI, MH, L, CT>::TOTAL * sizeof(float);                                                    \
+    if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;                                                                      \
+    (void)hipFuncSetAttribute((const void*)k_field_bwd<MI, MH, L, NC, EG, HS, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                                \
-    hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG, HS>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);                \
+    hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG, HS, CT>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);            \
   } while (0)
+  const bool cat = a.fc.skip_mode == NGM_SKIP_CONCAT;      // compiled for the Fourier encoding and for no encoding
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LB(false, false, true);
+    if (cat) return NGM_E_UNSUPPORTED;
+    if constexpr (MI == 1) NGM_LB(false, false, true, false);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LB(false, true, false);
-  else if (a.fc.encoding == NGM_ENC_NERF) NGM_LB(true, false, false);
-  else NGM_LB(false, false, false);
+  } else if (a.fc.encoding == NGM_ENC_FOURIER) { if (cat) NGM_LB(false, true, false, true); else NGM_LB(false, true, false, false); }
+  else if (a.fc.encoding == NGM_ENC_NERF) { if (cat) return NGM_E_UNSUPPORTED; NGM_LB(true, false, false, false); }
+  else { if (cat) NGM_LB(false, false, false, true); else NGM_LB(false, false, false, false); }
 #undef NGM_LB
   return 0;
 }

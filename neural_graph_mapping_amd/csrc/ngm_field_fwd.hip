@@ -18,13 +18,13 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   {
-    FieldStage<MI, MH, L> fstage;       // every parameter load in flight at once, then the permuting LDS writes
+    FieldStage<MI, MH, L, SKIP == 2> fstage;       // every parameter load in flight at once, then the permuting LDS writes
     fstage.issue(a.fc, a.pr, row);
     fstage.commit(sm, a.fc);
   }
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -85,10 +85,10 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  using LY = FieldLds<MI, MH, L>;
+  using LY = FieldLds<MI, MH, L, SKIP == 2>;
   const int F = a.rays.F, R = a.rays.R;
   const int f = blockIdx.x % F, chunk = blockIdx.x / F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #endif
   // the field parameters travel while the first batch of rays is set up (both are latency chains, and every
   // wave of the chip is in this phase at the same time, so there is no matrix work to hide them under)
-  FieldStage<MI, MH, L> fstage;
+  FieldStage<MI, MH, L, SKIP == 2> fstage;
   fstage.issue(a.fc, a.pr, row);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #else
       PTICK(pc, 3);
 #ifdef NGM_PHASE_TIMING
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast, pc);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc, &ast, pc);
 #else
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc, &ast);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc, &ast);
 #endif
 #endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
@@ -387,43 +387,48 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-// the skip-add variants exist for the non-hash encodings only
-#define NGM_LAUNCH_ONE(KERNEL, NC, HS, AD, GRID, BLK, LDS)                                                              \
+// the skip variants exist for the non-hash encodings only; concat (SKIP = 2) for Fourier / no encoding
+#define NGM_LAUNCH_ONE(KERNEL, NC, HS, SK, GRID, BLK, LDSW, LDSX)                                                       \
   do {                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)KERNEL<MI, MH, L, NC, HS, AD>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              (int)(LDS));                                                                             \
-    hipLaunchKernelGGL((KERNEL<MI, MH, L, NC, HS, AD>), dim3(GRID), BLK, LDS, st, a);                                  \
+    const size_t lds_ = (FieldLds<MI, MH, L, (SK) == 2>::TOTAL + (LDSX)) * sizeof(float);                              \
+    (void)(LDSW);                                                                                                      \
+    (void)hipFuncSetAttribute((const void*)KERNEL<MI, MH, L, NC, HS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)lds_);                                                                              \
+    hipLaunchKernelGGL((KERNEL<MI, MH, L, NC, HS, SK>), dim3(GRID), BLK, lds_, st, a);                                 \
   } while (0)
-#define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDS)                                   \
-  do {                                                                                       \
-    if constexpr (!(HS)) {                                                                   \
-      if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, true, GRID, BLK, LDS); \
-      else NGM_LAUNCH_ONE(KERNEL, NC, HS, false, GRID, BLK, LDS);                            \
-    } else {                                                                                 \
-      NGM_LAUNCH_ONE(KERNEL, NC, HS, false, GRID, BLK, LDS);                                 \
-    }                                                                                        \
+#define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDSW, LDSX)                               \
+  do {                                                                                          \
+    if constexpr (!(HS)) {                                                                      \
+      if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, 1, GRID, BLK, LDSW, LDSX); \
+      else if (a.fc.skip_mode == NGM_SKIP_CONCAT) {                                             \
+        if constexpr (!(NC)) NGM_LAUNCH_ONE(KERNEL, NC, HS, 2, GRID, BLK, LDSW, LDSX);          \
+        else return NGM_E_UNSUPPORTED;                                                          \
+      } else NGM_LAUNCH_ONE(KERNEL, NC, HS, 0, GRID, BLK, LDSW, LDSX);                          \
+    } else {                                                                                    \
+      if (a.fc.skip_mode != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;                              \
+      NGM_LAUNCH_ONE(KERNEL, NC, HS, 0, GRID, BLK, LDSW, LDSX);                                 \
+    }                                                                                           \
   } while (0)
 
 template <int MI, int MH, int L>
 static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
-  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
   const dim3 blk(NGM_BLOCK);
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, true, blocks, blk, lds);
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, true, blocks, blk, 0, 0);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_field_points_fwd, true, false, blocks, blk, lds);
-  else NGM_LAUNCH_VARIANT(k_field_points_fwd, false, false, blocks, blk, lds);
+  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_field_points_fwd, true, false, blocks, blk, 0, 0);
+  else NGM_LAUNCH_VARIANT(k_field_points_fwd, false, false, blocks, blk, 0, 0);
   return 0;
 }
 template <int MI, int MH, int L>
 static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
-  const size_t lds = (FieldLds<MI, MH, L>::TOTAL + a.waves_per_block * RenderWaveLds::floats(a.maxs)) * sizeof(float);
+  const size_t wave_lds = (size_t)a.waves_per_block * RenderWaveLds::floats(a.maxs);
   const dim3 blk(64 * a.waves_per_block);
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, true, blocks, blk, lds);
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, true, blocks, blk, 0, wave_lds);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, false, blocks, blk, lds);
-  else NGM_LAUNCH_VARIANT(k_render_fwd, false, false, blocks, blk, lds);
+  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, false, blocks, blk, 0, wave_lds);
+  else NGM_LAUNCH_VARIANT(k_render_fwd, false, false, blocks, blk, 0, wave_lds);
   return 0;
 }
 

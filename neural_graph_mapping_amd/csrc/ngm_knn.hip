@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
     if (fld[k] >= 0) a.sorted[hist[fld[k]] + rnk[k]] = (int)(base + k * 256 + threadIdx.x);
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, bool ADD>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
 __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   const int beg = a.seg_off[f] + tile * KNN_TILE, end = min(a.seg_off[f + 1], beg + KNN_TILE);
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   {
-    FieldStage<MI, MH, L> fstage;       // every parameter load in flight at once, then the permuting LDS writes
+    FieldStage<MI, MH, L, SKIP == 2> fstage;       // every parameter load in flight at once, then the permuting LDS writes
     fstage.issue(a.fc, a.pr, row);
     fstage.commit(sm, a.fc);
   }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, ADD>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc);
     if (valid) a.pair_out[pair] = o;
   }
 }
@@ -280,20 +280,26 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
 }
 
 template <int MI, int MH, int L>
-static void launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
-  const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float);
-#define NGM_KE(NC, HS, AD)                                                                                             \
+static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
+#define NGM_KE(NC, HS, SK)                                                                                             \
   do {                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, NC, HS, AD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    const size_t lds = FieldLds<MI, MH, L, (SK) == 2>::TOTAL * sizeof(float);                                          \
+    (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, NC, HS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                               \
-    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS, AD>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
+    hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS, SK>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
   } while (0)
-  const bool add = a.fc.skip_mode == NGM_SKIP_ADD;
+  const int sk = a.fc.skip_mode;
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_KE(false, true, false);
-  } else if (a.fc.encoding == NGM_ENC_NERF) { if (add) NGM_KE(true, false, true); else NGM_KE(true, false, false); }
-  else { if (add) NGM_KE(false, false, true); else NGM_KE(false, false, false); }
+    if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
+    if constexpr (MI == 1) NGM_KE(false, true, 0);
+    else return NGM_E_UNSUPPORTED;
+  } else if (a.fc.encoding == NGM_ENC_NERF) {
+    if (sk == NGM_SKIP_ADD) NGM_KE(true, false, 1); else if (sk == NGM_SKIP_NO) NGM_KE(true, false, 0); else return NGM_E_UNSUPPORTED;
+  } else {
+    if (sk == NGM_SKIP_ADD) NGM_KE(false, false, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, false, 2); else NGM_KE(false, false, 0);
+  }
 #undef NGM_KE
+  return 0;
 }
 
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
@@ -331,14 +337,15 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), (size_t)num_fields * 4, st, a);
   const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
   const FieldShape s = field_shape(fc);
-  if (s.MI == 2 && s.MH == 2 && s.L == 2) launch_eval<2, 2, 2>(a, max_tiles, st);
+  int le = NGM_E_UNSUPPORTED;
+  if (s.MI == 2 && s.MH == 2 && s.L == 2) le = launch_eval<2, 2, 2>(a, max_tiles, st);
 #ifndef NGM_FAST_BUILD
-  else if (s.MI == 2 && s.MH == 2 && s.L == 1) launch_eval<2, 2, 1>(a, max_tiles, st);
-  else if (s.MI == 1 && s.MH == 1 && s.L == 1) launch_eval<1, 1, 1>(a, max_tiles, st);
-  else if (s.MI == 1 && s.MH == 1 && s.L == 2) launch_eval<1, 1, 2>(a, max_tiles, st);
-  else if (s.MI == 2 && s.MH == 2 && s.L == 3) launch_eval<2, 2, 3>(a, max_tiles, st);
+  else if (s.MI == 2 && s.MH == 2 && s.L == 1) le = launch_eval<2, 2, 1>(a, max_tiles, st);
+  else if (s.MI == 1 && s.MH == 1 && s.L == 1) le = launch_eval<1, 1, 1>(a, max_tiles, st);
+  else if (s.MI == 1 && s.MH == 1 && s.L == 2) le = launch_eval<1, 1, 2>(a, max_tiles, st);
+  else if (s.MI == 2 && s.MH == 2 && s.L == 3) le = launch_eval<2, 2, 3>(a, max_tiles, st);
 #endif
-  else return NGM_E_UNSUPPORTED;
+  if (le) return le;
   hipLaunchKernelGGL(k_knn_blend, dim3(std::max(pb, 1)), dim3(256), 0, st, a);
   return 0;
 }

@@ -154,7 +154,7 @@ __host__ __device__ static inline int64_t ngm_param_offsets(const ngm_field_cfg*
   *enc_off = 0;
   if (fc->encoding == NGM_ENC_FOURIER) o += (int64_t)(fc->raw_coords ? fc->dim_enc - 3 : fc->dim_enc) * 3;
   for (int l = 0; l <= fc->num_layers; ++l) {
-    const int din = (l == 0) ? fc->dim_enc : fc->dim_hidden;
+    const int din = (l == 0) ? fc->dim_enc : fc->dim_hidden + (fc->skip_mode == NGM_SKIP_CONCAT ? fc->dim_enc : 0);
     const int dout = (l == fc->num_layers) ? fc->dim_out : fc->dim_hidden;
     w_off[l] = o; o += (int64_t)din * dout;
     b_off[l] = o; o += dout;

@@ -121,8 +121,8 @@ class NeuralField(torch.nn.Module):
                  initial_geometry_bias: float = 0.0, neus_initial_sd: Optional[float] = None) -> None:
         super().__init__()
         if skip_mode not in K.SKIP:
-            raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no' and 'add' have kernels ('concat' is not built; the "
-                                      "reference's own constructor raises for 'rezero', models.py:131-132)")
+            raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no', 'add' and 'concat' have kernels (the reference's own "
+                                      "constructor raises for 'rezero', models.py:131-132)")
         self._encoding = str_to_object(encoding_type)(**encoding_kwargs)
         self._dim_encoding = self._encoding.get_out_dim()
         self._dim_out = dim_out
@@ -131,7 +131,8 @@ class NeuralField(torch.nn.Module):
         self._skip_mode = skip_mode
         if neus_initial_sd is not None:
             self._neus_sd = torch.nn.Parameter(torch.tensor(float(neus_initial_sd)))
-        dims_in = [self._dim_encoding] + [self._dim_mlp_out] * num_layers
+        dim_mlp_in = self._dim_mlp_out + (self._dim_encoding if skip_mode == "concat" else 0)      # models.py:105-110
+        dims_in = [self._dim_encoding] + [dim_mlp_in] * num_layers
         dims_out = [self._dim_mlp_out] * num_layers + [dim_out]
         self._linears = torch.nn.ModuleList(torch.nn.Linear(i, o) for i, o in zip(dims_in, dims_out))
         with torch.no_grad():

@@ -102,6 +102,15 @@ def alloc_grads(fc: K.FieldCfg, F: int, device, flat: Optional[torch.Tensor] = N
     return grads, K.grads_struct(fc, ptrs, strides), flat
 
 
+def alloc_grads_separate(fc: K.FieldCfg, F: int, device):
+    """One tensor per parameter name (custom-op outputs may not alias each other, so no shared arena here)."""
+    shapes = K.param_shapes(fc)
+    grads = {n: torch.zeros(F, *shp, device=device, dtype=torch.float32) for n, shp in shapes.items()}
+    ptrs = {n: g.data_ptr() for n, g in grads.items()}
+    strides = {n: int(torch.tensor(shp).prod()) for n, shp in shapes.items()}
+    return grads, K.grads_struct(fc, ptrs, strides)
+
+
 # ------------------------------------------------------------------------------------------------
 # K2+K3: NeuralFieldSet.forward(use_vmap=True) with autograd
 # ------------------------------------------------------------------------------------------------
@@ -130,7 +139,7 @@ def _field_eval_bwd_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[t
     names = K.param_names(fc)
     pd = dict(zip(names, params))
     F, P, _ = points.shape
-    grads, gs, _ = alloc_grads(fc, F, points.device)
+    grads, gs = alloc_grads_separate(fc, F, points.device)
     ps = params_struct(fc, pd)
     L = K.lib()
     wsb = L.ngm_field_eval_bwd_workspace(C.byref(fc), F, P)
@@ -390,7 +399,7 @@ def _render_ijs_bwd_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor
     keep = []
     rays = _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, keep)
     names = K.param_names(fc)
-    grads, gs, _ = alloc_grads(fc, rays.F, ijs.device)
+    grads, gs = alloc_grads_separate(fc, rays.F, ijs.device)
     ps = params_struct(fc, dict(zip(names, params)))
     K.check(K.lib().ngm_render_bwd_seeded(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), _ptr(d_rgbds), _ptr(d_term),
                                           _ptr(d_geoms), C.byref(gs), workspace.data_ptr(), workspace.numel(), _stream()),

@@ -113,6 +113,59 @@ def test_skip_add_golden(name):
         grad_close(params[k].grad, gr, 2e-3, k)
 
 
+@pytest.mark.parametrize("name", ["g12_skip_concat_D32", "g12_skip_concat_D64"])
+def test_skip_concat_golden(name):
+    """skip_mode "concat" (models.py:159-161) against the reference: every layer after the first and the output layer
+    read cat(hidden, encoding) -- "_linears.{i}.weight" is (out, H + D) for i >= 1.  Forward and every gradient."""
+    g = load_golden(name)
+    D = int(name.split("D")[-1])
+    fc = K.field_cfg(encoding="fourier", dim_enc=D, dim_hidden=int(g["dim_hidden"]), num_layers=2, skip_mode="concat")
+    assert K.param_shapes(fc)["_linears.1.weight"] == tuple(g["p::_linears.1.weight"].shape[1:])
+    params = {k: v.to(DEV).requires_grad_() for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"}
+    out = ops.field_eval(fc, params, g["query"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV))
+    close(out, g["out"], rtol=2e-4, atol=3e-5)
+    (out * g["seed"].to(DEV)).sum().backward()
+    assert K.lib().ngm_debug_last_bwd_variant() == 0              # skip connections run on the 32-sample-tile kernel
+    for k, gr in split_prefix(g, "g::").items():
+        grad_close(params[k].grad, gr, 2e-3, k)
+    # the kNN-blended evaluation path uses the same weights (one field, every point inside it: blend weight 1)
+    pts = g["pos"][:1] + 0.4 * (torch.rand(200, 3) - 0.5)
+    one = {k: v[:1].detach() for k, v in params.items()}
+    a = ops.field_eval_knn(fc, one, pts.to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV), 1, 10.0, 1.0)
+    b = ops.field_eval(fc, one, pts[None].to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV))[0]
+    close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,layers", [(64, 2), (32, 1), (61, 2)])
+def test_skip_concat_fused_train_step_vs_oracle(D, layers):
+    """skip_mode "concat" through the fused render / train step (forward kernel + 32-sample-tile backward)."""
+    F, R, n_c, n_g = 2, 33, 6, 10
+    torch.manual_seed(8)
+    fkw = dict(encoding="fourier", dim_enc=D, num_layers=layers, skip_mode="concat")
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos, quat, t = synth_target(F, R, seed=4)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params = O.init_params(fs, F, seed=11, sigma=3.0)
+    params[f"_linears.{layers}.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    assert r._model.all_fields_params[f"_linears.{layers}.weight"].shape[-1] == 2 * D       # H + D inputs (H = D here)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+    out = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)   # fused Adam
+    assert torch.isfinite(out["combined"])
+
+
 def test_skip_add_fused_train_step_vs_oracle():
     """skip_mode "add" through the fused render / train step."""
     F, R, n_c, n_g = 2, 33, 6, 10

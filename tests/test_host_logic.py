@@ -44,7 +44,9 @@ def test_field_set_parameter_store_matches_reference_layout():
 def test_unsupported_variants_raise():
     import pytest
     with pytest.raises(NotImplementedError):
-        M.NeuralField(**{**FIELD_KW, "skip_mode": "concat"})
+        M.NeuralField(**{**FIELD_KW, "skip_mode": "rezero"})      # the reference's own constructor raises too
+    cat = M.NeuralField(**{**FIELD_KW, "skip_mode": "concat"})    # models.py:105-119: layers after the first read H + D
+    assert cat._linears[1].weight.shape == (64, 128) and cat._linears[2].weight.shape == (4, 128)
     with pytest.raises(ValueError):
         M.NeuralFieldSet(**{**SET_KW, "field_radius": None})
 

@@ -64,7 +64,7 @@ def synth_target(F, Rn, seed, field_offset=0):
     return pos, quat, tgt
 
 
-def build_renderer(device, num_fields, variant="fourier"):
+def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, matmul="f32"):
     from neural_graph_mapping_amd import models as M
     from neural_graph_mapping_amd import renderer as Rr
     torch.manual_seed(0)
@@ -82,7 +82,8 @@ def build_renderer(device, num_fields, variant="fourier"):
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
                termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0,
-               num_samples_coarse=S_C, num_samples_depth_guided=S_G)
+               num_samples_coarse=S_C if s_c is None else s_c, num_samples_depth_guided=S_G if s_g is None else s_g,
+               mlp_matmul=matmul)
     cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=device)
     r.add_fields(num_fields)
@@ -152,6 +153,90 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def scene_sim(args, rank, world, dev):
+    """Strong-scaling picture of a REAL mapping iteration (not the weak-scaling headline): 200 pose-graph fields in the
+    map, sharded owner = id % world; every iteration trains 32 of them (the count of config/neural_graph_map.yaml:60,
+    drawn like rm.py:1280-1319 draws its random half: uniformly without replacement, same seed on every rank) with 512
+    rays each.  A rank renders only the active fields it owns; the one collective is the 64-byte loss all-reduce.
+    Reports ms per iteration (max over ranks, barrier-bracketed) for the default sample count 8+16 and for the metric's
+    64+64, the spread of active fields per rank, and on one GPU the step time against the number of active fields."""
+    from neural_graph_mapping_amd import distributed as D
+    NF, FA, Rn, NB = 200, 32, 512, 8
+    out = dict(mode="scene-sim", n_gpus=world, fields_total=NF, active_per_iteration=FA, rays_per_field=Rn,
+               launch="eager (the active set and with it the per-rank batch shape change every iteration)", configs={})
+    gen = torch.Generator().manual_seed(2024)
+    active_sets = [torch.randperm(NF, generator=gen)[:FA].sort().values for _ in range(NB)]
+    for label, (s_c, s_g) in dict(default_8p16=(8, 16), metric_64p64=(64, 64)).items():
+        owned = D.local_field_slots(NF, rank, world)
+        r = build_renderer(dev, len(owned), args.variant, s_c, s_g)
+        pos_all, quat_all, _ = synth_target(NF, 1, seed=77)
+        r.set_field_poses(pos_all[owned].to(dev), quat_all[owned].to(dev))
+        if world > 1:
+            r.process_group = torch.distributed.group.WORLD
+        batches, counts = [], []
+        for b, ids in enumerate(active_sets):
+            _, _, t = synth_target(FA, Rn, seed=500 + b)
+            shift = (pos_all[ids] - synth_target(FA, 1, seed=500 + b)[0])[:, None]     # rays around the map's field centres
+            c2w = t.c2ws.clone()
+            c2w[..., :3, 3] += shift
+            t = t._replace(c2ws=c2w, field_ids=ids)
+            tl = D.shard_target(t, rank, world)
+            tl = tl._replace(field_ids=D.global_to_local(tl.field_ids, world))
+            batches.append(type(tl)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tl]))
+            counts.append(int(tl.ijs.shape[0]))
+
+        def run(n):
+            for i in range(n):
+                r.optimization_iteration(batches[i % NB], seed=3, update=True)
+        run(args.warmup)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        cnt = torch.tensor(counts, device=dev, dtype=torch.float32)
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+            allc = [torch.empty_like(cnt) for _ in range(world)]
+            torch.distributed.all_gather(allc, cnt)
+            cnt = torch.stack(allc)                                           # (world, NB)
+        else:
+            cnt = cnt[None]
+        S = s_c + s_g
+        res = dict(ms_per_iteration=1e3 * dt / args.steps, ray_samples_per_s=FA * Rn * S * args.steps / dt,
+                   active_fields_per_rank=dict(mean=float(cnt.mean()), min=float(cnt.min()), max=float(cnt.max()),
+                                               max_over_ranks_mean=float(cnt.max(0).values.mean())))
+        if world == 1:                         # fixed cost vs batch size: what a rank with few active fields pays
+            sweep = {}
+            for Fa in (1, 2, 4, 8, 32):
+                _, _, t = synth_target(Fa, Rn, seed=900 + Fa)
+                ids = torch.arange(Fa)
+                t = t._replace(c2ws=t.c2ws + 0, field_ids=ids)
+                c2w = t.c2ws.clone()
+                c2w[..., :3, 3] += (pos_all[ids] - synth_target(Fa, 1, seed=900 + Fa)[0])[:, None]
+                tb = type(t)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in t._replace(c2ws=c2w)])
+                for graph in (False, True):
+                    step = r.capture_iteration(tb, seed=3) if graph else (lambda: r.optimization_iteration(tb, seed=3, update=True))
+                    for _ in range(10):
+                        step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        step()
+                    torch.cuda.synchronize()
+                    sweep[f"F={Fa},{'graph' if graph else 'eager'}"] = round(1e3 * (time.perf_counter() - t0) / 50, 4)
+            res["ms_per_step_vs_active_fields"] = sweep
+        out["configs"][label] = res
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +250,12 @@ def main():
     ap.add_argument("--variant", choices=["fourier", "hash"], default="fourier",
                     help="field network: fourier = the headline M1 workload (default); hash = the reference's default "
                          "permutohedral-hash network on the same batch (auxiliary measurement)")
+    ap.add_argument("--matmul", choices=["f32", "bf16x3"], default="f32",
+                    help="hidden layers of the fused forward: f32 = exact-fp32 MFMA (default, the headline arithmetic); bf16x3 = "
+                         "opt-in exact three-way bf16 split with fp32 accumulation (same tolerances, deterministic)")
+    ap.add_argument("--scene-sim", action="store_true",
+                    help="auxiliary strong-scaling measurement of a realistic mapping iteration (200 fields, 32 active per "
+                         "iteration, sharded id %% world) instead of the headline line; see scene_sim()")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -197,13 +288,18 @@ def main():
         if ranks_seen != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the all-reduce saw {ranks_seen} ranks")
     L = K.lib()
+    if args.scene_sim:
+        scene_sim(args, rank, world, dev)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
 
     # field-per-GPU sharding: rank r owns global fields r, r+world, ... ; local slot = id // world
     strong = args.fields_total > 0
     if strong and args.fields_total % world:
         raise SystemExit("--fields-total must be a multiple of the number of GPUs")
     F_PER_GPU = args.fields_total // world if strong else globals()["F_PER_GPU"]
-    r = build_renderer(dev, F_PER_GPU, args.variant)
+    r = build_renderer(dev, F_PER_GPU, args.variant, matmul=args.matmul)
     pos, quat, tgt_cpu = synth_target(F_PER_GPU, R, seed=1000 + rank)
     r.set_field_poses(pos.to(dev), quat.to(dev))
     tgt = type(tgt_cpu)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tgt_cpu])
@@ -268,7 +364,8 @@ def main():
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
                    value=value, unit="ray-samples/s", n_gpus=ranks_seen, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
-                   dtype="f32", data="synthetic",
+                   dtype="f32" if args.matmul == "f32" else "f32 via 3xbf16 split, fp32 accumulate (forward hidden layers); f32 MFMA (backward)",
+                   data="synthetic",
                    config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
                                            "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
@@ -301,6 +398,11 @@ def main():
                 res["roofline_fwd"] = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=a_f,
                                            peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=a_f / PEAK_F32_MFMA_TF,
                                            avg_launch_us=ff["avg_us"], algorithmic_flop_per_launch=FLOP_FWD * n_local)
+                if args.matmul == "bf16x3":     # both fractions: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
+                    issued = 6 * 2 * (64 * 64 + 64 * 64) * n_local         # six bf16 products per fp32 product, hidden layers
+                    res["roofline_fwd"].update(kernel="k_render_fwd<2,2,2,bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)",
+                                               issued_bf16_tflops=issued / (ff["avg_us"] * 1e-6) / 1e12, peak_bf16=2500.0,
+                                               frac_bf16=issued / (ff["avg_us"] * 1e-6) / 1e12 / 2500.0)
             a_s = (FLOP_FWD + FLOP_BWD) * n_local / (dt / args.steps) / 1e12
             res["roofline_step"] = dict(bound="mfma", achieved=a_s, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                                         frac=a_s / PEAK_F32_MFMA_TF, note="whole timed step (all kernels + launch gaps), "

@@ -38,6 +38,12 @@ enum ngm_status {
 
 enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3 };
 enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /* models.py:159-180; rezero: the reference's constructor raises */
+/* NGM_MATMUL_F32: exact-fp32 MFMA (default, what every parity number is quoted on).  NGM_MATMUL_BF16X3 (opt-in):
+ * every fp32 operand is split exactly into three bf16 (hi + mid + lo) and the six leading cross products are summed
+ * in fp32 on the bf16 matrix pipe -- fp32-level accuracy (dropped terms < 2^-23 relative), not narrower arithmetic;
+ * bitwise deterministic.  Honoured by ngm_render_fwd for 49..64-wide layers, <= 2 hidden layers, Fourier / no
+ * encoding, skip_mode no; anything else returns NGM_E_UNSUPPORTED rather than silently falling back. */
+enum ngm_matmul_mode { NGM_MATMUL_F32 = 0, NGM_MATMUL_BF16X3 = 1 };
 enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
 enum ngm_geometry_mode { NGM_GEO_NRGBD = 0, NGM_GEO_OCCUPANCY = 1, NGM_GEO_DENSITY = 2, NGM_GEO_NEUS = 3 };
 
@@ -80,6 +86,7 @@ typedef struct ngm_field_cfg {
                               /* hidden layer (models.py:162-169); needs dim_hidden >= dim_enc.  "concat"       */
                               /* appends it (models.py:159-161): layers 1..L (incl. the output layer) then have */
                               /* H + D inputs, "_linears.{i}.weight" is (out_i, H + D) for i >= 1               */
+  int32_t matmul_mode;        /* ngm_matmul_mode of the fused forward's hidden layers (other kernels: fp32 MFMA) */
 } ngm_field_cfg;
 
 /* fills cfg->level_scale from nr_levels / coarsest_scale / finest_scale (double precision) */

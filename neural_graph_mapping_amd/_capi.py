@@ -34,7 +34,7 @@ class FieldCfg(C.Structure):
                 ("dim_hidden", C.c_int32), ("dim_out", C.c_int32), ("scale_mode", C.c_int32),
                 ("field_radius", C.c_float), ("nr_levels", C.c_int32), ("nr_feat_per_level", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("coarsest_scale", C.c_float), ("finest_scale", C.c_float),
-                ("level_scale", C.c_float * 48), ("skip_mode", C.c_int32)]
+                ("level_scale", C.c_float * 48), ("skip_mode", C.c_int32), ("matmul_mode", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -199,12 +199,13 @@ def check(rc, what=""):
 # struct builders from plain python values / raw device addresses
 # ------------------------------------------------------------------------------------------------
 SKIP = {"no": 0, "add": 1, "concat": 2}
+MATMUL = {"f32": 0, "bf16x3": 1}
 
 
 def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,
               num_layers=2, dim_hidden=None, dim_out=4, scale_mode="unit_cube", field_radius=1.0,
               nr_levels=16, nr_feat_per_level=2, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4,
-              skip_mode="no"):
+              skip_mode="no", matmul_mode="f32"):
     if skip_mode not in SKIP:
         raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no', 'add' and 'concat' have kernels; the reference's own "
                                   "constructor raises for 'rezero' (models.py:131-132)")
@@ -220,6 +221,7 @@ def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, st
                   num_layers, dim_hidden, dim_out, SCALE[scale_mode], float(field_radius), nr_levels,
                   nr_feat_per_level, log2_hashmap_size, float(coarsest_scale), float(finest_scale))
     fc.skip_mode = SKIP[skip_mode]
+    fc.matmul_mode = MATMUL[matmul_mode]
     if encoding == "permuto":
         import math
         import numpy as np

@@ -460,7 +460,10 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     int64_t maxs = align_up((int64_t)(rpw < 32 ? rpw : 32) * p.S, 64);
     if (maxs > 1024) maxs = 1024;
     if (maxs < align_up(p.S, 64)) maxs = align_up(p.S, 64);
-    const int64_t lds = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs));
+    // + the bf16 weight planes of the opt-in split path: 3 planes x 2 bytes per hidden weight
+    const int64_t MIp = (fc->dim_enc + 31) / 32, MHp = (fc->dim_hidden + 31) / 32;
+    const int64_t b3 = fc->matmul_mode == NGM_MATMUL_BF16X3 ? 3 * 2 * 1024 * MHp * (MIp + (fc->num_layers - 1) * MHp) : 0;
+    const int64_t lds = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs)) + b3;
     if (waves == 8 && (lds > 160 * 1024 || R < 8)) { waves = 4; continue; }
     p.rays_per_block = rpb; p.waves_fwd = waves; p.maxs = (int)maxs;
     p.blocks_fwd = F * ((R + rpb - 1) / rpb);

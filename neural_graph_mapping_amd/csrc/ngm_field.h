@@ -416,6 +416,150 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 via a three-way bf16 split (opt-in, ngm_field_cfg.matmul_mode = NGM_MATMUL_BF16X3).
+// Every fp32 operand is written EXACTLY as hi + mid + lo, three bf16 (8 + 8 + 8 mantissa bits, split by
+// truncation so that each residual is exact); the product a b is then the sum of nine bf16 products, of which
+// the six with relative weight >= 2^-16 are issued on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): hi hi, hi mid,
+// mid hi, mid mid, hi lo, lo hi.  The three dropped terms are below 2^-23 |a b| -- the rounding of one fp32
+// operation.  Six bf16 MFMAs of 16 k-steps replace eight fp32 MFMAs of 2 k-steps at 16x the flop rate, and the
+// bf16 matrix pipe does not share the fp32 FMA lanes with the VALU (tools/micro/coexec.hip), so the split
+// arithmetic overlaps the partner wave's MFMAs.
+// K order: k-block kb = 2 mi + b, lane half kh, element e  <->  feature 32 mi + frow(8 b + e, kh), i.e. register
+// 8 b + e of input tile mi: the B operand of a k-block is eight consecutive C-layout registers of the previous
+// layer's output (packed in place, no data movement between lanes), the weights are stored in the same order.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 ngm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t ngm_u32x4 __attribute__((ext_vector_type(4)));
+
+// x == hi + mid + lo with hi, mid, lo bf16 (bit patterns in the upper halves of h, m, l)
+__device__ __forceinline__ void b3_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);            // exact
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);           // exact, <= 8 significant bits
+  l = __float_as_uint(r2);
+}
+// two bf16 (upper halves of even / odd) -> one packed word, even element in the low half
+__device__ __forceinline__ uint32_t b3_pack(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
+
+__device__ __forceinline__ void b3_split8(const float (&x)[8], ngm_bf16x8& H, ngm_bf16x8& M, ngm_bf16x8& Lo) {
+  ngm_u32x4 h4, m4, l4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    b3_split(x[2 * p], h0, m0, l0);
+    b3_split(x[2 * p + 1], h1, m1, l1);
+    h4[p] = b3_pack(h0, h1); m4[p] = b3_pack(m0, m1); l4[p] = b3_pack(l0, l1);
+  }
+  H = __builtin_bit_cast(ngm_bf16x8, h4); M = __builtin_bit_cast(ngm_bf16x8, m4); Lo = __builtin_bit_cast(ngm_bf16x8, l4);
+}
+
+// LDS plane store of one hidden layer (16-byte units): [plane 3][mo][kb = 2 MIN][kh 2][io 32]
+template <int MIN, int MOUT>
+struct B3Planes {
+  static constexpr int KB = 2 * MIN;
+  static constexpr int PLANE = MOUT * KB * 2 * 32;        // ngm_u32x4 units per plane
+  static constexpr int LAYER = 3 * PLANE;
+  static constexpr int idx(int p, int mo, int kb, int kh, int io) { return p * PLANE + ((mo * KB + kb) * 2 + kh) * 32 + io; }
+};
+template <int MI, int MH, int L>
+struct B3Lds {                                             // all hidden layers of a field (skip_mode "no")
+  static constexpr int off(int l) { return l == 0 ? 0 : B3Planes<MI, MH>::LAYER + (l - 1) * B3Planes<MH, MH>::LAYER; }
+  static constexpr int TOTAL = off(L);                     // 16-byte units
+};
+
+// build the planes from the fp32 A-fragments FieldStage::commit() wrote (call after its barrier; barrier after this)
+template <int MI, int MH, int L>
+__device__ __forceinline__ void b3_build_planes(const float* sm, ngm_u32x4* planes) {
+  using LY = FieldLds<MI, MH, L, false>;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int MIN = (l == 0) ? MI : MH, KB = 2 * MIN;
+    const float* W = sm + LY::w_off(l);
+    ngm_u32x4* P = planes + B3Lds<MI, MH, L>::off(l);
+    const int plane = MH * KB * 2 * 32;
+    for (int e4 = threadIdx.x; e4 < plane; e4 += blockDim.x) {
+      const int io = e4 & 31, kh = (e4 >> 5) & 1, kb = (e4 >> 6) % KB, mo = (e4 >> 6) / KB;
+      const int mi = kb >> 1, b = kb & 1;
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = W[((((mo * MIN + mi) * 16 + 8 * b + e) * 2 + kh) * NGM_WGS) + io];
+      ngm_bf16x8 H, M, Lo;
+      b3_split8(x, H, M, Lo);
+      P[e4] = __builtin_bit_cast(ngm_u32x4, H);
+      P[plane + e4] = __builtin_bit_cast(ngm_u32x4, M);
+      P[2 * plane + e4] = __builtin_bit_cast(ngm_u32x4, Lo);
+    }
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(ngm_bf16x8 a, ngm_bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Y = relu(W X + b) like layer_fwd, through the six-product bf16 split
+template <int MIN, int MOUT, int NT>
+__device__ __forceinline__ void layer_fwd_b3(const ngm_u32x4* __restrict__ P, const float* __restrict__ B, int lane,
+                                             const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT]) {
+  using PL = B3Planes<MIN, MOUT>;
+  const int io = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < PL::KB; ++kb) {
+    const int mi = kb >> 1, b = kb & 1;
+    // weights of this k-block (three 16-byte reads per output tile), issued before the split so that they travel under it
+    ngm_bf16x8 ah[MOUT], am[MOUT], al[MOUT];
+#pragma unroll
+    for (int mo = 0; mo < MOUT; ++mo) {
+      ah[mo] = __builtin_bit_cast(ngm_bf16x8, P[PL::idx(0, mo, kb, hi, io)]);
+      am[mo] = __builtin_bit_cast(ngm_bf16x8, P[PL::idx(1, mo, kb, hi, io)]);
+      al[mo] = __builtin_bit_cast(ngm_bf16x8, P[PL::idx(2, mo, kb, hi, io)]);
+    }
+    ngm_bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = X[nt][mi][8 * b + e];
+      b3_split8(x, bh[nt], bm[nt], bl[nt]);
+    }
+#pragma unroll
+    for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 y = Y[nt][mo];
+        y = mfma_bf16(al[mo], bh[nt], y);            // small terms first
+        y = mfma_bf16(ah[mo], bl[nt], y);
+        y = mfma_bf16(am[mo], bm[nt], y);
+        y = mfma_bf16(am[mo], bh[nt], y);
+        y = mfma_bf16(ah[mo], bm[nt], y);
+        y = mfma_bf16(ah[mo], bh[nt], y);
+        Y[nt][mo] = y;
+      }
+  }
+#pragma unroll
+  for (int mo = 0; mo < MOUT; ++mo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
+      const ngm_v2f b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const ngm_v2f y01 = ngm_v2f{Y[nt][mo][4 * q], Y[nt][mo][4 * q + 1]} + b01;
+        const ngm_v2f y23 = ngm_v2f{Y[nt][mo][4 * q + 2], Y[nt][mo][4 * q + 3]} + b23;
+        Y[nt][mo][4 * q] = ngm_relu(y01.x); Y[nt][mo][4 * q + 1] = ngm_relu(y01.y);
+        Y[nt][mo][4 * q + 2] = ngm_relu(y23.x); Y[nt][mo][4 * q + 3] = ngm_relu(y23.y);
+      }
+    }
+  }
+}
+
 // Output layer (4 x H) on the VALU: each lane reduces over ITS 16*MH features; the two lane halves
 // of a sample hold disjoint feature sets and are combined by the caller.
 template <int MH, int NT>
@@ -500,11 +644,14 @@ __device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[
 
 // SKIP (0 no, 1 add, 2 concat) is a template parameter on purpose: as a run-time flag it kept the encoding registers
 // alive through every layer of the default path as well and cost the fused forward 14 us.
-template <int MI, int MH, int L, int NT, int SKIP = 0>
+template <int MI, int MH, int L, int NT, int SKIP = 0, bool B3 = false>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
-                                        const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
+                                        const ActStash* st = nullptr, PhaseClock* pc = nullptr,
+                                        const ngm_u32x4* b3w = nullptr) {
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
-  layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
+  static_assert(!B3 || SKIP == 0, "the bf16 split path is compiled for skip_mode no");
+  if constexpr (B3) layer_fwd_b3<MI, MH, NT>(b3w + B3Lds<MI, MH, L>::off(0), sm + LY::b_off(0), lane, E, Hlast);
+  else layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
   if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
   PTICK(pc, 5);
   if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
@@ -523,6 +670,8 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
         for (int m = 0; m < MI; ++m) Xc[nt][MH + m] = E[nt][m];
       }
       layer_fwd<MH + MI, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Xc, T);
+    } else if constexpr (B3) {
+      layer_fwd_b3<MH, MH, NT>(b3w + B3Lds<MI, MH, L>::off(l), sm + LY::b_off(l), lane, Hlast, T);
     } else {
       layer_fwd<MH, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hlast, T);
     }
@@ -539,9 +688,10 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
-template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, int SKIP = 0>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, int SKIP = 0, bool B3 = false>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
-                                          const ActStash* st = nullptr, PhaseClock* pc = nullptr) {
+                                          const ActStash* st = nullptr, PhaseClock* pc = nullptr,
+                                          const ngm_u32x4* b3w = nullptr) {
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
@@ -571,7 +721,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, SKIP>(sm, lane, E, Hl, HASH ? nullptr : st, pc);
+  mlp_fwd<MI, MH, L, 2, SKIP, B3>(sm, lane, E, Hl, HASH ? nullptr : st, pc, b3w);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);

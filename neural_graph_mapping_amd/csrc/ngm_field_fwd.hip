@@ -85,7 +85,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
@@ -213,6 +213,12 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   if (r_beg < r_end) prepare(r_beg);
   fstage.commit(sm, a.fc);
   __syncthreads();
+  // opt-in bf16 three-way split of the hidden layers: weight planes behind the per-wave regions
+  ngm_u32x4* const b3w = reinterpret_cast<ngm_u32x4*>(sm + LY::TOTAL + nwaves * RenderWaveLds::floats(a.maxs));
+  if constexpr (B3) {
+    b3_build_planes<MI, MH, L>(sm, b3w);
+    __syncthreads();
+  }
   PTICK(pc, 0);
   for (int rb = r_beg; rb < r_end; rb += BR) {
     const int nb = min(BR, r_end - rb);
@@ -243,9 +249,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #else
       PTICK(pc, 3);
 #ifdef NGM_PHASE_TIMING
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc, &ast, pc);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, pc, b3w);
 #else
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc, &ast);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w);
 #endif
 #endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
@@ -424,6 +430,20 @@ template <int MI, int MH, int L>
 static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   const size_t wave_lds = (size_t)a.waves_per_block * RenderWaveLds::floats(a.maxs);
   const dim3 blk(64 * a.waves_per_block);
+  if (a.fc.matmul_mode == NGM_MATMUL_BF16X3) {
+    // opt-in: hidden layers as a three-way bf16 split on v_mfma_f32_32x32x16_bf16 (ngm_field.h, layer_fwd_b3)
+    if constexpr (MI == 2 && MH == 2 && L <= 2) {
+      if (a.fc.skip_mode == NGM_SKIP_NO && (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
+        const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
+        if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;
+        (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, false, 0, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, false, 0, true>), dim3(blocks), blk, lds, st, a);
+        return 0;
+      }
+    }
+    return NGM_E_UNSUPPORTED;
+  }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, true, blocks, blk, 0, wave_lds);
     else return NGM_E_UNSUPPORTED;

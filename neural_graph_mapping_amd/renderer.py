@@ -68,6 +68,8 @@ class NeuralGraphRenderer:
         self._model, self._camera, self._config, self._device = model, camera, dict(config), device
         self._field_radius = config.get("field_radius", model._field_radius)
         self._fc = model.field_cfg(self._field_radius)
+        # opt-in: hidden layers of the fused forward as an exact three-way bf16 split (include/ngm_hip.h, ngm_matmul_mode)
+        self._fc.matmul_mode = K.MATMUL[config.get("mlp_matmul", "f32")]
         self._rc_train = make_render_cfg(camera, config, guided=True)
         self._rc_plain = make_render_cfg(camera, config, guided=False)
         self._global_map_dict = None       # supplied by the mapping loop: positions / orientations

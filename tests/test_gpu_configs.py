@@ -206,3 +206,69 @@ def test_eval_style_fused_render_4096_rays_x_640_samples_properties():
     assert torch.isfinite(a.rgbds).all() and torch.equal(a.rgbds, b.rgbds)
     assert float(a.term_probs.min()) >= -1e-6 and float(a.term_probs.max()) <= 1 + 1e-5
     assert (a.depth_vars >= -1e-7).all()
+
+
+# ------------------------------------------------------------------------------------------------ opt-in bf16 split
+def test_bf16x3_split_forward_meets_the_fp32_tolerances_and_is_bitwise_deterministic():
+    """mlp_matmul = "bf16x3" (ngm_matmul_mode): the fused forward's hidden layers as an exact three-way bf16 split on the
+    bf16 matrix pipe.  Same fixtures, UNCHANGED tolerances as the fp32 path (reference prediction / loss / gradients of
+    G6), error against the fp32-MFMA path at fp32 round-off level, and bitwise identical results over 1000 launches of
+    a ragged batch + 100 launches of the full 4096 x 128 batch (training mode: activation stash written)."""
+    from conftest import load_golden, split_prefix
+    from gpu_common import CASES
+    for name in ("g6_train_cfg0", "g6_train_3field"):
+        g = load_golden(name)
+        fkw, ckw = CASES[name]
+        F = g["pos"].shape[0]
+        outs = {}
+        for mm in ("f32", "bf16x3"):
+            r = make_renderer(fkw, {**ckw, "mlp_matmul": mm}, F, split_prefix(g, "p::"))
+            r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+            tgt = make_target(split_prefix(g, "t::"), torch.arange(F))
+            res = r.optimization_iteration(tgt, g["u_coarse"].to(DEV), g["u_guided"].to(DEV), update=False)
+            close(res["prediction"].rgbds, g["pred_rgbds"])
+            close(res["prediction"].term_probs, g["pred_term_probs"])
+            for k, v in split_prefix(g, "loss::").items():
+                close(res[k], v, rtol=2e-4, atol=1e-5)
+            for k, v in split_prefix(g, "g::").items():
+                grad_close(res["grads"][k], v, 2e-3, k)
+            outs[mm] = res["prediction"].rgbds.clone()
+        assert float((outs["f32"] - outs["bf16x3"]).abs().max()) < 2e-5
+        assert not torch.equal(outs["f32"], outs["bf16x3"])            # it really is the other arithmetic
+    # determinism, ragged batch (partial tiles, fields starting mid-tile)
+    F, R = 3, 37
+    ckw = dict(num_samples_coarse=20, num_samples_depth_guided=4, mlp_matmul="bf16x3")
+    r = make_renderer(FOURIER, ckw, F)
+    _perturb(r)
+    pos, quat, t = synth_target(F, R, seed=5)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    first = r.optimization_iteration(tgt, seed=9, update=False)
+    ref_p, ref_g = first["prediction"].rgbds.clone(), {k: v.clone() for k, v in first["grads"].items()}
+    for _ in range(1000):
+        o = r.optimization_iteration(tgt, seed=9, update=False)
+        assert torch.equal(o["prediction"].rgbds, ref_p)
+    for k in ref_g:
+        assert torch.equal(o["grads"][k], ref_g[k]), k
+    # full metric batch
+    F, R = 8, 512
+    r = make_renderer(FOURIER, dict(num_samples_coarse=64, num_samples_depth_guided=64, mlp_matmul="bf16x3"), F)
+    _perturb(r)
+    pos, quat, t = synth_target(F, R)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    first = r.optimization_iteration(tgt, seed=11, update=False)
+    ref_p, ref_t = first["prediction"].rgbds.clone(), first["prediction"].term_probs.clone()
+    ref_g = {k: v.clone() for k, v in first["grads"].items()}
+    for _ in range(100):
+        o = r.optimization_iteration(tgt, seed=11, update=False)
+        assert torch.equal(o["prediction"].rgbds, ref_p) and torch.equal(o["prediction"].term_probs, ref_t)
+        for k in ref_g:
+            assert torch.equal(o["grads"][k], ref_g[k]), k
+    # a configuration the split path is not compiled for must fail loudly, not fall back
+    r = make_renderer(dict(encoding="fourier", dim_enc=32, num_layers=1), dict(num_samples_coarse=4, num_samples_depth_guided=4,
+                                                                              mlp_matmul="bf16x3"), 1)
+    r.set_field_poses(pos[:1].to(DEV), quat[:1].to(DEV))
+    _, _, t1 = synth_target(1, 8, seed=1)
+    with pytest.raises(K.NgmError):
+        r.optimization_iteration(make_target(t1, torch.arange(1)), seed=1, update=False)

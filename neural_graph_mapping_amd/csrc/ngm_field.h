@@ -504,12 +504,21 @@ __device__ __forceinline__ void layer_fwd_b3(const ngm_u32x4* __restrict__ P, co
                                              const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT]) {
   using PL = B3Planes<MIN, MOUT>;
   const int io = lane & 31, hi = lane >> 5;
+  // The accumulators START from the bias (loaded from LDS), not from the inline constant 0: with a constant SrcC the
+  // compiler is free to let the destination tile overlap the A / B operand registers of the same v_mfma (observed:
+  // `v_mfma_f32_32x32x16_bf16 v[2:17], v[6:9], v[218:221], 0`), and launches of such code were not bitwise
+  // reproducible; a tied SrcC = VDST chain cannot be allocated that way.  (Rounding order differs from the fp32 path's
+  // bias-last epilogue by one fp32 addition; inside every tolerance.)
 #pragma unroll
   for (int mo = 0; mo < MOUT; ++mo)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        Y[nt][mo][4 * q] = b4.x; Y[nt][mo][4 * q + 1] = b4.y; Y[nt][mo][4 * q + 2] = b4.z; Y[nt][mo][4 * q + 3] = b4.w;
+      }
+    }
 #pragma unroll
   for (int kb = 0; kb < PL::KB; ++kb) {
     const int mi = kb >> 1, b = kb & 1;
@@ -529,35 +538,41 @@ __device__ __forceinline__ void layer_fwd_b3(const ngm_u32x4* __restrict__ P, co
       for (int e = 0; e < 8; ++e) x[e] = X[nt][mi][8 * b + e];
       b3_split8(x, bh[nt], bm[nt], bl[nt]);
     }
-#pragma unroll
-    for (int mo = 0; mo < MOUT; ++mo)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x16 y = Y[nt][mo];
-        y = mfma_bf16(al[mo], bh[nt], y);            // small terms first
-        y = mfma_bf16(ah[mo], bl[nt], y);
-        y = mfma_bf16(am[mo], bm[nt], y);
-        y = mfma_bf16(am[mo], bh[nt], y);
-        y = mfma_bf16(ah[mo], bm[nt], y);
-        y = mfma_bf16(ah[mo], bh[nt], y);
-        Y[nt][mo] = y;
-      }
+    // product-major: consecutive MFMAs go to DIFFERENT accumulators (MOUT * NT independent chains), so no MFMA
+    // waits for (or depends on the forwarding of) the one issued right before it; small terms first
+#define NGM_B3_PRODUCT(AW, BX)                                                                        \
+    _Pragma("unroll") for (int mo = 0; mo < MOUT; ++mo)                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma_bf16(AW[mo], BX[nt], Y[nt][mo]); \
+    __builtin_amdgcn_sched_barrier(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NGM_B3_PRODUCT(al, bh);
+    NGM_B3_PRODUCT(ah, bl);
+    NGM_B3_PRODUCT(am, bm);
+    NGM_B3_PRODUCT(am, bh);
+    NGM_B3_PRODUCT(ah, bm);
+    NGM_B3_PRODUCT(ah, bh);
+#undef NGM_B3_PRODUCT
   }
+  // The ReLU below is inline asm (one v_max_f32, ngm_relu) applied DIRECTLY to MFMA results: the compiler's hazard
+  // recognizer does not look into asm statements, so the MFMA -> VALU read wait states (passes + 2 after the last
+  // v_mfma; there is no hardware interlock) are supplied here by hand.  Without them the v_max read accumulators the
+  // matrix pipe had not written yet whenever the partner wave kept the pipe busy: results differed from launch to
+  // launch.  (The fp32 path adds the bias with compiler-visible instructions first, which get their wait states.)
 #pragma unroll
-  for (int mo = 0; mo < MOUT; ++mo) {
+  for (int mo = 0; mo < MOUT; ++mo)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 b4 = *reinterpret_cast<const float4*>(B + 32 * mo + 8 * q + 4 * hi);
-      const ngm_v2f b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const ngm_v2f y01 = ngm_v2f{Y[nt][mo][4 * q], Y[nt][mo][4 * q + 1]} + b01;
-        const ngm_v2f y23 = ngm_v2f{Y[nt][mo][4 * q + 2], Y[nt][mo][4 * q + 3]} + b23;
-        Y[nt][mo][4 * q] = ngm_relu(y01.x); Y[nt][mo][4 * q + 1] = ngm_relu(y01.y);
-        Y[nt][mo][4 * q + 2] = ngm_relu(y23.x); Y[nt][mo][4 * q + 3] = ngm_relu(y23.y);
-      }
+    for (int nt = 0; nt < NT; ++nt) {
+      // volatile asm statements keep their order: the wait is issued once, after every MFMA; the empty ones only pin
+      // the other accumulators' first VALU use behind it
+      if (mo == 0 && nt == 0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Y[nt][mo]));
+      else asm volatile("" : "+v"(Y[nt][mo]));
     }
-  }
+#pragma unroll
+  for (int mo = 0; mo < MOUT; ++mo)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[nt][mo][r] = ngm_relu(Y[nt][mo][r]);
 }
 
 // Output layer (4 x H) on the VALU: each lane reduces over ITS 16*MH features; the two lane halves

@@ -188,11 +188,9 @@ def scene_sim(args, rank, world, dev):
         def run(n):
             for i in range(n):
                 r.optimization_iteration(batches[i % NB], seed=3, update=True)
-        run(args.warmup)
-        t_spin = time.perf_counter()                     # the clocks of an idle GPU take ~0.1 s to ramp: spin up by time as well
-        while time.perf_counter() - t_spin < 0.5:
-            run(NB)
-            torch.cuda.synchronize()
+        # the clocks of an idle GPU take ~0.1 s to ramp up: a generous, FIXED number of untimed iterations (the same on
+        # every rank: each iteration contains a collective)
+        run(max(args.warmup, 256))
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()

@@ -43,6 +43,7 @@ enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /
  * in fp32 on the bf16 matrix pipe -- fp32-level accuracy (dropped terms < 2^-23 relative), not narrower arithmetic;
  * bitwise deterministic.  Honoured by ngm_render_fwd for 49..64-wide layers, <= 2 hidden layers, Fourier / no
  * encoding, skip_mode no; anything else returns NGM_E_UNSUPPORTED rather than silently falling back. */
+enum ngm_param_dtype { NGM_DT_F32 = 0, NGM_DT_BF16 = 1, NGM_DT_F16 = 2 };
 enum ngm_matmul_mode { NGM_MATMUL_F32 = 0, NGM_MATMUL_BF16X3 = 1 };
 enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
 enum ngm_geometry_mode { NGM_GEO_NRGBD = 0, NGM_GEO_OCCUPANCY = 1, NGM_GEO_DENSITY = 2, NGM_GEO_NEUS = 3 };
@@ -106,8 +107,14 @@ typedef struct ngm_params {
   const int64_t* field_index;
   const float* lattice; /* "_encoding.lattice_values" (N, L, T, 2); NULL unless permutohedral */
   int64_t lattice_stride;
-  const float* shift;   /* "_encoding.random_shift_per_level" (N, L, 3) */
+  const float* shift;   /* "_encoding.random_shift_per_level" (N, L, 3); always fp32 (constants) */
   int64_t shift_stride;
+  int32_t dtype;        /* ngm_param_dtype: STORAGE type of enc_w, w[], b[] and lattice.  NGM_DT_BF16 / NGM_DT_F16: the
+                         * pointers above address 16-bit elements (strides stay element counts); the kernels widen
+                         * them to fp32 when they stage a field's weights into LDS / gather the hash table, and
+                         * compute in fp32 exactly as for fp32 storage (BASELINE configs 1 and 4: bf16 / fp16 weights;
+                         * the reference itself is fp32 only).  Gradients and Adam moments stay fp32.            */
+  int32_t reserved_;
 } ngm_params;
 
 /* Gradient outputs, same layout rules as ngm_params (row f of each tensor = batch field f). */
@@ -296,6 +303,9 @@ typedef struct ngm_adam_tensor {
   float* param; float* exp_avg; float* exp_avg_sq; /* (N, numel) rows with `stride` elements between fields */
   const float* grad;                               /* (F, numel) rows with `grad_stride`                    */
   int64_t stride, grad_stride, numel;
+  void* param_lp;                                  /* optional reduced-precision copy of `param` (same row layout,  */
+  int32_t lp_dtype;                                /* 16-bit elements, ngm_param_dtype): refreshed with every update */
+  int32_t reserved_;                               /* (fp32 master weights + the copy the kernels read)              */
 } ngm_adam_tensor;
 int ngm_adam_sparse_multi(const ngm_adam_tensor* tensors, int32_t num_tensors, const int64_t* field_index,
                           int32_t F, int64_t step, int64_t* step_dev, float lr, float beta1, float beta2,

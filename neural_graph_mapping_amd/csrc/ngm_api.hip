@@ -166,6 +166,7 @@ static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
   if (fc->encoding == NGM_ENC_PERMUTO && (!pr->lattice || !pr->shift)) return fail(NGM_E_INVALID, "permutohedral encoding needs lattice + shift");
   for (int l = 0; l <= fc->num_layers; ++l)
     if (!pr->w[l] || !pr->b[l]) return fail(NGM_E_INVALID, "missing layer weight/bias pointer");
+  if (pr->dtype != NGM_DT_F32 && pr->dtype != NGM_DT_BF16 && pr->dtype != NGM_DT_F16) return fail(NGM_E_INVALID, "params.dtype");
   return NGM_OK;
 }
 

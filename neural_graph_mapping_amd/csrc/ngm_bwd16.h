@@ -90,34 +90,31 @@ struct FieldStage16 {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int TIN = (l == 0) ? TI : TH, Din = (l == 0) ? D : H;
-      const float* W = pr.w[l] + row * pr.w_stride[l];
+      const int dt = pr.dtype;
+      const float* W = pr.w[l];                          // element offsets from here: the storage may be 16-bit
+      const int64_t w0 = row * pr.w_stride[l];
       const int ncol4 = TIN * 4, total4 = TH * 16 * ncol4;
-      const bool vec = ((Din & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+      const uintptr_t wa = reinterpret_cast<uintptr_t>(W) + (uintptr_t)w0 * (dt == NGM_DT_F32 ? 4 : 2);
+      const bool vec = ((Din & 3) == 0) && ((wa & (dt == NGM_DT_F32 ? 15 : 7)) == 0);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int e4 = tid + it * B16_THREADS;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e4 < total4) {
           const int o = e4 / ncol4, c = 4 * (e4 - o * ncol4);
-          if (o < H && c < Din) {
-            const float* src = W + (int64_t)o * Din + c;
-            if (vec) x = *reinterpret_cast<const float4*>(src);
-            else {
-              x.x = src[0];
-              if (c + 1 < Din) x.y = src[1];
-              if (c + 2 < Din) x.z = src[2];
-              if (c + 3 < Din) x.w = src[3];
-            }
-          }
+          if (o < H && c < Din) x = ngm_ldp4(W, w0 + (int64_t)o * Din + c, dt, vec, Din - c);
         }
         v[l][it] = x;
       }
-      bias[l] = (tid < H) ? pr.b[l][row * pr.b_stride[l] + tid] : 0.f;
+      bias[l] = (tid < H) ? ngm_ldp(pr.b[l], row * pr.b_stride[l] + tid, dt) : 0.f;
     }
+    const int dt = pr.dtype;
     wout = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < H) {
-      const float* W = pr.w[L] + row * pr.w_stride[L];
-      wout = make_float4(W[tid], W[H + tid], W[2 * H + tid], W[3 * H + tid]);
+      const float* W = pr.w[L];
+      const int64_t w0 = row * pr.w_stride[L];
+      wout = make_float4(ngm_ldp(W, w0 + tid, dt), ngm_ldp(W, w0 + H + tid, dt), ngm_ldp(W, w0 + 2 * H + tid, dt),
+                         ngm_ldp(W, w0 + 3 * H + tid, dt));
     }
     enc0 = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
     enc1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,7 +130,10 @@ struct FieldStage16 {
       if (fc.encoding == NGM_ENC_FOURIER) {
         const int n_raw = fc.raw_coords ? 3 : 0;
         if (f < n_raw) enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-        else { const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3; enc0 = make_float4(w[0], w[1], w[2], NGM_FK_SIN); }
+        else {
+          const int64_t e0 = row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
+          enc0 = make_float4(ngm_ldp(pr.enc_w, e0, dt), ngm_ldp(pr.enc_w, e0 + 1, dt), ngm_ldp(pr.enc_w, e0 + 2, dt), NGM_FK_SIN);
+        }
       } else if (fc.encoding == NGM_ENC_NERF) {
         const int half = 3 * fc.num_octaves;
         const int g = (f < half) ? f : f - half;
@@ -228,10 +228,9 @@ __device__ __forceinline__ void encode_hash16(const float* sm_lvl, const HashCtx
       if (level < hc.nlev) {
         uint32_t idx[4]; float bw[4];
         permuto_simplex(x, y, z, sm_lvl + 8 * level, hc.mask, idx, bw);
-        const float2* t = hc.tab + (size_t)level * hc.T;
         float2 v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+        for (int r = 0; r < 4; ++r) v[r] = ngm_ldp2(hc.tab, (size_t)level * hc.T + idx[r], hc.dt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
       }

@@ -623,6 +623,10 @@ __global__ void k_adam_multi(AdamMultiK a) {
         pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
       }
       M4[i] = m; V4[i] = v; P4[i] = p;
+      if (t.param_lp) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ngm_stp(t.param_lp, row * t.stride + 4 * i + c, pp[c], t.lp_dtype);
+      }
     }
   } else
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.numel; i += (int64_t)gridDim.x * blockDim.x) {
@@ -632,7 +636,9 @@ __global__ void k_adam_multi(AdamMultiK a) {
     const float mn = a.beta1 * t.exp_avg[o] + (1.0f - a.beta1) * g;
     const float vn = a.beta2 * t.exp_avg_sq[o] + (1.0f - a.beta2) * g * g;
     t.exp_avg[o] = mn; t.exp_avg_sq[o] = vn;
-    t.param[o] = p - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+    const float pn = p - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+    t.param[o] = pn;
+    if (t.param_lp) ngm_stp(t.param_lp, o, pn, t.lp_dtype);
   }
   // end-of-iteration bookkeeping by the last block to finish (all blocks have read the step by then)
   if (a.advance_step || a.advance_offset) {

@@ -88,6 +88,52 @@ __device__ __forceinline__ float ngm_sinf(float x) {
   return __uint_as_float(__float_as_uint(s) ^ (__float_as_uint(n) << 31));
 }
 
+// ------------------------------------------------------------------------------------------------
+// reduced-precision parameter STORAGE (ngm_params.dtype): element i of a tensor whose nominal float* base addresses
+// fp32, bf16 or fp16 elements; always widened to fp32 (exact), all arithmetic stays fp32
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ngm_widen(uint32_t h16, int dt) {
+  if (dt == NGM_DT_BF16) return __uint_as_float(h16 << 16);
+  const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)h16);
+  return (float)h;
+}
+__device__ __forceinline__ float ngm_ldp(const float* base, int64_t i, int dt) {
+  if (dt == NGM_DT_F32) return base[i];
+  return ngm_widen(reinterpret_cast<const unsigned short*>(base)[i], dt);
+}
+// elements i..i+3; `vec`: one 16-byte (fp32) / 8-byte (16-bit) load is allowed (caller checked alignment and bounds)
+__device__ __forceinline__ float4 ngm_ldp4(const float* base, int64_t i, int dt, bool vec, int n_valid) {
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec) {
+    if (dt == NGM_DT_F32) return *reinterpret_cast<const float4*>(base + i);
+    const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + i);
+    return make_float4(ngm_widen(raw.x & 0xffffu, dt), ngm_widen(raw.x >> 16, dt), ngm_widen(raw.y & 0xffffu, dt),
+                       ngm_widen(raw.y >> 16, dt));
+  }
+  x.x = ngm_ldp(base, i, dt);
+  if (n_valid > 1) x.y = ngm_ldp(base, i + 1, dt);
+  if (n_valid > 2) x.z = ngm_ldp(base, i + 2, dt);
+  if (n_valid > 3) x.w = ngm_ldp(base, i + 3, dt);
+  return x;
+}
+// hash table entry (2 features): 8 bytes fp32, 4 bytes 16-bit
+__device__ __forceinline__ float2 ngm_ldp2(const void* tab, size_t entry, int dt) {
+  if (dt == NGM_DT_F32) return reinterpret_cast<const float2*>(tab)[entry];
+  const uint32_t raw = reinterpret_cast<const uint32_t*>(tab)[entry];
+  return make_float2(ngm_widen(raw & 0xffffu, dt), ngm_widen(raw >> 16, dt));
+}
+// fp32 -> storage type, round to nearest even (the copy an Adam update leaves for the kernels)
+__device__ __forceinline__ void ngm_stp(void* base, int64_t i, float v, int dt) {
+  unsigned short h;
+  if (dt == NGM_DT_BF16) {
+    const uint32_t u = __float_as_uint(v);
+    h = (v != v) ? (unsigned short)0x7fc0 : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  } else {
+    h = __builtin_bit_cast(unsigned short, (_Float16)v);
+  }
+  reinterpret_cast<unsigned short*>(base)[i] = h;
+}
+
 __device__ __forceinline__ float ngm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // relu on a matrix-core result in ONE instruction.  fmaxf(y, 0) on an MFMA output compiles to two v_max_f32 (the first

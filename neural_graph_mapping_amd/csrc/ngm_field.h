@@ -56,9 +56,12 @@ struct FieldStage {
       const int min_l = (l == 0) ? MI : MIN;
       const bool cat_l = CAT && l > 0;           // input = cat(hidden (H), encoding (D)): logical row length H + D
       const int Din = (l == 0) ? D : (cat_l ? H + D : H);
-      const float* W = pr.w[l] + row * pr.w_stride[l];
+      const int dt = pr.dtype;
+      const float* W = pr.w[l];                          // element offsets from here: the storage may be 16-bit
+      const int64_t w0 = row * pr.w_stride[l];
       const int ncol4 = min_l * 8, total4 = MH * 32 * ncol4;
-      const bool vec = ((Din & 3) == 0) && (!cat_l || (H & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+      const uintptr_t wa = reinterpret_cast<uintptr_t>(W) + (uintptr_t)w0 * (dt == NGM_DT_F32 ? 4 : 2);
+      const bool vec = ((Din & 3) == 0) && (!cat_l || (H & 3) == 0) && ((wa & (dt == NGM_DT_F32 ? 15 : 7)) == 0);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int e4 = tid + it * nthr;
@@ -69,31 +72,26 @@ struct FieldStage {
           const bool enc_part = cat_l && ct >= 32 * MH;
           const int c = enc_part ? H + (ct - 32 * MH) : ct;          // logical column
           const int lim = enc_part ? H + D : (cat_l ? H : Din);      // end of this part's logical columns
-          if (o < H && c < lim) {
-            const float* src = W + (int64_t)o * Din + c;
-            if (vec) x = *reinterpret_cast<const float4*>(src);
-            else {
-              x.x = src[0];
-              if (c + 1 < lim) x.y = src[1];
-              if (c + 2 < lim) x.z = src[2];
-              if (c + 3 < lim) x.w = src[3];
-            }
-          }
+          if (o < H && c < lim) x = ngm_ldp4(W, w0 + (int64_t)o * Din + c, dt, vec, lim - c);
         }
         v[l][it] = x;
       }
-      bias[l] = (tid < H) ? pr.b[l][row * pr.b_stride[l] + tid] : 0.f;
+      bias[l] = (tid < H) ? ngm_ldp(pr.b[l], row * pr.b_stride[l] + tid, dt) : 0.f;
     }
+    const int dt = pr.dtype;
     // output layer (4 x H) -> float4 per hidden feature
     wout = make_float4(0.f, 0.f, 0.f, 0.f);
     wout_e = make_float4(0.f, 0.f, 0.f, 0.f);
     {
       const int Dout_in = CAT ? H + D : H;                 // row length of the (4, .) output matrix
-      const float* W = pr.w[L] + row * pr.w_stride[L];
-      if (tid < H) wout = make_float4(W[tid], W[Dout_in + tid], W[2 * Dout_in + tid], W[3 * Dout_in + tid]);
-      if (CAT && tid < D) wout_e = make_float4(W[H + tid], W[Dout_in + H + tid], W[2 * Dout_in + H + tid], W[3 * Dout_in + H + tid]);
+      const float* W = pr.w[L];
+      const int64_t w0 = row * pr.w_stride[L];
+      if (tid < H) wout = make_float4(ngm_ldp(W, w0 + tid, dt), ngm_ldp(W, w0 + Dout_in + tid, dt),
+                                      ngm_ldp(W, w0 + 2 * Dout_in + tid, dt), ngm_ldp(W, w0 + 3 * Dout_in + tid, dt));
+      if (CAT && tid < D) wout_e = make_float4(ngm_ldp(W, w0 + H + tid, dt), ngm_ldp(W, w0 + Dout_in + H + tid, dt),
+                                               ngm_ldp(W, w0 + 2 * Dout_in + H + tid, dt), ngm_ldp(W, w0 + 3 * Dout_in + H + tid, dt));
     }
-    bout = (tid < 4) ? pr.b[L][row * pr.b_stride[L] + tid] : 0.f;
+    bout = (tid < 4) ? ngm_ldp(pr.b[L], row * pr.b_stride[L] + tid, dt) : 0.f;
     // encoding table: one float4 per feature (weights of the argument, kind)
     enc0 = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
     enc1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -111,8 +109,8 @@ struct FieldStage {
         if (f < n_raw) {
           enc0 = make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
         } else {
-          const float* w = pr.enc_w + row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
-          enc0 = make_float4(w[0], w[1], w[2], NGM_FK_SIN);
+          const int64_t e0 = row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
+          enc0 = make_float4(ngm_ldp(pr.enc_w, e0, dt), ngm_ldp(pr.enc_w, e0 + 1, dt), ngm_ldp(pr.enc_w, e0 + 2, dt), NGM_FK_SIN);
         }
       } else if (fc.encoding == NGM_ENC_NERF) {
         const int half = 3 * fc.num_octaves;
@@ -230,7 +228,8 @@ __device__ __forceinline__ void encode_pair_sin(const float* sm_encw, int hi, ng
 // lattice coordinates (up to ~1e5 at the finest level) round exactly like the oracle's torch ops.
 // ------------------------------------------------------------------------------------------------
 struct HashCtx {
-  const float2* tab;     // this field's table: [L][T] float2
+  const void* tab;       // this field's table: [L][T] x 2 features, fp32 or 16-bit storage (dt)
+  int dt;
   uint32_t mask;         // T - 1
   int T, nlev;
   float* gtab;           // gradient table (backward) or nullptr
@@ -313,10 +312,9 @@ __device__ __forceinline__ void encode_hash(const float* sm_lvl, const HashCtx& 
       if (level < hc.nlev) {
         uint32_t idx[4]; float bw[4];
         permuto_simplex(x, y, z, sm_lvl + 8 * level, hc.mask, idx, bw);
-        const float2* t = hc.tab + (size_t)level * hc.T;
         float2 v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+        for (int r = 0; r < 4; ++r) v[r] = ngm_ldp2(hc.tab, (size_t)level * hc.T + idx[r], hc.dt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
       }
@@ -352,7 +350,10 @@ __device__ __forceinline__ HashCtx make_hash_ctx(const ngm_field_cfg& fc, const 
   hc.T = 1 << fc.log2_hashmap_size;
   hc.mask = (uint32_t)hc.T - 1u;
   hc.nlev = fc.nr_levels;
-  hc.tab = (fc.encoding == NGM_ENC_PERMUTO) ? reinterpret_cast<const float2*>(pr.lattice + row * pr.lattice_stride) : nullptr;
+  hc.dt = pr.dtype;
+  hc.tab = nullptr;
+  if (fc.encoding == NGM_ENC_PERMUTO)
+    hc.tab = reinterpret_cast<const char*>(pr.lattice) + (size_t)(row * pr.lattice_stride) * (pr.dtype == NGM_DT_F32 ? 4 : 2);
   hc.gtab = gtab;
   return hc;
 }

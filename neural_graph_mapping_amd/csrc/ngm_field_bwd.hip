@@ -511,7 +511,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // deterministic reduction of the per-workgroup partial gradient vectors into the caller's tensors
 // ------------------------------------------------------------------------------------------------
-struct GradSeg { int64_t off, size; float* dst; int64_t stride; float* param; float* m; float* v; int64_t pstride; };
+struct GradSeg { int64_t off, size; float* dst; int64_t stride; float* param; float* m; float* v; int64_t pstride; void* lp; int lp_dt; };
 struct GradReduceK {
   int F, blocks_per_field, nseg;
   const float* partials;
@@ -562,7 +562,9 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
         const float mn = a.beta1 * a.seg[k].m[o] + (1.0f - a.beta1) * g;
         const float vn = a.beta2 * a.seg[k].v[o] + (1.0f - a.beta2) * g * g;
         a.seg[k].m[o] = mn; a.seg[k].v[o] = vn;
-        a.seg[k].param[o] = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+        const float pn = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+        a.seg[k].param[o] = pn;
+        if (a.seg[k].lp) ngm_stp(a.seg[k].lp, o, pn, a.seg[k].lp_dt);      // the reduced-precision copy the kernels read
       }
       break;
     }
@@ -578,13 +580,13 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
   int n = 0;
   if (g.fc.encoding == NGM_ENC_FOURIER) {
     const int64_t sz = (int64_t)(g.fc.raw_coords ? g.fc.dim_enc - 3 : g.fc.dim_enc) * 3;
-    k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride, nullptr, nullptr, nullptr, 0};
+    k.seg[n++] = GradSeg{enc_off, sz, g.gr.enc_w, g.gr.enc_w_stride, nullptr, nullptr, nullptr, 0, nullptr, 0};
   }
   for (int l = 0; l <= g.fc.num_layers; ++l) {
     const int din = (l == 0) ? g.fc.dim_enc : g.fc.dim_hidden + (g.fc.skip_mode == NGM_SKIP_CONCAT ? g.fc.dim_enc : 0);
     const int dout = (l == g.fc.num_layers) ? g.fc.dim_out : g.fc.dim_hidden;
-    k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l], nullptr, nullptr, nullptr, 0};
-    k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l], nullptr, nullptr, nullptr, 0};
+    k.seg[n++] = GradSeg{w_off[l], (int64_t)din * dout, g.gr.w[l], g.gr.w_stride[l], nullptr, nullptr, nullptr, 0, nullptr, 0};
+    k.seg[n++] = GradSeg{b_off[l], (int64_t)dout, g.gr.b[l], g.gr.b_stride[l], nullptr, nullptr, nullptr, 0, nullptr, 0};
   }
   k.nseg = n;
   k.field_index = nullptr; k.step_dev = nullptr; k.step = 1; k.lr = k.beta1 = k.beta2 = k.eps = k.wd = 0.f;
@@ -594,6 +596,7 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
       const ngm_adam_tensor& t = g.adam.tensors[i];
       if (t.numel != k.seg[i].size || !t.param || !t.exp_avg || !t.exp_avg_sq) return NGM_E_INVALID;
       k.seg[i].param = t.param; k.seg[i].m = t.exp_avg; k.seg[i].v = t.exp_avg_sq; k.seg[i].pstride = t.stride;
+      k.seg[i].lp = t.param_lp; k.seg[i].lp_dt = t.lp_dtype;
     }
     k.field_index = g.adam.field_index; k.step_dev = g.adam.step_dev; k.step = g.adam.step;
     k.lr = g.adam.lr; k.beta1 = g.adam.beta1; k.beta2 = g.adam.beta2; k.eps = g.adam.eps; k.wd = g.adam.wd;
@@ -664,7 +667,7 @@ struct HashGradArgs {
   float* gtab; int64_t gstride;
   float* part;     // [F][L][chunks][2T] per-workgroup partial tables (plain stores, reduced in fixed order)
   // optional fused sparse Adam on the tables (ad_param != NULL), as k_adam_multi
-  float* ad_param; float* ad_m; float* ad_v; int64_t ad_stride;
+  float* ad_param; float* ad_m; float* ad_v; int64_t ad_stride; void* ad_lp; int ad_lp_dt;
   const int64_t* ad_field_index; const int64_t* ad_step_dev; int64_t ad_step;
   float ad_lr, ad_beta1, ad_beta2, ad_eps, ad_wd;
 };
@@ -773,6 +776,10 @@ __global__ void k_hash_reduce(HashGradArgs a) {
     }
     reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
     reinterpret_cast<float4*>(a.ad_param)[o4] = p;
+    if (a.ad_lp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ngm_stp(a.ad_lp, 4 * o4 + c, pp[c], a.ad_lp_dt);
+    }
   }
 }
 
@@ -795,7 +802,7 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
   if (env_chunks && atoi(env_chunks) >= 1 && atoi(env_chunks) <= 8 && atoi(env_chunks) <= max_chunks) chunks = atoi(env_chunks);
   a.chunks = chunks; a.per_chunk = (fb.P + chunks - 1) / chunks;
   a.part = fb.hash_part;
-  a.ad_param = nullptr;
+  a.ad_param = nullptr; a.ad_lp = nullptr; a.ad_lp_dt = 0;
   if (fb.lattice_adam.tensors) {
     const ngm_adam_tensor& t = fb.lattice_adam.tensors[0];
     const int64_t per = (int64_t)fb.fc.nr_levels * T * 2;
@@ -803,6 +810,7 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
     if (t.numel == per && (t.stride & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0) {
       a.ad_param = t.param; a.ad_m = t.exp_avg; a.ad_v = t.exp_avg_sq; a.ad_stride = t.stride;
+      a.ad_lp = t.param_lp; a.ad_lp_dt = t.lp_dtype;
       a.ad_field_index = fb.lattice_adam.field_index; a.ad_step_dev = fb.lattice_adam.step_dev; a.ad_step = fb.lattice_adam.step;
       a.ad_lr = fb.lattice_adam.lr; a.ad_beta1 = fb.lattice_adam.beta1; a.ad_beta2 = fb.lattice_adam.beta2;
       a.ad_eps = fb.lattice_adam.eps; a.ad_wd = fb.lattice_adam.wd;

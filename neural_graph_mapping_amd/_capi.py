@@ -40,7 +40,8 @@ class FieldCfg(C.Structure):
 class Params(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
                 ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p),
-                ("lattice", f32p), ("lattice_stride", C.c_int64), ("shift", f32p), ("shift_stride", C.c_int64)]
+                ("lattice", f32p), ("lattice_stride", C.c_int64), ("shift", f32p), ("shift_stride", C.c_int64),
+                ("dtype", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Grads(C.Structure):
@@ -70,7 +71,8 @@ class Rays(C.Structure):
 
 class AdamTensor(C.Structure):
     _fields_ = [("param", f32p), ("exp_avg", f32p), ("exp_avg_sq", f32p), ("grad", f32p),
-                ("stride", C.c_int64), ("grad_stride", C.c_int64), ("numel", C.c_int64)]
+                ("stride", C.c_int64), ("grad_stride", C.c_int64), ("numel", C.c_int64),
+                ("param_lp", C.c_void_p), ("lp_dtype", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Targets(C.Structure):
@@ -277,9 +279,13 @@ def _fill_ptrs(struct, fc, ptrs, strides):
     return struct
 
 
-def params_struct(fc, ptrs, strides, field_index=None):
+DTYPE = {"float32": 0, "bfloat16": 1, "float16": 2}      # ngm_param_dtype: storage type of the weights
+
+
+def params_struct(fc, ptrs, strides, field_index=None, dtype=0):
     p = _fill_ptrs(Params(), fc, ptrs, strides)
     p.field_index = field_index
+    p.dtype = dtype
     return p
 
 

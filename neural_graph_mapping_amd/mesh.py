@@ -143,7 +143,7 @@ def extract_mesh(renderer, mesh_file_path=None, resolution: Optional[float] = No
         transform = transform.to(dev)
         pos = pos @ transform[:3, :3].T + transform[:3, 3]                     # utils.transform_points
         quat = _quat_mul(_matrix_to_quaternion(transform[:3, :3].cpu()).to(dev), quat)   # utils.transform_quaternions
-    params = {k: v for k, v in m.all_fields_params.items() if k != "_neus_sd"}
+    params = m.kernel_params()
     fidx = None
     if field_ids is not None:
         field_ids = field_ids[field_ids < num].to(dev)

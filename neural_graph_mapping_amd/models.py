@@ -159,8 +159,18 @@ class NeuralFieldSet(torch.nn.Module):
 
     def __init__(self, dim_points: int, field_type, field_kwargs: dict, num_knn: int, distance_factor: float,
                  outside_value: float, field_radius: Optional[float] = None,
-                 scale_mode: Literal["no", "unit_ball", "unit_cube"] = "no") -> None:
+                 scale_mode: Literal["no", "unit_ball", "unit_cube"] = "no",
+                 weight_dtype: Optional[str] = None) -> None:
+        """`weight_dtype` (not in the reference, which is fp32 only): "bfloat16" / "float16" keep a reduced-precision COPY
+        of every field's weights (`lp_fields_params`) that the evaluation and training kernels read (half the bytes
+        staged / gathered per field; arithmetic stays fp32).  `all_fields_params` remains the fp32 master set: what
+        Adam updates, what checkpoints hold, what the differentiable ops take.  The fused training step refreshes the
+        copy inside its Adam kernels; after editing the masters by hand call `refresh_lp()`."""
         super().__init__()
+        if weight_dtype not in (None, "float32", "bfloat16", "float16"):
+            raise ValueError(f"{weight_dtype=}: float32, bfloat16 or float16")
+        self._weight_dtype = None if weight_dtype in (None, "float32") else getattr(torch, weight_dtype)
+        self.lp_fields_params: Optional[Dict[str, torch.Tensor]] = None
         if scale_mode != "no" and field_radius is None:
             raise ValueError(f"{scale_mode=} requires field_radius to be specified.")
         if dim_points != 3:
@@ -186,6 +196,20 @@ class NeuralFieldSet(torch.nn.Module):
             self.all_fields_params = new
         else:
             self.all_fields_params = {k: torch.cat((v, new[k])) for k, v in self.all_fields_params.items()}
+        self.refresh_lp()
+
+    def refresh_lp(self) -> None:
+        """(re)build the reduced-precision copy from the fp32 masters (no-op without `weight_dtype`)"""
+        if self._weight_dtype is None or self.all_fields_params is None:
+            self.lp_fields_params = None
+            return
+        self.lp_fields_params = {k: (v if (k in K.NO_GRAD_PARAMS or k == "_neus_sd") else v.to(self._weight_dtype))
+                                 for k, v in self.all_fields_params.items()}
+
+    def kernel_params(self) -> Dict[str, torch.Tensor]:
+        """what the evaluation / training kernels read: the reduced-precision copy when there is one, else the masters"""
+        src = self.lp_fields_params if self.lp_fields_params is not None else self.all_fields_params
+        return {k: v for k, v in src.items() if k != "_neus_sd"}
 
     def set_vmap_fields(self, field_ids: Optional[torch.Tensor]) -> None:
         if field_ids is None:
@@ -197,6 +221,7 @@ class NeuralFieldSet(torch.nn.Module):
         super()._apply(fn, *a, **kw)
         if self.all_fields_params is not None:
             self.all_fields_params = {k: fn(v) for k, v in self.all_fields_params.items()}
+            self.refresh_lp()
         return self
 
     def numel(self) -> int:
@@ -211,7 +236,7 @@ class NeuralFieldSet(torch.nn.Module):
             params = {k: v for k, v in self.vmap_fields_params.items() if k != "_neus_sd"}
             return ops.field_eval(fc, params, query_points, field_positions, field_orientations)
         lead = query_points.shape[:-1]
-        params = {k: v for k, v in self.all_fields_params.items() if k != "_neus_sd"}
+        params = self.kernel_params()
         out = ops.field_eval_knn(fc, params, query_points.reshape(-1, 3), field_positions, field_orientations,
                                  self._num_knn, self._distance_factor, self._outside_value, field_ids)
         return out.reshape(*lead, -1)

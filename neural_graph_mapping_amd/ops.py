@@ -63,27 +63,40 @@ def _f32c(t, name="tensor"):
 # ------------------------------------------------------------------------------------------------
 # parameter plumbing: dict of stacked (N, ...) tensors <-> ngm_params / ngm_grads
 # ------------------------------------------------------------------------------------------------
+_TORCH_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
 def params_struct(fc: K.FieldCfg, params: Dict[str, torch.Tensor], field_index: Optional[torch.Tensor] = None):
+    """dict of stacked (N, ...) tensors -> ngm_params.  The weights may be stored as float32, bfloat16 or float16 (all
+    of them in the same type; the constant hash shifts stay float32): ngm_params.dtype tells the kernels, which widen to
+    fp32 when they stage a field (storage only: the arithmetic is fp32 either way)."""
     ptrs, strides = {}, {}
+    dts = set()
     for n, shp in K.param_shapes(fc).items():
         if n not in params:
             raise KeyError(f"missing parameter tensor '{n}'")
         t = params[n]
         _require_gpu(t)
-        if t.dtype != torch.float32 or tuple(t.shape[1:]) != tuple(shp):
-            raise ValueError(f"parameter '{n}' must be float32 (N,{shp}), got {t.dtype} {tuple(t.shape)}")
+        const = n in K.NO_GRAD_PARAMS
+        if t.dtype not in _TORCH_DT or (const and t.dtype != torch.float32) or tuple(t.shape[1:]) != tuple(shp):
+            raise ValueError(f"parameter '{n}' must be {'float32' if const else 'float32 / bfloat16 / float16'} (N,{shp}), "
+                             f"got {t.dtype} {tuple(t.shape)}")
+        if not const:
+            dts.add(t.dtype)
         inner = t[0] if t.shape[0] > 0 else t
         if t.shape[0] > 0 and not inner.is_contiguous():
             raise ValueError(f"parameter '{n}' rows must be contiguous")
         ptrs[n] = t.data_ptr()
         strides[n] = t.stride(0) if t.shape[0] > 1 else int(torch.tensor(shp).prod())
+    if len(dts) != 1:
+        raise ValueError(f"the weight tensors must share one storage type, got {sorted(str(d) for d in dts)}")
     fi = None
     if field_index is not None:
         _require_gpu(field_index)
         if field_index.dtype != torch.int64:
             raise TypeError("field_index must be int64")
         fi = field_index.contiguous().data_ptr()
-    return K.params_struct(fc, ptrs, strides, fi)
+    return K.params_struct(fc, ptrs, strides, fi, _TORCH_DT[dts.pop()])
 
 
 def alloc_grads(fc: K.FieldCfg, F: int, device, flat: Optional[torch.Tensor] = None):
@@ -575,33 +588,38 @@ def adam_sparse_(param, exp_avg, exp_avg_sq, grad, field_index, step, lr=1e-3, b
                                   float(betas[1]), float(eps), float(weight_decay))
 
 
-def adam_tensor_arrays(fc, params, state, grads):
-    """(mlp AdamTensor array in gradient-segment order, lattice AdamTensor or None) for ngm_render_bwd_adam."""
+def _adam_tensor(p, st, g, lp=None):
+    t = K.AdamTensor(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), g.data_ptr(), p.stride(0), g.stride(0),
+                     g[0].numel())
+    if lp is not None and lp.dtype != torch.float32:      # reduced-precision copy the kernels read: refreshed by the update
+        if lp.shape != p.shape or lp.stride(0) != p.stride(0):
+            raise ValueError("reduced-precision copy must mirror the master tensor's layout")
+        t.param_lp, t.lp_dtype = lp.data_ptr(), _TORCH_DT[lp.dtype]
+    return t
+
+
+def adam_tensor_arrays(fc, params, state, grads, lp=None):
+    """(mlp AdamTensor array in gradient-segment order, lattice AdamTensor or None) for ngm_render_bwd_adam.
+    `params` = fp32 master weights; `lp` (optional dict) = their reduced-precision copies, kept in sync by the update."""
     names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
     mlp = [n for n in names if n != "_encoding.lattice_values"]
     arr = (K.AdamTensor * len(mlp))()
     for i, n in enumerate(mlp):
-        p, g = params[n], grads[n]
-        arr[i] = K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
-                              g.data_ptr(), p.stride(0), g.stride(0), g[0].numel())
+        arr[i] = _adam_tensor(params[n], state[n], grads[n], None if lp is None else lp[n])
     lat = None
     if "_encoding.lattice_values" in names:
         n = "_encoding.lattice_values"
-        p, g = params[n], grads[n]
-        lat = (K.AdamTensor * 1)(K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
-                                             g.data_ptr(), p.stride(0), g.stride(0), g[0].numel()))
+        lat = (K.AdamTensor * 1)(_adam_tensor(params[n], state[n], grads[n], None if lp is None else lp[n]))
     return arr, len(mlp), lat
 
 
 def adam_sparse_multi_(fc, params, state, grads, field_index, step, step_dev=None, lr=1e-3, betas=(0.9, 0.999),
-                       eps=1e-15, weight_decay=1e-5, advance=False, philox_offset_dev=None):
+                       eps=1e-15, weight_decay=1e-5, advance=False, philox_offset_dev=None, lp=None):
     """One launch for every parameter tensor of the field set (rows `field_index` updated in place)."""
     names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
     arr = (K.AdamTensor * len(names))()
     for i, n in enumerate(names):
-        p, g = params[n], grads[n]
-        arr[i] = K.AdamTensor(p.data_ptr(), state[n]["exp_avg"].data_ptr(), state[n]["exp_avg_sq"].data_ptr(),
-                              g.data_ptr(), p.stride(0), g.stride(0), g[0].numel())
+        arr[i] = _adam_tensor(params[n], state[n], grads[n], None if lp is None else lp[n])
     K.check(K.lib().ngm_adam_sparse_multi(arr, len(names), _ptr(field_index), grads[names[0]].shape[0], int(step),
                                           _ptr(step_dev), lr, betas[0], betas[1], eps, weight_decay,
                                           int(bool(advance and step_dev is not None)),

@@ -111,6 +111,7 @@ class NeuralGraphRenderer:
         self._model.load_state_dict(ck["state_dict"])
         self._model.all_fields_params = {k: v.to(self._device) for k, v in ck["all_fields_params"].items()}
         self._global_map_dict = ck["map_dict"]
+        self._model.refresh_lp()
         self._optim_state = {k: {"exp_avg": torch.zeros_like(v), "exp_avg_sq": torch.zeros_like(v)}
                              for k, v in self._model.all_fields_params.items()}
 
@@ -121,7 +122,7 @@ class NeuralGraphRenderer:
         num = self._global_map_dict["num"]
         pos = self._global_map_dict["positions"][:num]
         quat = self._global_map_dict["orientations"][:num]
-        params = {k: v for k, v in self._model.all_fields_params.items() if k != "_neus_sd"}
+        params = self._model.kernel_params()
         m = self._model
         lead = points.shape[:-1]
         pts = points.reshape(-1, 3)
@@ -242,6 +243,7 @@ class NeuralGraphRenderer:
                                  lr=self._learning_rate, eps=self._adam_eps, weight_decay=self._adam_weight_decay)
         if self._step_dev is not None:
             self._step_dev.fill_(self._step)
+        self._model.refresh_lp()           # this path updates the fp32 masters tensor by tensor
         return out
 
     def compute_losses(self, target: Target, prediction: Prediction) -> dict:
@@ -341,7 +343,7 @@ class NeuralGraphRenderer:
         pos = self._global_map_dict["positions"][:num]
         quat = self._global_map_dict["orientations"][:num]
         if params is None:
-            params = self._model.all_fields_params
+            params = self._model.kernel_params()
         params = {k: v for k, v in params.items() if k != "_neus_sd"}
         m = self._model
         block = int(cfg.get("pixel_block_size", 8192))
@@ -438,8 +440,10 @@ class NeuralGraphRenderer:
         fids = target.field_ids
         F, R = target.ijs.shape[0], target.ijs.shape[1]
         names = K.param_names(fc)
-        allp = {n: self._model.all_fields_params[n] for n in names}
-        ps = ops.params_struct(fc, allp, fids)           # kernels read rows field_ids[f] in place: no gather
+        allp = {n: self._model.all_fields_params[n] for n in names}       # fp32 masters (Adam)
+        kp = self._model.kernel_params()                                   # what the kernels read (reduced precision or masters)
+        lp = None if self._model.lp_fields_params is None else {n: kp[n] for n in names}
+        ps = ops.params_struct(fc, {n: kp[n] for n in names}, fids)        # rows field_ids[f] in place: no gather
         w = self._workspace(F, R)
         keep = []
         if self._step_dev is None:
@@ -462,7 +466,7 @@ class NeuralGraphRenderer:
         defer = self.process_group is None
         K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                  None if defer else w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
-        return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp, defer=defer,
+        return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp, lp=lp, defer=defer,
                     keep=(keep, dm, tm, rgbds_t, target))
 
     def _iteration_backward(self, ctx: dict, update=True) -> dict:
@@ -479,7 +483,7 @@ class NeuralGraphRenderer:
             # backward + sparse Adam in one call: the gradient-reduction kernel applies the update of the MLP tensors
             # itself (rm.py:1183-1221); the device counter already holds the new step (the loss reduction advanced it)
             self._step += 1                                  # one counter for all fields (rm.py:380-385)
-            arr, n_mlp, lat = ops.adam_tensor_arrays(fc, allp, self._optim_state, grads)
+            arr, n_mlp, lat = ops.adam_tensor_arrays(fc, allp, self._optim_state, grads, ctx.get("lp"))
             K.check(L.ngm_render_bwd_adam(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                           sums_ptr, C.byref(gs), arr, n_mlp, lat, ops._ptr(fids), int(self._step),
                                           ops._ptr(self._step_dev), self._learning_rate, 0.9, 0.999, self._adam_eps,

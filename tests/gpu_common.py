@@ -71,7 +71,8 @@ def make_renderer(fkw, ckw, num_fields, params=None):
     model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
         encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0,
         skip_mode=fkw.get("skip_mode", "no")), num_knn=2,
-        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
+        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube",
+        weight_dtype=fkw.get("weight_dtype")).to(DEV)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
                termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0)
@@ -82,6 +83,7 @@ def make_renderer(fkw, ckw, num_fields, params=None):
     if params is not None:
         for k, v in params.items():
             model.all_fields_params[k].copy_(v.to(DEV))
+        model.refresh_lp()
     return r
 
 

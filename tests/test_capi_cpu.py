@@ -43,12 +43,12 @@ def test_struct_layouts_match_header(capi, tmp_path):
     src.write_text('#include <stdio.h>\n#include "ngm_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(ngm_field_cfg),sizeof(ngm_params),sizeof(ngm_grads),sizeof(ngm_render_cfg),"
                    "sizeof(ngm_rays),sizeof(ngm_targets),sizeof(ngm_prediction));"
-                   "printf(\" %zu %zu\\n\",sizeof(ngm_keyframes),sizeof(ngm_target_out));return 0;}\n")
+                   "printf(\" %zu %zu %zu\\n\",sizeof(ngm_keyframes),sizeof(ngm_target_out),sizeof(ngm_adam_tensor));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mirrors = [capi.FieldCfg, capi.Params, capi.Grads, capi.RenderCfg, capi.Rays, capi.Targets, capi.Prediction,
-               capi.Keyframes, capi.TargetOut]
+               capi.Keyframes, capi.TargetOut, capi.AdamTensor]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

@@ -272,3 +272,48 @@ def test_bf16x3_split_forward_meets_the_fp32_tolerances_and_is_bitwise_determini
     _, _, t1 = synth_target(1, 8, seed=1)
     with pytest.raises(K.NgmError):
         r.optimization_iteration(make_target(t1, torch.arange(1)), seed=1, update=False)
+
+
+# ------------------------------------------------------------------------------------------------ cfg1 / cfg4 weights
+@pytest.mark.parametrize("wd", ["bfloat16", "float16"])
+@pytest.mark.parametrize("net", ["fourier", "hash"])
+def test_reduced_precision_weight_storage(wd, net):
+    """BASELINE configs 1 (bf16) and 4 (fp16 MLP weights): the weights are STORED in 16 bits (ngm_params.dtype), widened
+    exactly when a field is staged / the hash table is gathered, arithmetic in fp32.  So a field set whose fp32 masters
+    hold 16-bit-representable values must give BITWISE the same results from either storage -- forward, gradients and the
+    kNN evaluation; and the fused Adam keeps the 16-bit copy equal to the rounded masters."""
+    dt = getattr(torch, wd)
+    fkw = dict(FOURIER) if net == "fourier" else dict(HASH)
+    F, R = 3, 37
+    ckw = dict(num_samples_coarse=20, num_samples_depth_guided=4)
+    ra = make_renderer(fkw, ckw, F)                                   # fp32 storage
+    _perturb(ra)
+    with torch.no_grad():                                             # make every weight 16-bit representable
+        for k, v in ra._model.all_fields_params.items():
+            if k not in K.NO_GRAD_PARAMS and k != "_neus_sd":
+                v.copy_(v.to(dt).float())
+    rb = make_renderer({**fkw, "weight_dtype": wd}, ckw, F, {k: v for k, v in ra._model.all_fields_params.items()})
+    lp = rb._model.lp_fields_params
+    assert lp["_linears.0.weight"].dtype == dt and rb._model.all_fields_params["_linears.0.weight"].dtype == torch.float32
+    pos, quat, t = synth_target(F, R, seed=5)
+    tgt = make_target(t, torch.arange(F))
+    outs = []
+    for r in (ra, rb):
+        r.set_field_poses(pos.to(DEV), quat.to(DEV))
+        o = r.optimization_iteration(tgt, seed=9, update=False)
+        outs.append((o["prediction"].rgbds.clone(), {k: v.clone() for k, v in o["grads"].items()}, float(o["combined"])))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    pts = (pos[:, None] + 0.5 * torch.randn(F, 200, 3)).reshape(-1, 3).to(DEV)
+    assert torch.equal(ra.evaluate_points(pts), rb.evaluate_points(pts))
+    # training: masters in fp32, the copy refreshed by the Adam kernels (round to nearest even)
+    for it in range(3):
+        out = rb.optimization_iteration(tgt, seed=it, update=True)
+    assert torch.isfinite(out["combined"])
+    for k, v in rb._model.all_fields_params.items():
+        if k in K.NO_GRAD_PARAMS or k == "_neus_sd":
+            continue
+        assert torch.equal(rb._model.lp_fields_params[k], v.to(dt)), k
+        assert not torch.equal(v, ra._model.all_fields_params[k])               # the masters did move
+        assert float((v - v.to(dt).float()).abs().max()) > 0                    # and are not themselves rounded

@@ -32,6 +32,8 @@ D_ENC, N_LAYERS = 64, 2
 FLOP_FWD = 2 * (64 * 64 + 64 * 64 + 64 * 4)      # 16 896 flop / sample
 FLOP_BWD = 2 * FLOP_FWD                          # wgrad + dgrad: 33 792 flop / sample
 PEAK_F32_MFMA_TF = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+DTYPE_LABEL = {"f32": "f32",
+               "bf16x3": "f32 via 3xbf16 split, fp32 accumulate (forward hidden layers); f32 MFMA (backward)"}
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -64,7 +66,7 @@ def synth_target(F, Rn, seed, field_offset=0):
     return pos, quat, tgt
 
 
-def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, matmul="f32"):
+def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, matmul="auto"):
     from neural_graph_mapping_amd import models as M
     from neural_graph_mapping_amd import renderer as Rr
     torch.manual_seed(0)
@@ -252,9 +254,10 @@ def main():
     ap.add_argument("--variant", choices=["fourier", "hash"], default="fourier",
                     help="field network: fourier = the headline M1 workload (default); hash = the reference's default "
                          "permutohedral-hash network on the same batch (auxiliary measurement)")
-    ap.add_argument("--matmul", choices=["f32", "bf16x3"], default="f32",
-                    help="hidden layers of the fused forward: f32 = exact-fp32 MFMA (default, the headline arithmetic); bf16x3 = "
-                         "opt-in exact three-way bf16 split with fp32 accumulation (same tolerances, deterministic)")
+    ap.add_argument("--matmul", choices=["auto", "f32", "bf16x3"], default="auto",
+                    help="hidden layers of the forward kernels: auto (library default) = the exact three-way bf16 split with fp32 "
+                         "accumulation where it is compiled (this workload), f32 = exact-fp32 MFMA everywhere; the line's `dtype` "
+                         "says which ran, and the other one is measured next to it (`matmul_alternative`)")
     ap.add_argument("--scene-sim", action="store_true",
                     help="auxiliary strong-scaling measurement of a realistic mapping iteration (200 fields, 32 active per "
                          "iteration, sharded id %% world) instead of the headline line; see scene_sim()")
@@ -354,11 +357,12 @@ def main():
         if n.value:
             kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
 
-    # side measurement (never the headline): the same K steps with the opt-in bf16 three-way split of the forward's hidden
-    # layers (ngm_matmul_mode; same tolerances, bitwise deterministic), after and outside the timed region above
+    # side measurement, after and outside the timed region above: the same K steps with the OTHER arithmetic of the forward's
+    # hidden layers (exact-fp32 MFMA <-> exact three-way bf16 split), so that one line carries both
     side = None
-    if world == 1 and args.variant == "fourier" and args.matmul == "f32" and not strong:
-        r3 = build_renderer(dev, F_PER_GPU, args.variant, matmul="bf16x3")
+    if world == 1 and args.variant == "fourier" and args.matmul == "auto" and not strong:
+        other = "f32" if r.mlp_matmul == "bf16x3" else "bf16x3"
+        r3 = build_renderer(dev, F_PER_GPU, args.variant, matmul=other)
         r3.set_field_poses(pos.to(dev), quat.to(dev))
         rep3 = r3.capture_iteration(tgt, seed=7) if use_graph else (lambda: r3.optimization_iteration(tgt, seed=7, update=True))
         for _ in range(args.warmup):
@@ -369,9 +373,9 @@ def main():
             o3 = rep3()
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t3
-        side = dict(ms_per_step=1e3 * dt3 / args.steps, value=F_PER_GPU * R * (S_C + S_G) * args.steps / dt3,
-                    dtype="f32 via 3xbf16 split, fp32 accumulate (forward hidden layers); f32 MFMA (backward)",
-                    final_loss=float(o3["combined"]), note="python bench.py --matmul bf16x3 makes this the measured path")
+        side = dict(matmul=other, ms_per_step=1e3 * dt3 / args.steps, value=F_PER_GPU * R * (S_C + S_G) * args.steps / dt3,
+                    dtype=DTYPE_LABEL[other], final_loss=float(o3["combined"]),
+                    note=f"python bench.py --matmul {other} makes this the measured path")
         del r3, rep3
 
     devs = [dev_index]
@@ -386,8 +390,7 @@ def main():
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
                    value=value, unit="ray-samples/s", n_gpus=ranks_seen, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
-                   dtype="f32" if args.matmul == "f32" else "f32 via 3xbf16 split, fp32 accumulate (forward hidden layers); f32 MFMA (backward)",
-                   data="synthetic",
+                   dtype=DTYPE_LABEL[r.mlp_matmul], data="synthetic",
                    config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
                                            "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
@@ -420,7 +423,7 @@ def main():
                 res["roofline_fwd"] = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=a_f,
                                            peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=a_f / PEAK_F32_MFMA_TF,
                                            avg_launch_us=ff["avg_us"], algorithmic_flop_per_launch=FLOP_FWD * n_local)
-                if args.matmul == "bf16x3":     # both fractions: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
+                if r.mlp_matmul == "bf16x3":     # both fractions: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
                     issued = 6 * 2 * (64 * 64 + 64 * 64) * n_local         # six bf16 products per fp32 product, hidden layers
                     res["roofline_fwd"].update(kernel="k_render_fwd<2,2,2,bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)",
                                                issued_bf16_tflops=issued / (ff["avg_us"] * 1e-6) / 1e12, peak_bf16=2500.0,
@@ -443,7 +446,7 @@ def main():
                                         "itself accumulates in LDS and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
         res["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in kern.items()}
         if side:
-            res["bf16x3_opt_in"] = side
+            res["matmul_alternative"] = side
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -38,13 +38,16 @@ enum ngm_status {
 
 enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3 };
 enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /* models.py:159-180; rezero: the reference's constructor raises */
-/* NGM_MATMUL_F32: exact-fp32 MFMA (default, what every parity number is quoted on).  NGM_MATMUL_BF16X3 (opt-in):
- * every fp32 operand is split exactly into three bf16 (hi + mid + lo) and the six leading cross products are summed
- * in fp32 on the bf16 matrix pipe -- fp32-level accuracy (dropped terms < 2^-23 relative), not narrower arithmetic;
- * bitwise deterministic.  Honoured by ngm_render_fwd for 49..64-wide layers, <= 2 hidden layers, Fourier / no
- * encoding, skip_mode no; anything else returns NGM_E_UNSUPPORTED rather than silently falling back. */
-enum ngm_param_dtype { NGM_DT_F32 = 0, NGM_DT_BF16 = 1, NGM_DT_F16 = 2 };
-enum ngm_matmul_mode { NGM_MATMUL_F32 = 0, NGM_MATMUL_BF16X3 = 1 };
+/* Arithmetic of the hidden layers in the forward kernels (fused render, point evaluation, kNN evaluation).
+ * NGM_MATMUL_F32: exact-fp32 MFMA.  NGM_MATMUL_BF16X3: every fp32 operand is split exactly into three bf16
+ * (hi + mid + lo) and the six leading cross products are summed in fp32 on the bf16 matrix pipe -- fp32-level accuracy
+ * (dropped terms < 2^-23 relative), not narrower arithmetic; bitwise deterministic; compiled for 33..64-wide layers,
+ * <= 2 hidden layers, Fourier / no encoding, skip_mode no.  As an explicit request ngm_render_fwd returns
+ * NGM_E_UNSUPPORTED where it is not compiled or its weight planes (24 KB of LDS per layer) do not fit -- never a silent
+ * fallback.  NGM_MATMUL_AUTO: the split wherever it is compiled and fits, exact-fp32 MFMA otherwise (resolved per batch
+ * shape by the same plan in forward and backward).  The backward kernels always use fp32 MFMA. */
+enum ngm_matmul_mode { NGM_MATMUL_F32 = 0, NGM_MATMUL_BF16X3 = 1, NGM_MATMUL_AUTO = 2 };
+enum ngm_param_dtype { NGM_DT_F32 = 0, NGM_DT_BF16 = 1, NGM_DT_F16 = 2 };   /* storage type of the weights (ngm_params.dtype) */
 enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
 enum ngm_geometry_mode { NGM_GEO_NRGBD = 0, NGM_GEO_OCCUPANCY = 1, NGM_GEO_DENSITY = 2, NGM_GEO_NEUS = 3 };
 

@@ -201,7 +201,7 @@ def check(rc, what=""):
 # struct builders from plain python values / raw device addresses
 # ------------------------------------------------------------------------------------------------
 SKIP = {"no": 0, "add": 1, "concat": 2}
-MATMUL = {"f32": 0, "bf16x3": 1}
+MATMUL = {"f32": 0, "bf16x3": 1, "auto": 2}
 
 
 def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,

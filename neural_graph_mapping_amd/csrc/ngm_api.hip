@@ -422,7 +422,7 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 // fused render / train step
 // ------------------------------------------------------------------------------------------------
 struct RenderPlan {
-  int S, rays_per_block, blocks_fwd, waves_fwd, maxs;
+  int S, rays_per_block, blocks_fwd, waves_fwd, maxs, b3;
   int64_t per_block_bwd; int blocks_per_field_bwd;
   int64_t p_pad;
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
@@ -449,8 +449,12 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   const int ncu = num_cus();
   // forward: one workgroup per CU-slot; 8 waves (2 per SIMD: latency hiding) unless the per-wave LDS
   // sample planes would not fit in 160 KiB, then 4 waves
-  int waves = 8;
-  for (;;) {
+  // the bf16 weight planes of the split path (ngm_matmul_mode): 3 planes x 2 bytes per hidden weight
+  const int64_t MIp = (fc->dim_enc + 31) / 32, MHp = (fc->dim_hidden + 31) / 32;
+  const int64_t b3_bytes = 3 * 2 * 1024 * MHp * (MIp + (fc->num_layers - 1) * MHp);
+  const bool b3_compiled = MIp == 2 && MHp == 2 && fc->num_layers <= 2 && fc->skip_mode == NGM_SKIP_NO &&
+                           (fc->encoding == NGM_ENC_FOURIER || fc->encoding == NGM_ENC_NONE);
+  auto shape = [&](int waves, int64_t extra, int64_t* lds_out) {
     int ch = (ncu + F - 1) / F;
     const int max_ch = (R + waves - 1) / waves;
     if (ch > max_ch) ch = max_ch;
@@ -461,14 +465,21 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     int64_t maxs = align_up((int64_t)(rpw < 32 ? rpw : 32) * p.S, 64);
     if (maxs > 1024) maxs = 1024;
     if (maxs < align_up(p.S, 64)) maxs = align_up(p.S, 64);
-    // + the bf16 weight planes of the opt-in split path: 3 planes x 2 bytes per hidden weight
-    const int64_t MIp = (fc->dim_enc + 31) / 32, MHp = (fc->dim_hidden + 31) / 32;
-    const int64_t b3 = fc->matmul_mode == NGM_MATMUL_BF16X3 ? 3 * 2 * 1024 * MHp * (MIp + (fc->num_layers - 1) * MHp) : 0;
-    const int64_t lds = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs)) + b3;
-    if (waves == 8 && (lds > 160 * 1024 || R < 8)) { waves = 4; continue; }
+    *lds_out = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs)) + extra;
     p.rays_per_block = rpb; p.waves_fwd = waves; p.maxs = (int)maxs;
     p.blocks_fwd = F * ((R + rpb - 1) / rpb);
-    break;
+  };
+  const int64_t LDS_MAX = 160 * 1024;
+  int64_t lds = 0;
+  shape(8, 0, &lds);                                    // exact-fp32 plan first: 8 waves unless its LDS does not fit
+  if (lds > LDS_MAX || R < 8) shape(4, 0, &lds);
+  p.b3 = 0;
+  if (fc->matmul_mode == NGM_MATMUL_BF16X3) {           // explicit: whatever wave count makes it fit, else the launcher fails loudly
+    p.b3 = 1;
+    shape(8, b3_bytes, &lds);
+    if (lds > LDS_MAX || R < 8) shape(4, b3_bytes, &lds);
+  } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && lds + b3_bytes <= LDS_MAX) {
+    p.b3 = 1;                                           // auto: only when the planes fit next to the fp32 plan's wave count
   }
   p.p_pad = param_pad(fc);
   int64_t o = 0;
@@ -545,6 +556,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   RenderFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.rc = *rcfg; a.rays = *rays; a.pred = *pred;
+  a.fc.matmul_mode = p.b3 ? NGM_MATMUL_BF16X3 : NGM_MATMUL_F32;       // AUTO resolved by the plan (LDS budget of this batch shape)
   a.has_targets = has_tg ? 1 : 0;
   if (has_tg) a.tg = *targets;
   a.S = p.S; a.rays_per_block = p.rays_per_block; a.waves_per_block = p.waves_fwd; a.maxs = p.maxs;

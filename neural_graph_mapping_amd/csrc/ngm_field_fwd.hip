@@ -18,7 +18,7 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
@@ -29,6 +29,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
     fstage.commit(sm, a.fc);
   }
   __syncthreads();
+  ngm_u32x4* const b3w = reinterpret_cast<ngm_u32x4*>(sm + FieldLds<MI, MH, L, SKIP == 2>::TOTAL);
+  if constexpr (B3) {          // ngm_matmul_mode BF16X3: bf16 weight planes behind the fp32 fragments (ngm_field.h)
+    b3_build_planes<MI, MH, L>(sm, b3w);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float div, off;
   scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -416,9 +421,26 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     }                                                                                           \
   } while (0)
 
+// the bf16 split path (ngm_matmul_mode) is compiled for 49..64-wide layers, <= 2 hidden layers, Fourier / no encoding, skip no
+template <int MI, int MH, int L>
+static constexpr bool b3_shape() { return MI == 2 && MH == 2 && L <= 2; }
+static bool b3_wanted(const ngm_field_cfg& fc) {
+  return (fc.matmul_mode == NGM_MATMUL_BF16X3 || fc.matmul_mode == NGM_MATMUL_AUTO) && fc.skip_mode == NGM_SKIP_NO &&
+         (fc.encoding == NGM_ENC_FOURIER || fc.encoding == NGM_ENC_NONE);
+}
+
 template <int MI, int MH, int L>
 static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
   const dim3 blk(NGM_BLOCK);
+  if constexpr (b3_shape<MI, MH, L>()) {
+    if (b3_wanted(a.fc)) {       // standalone evaluation: the mode is a preference here (fp32 MFMA where not compiled)
+      const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
+      (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, false, 0, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false, false, 0, true>), dim3(blocks), blk, lds, st, a);
+      return 0;
+    }
+  }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, true, blocks, blk, 0, 0);
     else return NGM_E_UNSUPPORTED;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
     if (fld[k] >= 0) a.sorted[hist[fld[k]] + rnk[k]] = (int)(base + k * 256 + threadIdx.x);
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
@@ -236,6 +236,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
     fstage.commit(sm, a.fc);
   }
   __syncthreads();
+  ngm_u32x4* const b3w = reinterpret_cast<ngm_u32x4*>(sm + FieldLds<MI, MH, L, SKIP == 2>::TOTAL);
+  if constexpr (B3) {          // ngm_matmul_mode BF16X3: bf16 weight planes behind the fp32 fragments (ngm_field.h)
+    b3_build_planes<MI, MH, L>(sm, b3w);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float div, off;
   scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP>(sm, lane, x, y, z, &hc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w);
     if (valid) a.pair_out[pair] = o;
   }
 }
@@ -289,6 +294,16 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS, SK>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
   } while (0)
   const int sk = a.fc.skip_mode;
+  if constexpr (MI == 2 && MH == 2 && L <= 2) {
+    if ((a.fc.matmul_mode == NGM_MATMUL_BF16X3 || a.fc.matmul_mode == NGM_MATMUL_AUTO) && sk == NGM_SKIP_NO &&
+        (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
+      const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
+      (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, false, 0, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false, false, 0, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
+      return 0;
+    }
+  }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
     if constexpr (MI == 1) NGM_KE(false, true, 0);

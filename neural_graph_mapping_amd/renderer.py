@@ -68,8 +68,16 @@ class NeuralGraphRenderer:
         self._model, self._camera, self._config, self._device = model, camera, dict(config), device
         self._field_radius = config.get("field_radius", model._field_radius)
         self._fc = model.field_cfg(self._field_radius)
-        # opt-in: hidden layers of the fused forward as an exact three-way bf16 split (include/ngm_hip.h, ngm_matmul_mode)
-        self._fc.matmul_mode = K.MATMUL[config.get("mlp_matmul", "f32")]
+        # hidden layers of the forward kernels: "f32" = exact-fp32 MFMA; "bf16x3" = exact three-way bf16 split with fp32
+        # accumulation (include/ngm_hip.h ngm_matmul_mode; fp32-level accuracy, same tolerances, bitwise deterministic,
+        # 16x the matrix rate; fails loudly where not compiled); "auto" (default) = the split wherever it is compiled
+        mm = config.get("mlp_matmul", "auto")
+        self._fc.matmul_mode = K.MATMUL[mm]
+        fc = self._fc
+        compiled = (fc.encoding in (K.ENC["fourier"], K.ENC["none"]) and fc.skip_mode == K.SKIP["no"] and 1 <= fc.num_layers <= 2
+                    and 32 < fc.dim_enc <= 64 and 32 < fc.dim_hidden <= 64)
+        # what the library resolves "auto" to for batch shapes whose LDS plan has room for the weight planes
+        self.mlp_matmul = ("bf16x3" if compiled else "f32") if mm == "auto" else mm
         self._rc_train = make_render_cfg(camera, config, guided=True)
         self._rc_plain = make_render_cfg(camera, config, guided=False)
         self._global_map_dict = None       # supplied by the mapping loop: positions / orientations

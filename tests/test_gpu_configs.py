@@ -208,7 +208,7 @@ def test_eval_style_fused_render_4096_rays_x_640_samples_properties():
     assert (a.depth_vars >= -1e-7).all()
 
 
-# ------------------------------------------------------------------------------------------------ opt-in bf16 split
+# ------------------------------------------------------------------------------------------------ bf16 split vs fp32 MFMA
 def test_bf16x3_split_forward_meets_the_fp32_tolerances_and_is_bitwise_deterministic():
     """mlp_matmul = "bf16x3" (ngm_matmul_mode): the fused forward's hidden layers as an exact three-way bf16 split on the
     bf16 matrix pipe.  Same fixtures, UNCHANGED tolerances as the fp32 path (reference prediction / loss / gradients of

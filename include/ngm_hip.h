@@ -118,6 +118,8 @@ typedef struct ngm_params {
                          * compute in fp32 exactly as for fp32 storage (BASELINE configs 1 and 4: bf16 / fp16 weights;
                          * the reference itself is fp32 only).  Gradients and Adam moments stay fp32.            */
   int32_t reserved_;
+  const float* neus_sd; /* "_neus_sd" (N,), fp32: per-field standard deviation of the neus geometry mode (rm.py:641-644); */
+  int64_t neus_sd_stride; /* required by the fused render entry points in that mode, ignored otherwise                      */
 } ngm_params;
 
 /* Gradient outputs, same layout rules as ngm_params (row f of each tensor = batch field f). */
@@ -130,6 +132,7 @@ typedef struct ngm_grads {
   int64_t b_stride[NGM_MAX_LAYERS + 1];
   float* lattice;       /* (F, L, T, 2): fully overwritten by the backward entry points                */
   int64_t lattice_stride;
+  float* neus_sd;       /* (F,) d loss / d "_neus_sd" (neus geometry mode, fused render backward) or NULL */
 } ngm_grads;
 
 /* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */

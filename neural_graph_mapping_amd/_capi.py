@@ -41,12 +41,12 @@ class Params(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
                 ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p),
                 ("lattice", f32p), ("lattice_stride", C.c_int64), ("shift", f32p), ("shift_stride", C.c_int64),
-                ("dtype", C.c_int32), ("reserved_", C.c_int32)]
+                ("dtype", C.c_int32), ("reserved_", C.c_int32), ("neus_sd", f32p), ("neus_sd_stride", C.c_int64)]
 
 
 class Grads(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
-                ("b", LArr), ("b_stride", SArr), ("lattice", f32p), ("lattice_stride", C.c_int64)]
+                ("b", LArr), ("b_stride", SArr), ("lattice", f32p), ("lattice_stride", C.c_int64), ("neus_sd", f32p)]
 
 
 class RenderCfg(C.Structure):

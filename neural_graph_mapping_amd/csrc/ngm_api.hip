@@ -12,6 +12,8 @@ int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, fl
                        float* dirs, float* points_world, hipStream_t st);
 int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st);
 int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, uint64_t* counter, hipStream_t st);
+int ngm_launch_neus_sd_grad(const float* d_isd_rays, int F, int R, const float* neus_sd, int64_t sd_stride,
+                            const int64_t* field_index, float* d_sd, hipStream_t st);
 int ngm_launch_read_stash(const float4* sa, const float2* sb, int64_t n, float* geoms, float* dists, hipStream_t st);
 int ngm_launch_adam(float* param, float* m, float* v, int64_t stride, const float* grad, int64_t gstride,
                     const int64_t* field_index, int F, int64_t numel, int64_t step, float lr, float beta1, float beta2,
@@ -426,6 +428,7 @@ struct RenderPlan {
   int64_t per_block_bwd; int blocks_per_field_bwd;
   int64_t p_pad;
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
+  int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
 };
 // The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
 // has a kernel that consumes them: 49..64-wide hidden layers, 1-2 layers, non-hash encoding.  The
@@ -478,7 +481,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     p.b3 = 1;
     shape(8, b3_bytes, &lds);
     if (lds > LDS_MAX || R < 8) shape(4, b3_bytes, &lds);
-  } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && lds + b3_bytes <= LDS_MAX) {
+  } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && rc->geometry_mode != NGM_GEO_NEUS && lds + b3_bytes <= LDS_MAX) {
     p.b3 = 1;                                           // auto: only when the planes fit next to the fp32 plan's wave count
   }
   p.p_pad = param_pad(fc);
@@ -489,6 +492,10 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     p.off_stashA = o; o = align_up(o + NS * 16, 256);
     p.off_stashB = o; o = align_up(o + NS * 8, 256);
     p.off_losspart = o; o = align_up(o + (int64_t)p.blocks_fwd * NGM_NUM_LOSS_SUMS * 4, 256);
+    if (rc->geometry_mode == NGM_GEO_NEUS) {
+      p.off_dout = o; o = align_up(o + NS * 16, 256);
+      p.off_disd = o; o = align_up(o + NR * 4, 256);
+    }
     plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
@@ -531,8 +538,8 @@ static int check_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const
   if (!rc || !rays || !rays->ijs || !rays->c2ws || !rays->field_pos || !rays->field_quat)
     return fail(NGM_E_INVALID, "render: NULL ray argument");
   if (rays->F < 1 || rays->R < 1) return fail(NGM_E_INVALID, "render: empty batch");
-  if (rc->geometry_mode == NGM_GEO_NEUS)
-    return fail(NGM_E_UNSUPPORTED, "fused render: neus needs the per-field _neus_sd parameter (use ngm_composite_fwd/bwd)");
+  if (rc->geometry_mode == NGM_GEO_NEUS && !pr->neus_sd)
+    return fail(NGM_E_INVALID, "fused render: the neus geometry mode needs params.neus_sd (the per-field _neus_sd, rm.py:641-644)");
   const int S = rc->num_samples_coarse + (rays->gt ? rc->num_samples_guided : 0);
   if (S < 1 || S > 1024) return fail(NGM_E_UNSUPPORTED, "fused render: samples per ray must be in [1,1024]");
   return NGM_OK;
@@ -557,6 +564,11 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.rc = *rcfg; a.rays = *rays; a.pred = *pred;
   a.fc.matmul_mode = p.b3 ? NGM_MATMUL_BF16X3 : NGM_MATMUL_F32;       // AUTO resolved by the plan (LDS budget of this batch shape)
+  if (rcfg->geometry_mode == NGM_GEO_NEUS) {                          // compiled with exact-fp32 MFMA
+    if (fcfg->matmul_mode == NGM_MATMUL_BF16X3) return fail(NGM_E_UNSUPPORTED, "render_fwd: neus runs the fp32-MFMA kernel");
+    a.fc.matmul_mode = NGM_MATMUL_F32;
+    a.neus_sd = params->neus_sd; a.neus_sd_stride = params->neus_sd_stride;
+  }
   a.has_targets = has_tg ? 1 : 0;
   if (has_tg) a.tg = *targets;
   a.S = p.S; a.rays_per_block = p.rays_per_block; a.waves_per_block = p.waves_fwd; a.maxs = p.maxs;
@@ -596,6 +608,12 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   sb.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
   sb.stashB = reinterpret_cast<const float2*>(ws + p.off_stashB);
   sb.raytab = reinterpret_cast<const float*>(ws + p.off_raytab);
+  const bool neus = rcfg->geometry_mode == NGM_GEO_NEUS;
+  if (neus) {
+    sb.neus_sd = params->neus_sd; sb.neus_sd_stride = params->neus_sd_stride; sb.field_index = params->field_index;
+    sb.d_out = reinterpret_cast<float4*>(ws + p.off_dout);
+    sb.d_isd_rays = reinterpret_cast<float*>(ws + p.off_disd);
+  }
   if (sb.seed_mode == 0 && !sb.loss_sums) {      // deferred loss reduction: the forward left its partials in the workspace
     sb.loss_partials = reinterpret_cast<const float*>(ws + p.off_losspart);
     sb.n_partials = p.blocks_fwd;
@@ -610,7 +628,10 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
-  a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = sb.stashA;
+  a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
+  if (neus && grads->neus_sd)
+    ngm_launch_neus_sd_grad(sb.d_isd_rays, rays->F, rays->R, params->neus_sd, params->neus_sd_stride, params->field_index,
+                            grads->neus_sd, st);
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
   if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }

@@ -443,9 +443,20 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     }
     const float depth = -(dzc * t);
     float dodg = 0.f, occ = 0.f;
+    // neus (rm.py:753-758): tno = sigmoid(isd gamma g), occ_k = max((tno_k - tno_{k+1}) / (tno_k + eps), 0), k < S - 1
+    float tno = 0.f, tnx = 0.f, isd = 0.f;
     if (valid) {
       if (mode == NGM_GEO_DENSITY) { if (k < S - 1) occ = occ_density(geom, a.stashB[g + 1].x - t, &dodg); }   // last sample dropped
-      else occ = occ_pointwise(mode, gamma, geom, &dodg);
+      else if (mode == NGM_GEO_NEUS) {
+        const int64_t fld = ray / a.R;
+        const int64_t row = a.field_index ? a.field_index[fld] : fld;
+        isd = 1.0f / fabsf(a.neus_sd[row * a.neus_sd_stride]);
+        tno = ngm_sigmoid(isd * gamma * geom);
+        if (k < S - 1) {
+          tnx = ngm_sigmoid(isd * gamma * a.stashA[g + 1].w);
+          occ = fmaxf((tno - tnx) / (tno + 1e-5f), 0.f);
+        }
+      } else occ = occ_pointwise(mode, gamma, geom, &dodg);
     }
     const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * depth + dT;
     float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
@@ -456,9 +467,30 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     const float Qk = (kr >= 1 && lane < 63) ? fmaf(nB, Qend, nA) : Qend;
     const float Qbefore = fmaf(B, Qend, A);
     carryQ = lane_value(Qbefore, 0);
+    float di_lane = 0.f;
     if (valid) {
       const float w = occ * T;
       float dg = T * (ak - Qk) * dodg;
+      if (mode == NGM_GEO_NEUS) {
+        // d loss / d tno_k = D_k docc_k/dtno_k + D_{k-1} docc_{k-1}/dtno_k with D_j = T_j (a_j - Q_j) = d loss / d occ_j.
+        // D_{k-1} is rebuilt locally from the neighbour's saved values: Q_{k-1} = a_k occ_k + (1 - occ_k) Q_k is this
+        // lane's own suffix value (the recursion of the reverse scan), T_{k-1}, colours, t of sample k - 1 come from the stash.
+        float dtno = 0.f;
+        if (k < S - 1 && tno > tnx) dtno = T * (ak - Qk) * (tnx + 1e-5f) / ((tno + 1e-5f) * (tno + 1e-5f));
+        if (k > 0) {
+          const float4 pa = a.stashA[g - 1];
+          const float2 pb = a.stashB[g - 1];
+          const float tnp = ngm_sigmoid(isd * gamma * pa.w);
+          if (tnp > tno) {                                          // occ_{k-1} > 0: the clamp is inactive
+            const float a_prev = dC0 * pa.x + dC1 * pa.y + dC2 * pa.z + dD * (-(dzc * pb.x)) + dT;
+            const float Q_prev = fmaf(1.0f - occ, Qk, ak * occ);
+            dtno -= pb.y * (a_prev - Q_prev) / (tnp + 1e-5f);
+          }
+        }
+        const float ds = tno * (1.0f - tno);
+        dg = dtno * isd * gamma * ds;
+        di_lane = dtno * gamma * geom * ds;                        // d loss / d isd of this sample (also through the constant
+      }                                                            // geometry of samples behind the camera, as in the reference)
       if (a.seed_mode == 0) {
         const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);
         if (t < thr) dg += k_fs * (geom * tau - tau) * tau;
@@ -471,15 +503,25 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
       {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f dv = {cf * w * dC0, cf * w * dC1, cf * w * dC2, dg};
-        __builtin_nontemporal_store(dv, reinterpret_cast<v4f*>(a.stashA + g));     // read once, by the MLP backward
+        // in place over the saved forward values, except in neus mode (neighbouring lanes / waves still read them)
+        __builtin_nontemporal_store(dv, reinterpret_cast<v4f*>((a.d_out ? a.d_out : a.stashA) + g));   // read once, by the MLP backward
       }
+    }
+    if (mode == NGM_GEO_NEUS && a.d_isd_rays) {      // kernel-uniform: per-ray sums of d loss / d isd
+      const float si = seg_scan_add(di_lane, k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp_all - 1);
+      // a ray split over two steps adds twice, from the same wave in program order: deterministic
+      if (tail) atomicAdd(a.d_isd_rays + ray, si);
     }
   }
 }
 
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
   NgmProfScope prof_(NGM_K_STASH_BWD, st);
-  if (a.rc.geometry_mode == NGM_GEO_NEUS) return NGM_E_UNSUPPORTED;   // needs the per-field _neus_sd parameter: standalone quadrature only
+  if (a.rc.geometry_mode == NGM_GEO_NEUS) {
+    if (!a.neus_sd || !a.d_out) return NGM_E_UNSUPPORTED;             // per-field _neus_sd and a separate gradient buffer
+    if (a.d_isd_rays) (void)hipMemsetAsync(a.d_isd_rays, 0, sizeof(float) * (size_t)a.F * a.R, st);
+  }
   int rpw;
   const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);
   hipLaunchKernelGGL(k_stash_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
@@ -532,6 +574,31 @@ __global__ void k_loss_reduce(const float* partials, int nblocks, float* sums, u
 int ngm_launch_loss_reduce(const float* partials, int nblocks, float* sums, uint64_t* counter, hipStream_t st) {
   NgmProfScope prof_(NGM_K_LOSS_REDUCE, st);
   hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, partials, nblocks, sums, reinterpret_cast<unsigned long long*>(counter));
+  return 0;
+}
+
+// neus: d loss / d _neus_sd[f] = (sum over the field's rays of d loss / d isd) * d(1 / |sd|) / d sd (rm.py:641-644);
+// one workgroup per field, fixed-order tree -> deterministic
+__global__ void k_neus_sd_grad(const float* d_isd_rays, int R, const float* neus_sd, int64_t sd_stride,
+                               const int64_t* field_index, float* d_sd) {
+  __shared__ float red[256];
+  const int f = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) s += d_isd_rays[(int64_t)f * R + r];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float sd = neus_sd[(field_index ? field_index[f] : f) * sd_stride];
+    d_sd[f] = red[0] * (-(sd > 0.f ? 1.0f : -1.0f) / (sd * sd));
+  }
+}
+int ngm_launch_neus_sd_grad(const float* d_isd_rays, int F, int R, const float* neus_sd, int64_t sd_stride,
+                            const int64_t* field_index, float* d_sd, hipStream_t st) {
+  hipLaunchKernelGGL(k_neus_sd_grad, dim3(F), dim3(256), 0, st, d_isd_rays, R, neus_sd, sd_stride, field_index, d_sd);
   return 0;
 }
 

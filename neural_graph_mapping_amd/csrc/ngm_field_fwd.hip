@@ -90,7 +90,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
+template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false, bool NEUS = false>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
@@ -136,6 +136,8 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) ls[i] = 0.f;
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+  float neus_isd = 0.f;                                             // rm.py:641-644: 1 / |_neus_sd| of this field
+  if constexpr (NEUS) neus_isd = 1.0f / fabsf(a.neus_sd[row * a.neus_sd_stride]);
 
   // phases (1)+(2) of a batch; run for batch b+1 at the end of batch b's pass (and for the first batch while the
   // weights are still in flight)
@@ -225,9 +227,43 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     __syncthreads();
   }
   PTICK(pc, 0);
+  // compositing of one 64-sample step (transmittance scan carried across steps, weights, per-ray sums, stash)
+  int rb_cur = 0, nsamp_cur = 0;
+  auto composite = [&](int idx, bool valid, int ci, int rl, int k, float t, float c0, float c1, float c2, float depth,
+                       float geom, float occ, float& carry) __attribute__((always_inline)) {
+    const int rb = rb_cur, nsamp = nsamp_cur;
+      // transmittance: segmented inclusive product of (1-occ), carried across steps
+      float q = seg_scan_mul(1.0f - occ, k, lane);
+      if (k > lane) q *= carry;
+      const float up = lane_prev(q, carry);
+      const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
+      carry = lane_value(q, 63);
+      const float w = valid ? occ * T_excl : 0.f;
+      if (valid) {
+        wl.wbuf[idx] = w; wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2;
+        if (a.stashA) {
+          const int64_t gs = ((int64_t)f * R + rb) * S + idx;
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v4f sa = {c0, c1, c2, geom};
+          const v2f sb = {t, T_excl};
+          __builtin_nontemporal_store(sa, reinterpret_cast<v4f*>(a.stashA + gs));   // read once, by the next kernel
+          __builtin_nontemporal_store(sb, reinterpret_cast<v2f*>(a.stashB + gs));
+        }
+      }
+      const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
+                  s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * depth, k, lane),
+                  s4 = seg_scan_add(w, k, lane);
+      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
+      if (tail) {
+        float* ra = wl.ra[rl];
+        ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4;
+      }
+  };
   for (int rb = r_beg; rb < r_end; rb += BR) {
     const int nb = min(BR, r_end - rb);
     const int nsamp = nb * S;
+    rb_cur = rb; nsamp_cur = nsamp;
     // ---- (3) MLP + compositing pass, 64 consecutive flat samples per step
     float carry = 1.0f;
     for (int base = 0; base < nsamp; base += 64) {
@@ -263,39 +299,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float depth = -(rt[6] * t);
       // samples behind the camera (z_cam = dz * t > 0; only possible with near < 0): constant geometry, rm.py:614-622
       const float geom = (a.rc.overwrite_behind_camera && rt[6] * t > 0.f) ? behind_camera_geometry(mode) : o.w;
-      float occ;
-      if (mode == NGM_GEO_DENSITY) {                                       // rm.py:746-749, last sample dropped
-        const float o_d = occ_density(geom, wl.tbuf[min(ci + 1, nsamp - 1)] - t, nullptr);
-        occ = (k < S - 1) ? o_d : 0.f;
-      } else occ = occ_pointwise(mode, gamma, geom, nullptr);
-      occ = valid ? occ : 0.f;
-      // transmittance: segmented inclusive product of (1-occ), carried across steps
-      float q = seg_scan_mul(1.0f - occ, k, lane);
-      if (k > lane) q *= carry;
-      const float up = lane_prev(q, carry);
-      const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
-      carry = lane_value(q, 63);
-      const float w = valid ? occ * T_excl : 0.f;
-      if (valid) {
-        wl.wbuf[idx] = w; wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2;
-        if (a.stashA) {
-          const int64_t gs = ((int64_t)f * R + rb) * S + idx;
-          typedef float v4f __attribute__((ext_vector_type(4)));
-          typedef float v2f __attribute__((ext_vector_type(2)));
-          const v4f sa = {c0, c1, c2, geom};
-          const v2f sb = {t, T_excl};
-          __builtin_nontemporal_store(sa, reinterpret_cast<v4f*>(a.stashA + gs));   // read once, by the next kernel
-          __builtin_nontemporal_store(sb, reinterpret_cast<v2f*>(a.stashB + gs));
-        }
-      }
-      const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
-                  s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * depth, k, lane),
-                  s4 = seg_scan_add(w, k, lane);
-      const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
-      if (tail) {
-        float* ra = wl.ra[rl];
-        ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4;
-      }
+      // free-space / TSDF loss terms read the geometry itself (rm.py:624-639): same for every mode
       if (a.has_targets && valid) {
         const float gt = rt[11];
         const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);       // rm.py:625-627
@@ -305,8 +309,46 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
           const float e = geom * tau - dl; ls[NGM_LS_TSDF_SUM] += e * e; ls[NGM_LS_TSDF_CNT] += 1.f;
         }
       }
+      if constexpr (NEUS) {
+        // neus (rm.py:753-758): occ_k needs the geometry of sample k + 1, i.e. another lane's -- or the next step's --
+        // MLP output.  Colours and geometry are parked in the wave's LDS planes (the weight plane holds the geometry
+        // until the compositing pass below overwrites it with the weights); compositing runs once the batch is complete.
+        if (valid) { wl.wbuf[idx] = geom; wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2; }
+      } else {
+      float occ;
+      if (mode == NGM_GEO_DENSITY) {                                       // rm.py:746-749, last sample dropped
+        const float o_d = occ_density(geom, wl.tbuf[min(ci + 1, nsamp - 1)] - t, nullptr);
+        occ = (k < S - 1) ? o_d : 0.f;
+      } else occ = occ_pointwise(mode, gamma, geom, nullptr);
+      occ = valid ? occ : 0.f;
+        composite(idx, valid, ci, rl, k, t, c0, c1, c2, depth, geom, occ, carry);
+      }
       WAVE_SYNC();
       PTICK(pc, 8);
+    }
+    if constexpr (NEUS) {
+      // ---- (3b) neus compositing over the parked planes: tno = sigmoid(isd gamma g), occ_k = max((tno_k - tno_{k+1}) /
+      // (tno_k + 1e-5), 0), last sample dropped (rm.py:753-758, last_index = -1)
+      const float isd_g = neus_isd * gamma;
+      carry = 1.0f;
+      for (int base = 0; base < nsamp; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < nsamp;
+        const int ci = min(idx, nsamp - 1);
+        const int rl = fdiv_idx(ci, inv_s, S);
+        const int k = valid ? ci - rl * S : 0;
+        const float* rt = wl.rt[rl];
+        const float t = valid ? wl.tbuf[ci] : 0.f;
+        const float geom = wl.wbuf[ci], gnext = wl.wbuf[min(ci + 1, nsamp - 1)];
+        const float c0 = wl.cbuf[0][ci], c1 = wl.cbuf[1][ci], c2 = wl.cbuf[2][ci];
+        const float depth = -(rt[6] * t);
+        const float tno = ngm_sigmoid(isd_g * geom), tnx = ngm_sigmoid(isd_g * gnext);
+        float occ = fmaxf((tno - tnx) / (tno + 1e-5f), 0.f);
+        occ = (valid && k < S - 1) ? occ : 0.f;
+        WAVE_SYNC();     // every lane has read its neighbour's geometry before the weights overwrite the plane
+        composite(idx, valid, ci, rl, k, t, c0, c1, c2, depth, geom, occ, carry);
+        WAVE_SYNC();
+      }
     }
     // ---- (4) variance pass around the finished means (rm.py:781-790)
 #ifdef NGM_ABLF_NOVAR
@@ -452,6 +494,16 @@ template <int MI, int MH, int L>
 static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   const size_t wave_lds = (size_t)a.waves_per_block * RenderWaveLds::floats(a.maxs);
   const dim3 blk(64 * a.waves_per_block);
+  if (a.rc.geometry_mode == NGM_GEO_NEUS) {
+    // neus in the fused kernel (two-pass compositing over the wave's LDS planes): Fourier / no encoding, skip no, fp32 MFMA
+    if (a.fc.skip_mode != NGM_SKIP_NO || (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NONE) || !a.neus_sd)
+      return NGM_E_UNSUPPORTED;
+    const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, false, 0, false, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, false, 0, false, true>), dim3(blocks), blk, lds, st, a);
+    return 0;
+  }
   if (a.fc.matmul_mode == NGM_MATMUL_BF16X3) {
     // opt-in: hidden layers as a three-way bf16 split on v_mfma_f32_32x32x16_bf16 (ngm_field.h, layer_fwd_b3)
     if constexpr (MI == 2 && MH == 2 && L <= 2) {

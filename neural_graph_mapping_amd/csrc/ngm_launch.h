@@ -40,6 +40,8 @@ struct RenderFwdArgs {
   float* loss_partials;   // (blocks, 16)
   float* act;             // hidden-activation stash [L][F*R*S][64] (train, 64-wide hidden layers) or NULL
   int64_t act_layer_stride;  // floats
+  const float* neus_sd;   // neus: "_neus_sd" (N,) rows like the other parameters (field_index), else NULL
+  int64_t neus_sd_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase shader-clock cycles of one wave
 };
 
@@ -127,6 +129,11 @@ struct StashBwdArgs {
   float* loss_out;            // (8) loss scalars from loss_sums (seed mode 0) or NULL
   // deferred loss reduction (single GPU: nothing happens between forward and backward): every workgroup sums the
   // forward's per-workgroup partials itself, in the fixed order of k_loss_reduce -> one launch less per step
+  // neus (rm.py:641-644, 753-758): per-field inverse standard deviations, a separate gradient buffer (the kernel reads
+  // its neighbours' saved geometry, so it cannot overwrite stashA in place) and per-ray d loss / d isd
+  const float* neus_sd; int64_t neus_sd_stride; const int64_t* field_index;
+  float4* d_out;              // (F*R*S) dL/d(raw MLP outputs) when not written over stashA (neus), else NULL
+  float* d_isd_rays;          // (F*R), zeroed by the launcher
   const float* loss_partials; // (n_partials, 16) or NULL -> loss_sums holds the (all-reduced) sums
   int n_partials;
   float* sums_out;            // (16) optional copy of the reduced sums

@@ -96,7 +96,14 @@ def params_struct(fc: K.FieldCfg, params: Dict[str, torch.Tensor], field_index: 
         if field_index.dtype != torch.int64:
             raise TypeError("field_index must be int64")
         fi = field_index.contiguous().data_ptr()
-    return K.params_struct(fc, ptrs, strides, fi, _TORCH_DT[dts.pop()])
+    ps = K.params_struct(fc, ptrs, strides, fi, _TORCH_DT[dts.pop()])
+    sd = params.get("_neus_sd")
+    if sd is not None:                 # per-field standard deviation of the neus geometry mode (fused render only)
+        _require_gpu(sd)
+        if sd.dtype != torch.float32 or sd.dim() != 1:
+            raise ValueError("'_neus_sd' must be float32 (N,)")
+        ps.neus_sd, ps.neus_sd_stride = sd.data_ptr(), sd.stride(0) if sd.shape[0] > 1 else 1
+    return ps
 
 
 def alloc_grads(fc: K.FieldCfg, F: int, device, flat: Optional[torch.Tensor] = None):

@@ -409,7 +409,7 @@ class NeuralGraphRenderer:
         update=False, also the gradients.  Every launch is asynchronous on the current stream and the
         sequence is hipGraph-capturable (device-side step / jitter counters, no allocation after the
         first call with a given batch shape)."""
-        if self._rc_train.geometry_mode == K.GEO["neus"]:
+        if self._rc_train.geometry_mode == K.GEO["neus"] and not self._neus_fused():
             return self.optimization_iteration_staged(target, u_coarse, u_guided, seed, update)
         if target.ijs.shape[0] == 0:
             return self._idle_iteration(update)
@@ -418,6 +418,13 @@ class NeuralGraphRenderer:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
             torch.distributed.all_reduce(ctx["w"]["sums"], group=self.process_group)
         return self._iteration_backward(ctx, update)
+
+    def _neus_fused(self) -> bool:
+        """the neus geometry mode runs in the fused kernels for the Fourier / no encoding without skip connections
+        (two-pass compositing in the forward, neighbour terms + per-field d/d _neus_sd in the backward); the staged path
+        (standalone sampler / field / quadrature kernels under autograd) serves the other encodings"""
+        fc = self._fc
+        return fc.encoding in (K.ENC["fourier"], K.ENC["none"]) and fc.skip_mode == K.SKIP["no"]
 
     def _idle_iteration(self, update=True) -> dict:
         """A rank none of whose fields is active in this iteration: it contributes zeros to the loss
@@ -451,7 +458,11 @@ class NeuralGraphRenderer:
         allp = {n: self._model.all_fields_params[n] for n in names}       # fp32 masters (Adam)
         kp = self._model.kernel_params()                                   # what the kernels read (reduced precision or masters)
         lp = None if self._model.lp_fields_params is None else {n: kp[n] for n in names}
-        ps = ops.params_struct(fc, {n: kp[n] for n in names}, fids)        # rows field_ids[f] in place: no gather
+        kernel_p = {n: kp[n] for n in names}
+        neus = rc.geometry_mode == K.GEO["neus"]
+        if neus:
+            kernel_p["_neus_sd"] = self._model.all_fields_params["_neus_sd"]
+        ps = ops.params_struct(fc, kernel_p, fids)                         # rows field_ids[f] in place: no gather
         w = self._workspace(F, R)
         keep = []
         if self._step_dev is None:
@@ -475,7 +486,7 @@ class NeuralGraphRenderer:
         K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                  None if defer else w["sums"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st), "ngm_render_fwd")
         return dict(fc=fc, rc=rc, ps=ps, rays=rays, tg=tg, pred=pred, w=w, F=F, fids=fids, allp=allp, lp=lp, defer=defer,
-                    keep=(keep, dm, tm, rgbds_t, target))
+                    neus=neus, keep=(keep, dm, tm, rgbds_t, target))
 
     def _iteration_backward(self, ctx: dict, update=True) -> dict:
         """Second half: compositing + MLP backward with the (global) loss sums, sparse Adam, counters."""
@@ -486,6 +497,9 @@ class NeuralGraphRenderer:
         if "grads" not in w:
             w["grads"], w["gs"], w["gflat"] = ops.alloc_grads(fc, F, self._device)
         grads, gs = w["grads"], w["gs"]
+        if ctx.get("neus") and "_neus_sd" not in grads:
+            grads["_neus_sd"] = torch.zeros(F, device=self._device)
+            gs.neus_sd = grads["_neus_sd"].data_ptr()
         sums_ptr = None if ctx.get("defer") else w["sums"].data_ptr()
         if update:
             # backward + sparse Adam in one call: the gradient-reduction kernel applies the update of the MLP tensors
@@ -497,6 +511,14 @@ class NeuralGraphRenderer:
                                           ops._ptr(self._step_dev), self._learning_rate, 0.9, 0.999, self._adam_eps,
                                           self._adam_weight_decay, w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st),
                     "ngm_render_bwd_adam")
+            if ctx.get("neus"):      # the per-field standard deviation is a parameter of its own (rm.py:641-644): same Adam
+                n = "_neus_sd"
+                sd, stt = self._model.all_fields_params[n], self._optim_state[n]
+                one = (K.AdamTensor * 1)(K.AdamTensor(sd.data_ptr(), stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(),
+                                                      grads[n].data_ptr(), 1, 1, 1))
+                K.check(L.ngm_adam_sparse_multi(one, 1, ops._ptr(fids), F, int(self._step), ops._ptr(self._step_dev),
+                                                self._learning_rate, 0.9, 0.999, self._adam_eps, self._adam_weight_decay, 0,
+                                                None, st), "ngm_adam_sparse_multi")
         else:
             K.check(L.ngm_render_bwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(tg), C.byref(pred),
                                      sums_ptr, C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
@@ -514,7 +536,7 @@ class NeuralGraphRenderer:
         replays it.  Tensors of `target` are read in place at every replay; the Adam step counter and the Philox
         jitter offset live on the device and advance inside the graph.  With a process group the iteration becomes
         two graphs (before / after the loss all-reduce) and the 64-byte collective is issued between the replays."""
-        if self._rc_train.geometry_mode == K.GEO["neus"]:
+        if self._rc_train.geometry_mode == K.GEO["neus"] and not self._neus_fused():
             raise NotImplementedError("capture_iteration: the staged (neus) iteration allocates under autograd; call "
                                       "optimization_iteration directly")
         s = torch.cuda.Stream()

@@ -382,6 +382,62 @@ def test_neus_staged_train_step_vs_oracle():
     assert torch.isfinite(res2["combined"]) and "_neus_sd" in res2["grads"]
 
 
+@pytest.mark.parametrize("F,R,n_c,n_g,layers", [(3, 40, 10, 6, 2), (2, 33, 1, 1, 1), (1, 5, 64, 64, 2), (4, 130, 20, 4, 2)])
+def test_neus_fused_train_step_vs_oracle(F, R, n_c, n_g, layers):
+    """geometry_mode = neus inside the FUSED kernels (rm.py:641-644, 753-758): occ_k depends on the geometry of samples k
+    and k + 1 and on the per-field learnable `_neus_sd`.  Forward: compositing as a second pass over the wave's LDS
+    planes; backward: neighbour terms rebuilt from the stash, d loss / d _neus_sd reduced per field.  Prediction, loss,
+    every gradient incl. `_neus_sd` against the oracle; the fused update moves `_neus_sd` of the trained fields only; the
+    iteration is capturable (device-side counters)."""
+    torch.manual_seed(7 + F)
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=layers)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode="neus",
+               geometry_factor=5.0)
+    pos, quat, t = synth_target(F, R, seed=4)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,
+                      geometry_mode="neus", geometry_factor=5.0)
+    params = O.init_params(fs, F, seed=11, sigma=3.0)
+    params[f"_linears.{layers}.weight"] *= 3.0
+    sd = torch.tensor([0.4, 0.8, -1.5, 1.1])[:F]                      # a negative one: isd = 1 / |sd| (rm.py:641-644)
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    sdo = sd.clone().requires_grad_()
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g,
+                        neus_isds=1.0 / sdo.abs().view(-1, 1, 1))
+    r = make_renderer(fkw, ckw, F + 1, None)                        # one extra field that is never trained
+    with torch.no_grad():
+        for k, v in params.items():
+            r._model.all_fields_params[k][:F].copy_(v.to(DEV))
+        r._model.all_fields_params["_neus_sd"][:F].copy_(sd.to(DEV))
+    r.set_field_poses(torch.cat([pos, torch.zeros(1, 3)]).to(DEV), torch.cat([quat, torch.tensor([[1.0, 0, 0, 0]])]).to(DEV))
+    assert r._neus_fused()
+    tgt = make_target(t, torch.arange(F))
+    res = r.optimization_iteration(tgt, u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    close(res["prediction"].term_probs, pred["term_probs"].detach())
+    close(res["prediction"].depth_vars, pred["depth_vars"].detach(), rtol=1e-3, atol=1e-5)
+    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
+    if min(n_m, pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())) == 0:
+        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    loss["combined"].backward()
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+    grad_close(res["grads"]["_neus_sd"].view(-1), sdo.grad, 2e-3, "_neus_sd")
+    again = r.optimization_iteration(tgt, u_c.to(DEV), u_g.to(DEV), update=False)          # deterministic
+    assert torch.equal(again["grads"]["_neus_sd"], res["grads"]["_neus_sd"]) and torch.equal(
+        again["grads"]["_linears.0.weight"], res["grads"]["_linears.0.weight"])
+    before = r._model.all_fields_params["_neus_sd"].clone()
+    replay = r.capture_iteration(tgt, u_coarse=u_c.to(DEV), u_guided=u_g.to(DEV))       # 2 warm-up updates + capture
+    replay()
+    torch.cuda.synchronize()
+    after = r._model.all_fields_params["_neus_sd"]
+    assert bool((after[:F] != before[:F]).all()) and bool(after[F] == before[F]) and r._step == 3
+
+
 # ------------------------------------------------------------------------- train step (G6, G7)
 @pytest.mark.parametrize("name", list(CASES))
 def test_fused_train_step_golden(name):

@@ -36,7 +36,8 @@ enum ngm_status {
   NGM_E_HIP = -4          /* HIP runtime error (launch / device)        */
 };
 
-enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3 };
+enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3, NGM_ENC_TRIPLANE = 4 };
+enum ngm_triplane_mode { NGM_TRI_SUM = 0, NGM_TRI_PRODUCT = 1, NGM_TRI_CONCAT = 2 };   /* positional_encodings.py:152-161 */
 enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /* models.py:159-180; rezero: the reference's constructor raises */
 /* Arithmetic of the hidden layers in the forward kernels (fused render, point evaluation, kNN evaluation).
  * NGM_MATMUL_F32: exact-fp32 MFMA.  NGM_MATMUL_BF16X3: every fp32 operand is split exactly into three bf16
@@ -91,6 +92,11 @@ typedef struct ngm_field_cfg {
                               /* appends it (models.py:159-161): layers 1..L (incl. the output layer) then have */
                               /* H + D inputs, "_linears.{i}.weight" is (out_i, H + D) for i >= 1               */
   int32_t matmul_mode;        /* ngm_matmul_mode of the fused forward's hidden layers (other kernels: fp32 MFMA) */
+  /* triplane encoding (positional_encodings.py:69-161): three (C, res, res) feature planes per field, bilinear lookup
+   * (grid_sample, align_corners, border padding) of the (x,y), (x,z), (y,z) projections of a point in [-1,1]^3,
+   * combined per ngm_triplane_mode; dim_enc = C (sum, product) or 3 C (concat) */
+  int32_t tri_resolution;
+  int32_t tri_mode;
 } ngm_field_cfg;
 
 /* fills cfg->level_scale from nr_levels / coarsest_scale / finest_scale (double precision) */
@@ -118,6 +124,8 @@ typedef struct ngm_params {
                          * compute in fp32 exactly as for fp32 storage (BASELINE configs 1 and 4: bf16 / fp16 weights;
                          * the reference itself is fp32 only).  Gradients and Adam moments stay fp32.            */
   int32_t reserved_;
+  const float* planes;  /* "_encoding.plane_coef" (N, 3, C, res, res), fp32; NULL unless triplane */
+  int64_t planes_stride;
   const float* neus_sd; /* "_neus_sd" (N,), fp32: per-field standard deviation of the neus geometry mode (rm.py:641-644); */
   int64_t neus_sd_stride; /* required by the fused render entry points in that mode, ignored otherwise                      */
 } ngm_params;
@@ -133,6 +141,8 @@ typedef struct ngm_grads {
   float* lattice;       /* (F, L, T, 2): fully overwritten by the backward entry points                */
   int64_t lattice_stride;
   float* neus_sd;       /* (F,) d loss / d "_neus_sd" (neus geometry mode, fused render backward) or NULL */
+  float* planes;        /* (F, 3, C, res, res): fully overwritten by the backward entry points (triplane) */
+  int64_t planes_stride;
 } ngm_grads;
 
 /* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libngm_hip.so")
 
 NGM_MAX_LAYERS = 4
 NGM_NUM_LOSS_SUMS = 16
-ENC = {"none": 0, "fourier": 1, "nerf": 2, "permuto": 3}
+ENC = {"none": 0, "fourier": 1, "nerf": 2, "permuto": 3, "triplane": 4}
+TRI = {"sum": 0, "product": 1, "concat": 2}
 SCALE = {"no": 0, "unit_ball": 1, "unit_cube": 2}
 GEO = {"nrgbd": 0, "occupancy": 1, "density": 2, "neus": 3}
 LS = dict(PHOTO_SUM=0, PHOTO_CNT=1, DEPTH_SUM=2, DEPTH_CNT=3, FS_SUM=4, FS_CNT=5, TSDF_SUM=6,
@@ -34,19 +35,22 @@ class FieldCfg(C.Structure):
                 ("dim_hidden", C.c_int32), ("dim_out", C.c_int32), ("scale_mode", C.c_int32),
                 ("field_radius", C.c_float), ("nr_levels", C.c_int32), ("nr_feat_per_level", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("coarsest_scale", C.c_float), ("finest_scale", C.c_float),
-                ("level_scale", C.c_float * 48), ("skip_mode", C.c_int32), ("matmul_mode", C.c_int32)]
+                ("level_scale", C.c_float * 48), ("skip_mode", C.c_int32), ("matmul_mode", C.c_int32),
+                ("tri_resolution", C.c_int32), ("tri_mode", C.c_int32)]
 
 
 class Params(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
                 ("b", LArr), ("b_stride", SArr), ("field_index", C.c_void_p),
                 ("lattice", f32p), ("lattice_stride", C.c_int64), ("shift", f32p), ("shift_stride", C.c_int64),
-                ("dtype", C.c_int32), ("reserved_", C.c_int32), ("neus_sd", f32p), ("neus_sd_stride", C.c_int64)]
+                ("dtype", C.c_int32), ("reserved_", C.c_int32), ("planes", f32p), ("planes_stride", C.c_int64),
+                ("neus_sd", f32p), ("neus_sd_stride", C.c_int64)]
 
 
 class Grads(C.Structure):
     _fields_ = [("enc_w", f32p), ("enc_w_stride", C.c_int64), ("w", LArr), ("w_stride", SArr),
-                ("b", LArr), ("b_stride", SArr), ("lattice", f32p), ("lattice_stride", C.c_int64), ("neus_sd", f32p)]
+                ("b", LArr), ("b_stride", SArr), ("lattice", f32p), ("lattice_stride", C.c_int64), ("neus_sd", f32p),
+                ("planes", f32p), ("planes_stride", C.c_int64)]
 
 
 class RenderCfg(C.Structure):
@@ -207,7 +211,7 @@ MATMUL = {"f32": 0, "bf16x3": 1, "auto": 2}
 def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, start_octave=0,
               num_layers=2, dim_hidden=None, dim_out=4, scale_mode="unit_cube", field_radius=1.0,
               nr_levels=16, nr_feat_per_level=2, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4,
-              skip_mode="no", matmul_mode="f32"):
+              skip_mode="no", matmul_mode="f32", resolution=32, num_components=64, tri_mode="sum"):
     if skip_mode not in SKIP:
         raise NotImplementedError(f"skip_mode={skip_mode!r}: 'no', 'add' and 'concat' have kernels; the reference's own "
                                   "constructor raises for 'rezero' (models.py:131-132)")
@@ -217,6 +221,8 @@ def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, st
         dim_enc = 3
     if encoding == "permuto":
         dim_enc = nr_levels * nr_feat_per_level
+    if encoding == "triplane":
+        dim_enc = num_components * (3 if tri_mode == "concat" else 1)      # positional_encodings.py:119-126
     if dim_hidden is None:
         dim_hidden = dim_enc
     fc = FieldCfg(ENC[encoding], dim_enc, int(bool(raw_coords)), num_octaves, start_octave,
@@ -224,6 +230,7 @@ def field_cfg(encoding="fourier", dim_enc=64, raw_coords=True, num_octaves=8, st
                   nr_feat_per_level, log2_hashmap_size, float(coarsest_scale), float(finest_scale))
     fc.skip_mode = SKIP[skip_mode]
     fc.matmul_mode = MATMUL[matmul_mode]
+    fc.tri_resolution, fc.tri_mode = int(resolution), TRI[tri_mode]
     if encoding == "permuto":
         import math
         import numpy as np
@@ -240,6 +247,8 @@ def param_names(fc: FieldCfg):
         names.append("_encoding._linear.weight")
     if fc.encoding == ENC["permuto"]:
         names += ["_encoding.lattice_values", "_encoding.random_shift_per_level"]
+    if fc.encoding == ENC["triplane"]:
+        names.append("_encoding.plane_coef")
     for i in range(fc.num_layers + 1):
         names += [f"_linears.{i}.weight", f"_linears.{i}.bias"]
     return names
@@ -252,6 +261,9 @@ def param_shapes(fc: FieldCfg):
     if fc.encoding == ENC["permuto"]:
         shapes["_encoding.lattice_values"] = (fc.nr_levels, 2 ** fc.log2_hashmap_size, fc.nr_feat_per_level)
         shapes["_encoding.random_shift_per_level"] = (fc.nr_levels, 3)
+    if fc.encoding == ENC["triplane"]:
+        comps = fc.dim_enc // 3 if fc.tri_mode == TRI["concat"] else fc.dim_enc
+        shapes["_encoding.plane_coef"] = (3, comps, fc.tri_resolution, fc.tri_resolution)
     for i in range(fc.num_layers + 1):
         din = fc.dim_enc if i == 0 else fc.dim_hidden + (fc.dim_enc if fc.skip_mode == SKIP["concat"] else 0)   # models.py:115-119
         dout = fc.dim_out if i == fc.num_layers else fc.dim_hidden
@@ -271,6 +283,9 @@ def _fill_ptrs(struct, fc, ptrs, strides):
         if hasattr(struct, "shift"):
             struct.shift = ptrs["_encoding.random_shift_per_level"]
             struct.shift_stride = strides["_encoding.random_shift_per_level"]
+    if fc.encoding == ENC["triplane"]:
+        struct.planes = ptrs["_encoding.plane_coef"]
+        struct.planes_stride = strides["_encoding.plane_coef"]
     for i in range(fc.num_layers + 1):
         struct.w[i] = ptrs[f"_linears.{i}.weight"]
         struct.w_stride[i] = strides[f"_linears.{i}.weight"]

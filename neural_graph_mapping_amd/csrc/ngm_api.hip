@@ -149,6 +149,12 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
     if (!(fc->level_scale[0] > 0.f)) return fail(NGM_E_INVALID, "permutohedral: level_scale not filled (ngm_permuto_fill_scales)");
   }
   if (fc->encoding == NGM_ENC_NERF && fc->dim_enc != 6 * fc->num_octaves) return fail(NGM_E_INVALID, "nerf: dim_enc != 6*octaves");
+  if (fc->encoding == NGM_ENC_TRIPLANE) {
+    if (fc->tri_resolution < 2 || fc->tri_resolution > 4096 || fc->tri_mode < NGM_TRI_SUM || fc->tri_mode > NGM_TRI_CONCAT ||
+        (fc->tri_mode == NGM_TRI_CONCAT && fc->dim_enc % 3))
+      return fail(NGM_E_INVALID, "triplane: resolution / mode / dim_enc inconsistent");
+    if (fc->skip_mode != NGM_SKIP_NO) return fail(NGM_E_UNSUPPORTED, "triplane: skip connections are not compiled");
+  }
   if (fc->encoding == NGM_ENC_NONE && fc->dim_enc != 3) return fail(NGM_E_INVALID, "no encoding: dim_enc must be 3");
   if (fc->dim_enc < 1 || fc->dim_enc > 64 || fc->dim_hidden < 1 || fc->dim_hidden > 64)
     return fail(NGM_E_UNSUPPORTED, "dim_enc / dim_hidden must be <= 64");
@@ -166,6 +172,7 @@ static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
   if (!pr) return fail(NGM_E_INVALID, "params is NULL");
   if (fc->encoding == NGM_ENC_FOURIER && !pr->enc_w) return fail(NGM_E_INVALID, "fourier encoding needs enc_w");
   if (fc->encoding == NGM_ENC_PERMUTO && (!pr->lattice || !pr->shift)) return fail(NGM_E_INVALID, "permutohedral encoding needs lattice + shift");
+  if (fc->encoding == NGM_ENC_TRIPLANE && (!pr->planes || pr->dtype != NGM_DT_F32)) return fail(NGM_E_INVALID, "triplane encoding needs fp32 planes");
   for (int l = 0; l <= fc->num_layers; ++l)
     if (!pr->w[l] || !pr->b[l]) return fail(NGM_E_INVALID, "missing layer weight/bias pointer");
   if (pr->dtype != NGM_DT_F32 && pr->dtype != NGM_DT_BF16 && pr->dtype != NGM_DT_F16) return fail(NGM_E_INVALID, "params.dtype");
@@ -318,13 +325,19 @@ static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf) {
   *bpf = (int)((P + per - 1) / per);
 }
 // permutohedral backward scratch: dL/dE per sample and level (8 B) + scaled local position (16 B)
+static int64_t tri_numel(const ngm_field_cfg* fc) {       // floats of one field's planes (3, C, res, res)
+  const int64_t C = fc->tri_mode == NGM_TRI_CONCAT ? fc->dim_enc / 3 : fc->dim_enc;
+  return 3 * C * fc->tri_resolution * fc->tri_resolution;
+}
 static int64_t hash_scratch_bytes(const ngm_field_cfg* fc, int F, int64_t P) {
+  if (fc->encoding == NGM_ENC_TRIPLANE) return align_up((int64_t)F * tri_numel(fc) * 8, 256);   // Q23.40 accumulators
   if (fc->encoding != NGM_ENC_PERMUTO) return 0;
   const int64_t part = (int64_t)F * fc->nr_levels * 8 * 2 * ((int64_t)1 << fc->log2_hashmap_size) * 4;
   return align_up((int64_t)fc->nr_levels * F * P * 8, 256) + align_up((int64_t)F * P * 16, 256) + align_up(part, 256);
 }
 static void carve_hash_scratch(const ngm_field_cfg* fc, int F, int64_t P, char* base, FieldBwdArgs& a) {
-  a.hash_dE = nullptr; a.hash_xyz = nullptr; a.hash_part = nullptr;
+  a.hash_dE = nullptr; a.hash_xyz = nullptr; a.hash_part = nullptr; a.tri_acc = nullptr; a.tri_numel = 0;
+  if (fc->encoding == NGM_ENC_TRIPLANE) { a.tri_acc = reinterpret_cast<long long*>(base); a.tri_numel = tri_numel(fc); return; }
   if (fc->encoding != NGM_ENC_PERMUTO) return;
   a.hash_dE = reinterpret_cast<float2*>(base);
   a.hash_xyz = reinterpret_cast<float4*>(base + align_up((int64_t)fc->nr_levels * F * P * 8, 256));
@@ -365,6 +378,7 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   if (rc) return fail(rc, "ngm_field_eval_bwd: no kernel for this (D,H,L)");
   rc = check_launch("ngm_field_eval_bwd");
   if (rc) return rc;
+  if (fcfg->encoding == NGM_ENC_TRIPLANE) { ngm_launch_tri_finish(a, (hipStream_t)stream); rc = check_launch("ngm_tri_finish"); if (rc) return rc; }
   if (fcfg->encoding == NGM_ENC_PERMUTO) {
     rc = ngm_launch_hash_grad(a, (hipStream_t)stream);
     if (rc) return fail(rc, "permutohedral backward: hash table too large for the LDS-staged scatter");
@@ -441,6 +455,7 @@ static int act_stash_kind(const ngm_field_cfg* fc) {
   if (off) return 0;
   const int th = (fc->dim_hidden + 15) / 16, ti = (fc->dim_enc + 15) / 16;
   if (fc->encoding == NGM_ENC_PERMUTO) return (ti == 2 && fc->dim_hidden <= 32) ? 2 : 0;
+  if (fc->encoding == NGM_ENC_TRIPLANE) return 0;      // 32-sample-tile backward (recompute: it needs the taps anyway)
   // with a skip connection the stashed activation no longer tells the ReLU mask
   return (fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2) ? 1 : 0;
 }
@@ -521,6 +536,14 @@ int64_t ngm_render_workspace(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
 // permutohedral: validate the gradient table (it is fully overwritten by k_hash_reduce)
 static int prep_lattice_grad(const ngm_field_cfg* fc, const ngm_grads* grads, int F, FieldBwdArgs& a, hipStream_t st) {
   a.lattice_grad = nullptr; a.lattice_grad_stride = 0;
+  a.planes_grad = nullptr; a.planes_grad_stride = 0;
+  if (fc->encoding == NGM_ENC_TRIPLANE) {
+    if (!grads->planes || grads->planes_stride < tri_numel(fc)) return fail(NGM_E_INVALID, "triplane: grads.planes missing / stride too small");
+    if (!a.tri_acc) return fail(NGM_E_WORKSPACE, "triplane: no accumulator scratch");
+    a.planes_grad = grads->planes; a.planes_grad_stride = grads->planes_stride;
+    (void)hipMemsetAsync(a.tri_acc, 0, (size_t)F * tri_numel(fc) * 8, st);
+    return NGM_OK;
+  }
   if (fc->encoding != NGM_ENC_PERMUTO) return NGM_OK;
   if (!grads->lattice) return fail(NGM_E_INVALID, "permutohedral: grads.lattice is NULL");
   const int64_t per = (int64_t)fc->nr_levels * ((int64_t)1 << fc->log2_hashmap_size) * 2;
@@ -641,6 +664,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_field_bwd");
   if (e) return e;
+  if (fcfg->encoding == NGM_ENC_TRIPLANE) { ngm_launch_tri_finish(a, st); e = check_launch("ngm_tri_finish"); if (e) return e; }
   if (fcfg->encoding == NGM_ENC_PERMUTO) {
     if (lattice_adam) a.lattice_adam = *lattice_adam;
     e = ngm_launch_hash_grad(a, st, lattice_adam_applied);

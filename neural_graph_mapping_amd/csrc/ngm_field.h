@@ -358,6 +358,105 @@ __device__ __forceinline__ HashCtx make_hash_ctx(const ngm_field_cfg& fc, const 
   return hc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Triplane encoding (positional_encodings.py:69-161): planes (3, C, res, res) of one field; plane p samples the
+// projection (u, v) = (x,y), (x,z), (y,z) of the point with torch.nn.functional.grid_sample semantics
+// (align_corners=True: pixel = (c + 1) / 2 * (res - 1); padding_mode="border": clamped; bilinear; u indexes the last
+// (width) axis, v the height axis).  Feature c: sum / product of the three plane values, or (concat) feature p C + c.
+// ------------------------------------------------------------------------------------------------
+struct TriCtx {
+  const float* planes;   // this field's (3, C, res, res)
+  int res, C, mode;
+  long long* acc;        // backward: Q23.40 fixed-point gradient accumulator, same layout, or nullptr
+};
+struct TriTap { int i00, i01, i10, i11; float w00, w01, w10, w11; };   // offsets inside one (res, res) plane + weights
+
+__device__ __forceinline__ TriTap tri_tap(float u, float v, int res) {
+  const float fu = fminf(fmaxf((u + 1.0f) * 0.5f * (float)(res - 1), 0.f), (float)(res - 1));
+  const float fv = fminf(fmaxf((v + 1.0f) * 0.5f * (float)(res - 1), 0.f), (float)(res - 1));
+  const float u0f = floorf(fu), v0f = floorf(fv);
+  const int u0 = (int)u0f, v0 = (int)v0f, u1 = min(u0 + 1, res - 1), v1 = min(v0 + 1, res - 1);
+  const float tu = fu - u0f, tv = fv - v0f;
+  TriTap t;
+  t.i00 = v0 * res + u0; t.i01 = v0 * res + u1; t.i10 = v1 * res + u0; t.i11 = v1 * res + u1;
+  t.w00 = (1.f - tu) * (1.f - tv); t.w01 = tu * (1.f - tv); t.w10 = (1.f - tu) * tv; t.w11 = tu * tv;
+  return t;
+}
+__device__ __forceinline__ float tri_fetch(const float* plane, const TriTap& t) {
+  return fmaf(plane[t.i11], t.w11, fmaf(plane[t.i10], t.w10, fmaf(plane[t.i01], t.w01, plane[t.i00] * t.w00)));
+}
+// the lane's features 32 mi + frow(r, hi) of one sample, straight into the MFMA B-operand registers
+template <int MI>
+__device__ __forceinline__ void encode_triplane(const TriCtx& tc, int hi, float x, float y, float z, f32x16 (&E)[MI]) {
+  const TriTap tp[3] = {tri_tap(x, y, tc.res), tri_tap(x, z, tc.res), tri_tap(y, z, tc.res)};
+  const int64_t ps = (int64_t)tc.res * tc.res, D = tc.mode == NGM_TRI_CONCAT ? 3 * tc.C : tc.C;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * mi + frow(r, hi);
+      float v = 0.f;
+      if (f < D) {
+        if (tc.mode == NGM_TRI_CONCAT) {
+          const int p = f / tc.C, c = f - p * tc.C;
+          v = tri_fetch(tc.planes + ((int64_t)p * tc.C + c) * ps, tp[p]);
+        } else {
+          const float a0 = tri_fetch(tc.planes + (int64_t)f * ps, tp[0]);
+          const float a1 = tri_fetch(tc.planes + ((int64_t)tc.C + f) * ps, tp[1]);
+          const float a2 = tri_fetch(tc.planes + ((int64_t)2 * tc.C + f) * ps, tp[2]);
+          v = tc.mode == NGM_TRI_SUM ? (a0 + a1) + a2 : (a0 * a1) * a2;
+        }
+      }
+      E[mi][r] = v;
+    }
+}
+__device__ __forceinline__ void tri_scatter(long long* plane_acc, const TriTap& t, float g) {
+  // 64-bit fixed point (Q23.40): integer atomics are order-independent -> the plane gradient is deterministic
+  auto fix = [](float v) { return (long long)((double)v * 1099511627776.0); };
+  atomicAdd(reinterpret_cast<unsigned long long*>(plane_acc + t.i00), (unsigned long long)fix(g * t.w00));
+  atomicAdd(reinterpret_cast<unsigned long long*>(plane_acc + t.i01), (unsigned long long)fix(g * t.w01));
+  atomicAdd(reinterpret_cast<unsigned long long*>(plane_acc + t.i10), (unsigned long long)fix(g * t.w10));
+  atomicAdd(reinterpret_cast<unsigned long long*>(plane_acc + t.i11), (unsigned long long)fix(g * t.w11));
+}
+// d loss / d planes from the lane's d loss / d E (same register map as encode_triplane)
+template <int MI>
+__device__ __forceinline__ void scatter_triplane_grad(const TriCtx& tc, int hi, float x, float y, float z, const f32x16 (&dE)[MI],
+                                                      bool valid) {
+  if (!valid) return;
+  const TriTap tp[3] = {tri_tap(x, y, tc.res), tri_tap(x, z, tc.res), tri_tap(y, z, tc.res)};
+  const int64_t ps = (int64_t)tc.res * tc.res, D = tc.mode == NGM_TRI_CONCAT ? 3 * tc.C : tc.C;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * mi + frow(r, hi);
+      const float g = dE[mi][r];
+      if (f >= D || g == 0.f) continue;
+      if (tc.mode == NGM_TRI_CONCAT) {
+        const int p = f / tc.C, c = f - p * tc.C;
+        tri_scatter(tc.acc + ((int64_t)p * tc.C + c) * ps, tp[p], g);
+      } else if (tc.mode == NGM_TRI_SUM) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) tri_scatter(tc.acc + ((int64_t)p * tc.C + f) * ps, tp[p], g);
+      } else {
+        float a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = tri_fetch(tc.planes + ((int64_t)p * tc.C + f) * ps, tp[p]);
+        tri_scatter(tc.acc + (int64_t)f * ps, tp[0], g * (a[1] * a[2]));
+        tri_scatter(tc.acc + ((int64_t)tc.C + f) * ps, tp[1], g * (a[0] * a[2]));
+        tri_scatter(tc.acc + ((int64_t)2 * tc.C + f) * ps, tp[2], g * (a[0] * a[1]));
+      }
+    }
+}
+__device__ __forceinline__ TriCtx make_tri_ctx(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, long long* acc) {
+  TriCtx tc;
+  tc.res = fc.tri_resolution; tc.mode = fc.tri_mode;
+  tc.C = fc.tri_mode == NGM_TRI_CONCAT ? fc.dim_enc / 3 : fc.dim_enc;
+  tc.planes = (fc.encoding == NGM_ENC_TRIPLANE) ? pr.planes + row * pr.planes_stride : nullptr;
+  tc.acc = acc;
+  return tc;
+}
+
 // One hidden layer on the matrix cores: Y = relu(W X + b), X/Y in C-layout registers, NT sample tiles.
 template <int MIN, int MOUT, int NT>
 __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const float* __restrict__ B, int lane,
@@ -704,17 +803,21 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
-template <int MI, int MH, int L, bool NEED_COS, bool HASH = false, int SKIP = 0, bool B3 = false>
+// HASH: 0 = encoding from the per-feature table (raw / sin / cos), 1 = permutohedral hash, 2 = triplane (tc)
+template <int MI, int MH, int L, bool NEED_COS, int HASH = 0, int SKIP = 0, bool B3 = false>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
                                           const ActStash* st = nullptr, PhaseClock* pc = nullptr,
-                                          const ngm_u32x4* b3w = nullptr) {
+                                          const ngm_u32x4* b3w = nullptr, const TriCtx* tc = nullptr) {
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
   const int hi = lane >> 5;
   // partner lane (same column j, other half) owns the sample of the other tile
   const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
   f32x16 E[2][MI], dummy[MI];
-  if constexpr (HASH) {
-    static_assert(!HASH || MI == 1, "hash encoding: 2*levels <= 32 features");
+  if constexpr (HASH == 2) {
+    encode_triplane<MI>(*tc, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0]);
+    encode_triplane<MI>(*tc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1]);
+  } else if constexpr (HASH == 1) {
+    static_assert(HASH != 1 || MI == 1, "hash encoding: 2*levels <= 32 features");
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? ox : x, hi ? oy : y, hi ? oz : z, E[0][0]);
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1][0]);
     // training: the encoding itself is what the backward cannot cheaply recompute (simplex search + 64 table
@@ -737,7 +840,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, SKIP, B3>(sm, lane, E, Hl, HASH ? nullptr : st, pc, b3w);
+  mlp_fwd<MI, MH, L, 2, SKIP, B3>(sm, lane, E, Hl, HASH == 1 ? nullptr : st, pc, b3w);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);

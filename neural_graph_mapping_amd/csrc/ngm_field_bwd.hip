@@ -9,6 +9,7 @@
 // registers for the whole kernel; every workgroup writes ONE partial gradient vector, reduced (in a
 // fixed order -> deterministic) by k_grad_reduce.
 #include <stdlib.h>
+#include <algorithm>
 #include "ngm_field.h"
 #include "ngm_launch.h"
 
@@ -185,7 +186,7 @@ __device__ __forceinline__ void outer_accum(const float* colbuf, int stride, con
   }
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD, bool HASH, bool CAT = false>
+template <int MI, int MH, int L, bool NEED_COS, bool ENC_GRAD, int HASH, bool CAT = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L, CAT>;
@@ -254,8 +255,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
   for (int c = 0; c < 4; ++c) { dwo[c] = 0.f; dbo[c] = 0.f; }
   dwf[0] = dwf[1] = dwf[2] = 0.f;
 
-  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, HASH ? a.lattice_grad + (int64_t)f * a.lattice_grad_stride : nullptr);
-  const bool add_enc = !HASH && MI <= MH && a.fc.skip_mode == NGM_SKIP_ADD;
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, HASH == 1 ? a.lattice_grad + (int64_t)f * a.lattice_grad_stride : nullptr);
+  const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, HASH == 2 ? a.tri_acc + (int64_t)f * a.tri_numel : nullptr);
+  const bool add_enc = HASH == 0 && MI <= MH && a.fc.skip_mode == NGM_SKIP_ADD;
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 32; base < end; base += 32 * NGM_WAVES_PER_BLOCK) {
     const int64_t n = base + j;
@@ -281,7 +283,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
     }
     // ---- forward recompute, staging every layer input
     f32x16 E[1][MI], dEa[MI];
-    if constexpr (HASH) encode_hash(sm + LY::ENCW, hc, hi, x, y, z, E[0][0]);
+    if constexpr (HASH == 1) encode_hash(sm + LY::ENCW, hc, hi, x, y, z, E[0][0]);
+    else if constexpr (HASH == 2) encode_triplane<MI>(tc, hi, x, y, z, E[0]);
     else encode_sample<MI, NEED_COS, ENC_GRAD>(sm + LY::ENCW, hi, x, y, z, E[0], dEa);
     WAVE_SYNC();   // previous tile's readers of the staging buffers are done (in-order LDS) - compiler fence
     store_tile<MI>(wl + BL::x_off(0), BL::STR_E, lane, E[0]);
@@ -358,7 +361,13 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
       dbh[l] += colsum<MH>(bufD, BL::STR_D, lane);
       if (l == 0) {
         layer_wgrad<MH, MI>(bufD, BL::STR_D, wl + BL::x_off(0), BL::STR_E, lane, acc0);
-        if constexpr (HASH) {
+        if constexpr (HASH == 2) {
+          // triplane: d loss / d planes scattered straight from the lane's dE registers (fixed-point atomics)
+          f32x16 dE[MI];
+          layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
+          scatter_triplane_grad<MI>(tc, hi, x, y, z, dE, valid);
+        }
+        if constexpr (HASH == 1) {
           f32x16 dE[MI];
           layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
           // hand dL/dE to k_hash_grad (level-major, coalesced); table scatter happens there in LDS
@@ -620,12 +629,28 @@ static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   const bool cat = a.fc.skip_mode == NGM_SKIP_CONCAT;      // compiled for the Fourier encoding and for no encoding
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if (cat) return NGM_E_UNSUPPORTED;
-    if constexpr (MI == 1) NGM_LB(false, false, true, false);
+    if constexpr (MI == 1) NGM_LB(false, false, 1, false);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_FOURIER) { if (cat) NGM_LB(false, true, false, true); else NGM_LB(false, true, false, false); }
-  else if (a.fc.encoding == NGM_ENC_NERF) { if (cat) return NGM_E_UNSUPPORTED; NGM_LB(true, false, false, false); }
-  else { if (cat) NGM_LB(false, false, false, true); else NGM_LB(false, false, false, false); }
+  } else if (a.fc.encoding == NGM_ENC_TRIPLANE) {
+    if (a.fc.skip_mode != NGM_SKIP_NO || !a.tri_acc) return NGM_E_UNSUPPORTED;
+    NGM_LB(false, false, 2, false);
+  } else if (a.fc.encoding == NGM_ENC_FOURIER) { if (cat) NGM_LB(false, true, 0, true); else NGM_LB(false, true, 0, false); }
+  else if (a.fc.encoding == NGM_ENC_NERF) { if (cat) return NGM_E_UNSUPPORTED; NGM_LB(true, false, 0, false); }
+  else { if (cat) NGM_LB(false, false, 0, true); else NGM_LB(false, false, 0, false); }
 #undef NGM_LB
+  return 0;
+}
+
+// triplane: Q23.40 accumulators -> the caller's gradient tensor (fully overwritten)
+__global__ void k_tri_finish(const long long* acc, int64_t numel, float* grad, int64_t gstride) {
+  const int f = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+    grad[(int64_t)f * gstride + i] = (float)((double)acc[(int64_t)f * numel + i] * (1.0 / 1099511627776.0));
+}
+int ngm_launch_tri_finish(const FieldBwdArgs& a, hipStream_t st) {
+  if (!a.tri_acc || !a.planes_grad) return NGM_E_INVALID;
+  const int bx = (int)std::min<int64_t>((a.tri_numel + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_tri_finish, dim3(bx, a.F), dim3(256), 0, st, a.tri_acc, a.tri_numel, a.planes_grad, a.planes_grad_stride);
   return 0;
 }
 

@@ -323,7 +323,7 @@ int ngm_launch_field_bwd16(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   const bool have = (TI == 4 && TH == 4 && (L == 1 || L == 2)) || (TI == 2 && TH == 2 && (L == 1 || L == 2)) ||
                     (TI == 3 && TH == 3 && L == 1);
 #endif
-  if (!have || !hash_ok || a.fc.skip_mode != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;   // skip connections: 32-sample-tile kernel
+  if (!have || !hash_ok || a.fc.skip_mode != NGM_SKIP_NO || a.fc.encoding == NGM_ENC_TRIPLANE) return NGM_E_UNSUPPORTED;   // skip connections: 32-sample-tile kernel
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   if (TI == 4 && TH == 4 && L == 2) return launch_bwd16<4, 4, 2>(a, blocks, st);
 #ifndef NGM_FAST_BUILD

@@ -533,7 +533,7 @@ static int launch_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 // returns NGM_E_UNSUPPORTED when the stash variant does not apply (caller falls back to the recompute kernels)
 int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   const int TI = (a.fc.dim_enc + 15) / 16, TH = (a.fc.dim_hidden + 15) / 16, L = a.fc.num_layers;
-  if (!a.act || a.points || a.fc.skip_mode != NGM_SKIP_NO || a.fc.encoding == NGM_ENC_PERMUTO || TI != 4 || TH != 4 || L < 1 || L > 2) return NGM_E_UNSUPPORTED;
+  if (!a.act || a.points || a.fc.skip_mode != NGM_SKIP_NO || a.fc.encoding == NGM_ENC_PERMUTO || a.fc.encoding == NGM_ENC_TRIPLANE || TI != 4 || TH != 4 || L < 1 || L > 2) return NGM_E_UNSUPPORTED;
   if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   if (L == 2) return launch_bwd16s<2>(a, blocks, st);

@@ -18,7 +18,7 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
     qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
   }
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+  const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 64; base < end; base += NGM_BLOCK) {
     const int64_t idx = base + lane;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
       if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }
@@ -90,7 +91,7 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false, bool NEUS = false>
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false, bool NEUS = false>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) ls[i] = 0.f;
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+  const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
   float neus_isd = 0.f;                                             // rm.py:641-644: 1 / |_neus_sd| of this field
   if constexpr (NEUS) neus_isd = 1.0f / fabsf(a.neus_sd[row * a.neus_sd_stride]);
 
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_ABLF_NOACT
       ast.base = nullptr; ast.layer_stride = 0;
 #else
-      ast.base = (HASH ? MI == 1 : MH == 2) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
+      ast.base = (HASH == 1 ? MI == 1 : (HASH == 0 && MH == 2)) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
 #endif
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
 #ifdef NGM_ABLF_NOMLP
@@ -290,9 +292,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #else
       PTICK(pc, 3);
 #ifdef NGM_PHASE_TIMING
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, pc, b3w);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, pc, b3w, &tc);
 #else
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w);
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
 #endif
 #endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   } while (0)
 #define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDSW, LDSX)                               \
   do {                                                                                          \
-    if constexpr (!(HS)) {                                                                      \
+    if constexpr ((HS) == 0) {                                                                  \
       if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, 1, GRID, BLK, LDSW, LDSX); \
       else if (a.fc.skip_mode == NGM_SKIP_CONCAT) {                                             \
         if constexpr (!(NC)) NGM_LAUNCH_ONE(KERNEL, NC, HS, 2, GRID, BLK, LDSW, LDSX);          \
@@ -477,17 +479,17 @@ static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
   if constexpr (b3_shape<MI, MH, L>()) {
     if (b3_wanted(a.fc)) {       // standalone evaluation: the mode is a preference here (fp32 MFMA where not compiled)
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
-      (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, false, 0, true>,
+      (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, 0, 0, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false, false, 0, true>), dim3(blocks), blk, lds, st, a);
+      hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false, 0, 0, true>), dim3(blocks), blk, lds, st, a);
       return 0;
     }
   }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, true, blocks, blk, 0, 0);
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, 1, blocks, blk, 0, 0);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_field_points_fwd, true, false, blocks, blk, 0, 0);
-  else NGM_LAUNCH_VARIANT(k_field_points_fwd, false, false, blocks, blk, 0, 0);
+  } else if (a.fc.encoding == NGM_ENC_TRIPLANE) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, 2, blocks, blk, 0, 0); else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_field_points_fwd, true, 0, blocks, blk, 0, 0);
+  else NGM_LAUNCH_VARIANT(k_field_points_fwd, false, 0, blocks, blk, 0, 0);
   return 0;
 }
 template <int MI, int MH, int L>
@@ -499,9 +501,9 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
     if (a.fc.skip_mode != NGM_SKIP_NO || (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NONE) || !a.neus_sd)
       return NGM_E_UNSUPPORTED;
     const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, false, 0, false, true>,
+    (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 0, 0, false, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, false, 0, false, true>), dim3(blocks), blk, lds, st, a);
+    hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 0, 0, false, true>), dim3(blocks), blk, lds, st, a);
     return 0;
   }
   if (a.fc.matmul_mode == NGM_MATMUL_BF16X3) {
@@ -510,19 +512,19 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
       if (a.fc.skip_mode == NGM_SKIP_NO && (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
         const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
         if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;
-        (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, false, 0, true>,
+        (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 0, 0, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, false, 0, true>), dim3(blocks), blk, lds, st, a);
+        hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 0, 0, true>), dim3(blocks), blk, lds, st, a);
         return 0;
       }
     }
     return NGM_E_UNSUPPORTED;
   }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, true, blocks, blk, 0, wave_lds);
+    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, 1, blocks, blk, 0, wave_lds);
     else return NGM_E_UNSUPPORTED;
-  } else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, false, blocks, blk, 0, wave_lds);
-  else NGM_LAUNCH_VARIANT(k_render_fwd, false, false, blocks, blk, 0, wave_lds);
+  } else if (a.fc.encoding == NGM_ENC_TRIPLANE) NGM_LAUNCH_VARIANT(k_render_fwd, false, 2, blocks, blk, 0, wave_lds); else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, 0, blocks, blk, 0, wave_lds);
+  else NGM_LAUNCH_VARIANT(k_render_fwd, false, 0, blocks, blk, 0, wave_lds);
   return 0;
 }
 

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
     if (fld[k] >= 0) a.sorted[hist[fld[k]] + rnk[k]] = (int)(base + k * 256 + threadIdx.x);
 }
 
-template <int MI, int MH, int L, bool NEED_COS, bool HASH, int SKIP, bool B3 = false>
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false>
 __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
   const float px = a.pos[3 * f], py = a.pos[3 * f + 1], pz = a.pos[3 * f + 2];
   const float qw = a.quat[4 * f], qx = a.quat[4 * f + 1], qy = a.quat[4 * f + 2], qz = a.quat[4 * f + 3];
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+  const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
   for (int base = beg + wave * 64; base < end; base += NGM_BLOCK) {
     const int idx = base + lane;
     const bool valid = idx < end;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
     if (valid) a.pair_out[pair] = o;
   }
 }
@@ -298,20 +299,23 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
     if ((a.fc.matmul_mode == NGM_MATMUL_BF16X3 || a.fc.matmul_mode == NGM_MATMUL_AUTO) && sk == NGM_SKIP_NO &&
         (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
-      (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, false, 0, true>,
+      (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, 0, 0, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false, false, 0, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false, 0, 0, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
       return 0;
     }
   }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
-    if constexpr (MI == 1) NGM_KE(false, true, 0);
+    if constexpr (MI == 1) NGM_KE(false, 1, 0);
     else return NGM_E_UNSUPPORTED;
+  } else if (a.fc.encoding == NGM_ENC_TRIPLANE) {
+    if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
+    NGM_KE(false, 2, 0);
   } else if (a.fc.encoding == NGM_ENC_NERF) {
-    if (sk == NGM_SKIP_ADD) NGM_KE(true, false, 1); else if (sk == NGM_SKIP_NO) NGM_KE(true, false, 0); else return NGM_E_UNSUPPORTED;
+    if (sk == NGM_SKIP_ADD) NGM_KE(true, 0, 1); else if (sk == NGM_SKIP_NO) NGM_KE(true, 0, 0); else return NGM_E_UNSUPPORTED;
   } else {
-    if (sk == NGM_SKIP_ADD) NGM_KE(false, false, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, false, 2); else NGM_KE(false, false, 0);
+    if (sk == NGM_SKIP_ADD) NGM_KE(false, 0, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, 0, 2); else NGM_KE(false, 0, 0);
   }
 #undef NGM_KE
   return 0;

@@ -77,6 +77,10 @@ struct FieldBwdArgs {
   float2* hash_dE;        // permutohedral: [L][F*P] dL/d(level features) per sample (level-major: coalesced)
   float4* hash_xyz;       // permutohedral: [F*P] scaled field-local sample positions
   float* hash_part;       // permutohedral: [F][L][8][2T] partial gradient tables
+  long long* tri_acc;     // triplane: [F][3 C res res] Q23.40 gradient accumulators (zeroed by the API before the launch)
+  int64_t tri_numel;      // 3 C res res
+  float* planes_grad;     // triplane: caller's (F, 3, C, res, res) gradient, stride between fields
+  int64_t planes_grad_stride;
   const float* act;       // hidden-activation stash written by the forward (ray mode) or NULL = recompute
   int64_t act_layer_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
@@ -143,6 +147,7 @@ struct StashBwdArgs {
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
+int ngm_launch_tri_finish(const FieldBwdArgs& a, hipStream_t st);
 int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st);  // 16-sample tiles, activations from the forward's stash
 int ngm_launch_field_bwd16(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 16-sample tiles, 8 waves; NGM_E_UNSUPPORTED -> fall back
 int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);

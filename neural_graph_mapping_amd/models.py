@@ -112,6 +112,26 @@ class PermutohedralEncoding(PositionalEncoding):
         return dict(encoding="permuto", **self.kw)
 
 
+class TriplaneEncoding(PositionalEncoding):
+    """Learned triplane encoding (positional_encodings.py:69-161): three (C, res, res) feature planes, bilinear lookup of
+    the (x,y), (x,z), (y,z) projections (grid_sample, align_corners=True, border padding; points expected in [-1,1]),
+    summed / multiplied / concatenated.  Same constructor kwargs and parameter name (`plane_coef`) as the reference."""
+
+    def __init__(self, resolution: int = 32, num_components: int = 64, init_scale: float = 0.1,
+                 mode: Literal["sum", "product", "concat"] = "sum") -> None:
+        super().__init__()
+        if mode not in K.TRI:
+            raise ValueError(f"{mode=} is not supported.")
+        self.resolution, self.num_components, self.init_scale, self.mode = resolution, num_components, init_scale, mode
+        self.plane_coef = torch.nn.Parameter(init_scale * torch.randn((3, num_components, resolution, resolution)))
+
+    def get_out_dim(self) -> int:
+        return self.num_components * (3 if self.mode == "concat" else 1)
+
+    def spec(self):
+        return dict(encoding="triplane", resolution=self.resolution, num_components=self.num_components, tri_mode=self.mode)
+
+
 # ------------------------------------------------------------------------------------------------
 class NeuralField(torch.nn.Module):
     """Positional encoding + MLP prototype (models.py:66-182); holds ONE field's parameters."""

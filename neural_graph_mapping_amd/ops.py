@@ -609,7 +609,7 @@ def adam_tensor_arrays(fc, params, state, grads, lp=None):
     """(mlp AdamTensor array in gradient-segment order, lattice AdamTensor or None) for ngm_render_bwd_adam.
     `params` = fp32 master weights; `lp` (optional dict) = their reduced-precision copies, kept in sync by the update."""
     names = [n for n in K.param_names(fc) if n not in K.NO_GRAD_PARAMS]
-    mlp = [n for n in names if n != "_encoding.lattice_values"]
+    mlp = [n for n in names if n not in ("_encoding.lattice_values", "_encoding.plane_coef")]   # these two: own reduction kernels
     arr = (K.AdamTensor * len(mlp))()
     for i, n in enumerate(mlp):
         arr[i] = _adam_tensor(params[n], state[n], grads[n], None if lp is None else lp[n])

@@ -511,6 +511,14 @@ class NeuralGraphRenderer:
                                           ops._ptr(self._step_dev), self._learning_rate, 0.9, 0.999, self._adam_eps,
                                           self._adam_weight_decay, w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"], st),
                     "ngm_render_bwd_adam")
+            if fc.encoding == K.ENC["triplane"]:      # the feature planes: gradient from the fixed-point scatter, same sparse Adam
+                n = "_encoding.plane_coef"
+                pl, stt, gp = allp[n], self._optim_state[n], grads[n]
+                one = (K.AdamTensor * 1)(K.AdamTensor(pl.data_ptr(), stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(),
+                                                      gp.data_ptr(), pl.stride(0), gp.stride(0), gp[0].numel()))
+                K.check(L.ngm_adam_sparse_multi(one, 1, ops._ptr(fids), F, int(self._step), ops._ptr(self._step_dev),
+                                                self._learning_rate, 0.9, 0.999, self._adam_eps, self._adam_weight_decay, 0,
+                                                None, st), "ngm_adam_sparse_multi")
             if ctx.get("neus"):      # the per-field standard deviation is a parameter of its own (rm.py:641-644): same Adam
                 n = "_neus_sd"
                 sd, stt = self._model.all_fields_params[n], self._optim_state[n]

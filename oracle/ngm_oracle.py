@@ -55,7 +55,7 @@ class CameraSpec:
 @dataclass
 class FieldSpec:
     """Architecture of one NeuralField (models.py:69-128)."""
-    encoding: str = "fourier"          # "fourier" | "nerf" | "none" | "permuto"
+    encoding: str = "fourier"          # "fourier" | "nerf" | "none" | "permuto" | "triplane"
     dim_enc: int = 64                  # encoding width D
     raw_coords: bool = True            # Fourier: cat(x, sin(Wx)) (positional_encodings.py:208-212)
     num_octaves: int = 8               # NeRF octaves (positional_encodings.py:230)
@@ -66,6 +66,10 @@ class FieldSpec:
     log2_hashmap_size: int = 12
     coarsest_scale: float = 1.0
     finest_scale: float = 1e-4
+    # triplane encoding (positional_encodings.py:69-161)
+    resolution: int = 32
+    num_components: int = 64
+    tri_mode: str = "sum"              # "sum" | "product" | "concat"
     num_layers: int = 2                # hidden layers L
     dim_hidden: Optional[int] = None   # H; None -> D (models.py:99-100)
     dim_out: int = 4
@@ -76,6 +80,8 @@ class FieldSpec:
             self.dim_enc = 3 * self.num_octaves * 2
         if self.encoding == "permuto":
             self.dim_enc = self.nr_levels * self.nr_feat_per_level
+        if self.encoding == "triplane":
+            self.dim_enc = self.num_components * (3 if self.tri_mode == "concat" else 1)   # positional_encodings.py:119-126
         if self.dim_hidden is None:
             self.dim_hidden = self.dim_enc
 
@@ -94,6 +100,8 @@ class FieldSpec:
         if self.encoding == "permuto":
             shapes["_encoding.lattice_values"] = (self.nr_levels, 2 ** self.log2_hashmap_size, self.nr_feat_per_level)
             shapes["_encoding.random_shift_per_level"] = (self.nr_levels, 3)
+        if self.encoding == "triplane":
+            shapes["_encoding.plane_coef"] = (3, self.num_components, self.resolution, self.resolution)
         if self.skip_mode == "rezero":
             shapes["_rezero"] = (self.num_layers,)                   # models.py:112-113
         for i, (di, do) in enumerate(self.layer_dims()):
@@ -239,7 +247,24 @@ def encode(x, params, fs: FieldSpec):
         return x
     if fs.encoding == "permuto":
         return encode_permuto(x, params["_encoding.lattice_values"], params["_encoding.random_shift_per_level"], fs)
+    if fs.encoding == "triplane":
+        return torch.stack([encode_triplane(x[f], params["_encoding.plane_coef"][f], fs.tri_mode) for f in range(x.shape[0])])
     raise NotImplementedError(fs.encoding)
+
+
+def encode_triplane(x, plane_coef, mode):
+    """TriplaneEncoding.forward (positional_encodings.py:128-161) for one field: x (P,3) in [-1,1], plane_coef
+    (3, C, res, res) -> (P, C | 3C).  grid_sample(align_corners=True, padding_mode="border") of the (x,y), (x,z), (y,z)
+    projections, then sum / product over the planes or concatenation."""
+    coord = torch.stack([x[..., [0, 1]], x[..., [0, 2]], x[..., [1, 2]]], 0).view(3, -1, 1, 2)
+    feat = torch.nn.functional.grid_sample(plane_coef, coord, align_corners=True, padding_mode="border")   # (3, C, P, 1)
+    if mode == "product":
+        return feat.prod(0).squeeze(-1).T
+    if mode == "sum":
+        return feat.sum(0).squeeze(-1).T
+    if mode == "concat":
+        return feat.squeeze(-1).reshape(3 * plane_coef.shape[1], -1).T
+    raise ValueError(mode)
 
 
 def permuto_scale_factors(fs: FieldSpec, dtype=torch.float32):
@@ -629,6 +654,8 @@ def init_params(fs: FieldSpec, num_fields: int, seed=0, mu=0.0, sigma=4.0,
             v = torch.randn(n, *shape, generator=g) * 0.1
         elif name == "_encoding.random_shift_per_level":
             v = torch.randn(n, *shape, generator=g) * 10.0
+        elif name == "_encoding.plane_coef":
+            v = torch.randn(n, *shape, generator=g) * 0.5
         elif name == "_rezero":
             v = 0.5 * torch.randn(n, *shape, generator=g)            # the reference initialises zeros (models.py:131-132)
         elif name.endswith("weight"):

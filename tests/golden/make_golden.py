@@ -331,6 +331,36 @@ def g12_skip_modes():
              dim_hidden=np.int64(dim_mlp or dim_enc), **arrays)
 
 
+def g15_triplane():
+    """TriplaneEncoding (positional_encodings.py:69-161) in all three modes: vmapped field forward and every parameter
+    gradient of sum(out * seed), points in and slightly outside [-1,1]^3 (border padding), scale_mode unit_ball."""
+    for mode, comps in (("sum", 32), ("product", 32), ("concat", 20), ("sum", 64)):
+        gen = torch.Generator().manual_seed(150 + comps + len(mode))
+        F, P, res = 2, 50, 12
+        torch.manual_seed(15)
+        fs = models.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+            encoding_type="neural_graph_mapping.positional_encodings.TriplaneEncoding",
+            encoding_kwargs=dict(resolution=res, num_components=comps, init_scale=0.5, mode=mode), num_layers=1, dim_out=4,
+            dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0), num_knn=2, distance_factor=10.0,
+            field_radius=1.0, scale_mode="unit_ball", outside_value=1.0)
+        fs.add_fields(F)
+        for k, v in fs.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.1 * torch.randn(v.shape, generator=gen))
+        fs.set_vmap_fields(None)
+        for v in fs.vmap_fields_params.values():
+            v.requires_grad_()
+        pos = 0.3 * torch.randn(F, 3, generator=gen)
+        quat = rand_quats(F, gen)
+        q = pos[:, None] + 2.3 * (torch.rand(F, P, 3, generator=gen) - 0.5)
+        seed = torch.randn(F, P, 4, generator=gen)
+        out = fs(q, pos, quat, None, True)
+        (out * seed).sum().backward()
+        vp = fs.vmap_fields_params
+        save(f"g15_triplane_{mode}_C{comps}", query=q, pos=pos, quat=quat, out=out, seed=seed, resolution=np.int64(res),
+             **{"p::" + k: v for k, v in vp.items()}, **{"g::" + k: v.grad for k, v in vp.items() if v.grad is not None})
+
+
 def g10_behind_camera():
     """Cameras inside the field sphere, near < 0: _render_ijs overwrites the geometry of the samples behind the
     camera (rm.py:494-495, 614-622) and no gradient flows through them."""
@@ -539,7 +569,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

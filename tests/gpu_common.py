@@ -65,6 +65,10 @@ def make_renderer(fkw, ckw, num_fields, params=None):
         ek = dict(pos_dim=3, log2_hashmap_size=fkw.get("log2_hashmap_size", 12), nr_levels=fkw.get("nr_levels", 16),
                   nr_feat_per_level=2, coarsest_scale=fkw.get("coarsest_scale", 1.0),
                   finest_scale=fkw.get("finest_scale", 1e-4), init_scale=fkw.get("init_scale", 1e-5))
+    elif fkw["encoding"] == "triplane":
+        et = "neural_graph_mapping.positional_encodings.TriplaneEncoding"
+        ek = dict(resolution=fkw.get("resolution", 32), num_components=fkw.get("num_components", 64), init_scale=0.5,
+                  mode=fkw.get("tri_mode", "sum"))
     else:
         et = "neural_graph_mapping.positional_encodings.PositionalEncodingNeRF"
         ek = dict(dim_in=3, num_octaves=fkw["num_octaves"], start_octave=0)

@@ -438,6 +438,64 @@ def test_neus_fused_train_step_vs_oracle(F, R, n_c, n_g, layers):
     assert bool((after[:F] != before[:F]).all()) and bool(after[F] == before[F]) and r._step == 3
 
 
+# ------------------------------------------------------------------------- triplane encoding (G15)
+@pytest.mark.parametrize("name", ["g15_triplane_sum_C32", "g15_triplane_product_C32", "g15_triplane_concat_C20",
+                                  "g15_triplane_sum_C64"])
+def test_triplane_golden(name):
+    """TriplaneEncoding (positional_encodings.py:69-161; pure torch in the reference, so this one IS pinned): vmapped
+    field forward and every gradient incl. the feature planes, points inside and outside [-1,1]^3 (border padding)."""
+    g = load_golden(name)
+    mode, comps = name.split("_")[2], int(name.split("_C")[-1])
+    fc = K.field_cfg(encoding="triplane", resolution=int(g["resolution"]), num_components=comps, tri_mode=mode, num_layers=1,
+                     scale_mode="unit_ball")
+    params = {k: v.to(DEV).requires_grad_() for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"}
+    out = ops.field_eval(fc, params, g["query"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV))
+    close(out, g["out"], rtol=2e-4, atol=3e-5)
+    (out * g["seed"].to(DEV)).sum().backward()
+    for k, gr in split_prefix(g, "g::").items():
+        grad_close(params[k].grad, gr, 2e-3, k)
+    untouched = split_prefix(g, "g::")["_encoding.plane_coef"] == 0          # texels no sample reaches: exactly zero
+    assert bool((params["_encoding.plane_coef"].grad.cpu()[untouched] == 0).all())
+    # kNN-blended evaluation path, one field, every point inside it
+    pts = g["pos"][:1] + 0.4 * (torch.rand(200, 3) - 0.5)
+    one = {k: v[:1].detach() for k, v in params.items()}
+    a = ops.field_eval_knn(fc, one, pts.to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV), 1, 10.0, 1.0)
+    b = ops.field_eval(fc, one, pts[None].to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV))[0]
+    close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tri_mode,comps", [("sum", 64), ("product", 32), ("concat", 20)])
+def test_triplane_fused_train_step_vs_oracle(tri_mode, comps):
+    F, R, n_c, n_g = 2, 33, 6, 10
+    torch.manual_seed(8)
+    fkw = dict(encoding="triplane", resolution=16, num_components=comps, tri_mode=tri_mode, num_layers=1)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos, quat, t = synth_target(F, R, seed=4)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params = O.init_params(fs, F, seed=11)
+    params["_linears.1.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    res = r.optimization_iteration(tgt, u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+    again = r.optimization_iteration(tgt, u_c.to(DEV), u_g.to(DEV), update=False)
+    assert torch.equal(again["grads"]["_encoding.plane_coef"], res["grads"]["_encoding.plane_coef"])   # fixed-point scatter
+    before = r._model.all_fields_params["_encoding.plane_coef"].clone()
+    out = r.optimization_iteration(tgt, u_c.to(DEV), u_g.to(DEV), update=True)                          # Adam on the planes too
+    assert torch.isfinite(out["combined"]) and not torch.equal(before, r._model.all_fields_params["_encoding.plane_coef"])
+
+
 # ------------------------------------------------------------------------- train step (G6, G7)
 @pytest.mark.parametrize("name", list(CASES))
 def test_fused_train_step_golden(name):

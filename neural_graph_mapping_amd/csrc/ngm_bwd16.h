@@ -40,6 +40,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TICK_REPORT
 #endif
 
+// ---- HBM -> LDS DMA ---------------------------------------------------------------------------------
+// global_load_lds_dwordx4: lane p's 16 bytes land at lds_base + 16 p.  M0 carries the LDS base.  Two address
+// forms: 64-bit per-lane pointer, or wave-uniform base (SGPR pair) + 32-bit per-lane byte offset (cheaper:
+// one VGPR, no 64-bit VALU arithmetic in the tile loop).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
+#ifdef NGM_ABLS_NOINP   // timing ablation: no input DMA (results meaningless)
+  return;
+#endif
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint32_t lds_base) {
+#ifdef NGM_ABLS_NODMA   // timing ablation: no activation DMA at all (results meaningless)
+  return;
+#endif
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+#define DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// Per-field bases (wave-uniform) of everything the tile loop streams in; sample indices inside the loop are
+// 32-bit and relative to the field (the API only selects this kernel when P * 256 B < 4 GiB).
+struct FieldStreams {
+  const char* raytab;     // + 32 B * ray-in-field
+  const char* dout;       // + 16 B * n
+  const char* tpair;      // 16-byte aligned (t,T,t,T) pairs: + 8 B * ((n + par) & ~1)
+  const char* act[2];     // tiled stash (ngm_field.h ActStash), base of the field's first 32-sample tile
+  uint32_t gb;            // (field's first global sample index) & 31
+  uint32_t par;           // parity of the field's first global sample index
+};
+
+// inputs of tile [n0, n0+16): lane group q fetches piece q of sample j (0: ray origin + dir.x, 1: rest of the
+// ray entry, 2: d_out, 3: the aligned stash pair holding t).  One instruction, per-lane 64-bit pointers.
+__device__ __forceinline__ void issue_inputs(const FieldStreams& fs, int S, uint32_t n0, uint32_t end, int lane, uint32_t lds) {
+  const int j = lane & 15, q = lane >> 4;
+  uint32_t n = n0 + j;
+  if (n >= end) n = end - 1;                       // clamp: finite data, its gradient contribution is zeroed via d_out
+  const uint32_t ray = n / (uint32_t)S;
+  const char* src;
+  if (q == 0) src = fs.raytab + 32 * (size_t)ray;
+  else if (q == 1) src = fs.raytab + 32 * (size_t)ray + 16;
+  else if (q == 2) src = fs.dout + 16 * (size_t)n;
+  else src = fs.tpair + 8 * (size_t)((n + fs.par) & ~1u);
+  dma16(src, lds);
+}
+
 #define B16_WAVES 8
 #define B16_THREADS 512
 #define B16_RS 17          // row stride of a 16x16 weight block in LDS ([k-row][out]), odd: transposed reads stay spread

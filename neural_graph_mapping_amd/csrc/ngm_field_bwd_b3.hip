@@ -1,0 +1,623 @@
+// Backward of encoding + MLP for the fused training step on the bf16 matrix pipe: every fp32 operand written
+// exactly as hi + mid + lo (three bf16), six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the arithmetic
+// of layer_fwd_b3 (ngm_field.h), selected by the same ngm_field_cfg.matmul_mode.  gfx950, 32-sample tiles, 4 waves
+// per workgroup (one per SIMD: the whole register file and 27 KB of LDS per wave).
+//
+// Why a kernel of its own and not a mode of k_field_bwd16s: an MFMA operand holds its contraction index in the
+// registers of a lane.  The data gradient contracts over FEATURES (operand lane = sample), the weight gradient over
+// SAMPLES (operand lane = feature), so every dY is needed in both orientations.  Here
+//   * the data gradient is computed TRANSPOSED, dX^T[s][i] = sum_o dY^T[s][o] W[o][i]: rows = the tile's 32 samples,
+//     columns = features, so its C fragment (lane = feature i, registers = 16 of the samples) IS the weight-gradient
+//     operand layout of the next layer down -- no data movement for that use;
+//   * the other orientation (lane = sample, eight consecutive features per k-block) comes from LDS: the activation
+//     tile lands there by DMA in [16-byte chunk][sample] order, each lane reads its feature's column (one ds_read_b32
+//     per value), and dY is written back IN PLACE over the activation it was masked with (same addresses: no
+//     hazard between lanes), then read as rows (two ds_read_b128 per k-block);
+//   * everything per feature -- ReLU masks, bias / output-weight / Fourier-matrix gradients -- is lane-local in
+//     the "lane = feature" orientation: sums over the tile's samples are register sums, no LDS reductions.
+// "lane = feature" layout: lane (i = lane & 31, hi = lane >> 5), tile m: feature 32 m + i, register r <-> sample
+// frow(r, hi) = 8 (r >> 2) + 4 hi + (r & 3) of the tile (the C layout of a 32x32 MFMA with samples on the rows).
+// A weight-gradient k-block b takes registers 8b..8b+7 of both operands.
+//
+// LDS tile [chunk c = feature >> 2][position][4 floats], sample s of chunk c at position s ^ (c & 7): the column read
+// of a half-wave (32 features = 8 chunks, one sample) then touches 32 different banks, the row read is a permutation
+// of 512 contiguous bytes.  The DMA (global_load_lds_dwordx4, lane p -> LDS base + 16 p) applies the permutation on
+// the source side.
+//
+// Supported: dim_enc and dim_hidden in 33..64, 1-2 hidden layers, Fourier / NeRF / no encoding, skip_mode no, ray mode
+// with the forward's activation stash.  Everything else (and matmul_mode f32) keeps the fp32-MFMA kernels.
+#include "ngm_bwd16.h"
+
+// -DNGM_DMAWAIT_TIMING: only the clocks spent in the tile-start DMA wait (slot 2) and the kernel total (slot 12)
+#ifdef NGM_DMAWAIT_TIMING
+#undef TICK_DECL
+#undef TICK
+#undef TICK_REPORT
+#define TICK_DECL unsigned long long tw_ = 0, tl_ = 0; const unsigned long long ts_ = __builtin_readcyclecounter()
+#define TICK(k)                                                                  \
+  do {                                                                           \
+    if ((k) == 10) tl_ = __builtin_readcyclecounter();                           \
+    if ((k) == 2) tw_ += __builtin_readcyclecounter() - tl_;                     \
+  } while (0)
+#define TICK_REPORT                                                                                \
+  if (a.debug_cycles && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64) {                        \
+    for (int k = 0; k < 13; ++k) a.debug_cycles[k] = 0;                                            \
+    a.debug_cycles[2] = tw_; a.debug_cycles[12] = __builtin_readcyclecounter() - ts_;              \
+  }
+#endif
+#define B3B_WAVES 4
+#define B3B_THREADS 256
+#define HT 2048                 // floats of one 32 x 64 activation tile
+#define PLANE_G 512             // 16-byte granules of one weight plane: [nt 2][kb 4][kh 2][n 32]
+
+template <int L, bool EG>
+struct LdsB3b {
+  static constexpr int NPL = (L - 1) + (EG ? 1 : 0);                 // layers whose data gradient is needed
+  static constexpr int plane_slot(int l) { return EG ? l : l - 1; }  // 16-byte units: slot * 3 * PLANE_G
+  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512;         // floats; + per-feature constants: float4 wout[64], enc[64]
+  static constexpr int CONSTS = NPL * 3 * PLANE_G * 4;
+  // per wave: the output layer's input tile, (L = 2) layer 1's input tile, the input landing buffer, points, d_out.
+  // Single buffers: the next tile's transfers are issued when all of them are free (see the tile loop).
+  static constexpr int HL = 0;
+  static constexpr int H1 = HT;
+  static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16]
+  static constexpr int PB = INB + 512;                               // float4 [32]
+  static constexpr int OB = PB + 128;                                // float4 [32]
+  static constexpr int WAVE_TOTAL = OB + 128;
+  static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave
+  static constexpr int EPI = B3B_WAVES * NT * 1024;
+  static constexpr int BODY = PLANES + B3B_WAVES * WAVE_TOTAL;
+  static constexpr int TOTAL = BODY > EPI ? BODY : EPI;
+};
+
+// one activation tile, samples [n0, n0 + 32) of the field (clamped to end - 1): 8 DMA instructions of two chunks each
+__device__ __forceinline__ void issue_tile32(const char* sbase, uint32_t gb, uint32_t n0, uint32_t end, int lane, uint32_t lds_tile) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t c = 2 * k + (lane >> 5);
+    uint32_t n = n0 + (((uint32_t)lane & 31u) ^ (c & 7u));
+    if (n >= end) n = end - 1;
+    const uint32_t u = n + gb;
+    dma16_so(sbase, (((u >> 5) * 16u + c) * 32u + (u & 31u)) * 16u, lds_tile + k * 1024);
+  }
+}
+
+struct B3Op { ngm_bf16x8 h, m, l; };
+template <int B>
+__device__ __forceinline__ B3Op b3_regs(const f32x16& v) {
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = v[8 * B + e];
+  B3Op o;
+  b3_split8(x, o.h, o.m, o.l);
+  return o;
+}
+__device__ __forceinline__ B3Op b3_rows(const float4& g0, const float4& g1) {
+  const float x[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  B3Op o;
+  b3_split8(x, o.h, o.m, o.l);
+  return o;
+}
+
+// dW[32 mo + .][32 mi + .] += sum_s dY[s][.] X[s][.] over the 16 samples of one k-block, both operands in the
+// lane = feature layout and already split.  Product-major: consecutive MFMAs go to different accumulators.
+__device__ __forceinline__ void wgrad_b3_block(const B3Op (&A)[2], const B3Op (&Bx)[2], f32x16 (&acc)[2][2]) {
+#define NGM_WG_PRODUCT(PA, PB_)                                                                       \
+  _Pragma("unroll") for (int mo = 0; mo < 2; ++mo)                                                    \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) acc[mo][mi] = mfma_bf16(A[mo].PA, Bx[mi].PB_, acc[mo][mi]); \
+  __builtin_amdgcn_sched_barrier(0)
+  NGM_WG_PRODUCT(l, h);
+  NGM_WG_PRODUCT(h, l);
+  NGM_WG_PRODUCT(m, m);
+  NGM_WG_PRODUCT(m, h);
+  NGM_WG_PRODUCT(h, m);
+  NGM_WG_PRODUCT(h, h);
+#undef NGM_WG_PRODUCT
+}
+// same MFMAs without scheduling fences, for regions whose order is given by NGM_INTERLEAVE
+__device__ __forceinline__ void wgrad_b3_block_free(const B3Op (&A)[2], const B3Op (&Bx)[2], f32x16 (&acc)[2][2]) {
+#define NGM_WG_PRODUCT(PA, PB_)                                                                       \
+  _Pragma("unroll") for (int mo = 0; mo < 2; ++mo)                                                    \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) acc[mo][mi] = mfma_bf16(A[mo].PA, Bx[mi].PB_, acc[mo][mi])
+  NGM_WG_PRODUCT(l, h);
+  NGM_WG_PRODUCT(h, l);
+  NGM_WG_PRODUCT(m, m);
+  NGM_WG_PRODUCT(m, h);
+  NGM_WG_PRODUCT(h, m);
+  NGM_WG_PRODUCT(h, h);
+#undef NGM_WG_PRODUCT
+}
+// scheduling directive for the region it closes: N times (1 MFMA, then K VALU instructions).  One wave per SIMD: an
+// MFMA occupies the matrix pipe for 32 clocks but the issue port for 4, and up to ~5 independent single-issue
+// instructions of the SAME wave go out in its shadow (MI355X_MICROARCH.md, "one wave per SIMD") -- so the operand
+// splits of the NEXT block are issued between the MFMAs of this one.
+#define NGM_INTERLEAVE(N, K)                                          \
+  _Pragma("unroll") for (int ii_ = 0; ii_ < (N); ++ii_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, (K), 0);               \
+  }
+
+template <int B>
+__device__ __forceinline__ void wgrad_b3_half(const f32x16 (&dY)[2], const f32x16 (&X)[2], f32x16 (&acc)[2][2]) {
+  B3Op A[2] = {b3_regs<B>(dY[0]), b3_regs<B>(dY[1])}, Bx[2] = {b3_regs<B>(X[0]), b3_regs<B>(X[1])};
+  __builtin_amdgcn_sched_barrier(0);
+  wgrad_b3_block(A, Bx, acc);
+}
+__device__ __forceinline__ B3Op b3_arr(const float (&x)[8]) {
+  B3Op o;
+  b3_split8(x, o.h, o.m, o.l);
+  return o;
+}
+
+// float offset of the 16-byte chunk c of sample s inside a tile
+__device__ __forceinline__ int tile_chunk(int c, int s) { return (c * 32 + (s ^ (c & 7))) * 4; }
+
+// rows of a tile for the data gradient's A operand (lane = sample n, k-half kh): chunks 4 kb + 2 kh, + 1 of every k-block
+struct RowRegs { float4 g[4][2]; };
+__device__ __forceinline__ void load_rows(const float* __restrict__ tile, int lane, RowRegs& R) {
+  const int n = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int c0 = 4 * kb + 2 * kh;
+    R.g[kb][0] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0, n));
+    R.g[kb][1] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0 + 1, n));
+  }
+}
+struct PlaneRegs { ngm_u32x4 h[2], m[2], l[2]; };
+__device__ __forceinline__ void load_planes(const ngm_u32x4* __restrict__ P, int kb, int lane, PlaneRegs& W) {
+  const int n = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int g = ((nt * 4 + kb) * 2 + kh) * 32 + n;
+    W.h[nt] = P[g]; W.m[nt] = P[PLANE_G + g]; W.l[nt] = P[2 * PLANE_G + g];
+  }
+}
+
+// dX^T[s][32 nt + n] = sum_o dY[s][o] W[o][32 nt + n]: A = rows of the tile (lane = sample, loaded by the caller well
+// ahead), B = weight planes, the next k-block's planes in flight under this one's MFMAs (one wave per SIMD: nothing
+// else hides the LDS latency).  W0 = planes of k-block 0, loaded by the caller.
+__device__ __forceinline__ void dgrad_b3_kb(const B3Op& A, const PlaneRegs& Wk, bool first, f32x16 (&dX)[2]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define NGM_DG_PRODUCT(PA, PW, Z) \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) dX[nt] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[nt]), (Z) ? zero : dX[nt]); \
+  __builtin_amdgcn_sched_barrier(0)
+  NGM_DG_PRODUCT(l, h, first);
+  NGM_DG_PRODUCT(h, l, false);
+  NGM_DG_PRODUCT(m, m, false);
+  NGM_DG_PRODUCT(m, h, false);
+  NGM_DG_PRODUCT(h, m, false);
+  NGM_DG_PRODUCT(h, h, false);
+#undef NGM_DG_PRODUCT
+}
+__device__ __forceinline__ void dgrad_b3(const ngm_u32x4* __restrict__ P, const RowRegs& R, const PlaneRegs& W0, int lane, f32x16 (&dX)[2]) {
+  PlaneRegs Wa, Wb;
+  load_planes(P, 1, lane, Wb);
+  { const B3Op A = b3_rows(R.g[0][0], R.g[0][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, W0, true, dX); }
+  __builtin_amdgcn_sched_barrier(0);
+  load_planes(P, 2, lane, Wa);
+  { const B3Op A = b3_rows(R.g[1][0], R.g[1][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wb, false, dX); }
+  __builtin_amdgcn_sched_barrier(0);
+  load_planes(P, 3, lane, Wb);
+  { const B3Op A = b3_rows(R.g[2][0], R.g[2][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wa, false, dX); }
+  __builtin_amdgcn_sched_barrier(0);
+  { const B3Op A = b3_rows(R.g[3][0], R.g[3][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wb, false, dX); }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// weight planes of layer l for the data gradient: granule (plane, nt, kb, kh, n) = W[16 kb + 8 kh + e][32 nt + n], e = 0..7
+__device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int l, ngm_u32x4* P) {
+  const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
+  const float* W = pr.w[l];
+  const int64_t w0 = row * pr.w_stride[l];
+  for (int g = threadIdx.x; g < PLANE_G; g += B3B_THREADS) {
+    const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
+    const int c = 32 * nt + n;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = 16 * kb + 8 * kh + e;
+      x[e] = (o < H && c < Din) ? ngm_ldp(W, w0 + (int64_t)o * Din + c, pr.dtype) : 0.f;
+    }
+    ngm_bf16x8 h, m, lo;
+    b3_split8(x, h, m, lo);
+    P[g] = __builtin_bit_cast(ngm_u32x4, h);
+    P[PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, m);
+    P[2 * PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, lo);
+  }
+}
+
+// encoding row of feature f: (w.x, w.y, w.z, kind) -- the table FieldStage16::issue builds, one entry per lane here
+__device__ __forceinline__ float4 enc_row_of(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int f) {
+  float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
+  if (f >= fc.dim_enc) return e;
+  if (fc.encoding == NGM_ENC_FOURIER) {
+    const int n_raw = fc.raw_coords ? 3 : 0;
+    if (f < n_raw) return make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+    const int64_t e0 = row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
+    return make_float4(ngm_ldp(pr.enc_w, e0, pr.dtype), ngm_ldp(pr.enc_w, e0 + 1, pr.dtype), ngm_ldp(pr.enc_w, e0 + 2, pr.dtype), NGM_FK_SIN);
+  }
+  if (fc.encoding == NGM_ENC_NERF) {
+    const int half = 3 * fc.num_octaves;
+    const int g = (f < half) ? f : f - half;
+    const int d = g / fc.num_octaves, o = g % fc.num_octaves;
+    const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
+    return make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
+  }
+  return make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int L, bool NEED_COS, bool ENC_GRAD>
+__global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  using LY = LdsB3b<L, ENC_GRAD>;
+  const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, hi = lane >> 5;
+  ngm_u32x4* planes = reinterpret_cast<ngm_u32x4*>(sm);
+  float* wl = sm + LY::PLANES + wave * LY::WAVE_TOTAL;
+  float* inb = wl + LY::INB;
+  float* pbuf = wl + LY::PB;
+  float* obuf = wl + LY::OB;
+  const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wl);
+
+  f32x16 acc[L][2][2];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[l][mo][mi][r] = 0.f;
+  float dbh[L][2], dwo[2][4], dwf[2][3], dbo[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) dbh[l][m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dwo[m][c] = 0.f;
+    dwf[m][0] = dwf[m][1] = dwf[m][2] = 0.f;
+  }
+  dbo[0] = dbo[1] = dbo[2] = dbo[3] = 0.f;
+
+  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
+  const uint32_t first = beg + 32u * (uint32_t)wave;
+  constexpr uint32_t TSTRIDE = 32 * B3B_WAVES;
+  FieldStreams fs;
+  {
+    const int64_t g0 = (int64_t)f * a.P;
+    fs.raytab = reinterpret_cast<const char*>(a.raytab) + 32 * (g0 / a.S);
+    fs.dout = reinterpret_cast<const char*>(a.d_out + g0);
+    fs.tpair = reinterpret_cast<const char*>(a.stashB + (g0 & ~(int64_t)1));
+    fs.par = (uint32_t)(g0 & 1);
+    fs.gb = (uint32_t)(g0 & 31);
+    fs.act[0] = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 2048);
+    fs.act[1] = reinterpret_cast<const char*>(a.act + a.act_layer_stride + (g0 >> 5) * 2048);
+  }
+  // first tile's transfers, then the per-lane constants and the weight planes while they are in flight
+  if (first < end) {
+    issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
+    issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+    issue_tile32(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::HL * 4);
+    if (L == 2) issue_tile32(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::H1 * 4);
+  }
+  // per-feature constants (output-layer column, encoding row): LDS, re-read by the phase that needs them -- as
+  // loop-long register residents they were spilled to scratch, and a scratch reload waits on vmcnt, i.e. on the DMA
+  float4* cwout = reinterpret_cast<float4*>(sm + LY::CONSTS);
+  float4* cenc = cwout + 64;
+  if (threadIdx.x < 64) {
+    const int ft = threadIdx.x, H = a.fc.dim_hidden;
+    const float* W = a.pr.w[L];
+    const int64_t w0 = row * a.pr.w_stride[L];
+    cwout[ft] = (ft < H) ? make_float4(ngm_ldp(W, w0 + ft, a.pr.dtype), ngm_ldp(W, w0 + H + ft, a.pr.dtype),
+                                       ngm_ldp(W, w0 + 2 * H + ft, a.pr.dtype), ngm_ldp(W, w0 + 3 * H + ft, a.pr.dtype))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    cenc[ft] = enc_row_of(a.fc, a.pr, row, ft);
+  }
+  if (ENC_GRAD) build_dgrad_planes(a.fc, a.pr, row, 0, planes + LY::plane_slot(0) * 3 * PLANE_G);
+  if (L == 2) build_dgrad_planes(a.fc, a.pr, row, 1, planes + LY::plane_slot(1) * 3 * PLANE_G);
+  __syncthreads();
+
+  // lane-constant LDS offsets (floats): column element (feature 32 m + i, sample frow(r, hi)) of a tile sits at
+  //   m * 1024 + (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))
+  int col[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
+#define COL_OFF(m, r) ((m) * 1024 + col[(r) & 3] + 32 * ((r) >> 2))
+
+  DMA_WAIT(0);
+  TICK_DECL;
+  TICK(0);
+  for (uint32_t base = first; base < end; base += TSTRIDE) {
+    const uint32_t nxt = base + TSTRIDE;
+    const bool more = nxt < end;
+    float* HLb = wl + LY::HL;
+    float* H1b = wl + LY::H1;
+    // ---- inputs: lane = sample (both halves compute, half 0 stores)
+    {
+      const int j = i, h = j >> 4, jj = j & 15;
+      const float4* in4 = reinterpret_cast<const float4*>(inb) + 64 * h;
+      const float4 r0 = in4[jj], r1 = in4[16 + jj], dd = in4[32 + jj], sp = in4[48 + jj];
+      const uint32_t n = base + (uint32_t)j;
+      const bool valid = n < end;
+      const uint32_t nc = valid ? n : end - 1;
+      const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
+      const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
+      const float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
+      WAVE_SYNC();
+      if (hi == 0) {
+        *reinterpret_cast<float4*>(pbuf + 4 * j) = make_float4(x, y, z, 0.f);
+        *reinterpret_cast<float4*>(obuf + 4 * j) = dout;
+        dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w;
+      }
+      WAVE_SYNC();
+    }
+    TICK(1);
+    // ---- output layer, lane = feature: dY = relu'(H) * (Wout^T d_out); output-weight and bias gradients.
+    // Every LDS read of a phase is issued at its top (sched_barrier keeps it there): one wave per SIMD, so the latency
+    // is hidden by this wave's own arithmetic or not at all.
+    f32x16 dY[2], Xc[2];
+    {
+      f32x16 Hc[2];
+      const float4 wout[2] = {cwout[i], cwout[32 + i]};
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hc[m][r] = HLb[COL_OFF(m, r)];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float4 dO[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dO[e] = *reinterpret_cast<const float4*>(obuf + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * half + e;
+          const float4 d = dO[e];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const float h = Hc[m][r];
+            const float dh = fmaf(wout[m].w, d.w, fmaf(wout[m].z, d.z, fmaf(wout[m].y, d.y, wout[m].x * d.x)));
+            const float g = (h > 0.f) ? dh : 0.f;
+            dY[m][r] = g;
+            dbh[L - 1][m] += g;
+            dwo[m][0] = fmaf(d.x, h, dwo[m][0]); dwo[m][1] = fmaf(d.y, h, dwo[m][1]);
+            dwo[m][2] = fmaf(d.z, h, dwo[m][2]); dwo[m][3] = fmaf(d.w, h, dwo[m][3]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      WAVE_SYNC();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) HLb[COL_OFF(m, r)] = dY[m][r];
+      WAVE_SYNC();
+    }
+    TICK(4);
+    float* Dtile = HLb;              // tile holding, as rows, dY of the layer whose input gradients come next
+    if constexpr (L == 2) {
+      RowRegs R;
+      PlaneRegs W0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, B0[2] = {b3_regs<0>(Xc[0]), b3_regs<0>(Xc[1])};
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(HLb, lane, R);       // consumed after the weight gradient
+        load_planes(planes + LY::plane_slot(1) * 3 * PLANE_G, 0, lane, W0);
+        B3Op A1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, B1[2] = {b3_regs<1>(Xc[0]), b3_regs<1>(Xc[1])};
+        wgrad_b3_block_free(A0, B0, acc[1]);
+        NGM_INTERLEAVE(24, 8)
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad_b3_block(A1, B1, acc[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TICK(6);
+      f32x16 dX[2];
+      dgrad_b3(planes + LY::plane_slot(1) * 3 * PLANE_G, R, W0, lane, dX);
+      TICK(7);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float g = (Xc[m][r] > 0.f) ? dX[m][r] : 0.f;
+          dY[m][r] = g;
+          dbh[0][m] += g;
+        }
+      WAVE_SYNC();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1b[COL_OFF(m, r)] = dY[m][r];
+      WAVE_SYNC();
+      Dtile = H1b;
+      TICK(9);
+    }
+    // ---- layer 0.  Data gradient first (only dY's rows are needed), so that cos(.) never has to be kept: the encoding
+    // is then evaluated k-block by k-block, each value feeding the Fourier-matrix gradient and the weight-gradient operand
+    f32x16 dE[2];
+    if constexpr (ENC_GRAD) {
+      RowRegs R0;
+      PlaneRegs W00;
+      load_rows(Dtile, lane, R0);
+      load_planes(planes + LY::plane_slot(0) * 3 * PLANE_G, 0, lane, W00);
+      __builtin_amdgcn_sched_barrier(0);
+      dgrad_b3(planes + LY::plane_slot(0) * 3 * PLANE_G, R0, W00, lane, dE);
+    }
+    TICK(8);
+    const float4 encw[2] = {cenc[i], cenc[32 + i]};
+    float Eb[2][2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float4 pp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pp[e] = *reinterpret_cast<const float4*>(pbuf + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+      __builtin_amdgcn_sched_barrier(0);
+      const float inv2pi = 0.15915494309189535f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float4 p = pp[e];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float4 w = encw[m];
+          const float arg = fmaf(w.z, p.z, fmaf(w.y, p.y, w.x * p.x));
+          const float rev = __builtin_amdgcn_fractf(arg * inv2pi);
+          const float sn = __builtin_amdgcn_sinf(rev);
+          float v = sn;
+          if (NEED_COS) v = (w.w == NGM_FK_COS) ? __builtin_amdgcn_cosf(rev) : sn;
+          if (m == 0) v = (w.w == NGM_FK_RAW) ? arg : v;            // raw coordinates are features 0..2
+          Eb[b][m][e] = v;
+          if (ENC_GRAD) {    // Fourier only: d sin(w.x)/d w = cos(w.x) x; raw rows carry no weight (their slot is never written)
+            const float g = dE[m][8 * b + e] * __builtin_amdgcn_cosf(rev);
+            dwf[m][0] = fmaf(g, p.x, dwf[m][0]); dwf[m][1] = fmaf(g, p.y, dwf[m][1]); dwf[m][2] = fmaf(g, p.z, dwf[m][2]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- next tile's transfers + this tile's last matrix work.  On gfx950 a wave's LDS instructions crawl while it
+    // has HBM -> LDS transfers it has not waited for (tools/micro/dma_lds.hip: 8 ds_read_b128 behind 8 transfers cost
+    // 1400 clocks instead of 250, whether the data has long arrived or not), and with one wave per SIMD nobody fills
+    // such holes.  So the transfers are issued where every landing buffer is free and NO LDS instruction follows until
+    // the wait: under the layer-0 weight gradient (48 MFMAs + operand splits, registers only).
+    WAVE_SYNC();
+    TICK(3);
+    if (more) {
+      issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
+      issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+      issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
+      if (L == 2) issue_tile32(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::H1 * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(5);
+    {
+      B3Op A[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, Bx[2] = {b3_arr(Eb[0][0]), b3_arr(Eb[0][1])};
+      __builtin_amdgcn_sched_barrier(0);
+      wgrad_b3_block(A, Bx, acc[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      B3Op A[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, Bx[2] = {b3_arr(Eb[1][0]), b3_arr(Eb[1][1])};
+      __builtin_amdgcn_sched_barrier(0);
+      wgrad_b3_block(A, Bx, acc[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(10);
+    DMA_WAIT(0);
+    TICK(2);
+    WAVE_SYNC();
+  }
+#undef COL_OFF
+  __syncthreads();
+
+  // ---- epilogue: the four waves' accumulators are summed in fixed wave order (all of LDS is free now)
+  float* stage = sm;
+  constexpr int NT = LY::NT;
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(wave * NT + (l * 4 + mo * 2 + mi)) * 1024 + r * 64 + lane] = acc[l][mo][mi][r];
+  __syncthreads();
+  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
+  (void)ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
+  float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
+  const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
+  for (int e = threadIdx.x; e < NT * 1024; e += B3B_THREADS) {
+    float s0 = 0.f;
+#pragma unroll
+    for (int w = 0; w < B3B_WAVES; ++w) s0 += stage[w * NT * 1024 + e];
+    const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    const int l = t >> 2, mo = (t >> 1) & 1, mi = t & 1;
+    const int o = 32 * mo + frow(r, ln >> 5), c = 32 * mi + (ln & 31), din = (l == 0) ? D : H;
+    if (o < H && c < din) dst[w_off[l] + (int64_t)o * din + c] = s0;
+  }
+  __syncthreads();
+  // per-feature vectors: lane (i, hi) holds the partial sums of feature 32 m + i over its half of the samples
+  constexpr int NV = 2 * L + 8 + 6 + 4;
+  {
+    float* sw = stage + wave * NV * 64;
+    int k = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) sw[(k++) * 64 + lane] = dbh[l][m];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sw[(k++) * 64 + lane] = dwo[m][c];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sw[(k++) * 64 + lane] = dwf[m][c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sw[(k++) * 64 + lane] = wave_sum(dbo[c]);
+  }
+  __syncthreads();
+  const bool fourier = ENC_GRAD && a.fc.encoding == NGM_ENC_FOURIER;
+  const int n_raw = a.fc.raw_coords ? 3 : 0;
+  for (int e = threadIdx.x; e < NV * 32; e += B3B_THREADS) {
+    const int k = e >> 5, ii = e & 31;
+    float s0 = 0.f;
+#pragma unroll
+    for (int w = 0; w < B3B_WAVES; ++w) s0 += stage[(w * NV + k) * 64 + ii] + stage[(w * NV + k) * 64 + 32 + ii];
+    if (k < 2 * L) {
+      const int l = k >> 1, ft = 32 * (k & 1) + ii;
+      if (ft < H) dst[b_off[l] + ft] = s0;
+    } else if (k < 2 * L + 8) {
+      const int u = k - 2 * L, ft = 32 * (u >> 2) + ii, c = u & 3;
+      if (ft < H) dst[w_off[L] + (int64_t)c * H + ft] = s0;
+    } else if (k < 2 * L + 14) {
+      const int u = k - 2 * L - 8, ft = 32 * (u / 3) + ii, c = u % 3;
+      if (fourier && ft < D && ft >= n_raw) dst[enc_off + (int64_t)(ft - n_raw) * 3 + c] = s0;
+    } else if (ii == 0) {
+      dst[b_off[L] + (k - 2 * L - 14)] = 0.5f * s0;     // wave_sum put the total into every lane: both halves counted it
+    }
+  }
+  if (!fourier)   // the encoding slot of the partial vector (if any) carries no gradient
+    for (int64_t p = enc_off + threadIdx.x; p < w_off[0]; p += B3B_THREADS) dst[p] = 0.f;
+  TICK(11);
+  TICK_REPORT
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int L>
+static int launch_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+#define NGM_LBB3(NC, EG)                                                                                              \
+  do {                                                                                                                \
+    const size_t lds = (size_t)LdsB3b<L, EG>::TOTAL * sizeof(float);                                                  \
+    if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;                                                                   \
+    (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)lds);                                                                              \
+    hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);                     \
+  } while (0)
+  if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LBB3(false, true);
+  else if (a.fc.encoding == NGM_ENC_NERF) NGM_LBB3(true, false);
+  else NGM_LBB3(false, false);
+#undef NGM_LBB3
+  return 0;
+}
+
+// returns NGM_E_UNSUPPORTED when this variant does not apply (caller falls back to the fp32-MFMA kernels)
+int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const int MI = (a.fc.dim_enc + 31) / 32, MH = (a.fc.dim_hidden + 31) / 32, L = a.fc.num_layers;
+  if (!a.act || a.points || a.fc.skip_mode != NGM_SKIP_NO || a.fc.matmul_mode == NGM_MATMUL_F32 || MI != 2 || MH != 2 || L < 1 || L > 2)
+    return NGM_E_UNSUPPORTED;
+  if (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NERF && a.fc.encoding != NGM_ENC_NONE) return NGM_E_UNSUPPORTED;
+  if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
+  NgmProfScope prof_(NGM_K_FIELD_BWD, st);
+  if (L == 2) return launch_bwd_b3<2>(a, blocks, st);
+#ifndef NGM_FAST_BUILD
+  if (L == 1) return launch_bwd_b3<1>(a, blocks, st);
+#endif
+  return NGM_E_UNSUPPORTED;
+}

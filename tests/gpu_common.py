@@ -169,10 +169,10 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
     raise AssertionError("kink_free_draws did not converge")
 
 
-def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0):
+def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0, **ckw_extra):
     torch.manual_seed(F * 1000 + R)
     ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geometry_mode,
-               geometry_factor=geometry_factor)
+               geometry_factor=geometry_factor, **ckw_extra)
     pos, quat, t = synth_target(F, R, seed=R)
     fs = O.FieldSpec(**fkw)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,

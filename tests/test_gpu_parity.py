@@ -663,14 +663,26 @@ def test_ragged_shapes_vs_oracle(F, R, n_c, n_g):
     ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=32, num_layers=1))
 
 
+@pytest.mark.parametrize("mm,variant", [("f32", 2), ("auto", 3)])
 @pytest.mark.parametrize("F,R,n_c,n_g,layers", [(2, 33, 1, 1, 2), (5, 7, 8, 16, 2), (3, 130, 20, 4, 2), (3, 37, 5, 2, 1),
-                                                (1, 1, 128, 0, 2)])
-def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers):
-    """64-wide layers: the training forward stashes the hidden activations and k_field_bwd16s consumes them
-    (partial 16-sample tiles, fields that start in the middle of a 32-sample stash tile)."""
-    ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers))
+                                                (1, 1, 128, 0, 2), (2, 9, 31, 0, 1)])
+def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
+    """64-wide layers: the training forward stashes the hidden activations and the backward consumes them --
+    k_field_bwd16s (fp32 MFMA, 16-sample tiles) or k_field_bwd_b3 (three-way bf16 split, 32-sample tiles): partial
+    tiles, fields that start in the middle of a 32-sample stash tile.  Same tolerances for both."""
+    ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
     from neural_graph_mapping_amd import _capi
-    assert _capi.lib().ngm_debug_last_bwd_variant() == 2
+    assert _capi.lib().ngm_debug_last_bwd_variant() == variant
+
+
+@pytest.mark.parametrize("enc", ["nerf", "fourier61"])
+def test_stash_backward_bf16_split_other_encodings(enc):
+    """NeRF octaves (no encoding gradient: one weight plane set) and zero-padded widths (61 of 64 features)."""
+    fkw = (dict(encoding="nerf", num_octaves=10, num_layers=2) if enc == "nerf" else
+           dict(encoding="fourier", dim_enc=61, num_layers=2))
+    ragged_case(3, 41, 9, 5, fkw, mlp_matmul="auto")
+    from neural_graph_mapping_amd import _capi
+    assert _capi.lib().ngm_debug_last_bwd_variant() == 3
 
 
 # ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)

@@ -291,7 +291,7 @@ def init_params_np(fc, F, seed=0, sigma=4.0):
 def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
     L = K.lib()
     fc = (K.field_cfg(encoding="permuto", num_layers=1) if hash_enc
-          else K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2))
+          else K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, matmul_mode=os.environ.get("NGM_MATMUL", "f32")))
     rc = K.render_cfg(num_samples_coarse=S_c, num_samples_guided=S_g, **NRGBD)
     b = synth_batch(F, R, S_c, S_g)
     params = init_params_np(fc, F)
@@ -333,6 +333,9 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
         if L.ngm_debug_phase_cycles(buf) == 0:
             names = ["prologue", "inputs", "encode", "fwd", "outlayer", "stage+colsum", "wgrad", "dgrad", "encgrad",
                      "relumask", "-", "epilogue", "TOTAL"]
+            if L.ngm_debug_last_bwd_variant() == 3:
+                names = ["prologue", "inputs", "dma_wait", "encode", "outlayer", "dma_issue", "wgrad1", "dgrad1", "dgrad0",
+                         "mask+store", "wgrad0", "epilogue", "TOTAL"]
             tot = buf[12] or 1
             print("phase cycles (wave 0, block 0):", {n: (int(buf[i]), round(100 * buf[i] / tot, 1)) for i, n in enumerate(names)})
             tl = ["entry", "prologue", "tile", "loopend", "barrier", "end"]

@@ -189,18 +189,39 @@ __device__ __forceinline__ void dgrad_b3_kb(const B3Op& A, const PlaneRegs& Wk, 
   NGM_DG_PRODUCT(h, h, false);
 #undef NGM_DG_PRODUCT
 }
+__device__ __forceinline__ void dgrad_b3_kb_free(const B3Op& A, const PlaneRegs& Wk, bool first, f32x16 (&dX)[2]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define NGM_DG_PRODUCT(PA, PW, Z) \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) dX[nt] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[nt]), (Z) ? zero : dX[nt])
+  NGM_DG_PRODUCT(l, h, first);
+  NGM_DG_PRODUCT(h, l, false);
+  NGM_DG_PRODUCT(m, m, false);
+  NGM_DG_PRODUCT(m, h, false);
+  NGM_DG_PRODUCT(h, m, false);
+  NGM_DG_PRODUCT(h, h, false);
+#undef NGM_DG_PRODUCT
+}
+// k-block kb's 12 MFMAs share their scheduling region with the row split of k-block kb + 1 (and the plane reads of kb + 1)
 __device__ __forceinline__ void dgrad_b3(const ngm_u32x4* __restrict__ P, const RowRegs& R, const PlaneRegs& W0, int lane, f32x16 (&dX)[2]) {
   PlaneRegs Wa, Wb;
+  const B3Op A0 = b3_rows(R.g[0][0], R.g[0][1]);
+  __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 1, lane, Wb);
-  { const B3Op A = b3_rows(R.g[0][0], R.g[0][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, W0, true, dX); }
+  const B3Op A1 = b3_rows(R.g[1][0], R.g[1][1]);
+  dgrad_b3_kb_free(A0, W0, true, dX);
+  NGM_INTERLEAVE(12, 4)
   __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 2, lane, Wa);
-  { const B3Op A = b3_rows(R.g[1][0], R.g[1][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wb, false, dX); }
+  const B3Op A2 = b3_rows(R.g[2][0], R.g[2][1]);
+  dgrad_b3_kb_free(A1, Wb, false, dX);
+  NGM_INTERLEAVE(12, 4)
   __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 3, lane, Wb);
-  { const B3Op A = b3_rows(R.g[2][0], R.g[2][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wa, false, dX); }
+  const B3Op A3 = b3_rows(R.g[3][0], R.g[3][1]);
+  dgrad_b3_kb_free(A2, Wa, false, dX);
+  NGM_INTERLEAVE(12, 4)
   __builtin_amdgcn_sched_barrier(0);
-  { const B3Op A = b3_rows(R.g[3][0], R.g[3][1]); __builtin_amdgcn_sched_barrier(0); dgrad_b3_kb(A, Wb, false, dX); }
+  dgrad_b3_kb(A3, Wb, false, dX);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -497,15 +518,13 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     TICK(5);
     {
-      B3Op A[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, Bx[2] = {b3_arr(Eb[0][0]), b3_arr(Eb[0][1])};
+      B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, B0[2] = {b3_arr(Eb[0][0]), b3_arr(Eb[0][1])};
       __builtin_amdgcn_sched_barrier(0);
-      wgrad_b3_block(A, Bx, acc[0]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      B3Op A[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, Bx[2] = {b3_arr(Eb[1][0]), b3_arr(Eb[1][1])};
+      B3Op A1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, B1[2] = {b3_arr(Eb[1][0]), b3_arr(Eb[1][1])};
+      wgrad_b3_block_free(A0, B0, acc[0]);
+      NGM_INTERLEAVE(24, 8)
       __builtin_amdgcn_sched_barrier(0);
-      wgrad_b3_block(A, Bx, acc[0]);
+      wgrad_b3_block(A1, B1, acc[0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(10);

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   // ---- epilogue: the four waves' accumulators are summed in fixed wave order (all of LDS is free now)
   float* stage = sm;
   constexpr int NT = LY::NT;
+  // staging layout [wave][tile][q = r >> 2][lane][4 floats]: 16-byte LDS accesses on both sides
 #pragma unroll
   for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -545,20 +546,33 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stage[(wave * NT + (l * 4 + mo * 2 + mi)) * 1024 + r * 64 + lane] = acc[l][mo][mi][r];
+        for (int q = 0; q < 4; ++q) {
+          const f32x16& c = acc[l][mo][mi];
+          *reinterpret_cast<float4*>(stage + (((wave * NT + (l * 4 + mo * 2 + mi)) * 4 + q) * 64 + lane) * 4) =
+              make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        }
   __syncthreads();
   int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
   (void)ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
   float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
   const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
-  for (int e = threadIdx.x; e < NT * 1024; e += B3B_THREADS) {
-    float s0 = 0.f;
+  for (int e4 = threadIdx.x; e4 < NT * 256; e4 += B3B_THREADS) {
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int w = 0; w < B3B_WAVES; ++w) s0 += stage[w * NT * 1024 + e];
-    const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    for (int w = 0; w < B3B_WAVES; ++w) {                           // fixed wave order: deterministic
+      const float4 v = *reinterpret_cast<const float4*>(stage + (w * NT * 256 + e4) * 4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    const int t = e4 >> 8, q = (e4 >> 6) & 3, ln = e4 & 63;
     const int l = t >> 2, mo = (t >> 1) & 1, mi = t & 1;
-    const int o = 32 * mo + frow(r, ln >> 5), c = 32 * mi + (ln & 31), din = (l == 0) ? D : H;
-    if (o < H && c < din) dst[w_off[l] + (int64_t)o * din + c] = s0;
+    const int o0 = 32 * mo + 8 * q + 4 * (ln >> 5), c = 32 * mi + (ln & 31), din = (l == 0) ? D : H;   // rows frow(4q + j, hi) = o0 + j
+    if (c < din) {
+      float* d = dst + w_off[l] + (int64_t)o0 * din + c;
+      if (o0 < H) d[0] = s4.x;
+      if (o0 + 1 < H) d[din] = s4.y;
+      if (o0 + 2 < H) d[2 * din] = s4.z;
+      if (o0 + 3 < H) d[3 * din] = s4.w;
+    }
   }
   __syncthreads();
   // per-feature vectors: lane (i, hi) holds the partial sums of feature 32 m + i over its half of the samples

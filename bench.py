@@ -34,7 +34,8 @@ FLOP_BWD = 2 * FLOP_FWD                          # wgrad + dgrad: 33 792 flop / 
 PEAK_F32_MFMA_TF = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 SPIN_UP = 200                                    # untimed iterations before the warm-up (clock ramp of an idle GPU, ~60 ms)
 DTYPE_LABEL = {"f32": "f32",
-               "bf16x3": "f32 via 3xbf16 split, fp32 accumulate (forward hidden layers); f32 MFMA (backward)"}
+               "bf16x3": "f32 via 3xbf16 split, fp32 accumulate (hidden-layer matrix products, forward and backward); "
+                         "everything else f32"}
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -356,14 +357,15 @@ def main():
     torch.cuda.synchronize()
     kern = {}
     L.ngm_profile_enable(0)
+    bwd_variant = L.ngm_debug_last_bwd_variant()     # of the measured path (read before the side measurement below runs the other one)
     for name, kid in K.KERNEL_IDS.items():
         ms, n = C.c_double(0), C.c_int64(0)
         L.ngm_profile_read(kid, C.byref(ms), C.byref(n))
         if n.value:
             kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
 
-    # side measurement, after and outside the timed region above: the same K steps with the OTHER arithmetic of the forward's
-    # hidden layers (exact-fp32 MFMA <-> exact three-way bf16 split), so that one line carries both
+    # side measurement, after and outside the timed region above: the same K steps with the OTHER arithmetic of the hidden
+    # layers' matrix products (exact-fp32 MFMA <-> exact three-way bf16 split, forward and backward), so that one line carries both
     side = None
     if world == 1 and args.variant == "fourier" and args.matmul == "auto" and not strong:
         other = "f32" if r.mlp_matmul == "bf16x3" else "bf16x3"
@@ -413,16 +415,25 @@ def main():
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/pmc_field_bwd.json: separate rocprofv3 --pmc pass of this workload, NOT this run"
-            variant = K.lib().ngm_debug_last_bwd_variant()
+            variant = bwd_variant
             kname = {0: "k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32, forward recompute)",
                      1: "k_field_bwd16<4,4,2> (v_mfma_f32_16x16x4_f32, forward recompute)",
-                     2: "k_field_bwd16s<2> (v_mfma_f32_16x16x4_f32, activations from the forward's stash)"}.get(variant, "?")
+                     2: "k_field_bwd16s<2> (v_mfma_f32_16x16x4_f32, activations from the forward's stash)",
+                     3: "k_field_bwd_b3<2> (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash)"
+                     }.get(variant, "?")
             res["roofline"] = dict(bound="mfma", kernel=kname, achieved=achieved,
                                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
                                    traffic=traffic, traffic_source=traffic_src, avg_launch_us=fb["avg_us"],
                                    launches_timed=fb["launches"],
                                    timing="HIP events on the launch stream, instrumented pass of the same steps",
                                    algorithmic_flop_per_launch=FLOP_BWD * n_local)
+            if variant == 3:    # both fractions, as for the forward: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
+                issued_b = 6 * 2 * 4 * (64 * 64) * n_local         # weight + data gradient of both 64x64 layers, six bf16 products each
+                res["roofline"].update(issued_bf16_tflops=issued_b / (fb["avg_us"] * 1e-6) / 1e12, peak_bf16=2500.0,
+                                       frac_bf16=issued_b / (fb["avg_us"] * 1e-6) / 1e12 / 2500.0,
+                                       note="frac = algorithmic fp32 flops against the fp32 MFMA peak (the arithmetic is fp32-exact "
+                                            "products on the bf16 pipe, so it may exceed what fp32 MFMA could reach); frac_bf16 = "
+                                            "issued bf16 flops against the dense bf16 peak")
             if ff:      # the second MFMA kernel and the whole step against the same peak (algorithmic MLP flops only)
                 a_f = FLOP_FWD * n_local / (ff["avg_us"] * 1e-6) / 1e12
                 res["roofline_fwd"] = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=a_f,

@@ -39,14 +39,17 @@ enum ngm_status {
 enum ngm_encoding { NGM_ENC_NONE = 0, NGM_ENC_FOURIER = 1, NGM_ENC_NERF = 2, NGM_ENC_PERMUTO = 3, NGM_ENC_TRIPLANE = 4 };
 enum ngm_triplane_mode { NGM_TRI_SUM = 0, NGM_TRI_PRODUCT = 1, NGM_TRI_CONCAT = 2 };   /* positional_encodings.py:152-161 */
 enum ngm_skip_mode { NGM_SKIP_NO = 0, NGM_SKIP_ADD = 1, NGM_SKIP_CONCAT = 2 }; /* models.py:159-180; rezero: the reference's constructor raises */
-/* Arithmetic of the hidden layers in the forward kernels (fused render, point evaluation, kNN evaluation).
+/* Arithmetic of the hidden layers' matrix products: forward kernels (fused render, point evaluation, kNN evaluation)
+ * and the fused training step's MLP backward.
  * NGM_MATMUL_F32: exact-fp32 MFMA.  NGM_MATMUL_BF16X3: every fp32 operand is split exactly into three bf16
  * (hi + mid + lo) and the six leading cross products are summed in fp32 on the bf16 matrix pipe -- fp32-level accuracy
  * (dropped terms < 2^-23 relative), not narrower arithmetic; bitwise deterministic; compiled for 33..64-wide layers,
  * <= 2 hidden layers, Fourier / no encoding, skip_mode no.  As an explicit request ngm_render_fwd returns
  * NGM_E_UNSUPPORTED where it is not compiled or its weight planes (24 KB of LDS per layer) do not fit -- never a silent
  * fallback.  NGM_MATMUL_AUTO: the split wherever it is compiled and fits, exact-fp32 MFMA otherwise (resolved per batch
- * shape by the same plan in forward and backward).  The backward kernels always use fp32 MFMA. */
+ * shape by the same plan in forward and backward).  The fused step's MLP backward follows the mode on its own terms:
+ * F32 -> fp32 MFMA; BF16X3 / AUTO -> the split kernel where it is compiled (49..64-wide layers, 1-2 hidden layers,
+ * Fourier / NeRF / no encoding, skip_mode no, activation stash present), fp32 MFMA otherwise. */
 enum ngm_matmul_mode { NGM_MATMUL_F32 = 0, NGM_MATMUL_BF16X3 = 1, NGM_MATMUL_AUTO = 2 };
 enum ngm_param_dtype { NGM_DT_F32 = 0, NGM_DT_BF16 = 1, NGM_DT_F16 = 2 };   /* storage type of the weights (ngm_params.dtype) */
 enum ngm_scale_mode { NGM_SCALE_NO = 0, NGM_SCALE_UNIT_BALL = 1, NGM_SCALE_UNIT_CUBE = 2 };
@@ -91,7 +94,7 @@ typedef struct ngm_field_cfg {
                               /* hidden layer (models.py:162-169); needs dim_hidden >= dim_enc.  "concat"       */
                               /* appends it (models.py:159-161): layers 1..L (incl. the output layer) then have */
                               /* H + D inputs, "_linears.{i}.weight" is (out_i, H + D) for i >= 1               */
-  int32_t matmul_mode;        /* ngm_matmul_mode of the fused forward's hidden layers (other kernels: fp32 MFMA) */
+  int32_t matmul_mode;        /* ngm_matmul_mode of the hidden layers' matrix products (see the enum)             */
   /* triplane encoding (positional_encodings.py:69-161): three (C, res, res) feature planes per field, bilinear lookup
    * (grid_sample, align_corners, border padding) of the (x,y), (x,z), (y,z) projections of a point in [-1,1]^3,
    * combined per ngm_triplane_mode; dim_enc = C (sum, product) or 3 C (concat) */

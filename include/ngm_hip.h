@@ -447,8 +447,12 @@ int ngm_debug_fwd_phase_cycles(unsigned long long* out528);   /* 16 summary slot
 
 /* Debug: which MLP backward kernel the last ngm_render_bwd* / ngm_field_eval_bwd call launched:
  * 0 = k_field_bwd (32-sample tiles, forward recompute), 1 = k_field_bwd16 (16-sample tiles, recompute),
- * 2 = k_field_bwd16s (16-sample tiles, hidden activations read from the forward's stash), -1 = none yet. */
+ * 2 = k_field_bwd16s (16-sample tiles, hidden activations read from the forward's stash), 3 = k_field_bwd_b3 (three-way
+ * bf16 split, 32-sample tiles, stash), 4 = k_field_bwd_b3p (the same on two waves per tile), -1 = none yet. */
 int ngm_debug_last_bwd_variant(void);
+/* Experiments: 1 = try k_field_bwd_b3p (a tile's two hidden layers on two waves; correct, ~9 % slower than k_field_bwd_b3
+ * as measured in round 2) before the default order; 0 = default.  Returns the previous setting. */
+int ngm_debug_prefer_paired_bwd(int on);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,8 @@ static int fail(int code, const char* msg) {
 // prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
 #define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
-static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash
+static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile
+static int g_prefer_paired_bwd = 0;
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
   static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
@@ -103,8 +104,11 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   // order of preference: stashed activations (no forward recompute) -> 16-sample-tile recompute ->
   // 32-sample-tile recompute
   static const bool no_b3 = getenv("NGM_NO_BWD_B3") != nullptr;
-  int e = (force32 || no_b3 || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3(a, blocks, st);
-  g_last_bwd_variant = 3;
+  static const bool env_b3p = getenv("NGM_BWD_B3P") != nullptr;
+  const bool try_b3p = env_b3p || g_prefer_paired_bwd;
+  int e = (force32 || no_b3 || !try_b3p || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3p(a, blocks, st);
+  g_last_bwd_variant = 4;
+  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
   if (e == NGM_E_UNSUPPORTED && !force32 && a.act) { e = ngm_launch_field_bwd16s(a, blocks, st); g_last_bwd_variant = 2; }
   if (e == NGM_E_UNSUPPORTED && !force32) { e = ngm_launch_field_bwd16(a, blocks, st); g_last_bwd_variant = 1; }
   if (e == NGM_E_UNSUPPORTED) { e = ngm_launch_field_bwd(a, blocks, st); g_last_bwd_variant = 0; }
@@ -250,6 +254,7 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
 }
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
+int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 
 static unsigned long long* g_debug_cycles_fwd = nullptr;
 int ngm_debug_fwd_phase_cycles(unsigned long long* out528) {

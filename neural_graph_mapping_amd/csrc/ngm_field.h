@@ -706,9 +706,13 @@ __device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, 
 // Hidden-activation stash written by the training forward and consumed by the backward kernel (which
 // then skips the forward recompute: one third of its MFMA work).  fp32, 32*MH floats per sample and layer,
 // tiled so that the forward's stores are fully coalesced:
-//     act[layer][tile = g >> 5][chunk c = feature >> 2][r = g & 31][4 floats],   g = global flat sample index
+//     act[layer][tile = g >> 5][chunk c = feature >> 2][position][4 floats],   g = global flat sample index
 // i.e. 16-byte granules (4 consecutive features of one sample); the 32 lanes of a C-layout half-wave hold
 // one chunk of 32 consecutive samples = 512 contiguous bytes per store instruction and half.
+// 64-wide layers (MH = 2): sample r = g & 31 sits at position r ^ (c & 7) -- the image k_field_bwd_b3 wants in LDS
+// (bank-conflict-free column reads), so that its HBM -> LDS transfers are plain linear copies: a transfer whose lanes
+// gather a permutation costs the issuing wave ~240 clocks, a linear one ~30 (the permutation moves inside 128-byte
+// groups, so the stores here stay whole lines).  Other widths (the hash encoding's 32 features): position = r.
 struct ActStash {
   float* base;            // NULL: nothing is stored
   int64_t layer_stride;   // floats between layers
@@ -727,7 +731,8 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
     const int s = 32 * nt + n;
     if (s < st.nvalid) {
       const int64_t g = st.g0 + s;
-      float* p = st.base + layer * st.layer_stride + (((g >> 5) * NGM_ACT_CHUNKS(MH) + hi) * 32 + (g & 31)) * 4;
+      float* p = st.base + layer * st.layer_stride + (((g >> 5) * NGM_ACT_CHUNKS(MH) + hi) * 32) * 4;
+      const int r = (int)(g & 31);
 #pragma unroll
       for (int m = 0; m < MH; ++m)
 #pragma unroll
@@ -735,7 +740,8 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
         {
           typedef float v4f __attribute__((ext_vector_type(4)));
           const v4f val = {H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]};
-          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128));   // streamed: read once, by the backward
+          const int pos = (MH == 2) ? (r ^ ((2 * g4 + hi) & 7)) : r;     // chunk = 8 m + 2 g4 + hi
+          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));   // streamed: read once, by the backward
         }
     }
   }

@@ -204,7 +204,8 @@ __device__ __forceinline__ void issue_act(const char* sbase, uint32_t gb, uint32
     if (n >= end) n = end - 1;
     const uint32_t u = n + gb;
     // LDS position lane -> (row lane >> 4, chunk position lane & 15) holds logical chunk (lane & 15) ^ 2 row
-    dma16_so(sbase, (((u >> 5) * 16u + ((lane & 15) ^ (2 * (lane >> 4)))) * 32u + (u & 31u)) * 16u, lds_tile + b * BK_STRIDE * 4);
+    const uint32_t c = (uint32_t)((lane & 15) ^ (2 * (lane >> 4)));              // logical chunk of this LDS position
+    dma16_so(sbase, (((u >> 5) * 16u + c) * 32u + ((u & 31u) ^ (c & 7u))) * 16u, lds_tile + b * BK_STRIDE * 4);   // stash position: ngm_field.h ActStash
   }
 }
 

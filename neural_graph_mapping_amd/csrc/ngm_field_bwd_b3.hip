@@ -26,246 +26,7 @@
 //
 // Supported: dim_enc and dim_hidden in 33..64, 1-2 hidden layers, Fourier / NeRF / no encoding, skip_mode no, ray mode
 // with the forward's activation stash.  Everything else (and matmul_mode f32) keeps the fp32-MFMA kernels.
-#include "ngm_bwd16.h"
-
-// -DNGM_DMAWAIT_TIMING: only the clocks spent in the tile-start DMA wait (slot 2) and the kernel total (slot 12)
-#ifdef NGM_DMAWAIT_TIMING
-#undef TICK_DECL
-#undef TICK
-#undef TICK_REPORT
-#define TICK_DECL unsigned long long tw_ = 0, tl_ = 0; const unsigned long long ts_ = __builtin_readcyclecounter()
-#define TICK(k)                                                                  \
-  do {                                                                           \
-    if ((k) == 10) tl_ = __builtin_readcyclecounter();                           \
-    if ((k) == 2) tw_ += __builtin_readcyclecounter() - tl_;                     \
-  } while (0)
-#define TICK_REPORT                                                                                \
-  if (a.debug_cycles && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64) {                        \
-    for (int k = 0; k < 13; ++k) a.debug_cycles[k] = 0;                                            \
-    a.debug_cycles[2] = tw_; a.debug_cycles[12] = __builtin_readcyclecounter() - ts_;              \
-  }
-#endif
-#define B3B_WAVES 4
-#define B3B_THREADS 256
-#define HT 2048                 // floats of one 32 x 64 activation tile
-#define PLANE_G 512             // 16-byte granules of one weight plane: [nt 2][kb 4][kh 2][n 32]
-
-template <int L, bool EG>
-struct LdsB3b {
-  static constexpr int NPL = (L - 1) + (EG ? 1 : 0);                 // layers whose data gradient is needed
-  static constexpr int plane_slot(int l) { return EG ? l : l - 1; }  // 16-byte units: slot * 3 * PLANE_G
-  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512;         // floats; + per-feature constants: float4 wout[64], enc[64]
-  static constexpr int CONSTS = NPL * 3 * PLANE_G * 4;
-  // per wave: the output layer's input tile, (L = 2) layer 1's input tile, the input landing buffer, points, d_out.
-  // Single buffers: the next tile's transfers are issued when all of them are free (see the tile loop).
-  static constexpr int HL = 0;
-  static constexpr int H1 = HT;
-  static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16]
-  static constexpr int PB = INB + 512;                               // float4 [32]
-  static constexpr int OB = PB + 128;                                // float4 [32]
-  static constexpr int WAVE_TOTAL = OB + 128;
-  static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave
-  static constexpr int EPI = B3B_WAVES * NT * 1024;
-  static constexpr int BODY = PLANES + B3B_WAVES * WAVE_TOTAL;
-  static constexpr int TOTAL = BODY > EPI ? BODY : EPI;
-};
-
-// one activation tile, samples [n0, n0 + 32) of the field (clamped to end - 1): 8 DMA instructions of two chunks each
-__device__ __forceinline__ void issue_tile32(const char* sbase, uint32_t gb, uint32_t n0, uint32_t end, int lane, uint32_t lds_tile) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t c = 2 * k + (lane >> 5);
-    uint32_t n = n0 + (((uint32_t)lane & 31u) ^ (c & 7u));
-    if (n >= end) n = end - 1;
-    const uint32_t u = n + gb;
-    dma16_so(sbase, (((u >> 5) * 16u + c) * 32u + (u & 31u)) * 16u, lds_tile + k * 1024);
-  }
-}
-
-struct B3Op { ngm_bf16x8 h, m, l; };
-template <int B>
-__device__ __forceinline__ B3Op b3_regs(const f32x16& v) {
-  float x[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = v[8 * B + e];
-  B3Op o;
-  b3_split8(x, o.h, o.m, o.l);
-  return o;
-}
-__device__ __forceinline__ B3Op b3_rows(const float4& g0, const float4& g1) {
-  const float x[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-  B3Op o;
-  b3_split8(x, o.h, o.m, o.l);
-  return o;
-}
-
-// dW[32 mo + .][32 mi + .] += sum_s dY[s][.] X[s][.] over the 16 samples of one k-block, both operands in the
-// lane = feature layout and already split.  Product-major: consecutive MFMAs go to different accumulators.
-__device__ __forceinline__ void wgrad_b3_block(const B3Op (&A)[2], const B3Op (&Bx)[2], f32x16 (&acc)[2][2]) {
-#define NGM_WG_PRODUCT(PA, PB_)                                                                       \
-  _Pragma("unroll") for (int mo = 0; mo < 2; ++mo)                                                    \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) acc[mo][mi] = mfma_bf16(A[mo].PA, Bx[mi].PB_, acc[mo][mi]); \
-  __builtin_amdgcn_sched_barrier(0)
-  NGM_WG_PRODUCT(l, h);
-  NGM_WG_PRODUCT(h, l);
-  NGM_WG_PRODUCT(m, m);
-  NGM_WG_PRODUCT(m, h);
-  NGM_WG_PRODUCT(h, m);
-  NGM_WG_PRODUCT(h, h);
-#undef NGM_WG_PRODUCT
-}
-// same MFMAs without scheduling fences, for regions whose order is given by NGM_INTERLEAVE
-__device__ __forceinline__ void wgrad_b3_block_free(const B3Op (&A)[2], const B3Op (&Bx)[2], f32x16 (&acc)[2][2]) {
-#define NGM_WG_PRODUCT(PA, PB_)                                                                       \
-  _Pragma("unroll") for (int mo = 0; mo < 2; ++mo)                                                    \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) acc[mo][mi] = mfma_bf16(A[mo].PA, Bx[mi].PB_, acc[mo][mi])
-  NGM_WG_PRODUCT(l, h);
-  NGM_WG_PRODUCT(h, l);
-  NGM_WG_PRODUCT(m, m);
-  NGM_WG_PRODUCT(m, h);
-  NGM_WG_PRODUCT(h, m);
-  NGM_WG_PRODUCT(h, h);
-#undef NGM_WG_PRODUCT
-}
-// scheduling directive for the region it closes: N times (1 MFMA, then K VALU instructions).  One wave per SIMD: an
-// MFMA occupies the matrix pipe for 32 clocks but the issue port for 4, and up to ~5 independent single-issue
-// instructions of the SAME wave go out in its shadow (MI355X_MICROARCH.md, "one wave per SIMD") -- so the operand
-// splits of the NEXT block are issued between the MFMAs of this one.
-#define NGM_INTERLEAVE(N, K)                                          \
-  _Pragma("unroll") for (int ii_ = 0; ii_ < (N); ++ii_) {              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
-    __builtin_amdgcn_sched_group_barrier(0x002, (K), 0);               \
-  }
-
-template <int B>
-__device__ __forceinline__ void wgrad_b3_half(const f32x16 (&dY)[2], const f32x16 (&X)[2], f32x16 (&acc)[2][2]) {
-  B3Op A[2] = {b3_regs<B>(dY[0]), b3_regs<B>(dY[1])}, Bx[2] = {b3_regs<B>(X[0]), b3_regs<B>(X[1])};
-  __builtin_amdgcn_sched_barrier(0);
-  wgrad_b3_block(A, Bx, acc);
-}
-__device__ __forceinline__ B3Op b3_arr(const float (&x)[8]) {
-  B3Op o;
-  b3_split8(x, o.h, o.m, o.l);
-  return o;
-}
-
-// float offset of the 16-byte chunk c of sample s inside a tile
-__device__ __forceinline__ int tile_chunk(int c, int s) { return (c * 32 + (s ^ (c & 7))) * 4; }
-
-// rows of a tile for the data gradient's A operand (lane = sample n, k-half kh): chunks 4 kb + 2 kh, + 1 of every k-block
-struct RowRegs { float4 g[4][2]; };
-__device__ __forceinline__ void load_rows(const float* __restrict__ tile, int lane, RowRegs& R) {
-  const int n = lane & 31, kh = lane >> 5;
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const int c0 = 4 * kb + 2 * kh;
-    R.g[kb][0] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0, n));
-    R.g[kb][1] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0 + 1, n));
-  }
-}
-struct PlaneRegs { ngm_u32x4 h[2], m[2], l[2]; };
-__device__ __forceinline__ void load_planes(const ngm_u32x4* __restrict__ P, int kb, int lane, PlaneRegs& W) {
-  const int n = lane & 31, kh = lane >> 5;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int g = ((nt * 4 + kb) * 2 + kh) * 32 + n;
-    W.h[nt] = P[g]; W.m[nt] = P[PLANE_G + g]; W.l[nt] = P[2 * PLANE_G + g];
-  }
-}
-
-// dX^T[s][32 nt + n] = sum_o dY[s][o] W[o][32 nt + n]: A = rows of the tile (lane = sample, loaded by the caller well
-// ahead), B = weight planes, the next k-block's planes in flight under this one's MFMAs (one wave per SIMD: nothing
-// else hides the LDS latency).  W0 = planes of k-block 0, loaded by the caller.
-__device__ __forceinline__ void dgrad_b3_kb(const B3Op& A, const PlaneRegs& Wk, bool first, f32x16 (&dX)[2]) {
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define NGM_DG_PRODUCT(PA, PW, Z) \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) dX[nt] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[nt]), (Z) ? zero : dX[nt]); \
-  __builtin_amdgcn_sched_barrier(0)
-  NGM_DG_PRODUCT(l, h, first);
-  NGM_DG_PRODUCT(h, l, false);
-  NGM_DG_PRODUCT(m, m, false);
-  NGM_DG_PRODUCT(m, h, false);
-  NGM_DG_PRODUCT(h, m, false);
-  NGM_DG_PRODUCT(h, h, false);
-#undef NGM_DG_PRODUCT
-}
-__device__ __forceinline__ void dgrad_b3_kb_free(const B3Op& A, const PlaneRegs& Wk, bool first, f32x16 (&dX)[2]) {
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define NGM_DG_PRODUCT(PA, PW, Z) \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) dX[nt] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[nt]), (Z) ? zero : dX[nt])
-  NGM_DG_PRODUCT(l, h, first);
-  NGM_DG_PRODUCT(h, l, false);
-  NGM_DG_PRODUCT(m, m, false);
-  NGM_DG_PRODUCT(m, h, false);
-  NGM_DG_PRODUCT(h, m, false);
-  NGM_DG_PRODUCT(h, h, false);
-#undef NGM_DG_PRODUCT
-}
-// k-block kb's 12 MFMAs share their scheduling region with the row split of k-block kb + 1 (and the plane reads of kb + 1)
-__device__ __forceinline__ void dgrad_b3(const ngm_u32x4* __restrict__ P, const RowRegs& R, const PlaneRegs& W0, int lane, f32x16 (&dX)[2]) {
-  PlaneRegs Wa, Wb;
-  const B3Op A0 = b3_rows(R.g[0][0], R.g[0][1]);
-  __builtin_amdgcn_sched_barrier(0);
-  load_planes(P, 1, lane, Wb);
-  const B3Op A1 = b3_rows(R.g[1][0], R.g[1][1]);
-  dgrad_b3_kb_free(A0, W0, true, dX);
-  NGM_INTERLEAVE(12, 4)
-  __builtin_amdgcn_sched_barrier(0);
-  load_planes(P, 2, lane, Wa);
-  const B3Op A2 = b3_rows(R.g[2][0], R.g[2][1]);
-  dgrad_b3_kb_free(A1, Wb, false, dX);
-  NGM_INTERLEAVE(12, 4)
-  __builtin_amdgcn_sched_barrier(0);
-  load_planes(P, 3, lane, Wb);
-  const B3Op A3 = b3_rows(R.g[3][0], R.g[3][1]);
-  dgrad_b3_kb_free(A2, Wa, false, dX);
-  NGM_INTERLEAVE(12, 4)
-  __builtin_amdgcn_sched_barrier(0);
-  dgrad_b3_kb(A3, Wb, false, dX);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// weight planes of layer l for the data gradient: granule (plane, nt, kb, kh, n) = W[16 kb + 8 kh + e][32 nt + n], e = 0..7
-__device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int l, ngm_u32x4* P) {
-  const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
-  const float* W = pr.w[l];
-  const int64_t w0 = row * pr.w_stride[l];
-  for (int g = threadIdx.x; g < PLANE_G; g += B3B_THREADS) {
-    const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
-    const int c = 32 * nt + n;
-    float x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int o = 16 * kb + 8 * kh + e;
-      x[e] = (o < H && c < Din) ? ngm_ldp(W, w0 + (int64_t)o * Din + c, pr.dtype) : 0.f;
-    }
-    ngm_bf16x8 h, m, lo;
-    b3_split8(x, h, m, lo);
-    P[g] = __builtin_bit_cast(ngm_u32x4, h);
-    P[PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, m);
-    P[2 * PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, lo);
-  }
-}
-
-// encoding row of feature f: (w.x, w.y, w.z, kind) -- the table FieldStage16::issue builds, one entry per lane here
-__device__ __forceinline__ float4 enc_row_of(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int f) {
-  float4 e = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
-  if (f >= fc.dim_enc) return e;
-  if (fc.encoding == NGM_ENC_FOURIER) {
-    const int n_raw = fc.raw_coords ? 3 : 0;
-    if (f < n_raw) return make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-    const int64_t e0 = row * pr.enc_w_stride + (int64_t)(f - n_raw) * 3;
-    return make_float4(ngm_ldp(pr.enc_w, e0, pr.dtype), ngm_ldp(pr.enc_w, e0 + 1, pr.dtype), ngm_ldp(pr.enc_w, e0 + 2, pr.dtype), NGM_FK_SIN);
-  }
-  if (fc.encoding == NGM_ENC_NERF) {
-    const int half = 3 * fc.num_octaves;
-    const int g = (f < half) ? f : f - half;
-    const int d = g / fc.num_octaves, o = g % fc.num_octaves;
-    const float m = exp2f((float)(fc.start_octave + o)) * 3.14159265358979323846f;
-    return make_float4(d == 0 ? m : 0.f, d == 1 ? m : 0.f, d == 2 ? m : 0.f, (f < half) ? NGM_FK_SIN : NGM_FK_COS);
-  }
-  return make_float4(f == 0 ? 1.f : 0.f, f == 1 ? 1.f : 0.f, f == 2 ? 1.f : 0.f, NGM_FK_RAW);
-}
+#include "ngm_bwd_b3.h"
 
 // ------------------------------------------------------------------------------------------------
 template <int L, bool NEED_COS, bool ENC_GRAD>
@@ -348,6 +109,8 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
 #define COL_OFF(m, r) ((m) * 1024 + col[(r) & 3] + 32 * ((r) >> 2))
 
+  uint32_t fvo[4];
+  tile32_fast_offsets(lane, fvo);
   DMA_WAIT(0);
   TICK_DECL;
   TICK(0);
@@ -512,8 +275,14 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     if (more) {
       issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
       issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
-      issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
-      if (L == 2) issue_tile32(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::H1 * 4);
+      const uint32_t u0 = nxt + fs.gb;
+      if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
+        issue_tile32_fast(fs.act[L - 1], u0 >> 5, fvo, wl_lds + LY::HL * 4);
+        if (L == 2) issue_tile32_fast(fs.act[0], u0 >> 5, fvo, wl_lds + LY::H1 * 4);
+      } else {
+        issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
+        if (L == 2) issue_tile32(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::H1 * 4);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(5);

@@ -673,6 +673,14 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
     ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
     from neural_graph_mapping_amd import _capi
     assert _capi.lib().ngm_debug_last_bwd_variant() == variant
+    if variant == 3 and layers == 2:                 # the experimental two-waves-per-tile kernel: same cases, same tolerances
+        L = _capi.lib()
+        L.ngm_debug_prefer_paired_bwd(1)
+        try:
+            ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
+            assert L.ngm_debug_last_bwd_variant() == 4
+        finally:
+            L.ngm_debug_prefer_paired_bwd(0)
 
 
 @pytest.mark.parametrize("enc", ["nerf", "fourier61"])

@@ -133,9 +133,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   const int BR = max(1, min(RF_BRMAX, a.maxs / S));
 
   const uint64_t poff = philox_launch_offset(a.rays);
+  // loss partial sums of this lane: five fp32 sums (indexed by their NGM_LS_*_SUM slot) and the five counts packed in two
+  // words (cnt_s: free-space | TSDF << 16, per sample; cnt_r: photometric | depth << 10 | termination << 20, per ray) --
+  // three registers less in a kernel that sits at the 256-register limit, where a spilled accumulator is reloaded behind
+  // the stash stores (one vmcnt for loads and stores: the reload waits for all of them)
   float ls[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) ls[i] = 0.f;
+  uint32_t cnt_s = 0, cnt_r = 0;
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
   const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
   float neus_isd = 0.f;                                             // rm.py:641-644: 1 / |_neus_sd| of this field
@@ -305,10 +310,10 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       if (a.has_targets && valid) {
         const float gt = rt[11];
         const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);       // rm.py:625-627
-        if (t < thr) { const float e = geom * tau - tau; ls[NGM_LS_FS_SUM] += e * e; ls[NGM_LS_FS_CNT] += 1.f; }
+        if (t < thr) { const float e = geom * tau - tau; ls[NGM_LS_FS_SUM] += e * e; cnt_s += 1u; }
         const float dl = gt - t;
         if (fabsf(dl) < tau && gt != 0.0f) {                              // rm.py:633-637
-          const float e = geom * tau - dl; ls[NGM_LS_TSDF_SUM] += e * e; ls[NGM_LS_TSDF_CNT] += 1.f;
+          const float e = geom * tau - dl; ls[NGM_LS_TSDF_SUM] += e * e; cnt_s += 0x10000u;
         }
       }
       if constexpr (NEUS) {
@@ -397,14 +402,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         const bool m = (ra[9] != 0.f) && (term > a.rc.term_threshold);  // rm.py:1787
         if (m) {
           ls[NGM_LS_PHOTO_SUM] += fabsf(tg.x - ra[0]) + fabsf(tg.y - ra[1]) + fabsf(tg.z - ra[2]);
-          ls[NGM_LS_PHOTO_CNT] += 1.f;
+          cnt_r += 1u;
           const float e = ra[3] - tg.w, ae = fabsf(e), dlt = a.rc.huber_delta;
           ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);
-          ls[NGM_LS_DEPTH_CNT] += 1.f;
+          cnt_r += 1u << 10;
         }
         if (ra[10] != 0.f) {
           const float e = term - ra[11];
-          ls[NGM_LS_TERM_SUM] += e * e; ls[NGM_LS_TERM_CNT] += 1.f;
+          ls[NGM_LS_TERM_SUM] += e * e; cnt_r += 1u << 20;
         }
       }
     }
@@ -416,6 +421,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   if (a.has_targets && a.loss_partials) {
     __syncthreads();
     float* red = sm + LY::TOTAL;  // reuse wave 0's scratch (>= 8*16 floats)
+    ls[NGM_LS_FS_CNT] = (float)(cnt_s & 0xffffu); ls[NGM_LS_TSDF_CNT] = (float)(cnt_s >> 16);
+    ls[NGM_LS_PHOTO_CNT] = (float)(cnt_r & 1023u); ls[NGM_LS_DEPTH_CNT] = (float)((cnt_r >> 10) & 1023u);
+    ls[NGM_LS_TERM_CNT] = (float)(cnt_r >> 20);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const float v = wave_sum(ls[i]);

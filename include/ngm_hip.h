@@ -392,6 +392,18 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
                     const float* bbox, const int64_t* frame_cids, const float* u_xy,
                     const ngm_target_out* out, void* stream);
 
+/* Device part of NeuralGraphMap._sample_target_sv (rm.py:1461-1583), the single-view variant (`update_mode: single_view`):
+ * hit (F,N) u8 = the segment camera origin -> point n of the (subsampled) back-projected depth image passes through the
+ * sphere of field f (geometry.py:67-105); field centres and points in the camera frame. */
+int ngm_target_sv_intersect(int32_t F, int64_t N, const float* field_pos_cam, const float* points_cam, float radius,
+                            uint8_t* hit, void* stream);
+/* rm.py:1536-1561: segments (F,R) i64 = sampled point indices, pts_ijs (N,2) i64 their pixels, image (H,W,4) the RGB-D
+ * frame; near / far are not clamped at 0 in this variant, rgb_mask = depth_mask = (gt < far), term_mask = 1, out->c2ws
+ * is not written (one pose for all rays). */
+int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float radius, const int64_t* pts_ijs,
+                       const int64_t* segments, const float* image, int32_t height, int32_t width, float fx, float fy, float cx,
+                       float cy, const ngm_target_out* out, void* stream);
+
 /* ---- mesh extraction -------------------------------------------------------------------
  * Marching cubes on a dense grid of field values: replaces the pytorch3d.ops.marching_cubes call of
  * NeuralGraphMap._extract_mesh (rm.py:2255-2298; the grid itself is filled by ngm_field_eval_knn, rm.py:2255-2261).

@@ -155,6 +155,10 @@ def lib():
     L.ngm_target_rays.argtypes = [P(Keyframes), i32, i32, vp, f32, vp, vp, vp, P(TargetOut), vp]
     L.ngm_target_visibility.restype = C.c_int
     L.ngm_target_rays.restype = C.c_int
+    L.ngm_target_sv_intersect.argtypes = [i32, i64, vp, vp, f32, vp, vp]
+    L.ngm_target_sv_intersect.restype = C.c_int
+    L.ngm_target_sv_rays.argtypes = [i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, f32, f32, P(TargetOut), vp]
+    L.ngm_target_sv_rays.restype = C.c_int
     L.ngm_marching_cubes_workspace.argtypes = [i32, i32, i32]
     L.ngm_marching_cubes_workspace.restype = i64
     L.ngm_marching_cubes_count.argtypes = [vp, i32, i32, i32, f32, vp, vp, i64, vp]
@@ -180,7 +184,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_prefer_paired_bwd", "ngm_target_visibility", "ngm_target_rays",
+            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_prefer_paired_bwd", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
             "ngm_marching_cubes_workspace", "ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;

@@ -253,6 +253,26 @@ int ngm_target_rays(const ngm_keyframes* kf, int32_t F, int32_t R, const float* 
   return check_launch("ngm_target_rays");
 }
 
+int ngm_target_sv_intersect(int32_t F, int64_t N, const float* field_pos_cam, const float* points_cam, float radius, uint8_t* hit,
+                            void* stream) {
+  if (F < 0 || N < 0 || radius < 0.f || (F > 0 && N > 0 && (!field_pos_cam || !points_cam || !hit)))
+    return fail(NGM_E_INVALID, "ngm_target_sv_intersect: bad argument");
+  if (F == 0 || N == 0) return NGM_OK;
+  if (F > 65535) return fail(NGM_E_UNSUPPORTED, "ngm_target_sv_intersect: more than 65535 candidate fields");
+  ngm_launch_target_sv_intersect(F, N, field_pos_cam, points_cam, radius, hit, (hipStream_t)stream);
+  return check_launch("ngm_target_sv_intersect");
+}
+int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float radius, const int64_t* pts_ijs, const int64_t* segments,
+                       const float* image, int32_t height, int32_t width, float fx, float fy, float cx, float cy,
+                       const ngm_target_out* out, void* stream) {
+  if (F < 0 || R < 1 || height < 1 || width < 1 || !field_pos_cam || !pts_ijs || !segments || !image || !out || !out->ijs || !out->near ||
+      !out->far || !out->gt || !out->rgbds || !out->rgb_mask || !out->depth_mask || !out->term_probs || !out->term_mask)
+    return fail(NGM_E_INVALID, "ngm_target_sv_rays: bad argument");
+  if (F == 0) return NGM_OK;
+  ngm_launch_target_sv_rays(F, R, field_pos_cam, radius, pts_ijs, segments, image, height, width, fx, fy, cx, cy, *out, (hipStream_t)stream);
+  return check_launch("ngm_target_sv_rays");
+}
+
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 

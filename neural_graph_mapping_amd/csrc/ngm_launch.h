@@ -159,6 +159,10 @@ int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st);
 
 int ngm_launch_target_visibility(const ngm_keyframes& kf, int F, const float* field_pos, int num_offsets, const float* offsets,
                                  float radius, uint8_t* kf_mask, float* bbox, hipStream_t st);
+int ngm_launch_target_sv_intersect(int F, int64_t N, const float* pos_c, const float* points, float radius, uint8_t* hit, hipStream_t st);
+int ngm_launch_target_sv_rays(int F, int R, const float* pos_c, float radius, const int64_t* pts_ijs, const int64_t* segments,
+                              const float* image, int height, int width, float fx, float fy, float cx, float cy, const ngm_target_out& o,
+                              hipStream_t st);
 int ngm_launch_target_rays(const ngm_keyframes& kf, int F, int R, const float* field_pos, float radius, const float* bbox,
                            const int64_t* frame_cids, const float* u_xy, const ngm_target_out& o, hipStream_t st);
 

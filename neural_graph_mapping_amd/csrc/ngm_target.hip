@@ -96,6 +96,64 @@ __global__ void k_target_rays(ngm_keyframes kf, int F, int R, const float* __res
   o.term_mask[idx] = (gt > nearv && vd) ? 1 : 0;
 }
 
+// ---- single-view variant (NeuralGraphMap._sample_target_sv, rm.py:1461-1583) ------------------------------------
+// k_target_sv_intersect: does the segment camera origin -> back-projected depth point n pass through the sphere of field f?
+//   geometry.LineSegments.closest_points / intersects_spheres (geometry.py:67-105) with p1 = 0: t = clamp(c.p / |p|^2, 0, 1)
+//   (|p|^2 == 0 -> 1), closest = p t, hit = |c - closest|^2 <= r^2.  One thread per (field, point); 50 000 points x up
+//   to a few hundred fields of byte output: HBM-bound.
+__global__ void k_target_sv_intersect(int F, int64_t N, const float* __restrict__ pos_c, const float* __restrict__ points, float radius,
+                                      uint8_t* __restrict__ hit) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y;
+  if (n >= N) return;
+  const float px = points[3 * n], py = points[3 * n + 1], pz = points[3 * n + 2];
+  const float cx = pos_c[3 * f], cy = pos_c[3 * f + 1], cz = pos_c[3 * f + 2];
+  float sq = (px * px + py * py) + pz * pz;
+  if (sq == 0.0f) sq = 1.0f;
+  const float t = fminf(fmaxf(((cx * px + cy * py) + cz * pz) / sq, 0.0f), 1.0f);
+  const float ex = cx - px * t, ey = cy - py * t, ez = cz - pz * t;
+  hit[(int64_t)f * N + n] = ((ex * ex + ey * ey) + ez * ez <= radius * radius) ? 1 : 0;
+}
+// k_target_sv_rays: per sampled segment: pixel, direction, near / far from the field sphere (NOT clamped at 0 here,
+// rm.py:1543-1544), RGB-D target, ray distance of the depth, masks (rm.py:1536-1561)
+__global__ void k_target_sv_rays(int F, int R, const float* __restrict__ pos_c, float radius, const int64_t* __restrict__ pts_ijs,
+                                 const int64_t* __restrict__ segments, const float* __restrict__ image, int height, int width,
+                                 float fx, float fy, float cx, float cy, ngm_target_out o) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)F * R) return;
+  const int f = (int)(idx / R);
+  const int64_t sgm = segments[idx];
+  const int64_t i = pts_ijs[2 * sgm], j = pts_ijs[2 * sgm + 1];
+  o.ijs[2 * idx] = i; o.ijs[2 * idx + 1] = j;
+  const float dx = ((float)j - cx) / fx, dy = ((float)i - cy) / fy;
+  const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + 1.0f), 1e-12f);
+  const float gx = dx / nrm, gy = (-dy) / nrm, gz = -1.0f / nrm;
+  const float center = pos_c[3 * f] * gx + pos_c[3 * f + 1] * gy + pos_c[3 * f + 2] * gz;
+  const float nearv = center - radius, farv = center + radius;
+  const float4 px = reinterpret_cast<const float4*>(image)[i * (int64_t)width + j];
+  const float gt = px.w / (1.0f / nrm);
+  const bool dm = gt < farv;
+  o.near[idx] = nearv; o.far[idx] = farv; o.gt[idx] = gt;
+  reinterpret_cast<float4*>(o.rgbds)[idx] = px;
+  o.rgb_mask[idx] = dm ? 1 : 0;
+  o.depth_mask[idx] = dm ? 1 : 0;
+  o.term_probs[idx] = dm ? 1.0f : 0.0f;
+  o.term_mask[idx] = 1;
+  (void)height;
+}
+int ngm_launch_target_sv_intersect(int F, int64_t N, const float* pos_c, const float* points, float radius, uint8_t* hit, hipStream_t st) {
+  hipLaunchKernelGGL(k_target_sv_intersect, dim3((unsigned)((N + 255) / 256), (unsigned)F), dim3(256), 0, st, F, N, pos_c, points, radius, hit);
+  return 0;
+}
+int ngm_launch_target_sv_rays(int F, int R, const float* pos_c, float radius, const int64_t* pts_ijs, const int64_t* segments,
+                              const float* image, int height, int width, float fx, float fy, float cx, float cy, const ngm_target_out& o,
+                              hipStream_t st) {
+  const int64_t n = (int64_t)F * R;
+  hipLaunchKernelGGL(k_target_sv_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F, R, pos_c, radius, pts_ijs, segments, image,
+                     height, width, fx, fy, cx, cy, o);
+  return 0;
+}
+
 int ngm_launch_target_visibility(const ngm_keyframes& kf, int F, const float* field_pos, int num_offsets, const float* offsets,
                                  float radius, uint8_t* kf_mask, float* bbox, hipStream_t st) {
   const int n = F * kf.num_frames;

@@ -683,3 +683,37 @@ def target_rays(kf: K.Keyframes, field_pos, radius, bbox, frame_cids, u_xy):
     for k in ("rgb_mask", "depth_mask", "term_mask"):
         o[k] = o[k].bool()
     return o
+
+
+def target_sv_intersect(pos_c, points, radius):
+    """(F, N) bool: the segment camera origin -> point n passes through the sphere of field f (geometry.py:67-105)."""
+    pos_c, points = _f32c(pos_c), _f32c(points)
+    F, N = pos_c.shape[0], points.shape[0]
+    hit = torch.empty(F, N, dtype=torch.uint8, device=points.device)
+    K.check(K.lib().ngm_target_sv_intersect(F, N, _ptr(pos_c), _ptr(points), float(radius), _ptr(hit), _stream()),
+            "ngm_target_sv_intersect")
+    return hit.bool()
+
+
+def target_sv_rays(pos_c, radius, pts_ijs, segments, image, fx, fy, cx, cy):
+    """Per-ray targets of the single-view sampler (rm.py:1536-1561), keyed like the reference's Target record."""
+    pos_c, image = _f32c(pos_c), _f32c(image)
+    pts_ijs, segments = pts_ijs.contiguous(), segments.contiguous()
+    F, R = segments.shape
+    H, W = image.shape[0], image.shape[1]
+    dev = pos_c.device
+    o = dict(ijs=torch.empty(F, R, 2, dtype=torch.int64, device=dev), near=torch.empty(F, R, device=dev),
+             far=torch.empty(F, R, device=dev), gt=torch.empty(F, R, device=dev), rgbds=torch.empty(F, R, 4, device=dev),
+             rgb_mask=torch.empty(F, R, dtype=torch.uint8, device=dev), depth_mask=torch.empty(F, R, dtype=torch.uint8, device=dev),
+             term_probs=torch.empty(F, R, device=dev), term_mask=torch.empty(F, R, dtype=torch.uint8, device=dev))
+    out = K.TargetOut()
+    out.ijs = o["ijs"].data_ptr()
+    for k in ("near", "far", "gt", "rgbds", "term_probs"):
+        setattr(out, k, C.cast(o[k].data_ptr(), K.f32p))
+    for k in ("rgb_mask", "depth_mask", "term_mask"):
+        setattr(out, k, o[k].data_ptr())
+    K.check(K.lib().ngm_target_sv_rays(F, R, _ptr(pos_c), float(radius), _ptr(pts_ijs), _ptr(segments), _ptr(image), H, W,
+                                       float(fx), float(fy), float(cx), float(cy), C.byref(out), _stream()), "ngm_target_sv_rays")
+    for k in ("rgb_mask", "depth_mask", "term_mask"):
+        o[k] = o[k].bool()
+    return o

@@ -321,6 +321,46 @@ class NeuralGraphRenderer:
                       gt_distances=o["gt"], field_ids=field_ids, rgbds=o["rgbds"], rgb_mask=o["rgb_mask"],
                       depth_mask=o["depth_mask"], term_probs=o["term_probs"], term_mask=o["term_mask"])
 
+    def sample_target_sv(self, rgbd_image, c2w, active_field_ids, num_train_fields, num_rays_per_field,
+                         camera: Optional[Camera] = None, draws: Optional[dict] = None, num_points: int = 50000) -> Target:
+        """NeuralGraphMap._sample_target_sv (`update_mode: single_view`, rm.py:1461-1583): fields and rays from ONE RGB-D
+        frame.  The depth image is back-projected, `num_points` (50 000 in the reference) of its points are drawn, fields
+        whose sphere is crossed by at least num_rays_per_field of the segments camera -> point are candidates, rays are
+        drawn among each field's crossing segments.  The three torch.multinomial draws are made on this device in the
+        reference's order; `draws` (dict: subset_points, subset_fields, segments) replays recorded ones.  The
+        segment-sphere test (fields x points) and the per-ray targets run in two HIP kernels."""
+        cam = camera or self._camera
+        dev = self._device
+        radius = self._field_radius + 0.0
+        d = draws or {}
+        rgbd_image = rgbd_image.to(dev).contiguous()
+        c2w = c2w.to(dev)
+        active = active_field_ids.to(dev)
+        pos_w = self._global_map_dict["positions"][active]
+        pos_c = (pos_w - c2w[:3, 3]) @ c2w[:3, :3]                          # utils.transform_points(..., inv=True): R^T (p - t)
+        fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
+        depth = rgbd_image[..., 3]
+        ijs = torch.nonzero(depth)                                         # camera.py:374: only pixels with depth
+        dv = depth[ijs[:, 0], ijs[:, 1]]
+        points = torch.stack(((ijs[:, 1].float() - cx) * dv / fx, -(ijs[:, 0].float() - cy) * dv / fy, -dv), -1)
+        sub = d["subset_points"].to(dev) if draws else torch.multinomial(torch.ones(len(points), device=dev), num_points)
+        points, ijs = points[sub].contiguous(), ijs[sub].contiguous()
+        mins, maxs = points.min(0)[0], points.max(0)[0]
+        aabb_mask = ((pos_c - radius) <= maxs).all(-1) & ((pos_c + radius) >= mins).all(-1)
+        pos_in = pos_c[aabb_mask].contiguous()
+        hit = ops.target_sv_intersect(pos_in, points, radius)
+        seg_mask = hit.sum(-1) >= num_rays_per_field
+        hit = hit[seg_mask]
+        ids, pc = active[aabb_mask][seg_mask], pos_in[seg_mask]
+        if len(hit) > num_train_fields:
+            sf = d["subset_fields"].to(dev) if draws else torch.multinomial(torch.ones(len(hit), device=dev), num_train_fields)
+            ids, pc, hit = ids[sf], pc[sf], hit[sf]
+        segments = d["segments"].to(dev) if draws else torch.multinomial(hit.float(), num_rays_per_field)
+        o = ops.target_sv_rays(pc.contiguous(), radius, ijs, segments, rgbd_image, fx, fy, cx, cy)
+        return Target(ijs=o["ijs"], c2ws=c2w, near_distances=o["near"], far_distances=o["far"], gt_distances=o["gt"],
+                      field_ids=ids, rgbds=o["rgbds"], rgb_mask=o["rgb_mask"], depth_mask=o["depth_mask"],
+                      term_probs=o["term_probs"], term_mask=o["term_mask"])
+
     # -- eval path: render_image / PSNR (rm.py:402-437, 1966-2000; evaluation.py:46-56) ----------
     def eval_num_samples(self) -> int:
         """rm.py:199-207: derived from the training sample spacing unless configured."""

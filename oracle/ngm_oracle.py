@@ -575,6 +575,51 @@ def sample_target_mv(cam: CameraSpec, c_c2w, nc_rgbd, frame_cid_to_ncid, positio
     return target, used, aux
 
 
+def sample_target_sv(cam: CameraSpec, rgbd_image, c2w, positions, active_field_ids, num_train_fields, num_rays_per_field,
+                     field_radius, draws=None, num_points=50000):
+    """NeuralGraphMap._sample_target_sv (rm.py:1461-1583, `update_mode: single_view`): fields and rays from one RGB-D
+    frame.  Randomness as in sample_target_mv: with draws=None the reference's three torch.multinomial calls are made in
+    its order; otherwise `draws` (subset_points, subset_fields, segments) replays recorded ones."""
+    radius = field_radius + 0.0                                            # MARGIN = 0.0, rm.py:1499-1501
+    d = draws or {}
+    pos_w = positions[active_field_ids]
+    pos_c = (pos_w - c2w[:3, 3]) @ c2w[:3, :3]                             # utils.transform_points(..., inv=True), utils.py:279-282
+    depth = rgbd_image[..., 3]
+    ijs = torch.nonzero(depth)                                             # Camera.depth_to_pointcloud, camera.py:371-386
+    dv = depth[ijs[:, 0], ijs[:, 1]]
+    points = torch.stack(((ijs[:, 1].float() - cam.cx) * dv / cam.fx, -(ijs[:, 0].float() - cam.cy) * dv / cam.fy, -dv), -1)
+    sub = d["subset_points"] if draws else torch.multinomial(torch.ones(len(points)), num_points)     # rm.py:1507
+    points, ijs = points[sub], ijs[sub]
+    mins, maxs = points.min(0)[0], points.max(0)[0]                        # geometry.AABBs.intersects_aabbs, geometry.py:26-42
+    aabb_mask = ((pos_c - radius) <= maxs).all(-1) & ((pos_c + radius) >= mins).all(-1)
+    pos_in = pos_c[aabb_mask]
+    # geometry.LineSegments(origin, points).intersects_spheres, geometry.py:67-105 (p1 = 0)
+    sq = (points * points).sum(-1, keepdim=True)
+    sq = torch.where(sq == 0, torch.ones_like(sq), sq)
+    t = ((pos_in[:, None, :] * points).sum(-1, keepdim=True) / sq).clamp(0.0, 1.0)
+    closest = points * t
+    hit = ((pos_in[:, None, :] - closest) ** 2).sum(-1) <= radius ** 2     # (F', N)
+    seg_mask = hit.sum(-1) >= num_rays_per_field                           # rm.py:1527-1529
+    hit = hit[seg_mask]
+    ids, pc = active_field_ids[aabb_mask][seg_mask], pos_in[seg_mask]
+    sf = None
+    if len(hit) > num_train_fields:                                        # rm.py:1532-1543
+        sf = d["subset_fields"] if draws else torch.multinomial(torch.ones(len(hit)), num_train_fields)
+        ids, pc, hit = ids[sf], pc[sf], hit[sf]
+    segments = d["segments"] if draws else torch.multinomial(hit.float(), num_rays_per_field)   # rm.py:1546
+    t_ijs = ijs[segments]
+    dirs = ijs_to_directions(t_ijs, cam)
+    center = (pc[:, None, :] * dirs).sum(-1)
+    near, far = center - radius, center + radius                           # not clamped at 0 here (rm.py:1553-1554)
+    rgbds = rgbd_image[t_ijs[..., 0], t_ijs[..., 1]]
+    gt = depth_to_distance(rgbds[..., 3], t_ijs, cam)
+    dm = gt < far
+    target = dict(ijs=t_ijs, c2ws=c2w, near=near, far=far, gt=gt, field_ids=ids, rgbds=rgbds, rgb_mask=dm, depth_mask=dm,
+                  term_probs=dm.float(), term_mask=torch.ones_like(dm))
+    used = dict(subset_points=sub, subset_fields=sf, segments=segments)
+    return target, used
+
+
 # ----------------------------------------------------------------------------------------
 # losses (rm.py:1769-1872, losses.py:10-75)
 # ----------------------------------------------------------------------------------------

@@ -301,6 +301,55 @@ def g11_target_sampler():
          o_term_probs=t.term_probs, o_term_mask=t.term_mask)
 
 
+def g16_target_sampler_sv():
+    """_sample_target_sv (rm.py:1461-1583, update_mode single_view) on a procedural RGB-D frame (tests/golden/scene.py:
+    sv_frame, regenerated from its seed); the three torch.multinomial draws made inside are recorded."""
+    cam = camera.Camera(width=scene.SV_W, height=scene.SV_H, fx=scene.SV_FX, fy=scene.SV_FY, cx=scene.SV_CX, cy=scene.SV_CY,
+                        pixel_center=0.0)
+    gen = torch.Generator().manual_seed(160)
+    NF = 14
+    img = scene.sv_frame(161)
+    # fields scattered through the viewing frustum of an identity-ish camera pose, some outside it
+    eye = torch.tensor([0.3, -0.2, 0.1])
+    c2w = look_at_c2w(eye[None, None], (eye + torch.tensor([0.0, 0.0, -1.0]) + 0.05 * torch.randn(3, generator=gen))[None, None], gen)[0, 0]
+    pts_c = torch.stack((2.0 * torch.rand(NF, generator=gen) - 1.0, 1.2 * torch.rand(NF, generator=gen) - 0.6,
+                         -(1.0 + 3.0 * torch.rand(NF, generator=gen))), -1)
+    pts_c[:3] *= torch.tensor([3.0, 3.0, 1.0])                            # three of them well outside the frustum
+    pos = pts_c @ c2w[:3, :3].T + c2w[:3, 3]
+    quat = rand_quats(NF, gen)
+    cfg = make_config(num_samples_coarse=4, num_samples_depth_guided=4)
+    cfg["num_train_fields"], cfg["num_rays_per_field"], cfg["field_radius"] = 4, 24, 0.35
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=160)
+    ngm._camera = cam
+    active = torch.tensor([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13])
+    rec, count = {}, dict(n=0)
+    orig = torch.multinomial
+
+    def wrapped(*a, **k):
+        out = orig(*a, **k)
+        rec[count["n"]] = (out, tuple(a[0].shape))
+        count["n"] += 1
+        return out
+    torch.manual_seed(162)
+    torch.multinomial = wrapped
+    try:
+        t = ngm._sample_target_sv(img, c2w, active)
+    finally:
+        torch.multinomial = orig
+    assert count["n"] in (2, 3), count
+    draws = dict(d_subset_points=rec[0][0].to(torch.int32))
+    if count["n"] == 3:
+        draws["d_subset_fields"] = rec[1][0]
+    draws["d_segments"] = rec[count["n"] - 1][0]
+    assert len(t.field_ids) >= 2, "fixture should train several fields"
+    save("g16_target_sampler_sv", frame_seed=np.int64(161), positions=pos, c2w=c2w, active_field_ids=active,
+         num_train_fields=np.int64(4), num_rays_per_field=np.int64(24), field_radius=np.float32(0.35), seed=np.int64(162),
+         num_candidates=np.int64(rec[count["n"] - 1][1][0]),
+         o_ijs=t.ijs, o_c2ws=t.c2ws, o_near=t.near_distances, o_far=t.far_distances, o_gt=t.gt_distances,
+         o_field_ids=t.field_ids, o_rgbds=t.rgbds, o_rgb_mask=t.rgb_mask, o_depth_mask=t.depth_mask,
+         o_term_probs=t.term_probs, o_term_mask=t.term_mask, **draws)
+
+
 def g12_skip_modes():
     """NeuralField skip connections (models.py:159-180): vmapped forward and d(sum out * seed)/d(params) for
     add / concat / rezero; H > D exercises the partial add (first D units only)."""
@@ -569,7 +618,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -70,3 +70,23 @@ def held_out_scores(rgbds: torch.Tensor, th: dict):
     mse = (((rgbds[..., :3].clamp(0, 1) - tgt[..., :3]) ** 2).mean(-1) * m).sum(-1) / n
     derr = ((rgbds[..., 3] - tgt[..., 3]).abs() * m).sum(-1) / n
     return (10.0 * torch.log10(1.0 / mse)).cpu(), derr.cpu()
+
+
+# ---- one RGB-D frame for the single-view target sampler (fixture G16): regenerated from its seed, not stored ----
+SV_H, SV_W = 200, 320
+SV_FX = SV_FY = 260.0
+SV_CX, SV_CY = 159.5, 99.5
+
+
+def sv_frame(seed: int) -> torch.Tensor:
+    """(H, W, 4) RGB-D: a smooth depth field between 1.5 and 4 m with a band of missing depth, colours from the pixel
+    position.  Only exactly reproducible torch-CPU arithmetic (no transcendental of a device)."""
+    g = torch.Generator().manual_seed(seed)
+    i = torch.arange(SV_H, dtype=torch.float32)[:, None].expand(SV_H, SV_W)
+    j = torch.arange(SV_W, dtype=torch.float32)[None, :].expand(SV_H, SV_W)
+    a = torch.rand(4, generator=g)
+    u, v = i / SV_H, j / SV_W
+    depth = 1.5 + 2.5 * ((a[0] * u + a[1] * v + a[2] * u * v + 0.25 * a[3] * (u - v) ** 2) % 1.0)
+    depth[40:48, 30:200] = 0.0                                            # missing depth
+    rgb = torch.stack((u, v, 0.5 * (u + v)), -1)
+    return torch.cat((rgb, depth[..., None]), -1).contiguous()

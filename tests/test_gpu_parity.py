@@ -884,6 +884,51 @@ def test_target_sampler_golden():
     assert bool((t2.ijs[..., 0] < 48).all()) and bool((t2.ijs[..., 1] < 64).all()) and bool((t2.ijs >= 0).all())
 
 
+def test_target_sampler_single_view_golden():
+    """_sample_target_sv (rm.py:1461-1583, update_mode single_view) with the reference's recorded draws on the procedural frame
+    of fixture G16: the field set, pixel indices and masks must be identical (so the segment-sphere test agrees on all
+    14 x 50 000 pairs that matter), distances / RGB-D within fp32 round-off."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import scene
+    g = load_golden("g16_target_sampler_sv")
+    NF = g["positions"].shape[0]
+    fkw = dict(encoding="fourier", dim_enc=32, num_layers=1)
+    r = make_renderer(fkw, dict(num_samples_coarse=4, num_samples_depth_guided=4, field_radius=float(g["field_radius"])), NF)
+    r.set_field_poses(g["positions"].to(DEV), torch.zeros(NF, 4, device=DEV))
+    cam = Rr.Camera(scene.SV_W, scene.SV_H, scene.SV_FX, scene.SV_FY, scene.SV_CX, scene.SV_CY, pixel_center=0.0)
+    img = scene.sv_frame(int(g["frame_seed"]))
+    draws = dict(subset_points=g["d_subset_points"].long(), segments=g["d_segments"],
+                 subset_fields=g["d_subset_fields"] if "d_subset_fields" in g else None)
+    R = int(g["num_rays_per_field"])
+    t = r.sample_target_sv(img, g["c2w"], g["active_field_ids"], int(g["num_train_fields"]), R, camera=cam, draws=draws)
+    assert torch.equal(t.field_ids.cpu(), g["o_field_ids"])
+    assert torch.equal(t.ijs.cpu(), g["o_ijs"].long())
+    for a, b in ((t.c2ws, "o_c2ws"), (t.near_distances, "o_near"), (t.far_distances, "o_far"), (t.gt_distances, "o_gt"),
+                 (t.rgbds, "o_rgbds"), (t.term_probs, "o_term_probs")):
+        close(a, g[b], rtol=2e-6, atol=2e-6)
+    for a, b in ((t.rgb_mask, "o_rgb_mask"), (t.depth_mask, "o_depth_mask"), (t.term_mask, "o_term_mask")):
+        assert torch.equal(a.cpu(), g[b]), b
+    # the segment-sphere test against the oracle's formula on every candidate pair
+    pos_c = (g["positions"][g["active_field_ids"]] - g["c2w"][:3, 3]) @ g["c2w"][:3, :3]
+    d = img[..., 3]
+    ij = torch.nonzero(d)[g["d_subset_points"].long()]
+    dv = d[ij[:, 0], ij[:, 1]]
+    pts = torch.stack(((ij[:, 1].float() - scene.SV_CX) * dv / scene.SV_FX, -(ij[:, 0].float() - scene.SV_CY) * dv / scene.SV_FY, -dv), -1)
+    hit = ops.target_sv_intersect(pos_c.to(DEV), pts.to(DEV), float(g["field_radius"])).cpu()
+    sq = (pts * pts).sum(-1, keepdim=True)
+    tt = ((pos_c[:, None, :] * pts).sum(-1, keepdim=True) / sq).clamp(0.0, 1.0)
+    ref = ((pos_c[:, None, :] - pts * tt) ** 2).sum(-1) <= float(g["field_radius"]) ** 2
+    assert int((hit != ref).sum()) <= 2, int((hit != ref).sum())          # pairs on the sphere to the last bit
+    # own draws on the device: structural checks
+    torch.manual_seed(5)
+    t2 = r.sample_target_sv(img, g["c2w"], g["active_field_ids"], int(g["num_train_fields"]), R, camera=cam)
+    assert t2.ijs.shape[1:] == (R, 2) and 1 <= t2.ijs.shape[0] == len(t2.field_ids) <= int(g["num_train_fields"])
+    assert bool((t2.near_distances < t2.far_distances).all()) and bool(t2.term_mask.all())
+    assert bool((t2.gt_distances > 0).all())                               # only pixels with depth are sampled
+
+
 # ------------------------------------------------------------------ trained-parameter / PSNR parity over a training run
 def _smooth_scene_batch(F, R, pos, quat_unused, seed):
     """rays of synth_target with a LEARNABLE supervision: colour = smooth function of the hit point."""

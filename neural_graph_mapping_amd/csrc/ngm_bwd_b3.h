@@ -76,22 +76,10 @@ __device__ __forceinline__ void dma16_x4(const char* sb, uint32_t voff, uint32_t
       : "v"(voff), "s"(sb), "s"(lds_base)
       : "memory");
 }
-__device__ __forceinline__ void tile32_fast_offsets(int lane, uint32_t (&fvo)[4]) {
-  fvo[0] = fvo[1] = fvo[2] = fvo[3] = (uint32_t)lane * 16u;
-}
-__device__ __forceinline__ void issue_tile32_fast(const char* sbase, uint32_t tile, const uint32_t (&fvo)[4], uint32_t lds_tile) {
+__device__ __forceinline__ void issue_tile32_fast(const char* sbase, uint32_t tile, int lane, uint32_t lds_tile) {
   const char* b0 = sbase + (size_t)__builtin_amdgcn_readfirstlane(tile) * 8192;     // wave-uniform by construction: SGPR pair
-  dma16_x4(b0, fvo[0], lds_tile);
-  dma16_x4(b0 + 4096, fvo[0], lds_tile + 4096);
-}
-
-// one of the eight transfers of a tile (chunks 2k, 2k + 1)
-__device__ __forceinline__ void issue_tile32_piece(const char* sbase, uint32_t gb, uint32_t n0, uint32_t end, int lane, uint32_t lds_tile, int k) {
-  const uint32_t c = 2 * k + (lane >> 5);
-  uint32_t n = n0 + (((uint32_t)lane & 31u) ^ (c & 7u));
-  if (n >= end) n = end - 1;
-  const uint32_t u = n + gb;
-  dma16_so(sbase, (((u >> 5) * 16u + c) * 32u + ((u & 31u) ^ (c & 7u))) * 16u, lds_tile + k * 1024);
+  dma16_x4(b0, (uint32_t)lane * 16u, lds_tile);
+  dma16_x4(b0 + 4096, (uint32_t)lane * 16u, lds_tile + 4096);
 }
 
 struct B3Op { ngm_bf16x8 h, m, l; };
@@ -158,12 +146,6 @@ __device__ __forceinline__ void wgrad_b3_block_free(const B3Op (&A)[2], const B3
     __builtin_amdgcn_sched_group_barrier(0x002, (K), 0);               \
   }
 
-template <int B>
-__device__ __forceinline__ void wgrad_b3_half(const f32x16 (&dY)[2], const f32x16 (&X)[2], f32x16 (&acc)[2][2]) {
-  B3Op A[2] = {b3_regs<B>(dY[0]), b3_regs<B>(dY[1])}, Bx[2] = {b3_regs<B>(X[0]), b3_regs<B>(X[1])};
-  __builtin_amdgcn_sched_barrier(0);
-  wgrad_b3_block(A, Bx, acc);
-}
 __device__ __forceinline__ B3Op b3_arr(const float (&x)[8]) {
   B3Op o;
   b3_split8(x, o.h, o.m, o.l);

@@ -109,8 +109,6 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
 #define COL_OFF(m, r) ((m) * 1024 + col[(r) & 3] + 32 * ((r) >> 2))
 
-  uint32_t fvo[4];
-  tile32_fast_offsets(lane, fvo);
   DMA_WAIT(0);
   TICK_DECL;
   TICK(0);
@@ -277,8 +275,8 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
       const uint32_t u0 = nxt + fs.gb;
       if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
-        issue_tile32_fast(fs.act[L - 1], u0 >> 5, fvo, wl_lds + LY::HL * 4);
-        if (L == 2) issue_tile32_fast(fs.act[0], u0 >> 5, fvo, wl_lds + LY::H1 * 4);
+        issue_tile32_fast(fs.act[L - 1], u0 >> 5, lane, wl_lds + LY::HL * 4);
+        if (L == 2) issue_tile32_fast(fs.act[0], u0 >> 5, lane, wl_lds + LY::H1 * 4);
       } else {
         issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
         if (L == 2) issue_tile32(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::H1 * 4);

@@ -166,8 +166,6 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3p(FieldBwdArgs a) {
   DMA_WAIT(0);
   __syncthreads();
 
-  uint32_t fvo[4];
-  tile32_fast_offsets(lane, fvo);
   int col[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
@@ -303,8 +301,8 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3p(FieldBwdArgs a) {
         issue_inputs(fs, a.S, nx, end, lane, pl_lds + (LY::INB + ((s + 1) & 1u) * 512) * 4);
         issue_inputs(fs, a.S, nx + 16, end, lane, pl_lds + (LY::INB + ((s + 1) & 1u) * 512) * 4 + 1024);
         if (((u0 & 31u) == 0u) && (nx + 32u <= end)) {
-          issue_tile32_fast(fs.act[0], u0 >> 5, fvo, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
-          issue_tile32_fast(fs.act[1], u0 >> 5, fvo, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);
+          issue_tile32_fast(fs.act[0], u0 >> 5, lane, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
+          issue_tile32_fast(fs.act[1], u0 >> 5, lane, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);
         } else {
           issue_tile32(fs.act[0], fs.gb, nx, end, lane, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
           issue_tile32(fs.act[1], fs.gb, nx, end, lane, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);
@@ -360,8 +358,8 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3p(FieldBwdArgs a) {
         issue_inputs(fs, a.S, nx, end, lane, pl_lds + (LY::INB + ((s + 1) & 1u) * 512) * 4);
         issue_inputs(fs, a.S, nx + 16, end, lane, pl_lds + (LY::INB + ((s + 1) & 1u) * 512) * 4 + 1024);
         if (((u0 & 31u) == 0u) && (nx + 32u <= end)) {
-          issue_tile32_fast(fs.act[0], u0 >> 5, fvo, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
-          issue_tile32_fast(fs.act[1], u0 >> 5, fvo, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);
+          issue_tile32_fast(fs.act[0], u0 >> 5, lane, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
+          issue_tile32_fast(fs.act[1], u0 >> 5, lane, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);
         } else {
           issue_tile32(fs.act[0], fs.gb, nx, end, lane, pl_lds + (LY::H1 + ((s + 1) % 3u) * HT) * 4);
           issue_tile32(fs.act[1], fs.gb, nx, end, lane, pl_lds + (LY::HL + ((s + 1) & 1u) * HT) * 4);

@@ -148,16 +148,25 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Hc[m][r] = HLb[COL_OFF(m, r)];
+      if (L == 2) {                  // layer 1's input columns: in flight under the output layer's arithmetic (one wave per SIMD:
+                                     // a load issued where it is needed is a stall of a full LDS round trip)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
+      }
+      float4 dOa[2][8];              // both halves' d_out rows up front, as for the positions below
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(obuf + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        float4 dO[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dO[e] = *reinterpret_cast<const float4*>(obuf + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int r = 8 * half + e;
-          const float4 d = dO[e];
+          const float4 d = dOa[half][e];
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const float h = Hc[m][r];
@@ -183,11 +192,6 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     if constexpr (L == 2) {
       RowRegs R;
       PlaneRegs W0;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
-      __builtin_amdgcn_sched_barrier(0);
       {
         B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, B0[2] = {b3_regs<0>(Xc[0]), b3_regs<0>(Xc[1])};
         __builtin_amdgcn_sched_barrier(0);
@@ -235,16 +239,18 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     TICK(8);
     const float4 encw[2] = {cenc[i], cenc[32 + i]};
     float Eb[2][2][8];
+    float4 ppa[2][8];                // both blocks' positions up front: the second block's read latency hides under the first's arithmetic
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pbuf + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      float4 pp[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pp[e] = *reinterpret_cast<const float4*>(pbuf + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
-      __builtin_amdgcn_sched_barrier(0);
       const float inv2pi = 0.15915494309189535f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float4 p = pp[e];
+        const float4 p = ppa[b][e];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           const float4 w = encw[m];

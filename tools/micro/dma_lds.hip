@@ -5,6 +5,9 @@
 //   mode 2: loop { 8 DMA into region B; 8 ds_read_b128 of region A; VALU work }                    (reads right behind the DMA)
 //   mode 3: loop { 8 plain global_load_dwordx4 into registers (kept); VALU work; 8 ds_read_b128 }  (same traffic, no LDS write)
 //   mode 4: like 1 with s_waitcnt vmcnt(0) right after the VALU work (cost of waiting for the data itself)
+//   mode 5: wave 0 as mode 4 while waves 1-3 of the CU stream ds_read_b128 (does OTHER waves' LDS traffic slow the issue?)
+//   mode 6: wave 0 as mode 4 while waves 1-3 issue bf16 MFMAs back to back
+//   mode 7: wave 0 as mode 4, waves 1-3 idle (the reference for 5 and 6; all three report wave 0's clocks)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -28,6 +31,44 @@ __global__ __launch_bounds__(256) void k(int mode, int iters, int work, const fl
   float4 keep[8];
   for (int e = 0; e < 8; ++e) keep[e] = make_float4(0, 0, 0, 0);
   __syncthreads();
+  if (mode >= 5) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    if (wave != 0) {
+      if (mode == 5) {
+        for (int it = 0; it < iters * 40; ++it) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float4 r = *reinterpret_cast<const float4*>(A + (((e * 64 + lane + it) * 4) & 4095)); acc += r.x + r.w; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (mode == 6) {
+        f32x16 c = {0};
+        bf16x8 x, y;
+        for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(lane * 1e-3f); y[e] = (__bf16)1.0f; }
+        for (int it = 0; it < iters * 100; ++it) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+        acc += c[0];
+      }
+      if (acc == 12345.678f) out[threadIdx.x] = acc;
+      return;
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+      const float4* p = mine + (size_t)(it & 63) * 512;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dma16_so(p, (uint32_t)((e * 64 + lane) * 16), ldsB + e * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int w = 0; w < work; ++w) v = fmaf(v, 0.999f, 1e-3f);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float4 r = *reinterpret_cast<const float4*>(A + ((e * 64 + lane) * 4 & 4095)); acc += r.x + r.w; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (acc + v == 12345.678f) out[threadIdx.x] = acc + B[lane];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[mode] = t1 - t0;
+    return;
+  }
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     const float4* p = mine + (size_t)(it & 63) * 512;
@@ -64,10 +105,10 @@ int main() {
   const size_t stride4 = 64 * 512;                       // float4 per wave: 64 distinct 8 KB tiles
   float4* src; float* out; unsigned long long* cyc;
   hipMalloc(&src, 256 * 4 * stride4 * 16); hipMemset(src, 0, 256 * 4 * stride4 * 16);
-  hipMalloc(&out, 4096); hipMalloc(&cyc, 64);
+  hipMalloc(&out, 4096); hipMalloc(&cyc, 128);
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192 * 4);
   for (int work : {100, 500, 2000}) {
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
       k<<<256, 256, 4 * 8192 * 4>>>(mode, 50, work, src, stride4, out, cyc);
       hipDeviceSynchronize();
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -76,7 +117,7 @@ int main() {
       k<<<256, 256, 4 * 8192 * 4>>>(mode, iters, work, src, stride4, out, cyc);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      unsigned long long c[8]; hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
+      unsigned long long c[16]; hipMemcpy(c, cyc, 128, hipMemcpyDeviceToHost);
       printf("work %4d mode %d: %.3f ms, %.0f clocks/iter (s_memtime), %.1f ns/iter\n", work, mode, ms, (double)c[mode] / iters, ms * 1e6 / iters);
     }
   }

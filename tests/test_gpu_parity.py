@@ -690,7 +690,14 @@ def test_stash_backward_bf16_split_other_encodings(enc):
            dict(encoding="fourier", dim_enc=61, num_layers=2))
     ragged_case(3, 41, 9, 5, fkw, mlp_matmul="auto")
     from neural_graph_mapping_amd import _capi
-    assert _capi.lib().ngm_debug_last_bwd_variant() == 3
+    L = _capi.lib()
+    assert L.ngm_debug_last_bwd_variant() == 3
+    L.ngm_debug_prefer_paired_bwd(1)                 # and the two-waves-per-tile kernel's instances for these encodings
+    try:
+        ragged_case(3, 41, 9, 5, fkw, mlp_matmul="auto")
+        assert L.ngm_debug_last_bwd_variant() == 4
+    finally:
+        L.ngm_debug_prefer_paired_bwd(0)
 
 
 # ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)

@@ -499,7 +499,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   const int64_t b3_bytes = 3 * 2 * 1024 * MHp * (MIp + (fc->num_layers - 1) * MHp);
   const bool b3_compiled = MIp == 2 && MHp == 2 && fc->num_layers <= 2 && fc->skip_mode == NGM_SKIP_NO &&
                            (fc->encoding == NGM_ENC_FOURIER || fc->encoding == NGM_ENC_NONE);
-  auto shape = [&](int waves, int64_t extra, int64_t* lds_out) {
+  auto shape = [&](int waves, int64_t extra, int64_t* lds_out, int64_t maxs_cap = 1024) {
     int ch = (ncu + F - 1) / F;
     const int max_ch = (R + waves - 1) / waves;
     if (ch > max_ch) ch = max_ch;
@@ -508,7 +508,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     rpb = (int)align_up(rpb, waves);
     const int rpw = rpb / waves;
     int64_t maxs = align_up((int64_t)(rpw < 32 ? rpw : 32) * p.S, 64);
-    if (maxs > 1024) maxs = 1024;
+    if (maxs > maxs_cap) maxs = maxs_cap;                // samples a wave buffers per ray batch (whole rays)
     if (maxs < align_up(p.S, 64)) maxs = align_up(p.S, 64);
     *lds_out = 4 * (field_lds_floats(fc) + (int64_t)waves * (32 * 28 + 5 * maxs)) + extra;
     p.rays_per_block = rpb; p.waves_fwd = waves; p.maxs = (int)maxs;
@@ -519,12 +519,25 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   shape(8, 0, &lds);                                    // exact-fp32 plan first: 8 waves unless its LDS does not fit
   if (lds > LDS_MAX || R < 8) shape(4, 0, &lds);
   p.b3 = 0;
-  if (fc->matmul_mode == NGM_MATMUL_BF16X3) {           // explicit: whatever wave count makes it fit, else the launcher fails loudly
+  // The split path's weight planes (48 KB for two 64-wide layers) compete with the per-wave sample planes for LDS: a
+  // batch of many samples per ray (8192 x 256: 1024 samples buffered per wave) leaves no room at 8 waves.  Smaller ray
+  // batches per wave do (one 256-sample ray at a time: 8.7 KB per wave), at no measurable cost -- tried in that order.
+  auto fit_b3 = [&]() {
+    for (int64_t cap : {(int64_t)1024, (int64_t)512, (int64_t)256}) {
+      shape(8, b3_bytes, &lds, cap);
+      if (lds <= LDS_MAX && R >= 8) return true;
+    }
+    shape(4, b3_bytes, &lds);
+    return lds <= LDS_MAX;
+  };
+  if (fc->matmul_mode == NGM_MATMUL_BF16X3) {           // explicit: whatever shape makes it fit, else the launcher fails loudly
     p.b3 = 1;
-    shape(8, b3_bytes, &lds);
-    if (lds > LDS_MAX || R < 8) shape(4, b3_bytes, &lds);
-  } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && rc->geometry_mode != NGM_GEO_NEUS && lds + b3_bytes <= LDS_MAX) {
-    p.b3 = 1;                                           // auto: only when the planes fit next to the fp32 plan's wave count
+    (void)fit_b3();
+  } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && rc->geometry_mode != NGM_GEO_NEUS) {
+    const int64_t lds_f32 = lds;
+    const RenderPlan keep = p;
+    if (fit_b3() && p.waves_fwd == 8) p.b3 = 1;                       // auto: the planes next to an 8-wave plan, else exact-fp32 MFMA
+    else { p = keep; lds = lds_f32; }
   }
   p.p_pad = param_pad(fc);
   int64_t o = 0;

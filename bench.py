@@ -84,7 +84,8 @@ def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, ma
         **enc, dim_out=4, dim_mlp_out=None, skip_mode="no", initial_geometry_bias=0.0, neus_initial_sd=1.0), num_knn=2,
         distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(device)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
-               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
+               termination_weight=0.0, photometric_weight=1.0, photometric_loss="l1", depth_weight=1.0, depth_loss="huber",
+               freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0,
                num_samples_coarse=S_C if s_c is None else s_c, num_samples_depth_guided=S_G if s_g is None else s_g,
                mlp_matmul=matmul)

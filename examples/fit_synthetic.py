@@ -72,7 +72,8 @@ def main(iters=300, device="cuda:0", quiet=False):
         encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
         num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=radius, scale_mode="unit_cube").to(dev)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=radius,
-               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
+               termination_weight=0.0, photometric_weight=1.0, photometric_loss="l1", depth_weight=1.0, depth_loss="huber",
+               freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=2e-3, adam_eps=1e-15, adam_weight_decay=1e-5, num_samples_coarse=8, num_samples_depth_guided=16,
                near_distance=0.0, far_distance=5.0, eval_near_distance=0.5, eval_far_distance=4.5, eval_num_samples=160)
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 2
+#define NGM_ABI_VERSION 3
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -148,6 +148,11 @@ typedef struct ngm_grads {
   int64_t planes_stride;
 } ngm_grads;
 
+/* Loss modes of losses.py built into the fused kernels.  The variance-weighted modes (gaussian_nll / laplacian_nll,
+ * losses.py:30-36, 64-75) need gradients through the rendered variances and are NOT built: the host layer raises. */
+typedef enum ngm_photometric_mode { NGM_PHOTO_L1 = 0, NGM_PHOTO_L2 = 1 } ngm_photometric_mode;
+typedef enum ngm_depth_mode { NGM_DEPTH_HUBER = 0 } ngm_depth_mode;
+
 /* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */
 typedef struct ngm_render_cfg {
   int32_t geometry_mode;       /* ngm_geometry_mode, rm.py:746-762            */
@@ -163,6 +168,8 @@ typedef struct ngm_render_cfg {
   float w_termination, w_photometric, w_depth, w_freespace, w_tsdf; /* rm.py:129-135 */
   float huber_delta;           /* 0.05, losses.py:63                          */
   float term_threshold;        /* 0.8, rm.py:1787                             */
+  int32_t photometric_mode;    /* ngm_photometric_mode (config key photometric_loss, losses.py:26-29); ABI 3 */
+  int32_t depth_mode;          /* ngm_depth_mode (config key depth_loss, losses.py:60-63): huber only        */
 } ngm_render_cfg;
 
 /* One batch of rays: the reference's Target record (rm.py:43-58) in device memory. */

@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libngm_hip.so")
+# NGM_LIB_PATH: developer experiments only (a variant build of the same sources, tools/variants.sh)
+LIB_PATH = os.environ.get("NGM_LIB_PATH") or os.path.join(HERE, "lib", "libngm_hip.so")
 
 NGM_MAX_LAYERS = 4
 NGM_NUM_LOSS_SUMS = 16
@@ -21,6 +22,8 @@ ENC = {"none": 0, "fourier": 1, "nerf": 2, "permuto": 3, "triplane": 4}
 TRI = {"sum": 0, "product": 1, "concat": 2}
 SCALE = {"no": 0, "unit_ball": 1, "unit_cube": 2}
 GEO = {"nrgbd": 0, "occupancy": 1, "density": 2, "neus": 3}
+PHOTO = {"l1": 0, "l2": 1}          # losses.py:26-29
+DEPTH = {"huber": 0}                # losses.py:60-63
 LS = dict(PHOTO_SUM=0, PHOTO_CNT=1, DEPTH_SUM=2, DEPTH_CNT=3, FS_SUM=4, FS_CNT=5, TSDF_SUM=6,
           TSDF_CNT=7, TERM_SUM=8, TERM_CNT=9)
 
@@ -61,7 +64,7 @@ class RenderCfg(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("w_termination", C.c_float), ("w_photometric", C.c_float), ("w_depth", C.c_float),
                 ("w_freespace", C.c_float), ("w_tsdf", C.c_float), ("huber_delta", C.c_float),
-                ("term_threshold", C.c_float)]
+                ("term_threshold", C.c_float), ("photometric_mode", C.c_int32), ("depth_mode", C.c_int32)]
 
 
 class Rays(C.Structure):
@@ -316,11 +319,18 @@ def render_cfg(geometry_mode="nrgbd", num_samples_coarse=8, num_samples_guided=1
                geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1,
                range_depth_guided=None, fx=554.2562584220408, fy=554.2562584220408, cx=319.5,
                cy=239.5, w_termination=0.0, w_photometric=1.0, w_depth=1.0, w_freespace=40.0,
-               w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8, overwrite_behind_camera=True):
+               w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8, overwrite_behind_camera=True,
+               photometric_loss="l1", depth_loss="huber"):
+    if photometric_loss not in PHOTO:
+        raise NotImplementedError(f"photometric_loss {photometric_loss!r}: the fused kernels build {sorted(PHOTO)} "
+                                  "(gaussian_nll needs gradients through the rendered variances, losses.py:30-36)")
+    if depth_loss not in DEPTH:
+        raise NotImplementedError(f"depth_loss {depth_loss!r}: the fused kernels build {sorted(DEPTH)} "
+                                  "(gaussian_nll / laplacian_nll need gradients through the rendered variances, losses.py:64-75)")
     if range_depth_guided is None:
         range_depth_guided = truncation_distance
     return RenderCfg(GEO[geometry_mode], num_samples_coarse, num_samples_guided, int(bool(overwrite_behind_camera)),
                      geometry_factor,
                      color_factor, truncation_distance, range_depth_guided, fx, fy, cx, cy,
                      w_termination, w_photometric, w_depth, w_freespace, w_tsdf, huber_delta,
-                     term_threshold)
+                     term_threshold, PHOTO[photometric_loss], DEPTH[depth_loss])

@@ -52,7 +52,11 @@ def _compile(src, flags):
     return obj
 
 
-def build(fast=False, force=False, verbose=True):
+def build(fast=False, force=False, verbose=True, out=None):
+    """out: file name of a VARIANT library (developer experiments: `NGM_HIPCC_EXTRA="-DX" ... --out=libngm_x.so`,
+    loaded by the tools through NGM_LIB_PATH); the product library is always lib/libngm_hip.so."""
+    global LIB
+    LIB = os.path.join(LIBDIR, out) if out else os.path.join(LIBDIR, "libngm_hip.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     flags = FLAGS + (["-DNGM_FAST_BUILD"] if fast else [])
@@ -62,7 +66,7 @@ def build(fast=False, force=False, verbose=True):
             os.remove(os.path.join(OBJ, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda s: _compile(s, flags), SOURCES))
-    stamp = os.path.join(OBJ, "link.stamp")
+    stamp = os.path.join(OBJ, "link.stamp" if not out else "link." + out + ".stamp")
     key = " ".join(objs)
     if force or not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != key:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
@@ -77,4 +81,5 @@ def build(fast=False, force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(fast="--fast" in sys.argv, force="--force" in sys.argv)
+    outs = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--out=")]
+    build(fast="--fast" in sys.argv, force="--force" in sys.argv, out=outs[0] if outs else None)

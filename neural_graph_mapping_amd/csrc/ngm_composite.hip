@@ -429,8 +429,12 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
         const bool m = a.tg.depth_mask[ray] && (term > a.rc.term_threshold);
         if (m) {
           const float e0 = pr.x - tg.x, e1 = pr.y - tg.y, e2 = pr.z - tg.z;
-          dC0 = k_photo * ((e0 > 0.f) - (e0 < 0.f)); dC1 = k_photo * ((e1 > 0.f) - (e1 < 0.f));
-          dC2 = k_photo * ((e2 > 0.f) - (e2 < 0.f));
+          if (a.rc.photometric_mode == NGM_PHOTO_L2) {      // d mean(e^2) (losses.py:28-29)
+            dC0 = 2.0f * k_photo * e0; dC1 = 2.0f * k_photo * e1; dC2 = 2.0f * k_photo * e2;
+          } else {                                           // d mean|e|  (losses.py:26-27)
+            dC0 = k_photo * ((e0 > 0.f) - (e0 < 0.f)); dC1 = k_photo * ((e1 > 0.f) - (e1 < 0.f));
+            dC2 = k_photo * ((e2 > 0.f) - (e2 < 0.f));
+          }
           const float e = pr.w - tg.w, dl = a.rc.huber_delta;
           dD = k_depth * ((fabsf(e) < dl) ? e : dl * ((e > 0.f) - (e < 0.f)));
         }

@@ -543,14 +543,55 @@ __device__ __forceinline__ void b3_split(float x, uint32_t& h, uint32_t& m, uint
 // two bf16 (upper halves of even / odd) -> one packed word, even element in the low half
 __device__ __forceinline__ uint32_t b3_pack(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
 
+// One pair of values -> the three packed words (even element in the low half).  Three forms of the same exact
+// arithmetic (bit-identical planes for normal numbers, tools/micro/dot2c_split.hip):
+//   default       h = x & 0xffff0000, r = x - h, ... : 4 VALU per element + 3 v_perm per pair
+//   NGM_SPLIT_DOT2C  the packed hi pair is formed FIRST (one v_perm straight from the fp32 registers), and each residual is
+//                 one v_dot2c_f32_bf16 (gfx950): r0 = x0 + hp.lo * (-1) + hp.hi * 0 -- exact, since r is representable --
+//                 2 VALU per element + 3 v_perm per pair
+//   NGM_SPLIT_PK  the two residual subtractions of a pair as one v_pk_add_f32
+__device__ __forceinline__ void b3_split2(float x0, float x1, uint32_t& hp, uint32_t& mp, uint32_t& lp) {
+#if defined(NGM_SPLIT_DOT2C)
+  typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+  uint32_t clo = 0x0000bf80u, chi = 0xbf800000u;        // (-1, 0) and (0, -1) as (low, high) bf16
+#if NGM_SPLIT_DOT2C == 1
+  asm("" : "+v"(clo)); asm("" : "+v"(chi));             // keep them in registers (no inline-constant folding)
+#endif
+  hp = b3_pack(__float_as_uint(x0), __float_as_uint(x1));
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_, hp), __builtin_bit_cast(bf2_, clo), x0, false);
+  const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_, hp), __builtin_bit_cast(bf2_, chi), x1, false);
+  mp = b3_pack(__float_as_uint(r0), __float_as_uint(r1));
+  const float q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_, mp), __builtin_bit_cast(bf2_, clo), r0, false);
+  const float q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_, mp), __builtin_bit_cast(bf2_, chi), r1, false);
+  lp = b3_pack(__float_as_uint(q0), __float_as_uint(q1));
+#elif defined(NGM_SPLIT_PK)
+  const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+  const ngm_v2f r = ngm_v2f{x0, x1} - ngm_v2f{__uint_as_float(h0), __uint_as_float(h1)};
+  const uint32_t m0 = __float_as_uint(r.x) & 0xffff0000u, m1 = __float_as_uint(r.y) & 0xffff0000u;
+  const ngm_v2f q = r - ngm_v2f{__uint_as_float(m0), __uint_as_float(m1)};
+  hp = b3_pack(h0, h1); mp = b3_pack(m0, m1); lp = b3_pack(__float_as_uint(q.x), __float_as_uint(q.y));
+#else
+  uint32_t h0, m0, l0, h1, m1, l1;
+  b3_split(x0, h0, m0, l0);
+  b3_split(x1, h1, m1, l1);
+  hp = b3_pack(h0, h1); mp = b3_pack(m0, m1); lp = b3_pack(l0, l1);
+#endif
+}
+
 __device__ __forceinline__ void b3_split8(const float (&x)[8], ngm_bf16x8& H, ngm_bf16x8& M, ngm_bf16x8& Lo) {
   ngm_u32x4 h4, m4, l4;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
+#if defined(NGM_SPLIT_DOT2C) || defined(NGM_SPLIT_PK)
+    uint32_t hp, mp, lp;
+    b3_split2(x[2 * p], x[2 * p + 1], hp, mp, lp);
+    h4[p] = hp; m4[p] = mp; l4[p] = lp;
+#else
     uint32_t h0, m0, l0, h1, m1, l1;
     b3_split(x[2 * p], h0, m0, l0);
     b3_split(x[2 * p + 1], h1, m1, l1);
     h4[p] = b3_pack(h0, h1); m4[p] = b3_pack(m0, m1); l4[p] = b3_pack(l0, l1);
+#endif
   }
   H = __builtin_bit_cast(ngm_bf16x8, h4); M = __builtin_bit_cast(ngm_bf16x8, m4); Lo = __builtin_bit_cast(ngm_bf16x8, l4);
 }

@@ -401,7 +401,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         const float4 tg = make_float4(rt[12], rt[13], rt[14], rt[15]);
         const bool m = (ra[9] != 0.f) && (term > a.rc.term_threshold);  // rm.py:1787
         if (m) {
-          ls[NGM_LS_PHOTO_SUM] += fabsf(tg.x - ra[0]) + fabsf(tg.y - ra[1]) + fabsf(tg.z - ra[2]);
+          const float p0 = tg.x - ra[0], p1 = tg.y - ra[1], p2 = tg.z - ra[2];
+          ls[NGM_LS_PHOTO_SUM] += (a.rc.photometric_mode == NGM_PHOTO_L2) ? fmaf(p2, p2, fmaf(p1, p1, p0 * p0))   // losses.py:28-29
+                                                                           : fabsf(p0) + fabsf(p1) + fabsf(p2);   // losses.py:26-27
           cnt_r += 1u;
           const float e = ra[3] - tg.w, ae = fabsf(e), dlt = a.rc.huber_delta;
           ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);

@@ -52,13 +52,16 @@ def allreduce_loss_sums(loss_sums: torch.Tensor, group=None) -> torch.Tensor:
     return loss_sums
 
 
-def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsdf) -> dict:
-    """rm.py:1803-1871 from the global sums (slot layout: include/ngm_hip.h ngm_loss_slot)."""
+def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsdf, photometric_loss="l1",
+                          depth_loss="huber") -> dict:
+    """rm.py:1803-1871 from the global sums (slot layout: include/ngm_hip.h ngm_loss_slot); the photometric / depth
+    keys carry the mode like rm.py:1827, 1837 (the sums already are of |e| or e^2, whichever the kernels were told)."""
     def mean(num, den, scale=1.0):
         return torch.where(den > 0, num / (scale * den.clamp_min(1.0)), torch.zeros_like(num))
-    out = dict(photometric_l1=mean(s[0], s[1], 3.0), depth_huber=mean(s[2], s[3]), freespace=mean(s[4], s[5]),
-               tsdf=mean(s[6], s[7]), termination=mean(s[8], s[9]))
-    out["combined"] = (w_term * out["termination"] + w_photo * out["photometric_l1"] + w_depth * out["depth_huber"]
+    pk, dk = "photometric_" + photometric_loss, "depth_" + depth_loss
+    out = {pk: mean(s[0], s[1], 3.0), dk: mean(s[2], s[3]), "freespace": mean(s[4], s[5]),
+           "tsdf": mean(s[6], s[7]), "termination": mean(s[8], s[9])}
+    out["combined"] = (w_term * out["termination"] + w_photo * out[pk] + w_depth * out[dk]
                        + w_fs * out["freespace"] + w_tsdf * out["tsdf"])
     return out
 

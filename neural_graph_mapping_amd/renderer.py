@@ -46,19 +46,55 @@ class LossConfig:
         self.depth_weight, self.freespace_weight, self.tsdf_weight = depth_weight, freespace_weight, tsdf_weight
 
 
+# keys NeuralGraphMap._read_config reads unconditionally (rm.py:116-220) among those this path consumes: a config the
+# reference would refuse with a KeyError is refused here too, instead of training with a silent default
+REQUIRED_CONFIG_KEYS = ("termination_weight", "photometric_weight", "photometric_loss", "depth_weight", "depth_loss",
+                        "freespace_weight", "geometry_mode", "num_samples_coarse", "num_samples_depth_guided")
+
+
+def shipped_config(**overrides) -> dict:
+    """The render / loss / optimiser keys of the shipped config (config/neural_graph_map.yaml:26-70) with their shipped
+    values -- a complete config for this path to start from (tests, tools, examples); `overrides` replace entries."""
+    cfg = dict(color_factor=1.0, geometry_factor=20.0, learning_rate=1e-3, field_radius=1.0, termination_weight=0.0,
+               photometric_weight=1.0, photometric_loss="l1", depth_weight=1.0, depth_loss="huber", freespace_weight=40.0,
+               tsdf_weight=50.0, near_distance=0.0, far_distance=8.0, pixel_block_size=8192, block_size=3000000,
+               geometry_mode="nrgbd", truncation_distance=0.1, num_train_fields=32, num_rays_per_field=512,
+               num_samples_coarse=8, num_samples_depth_guided=16, range_depth_guided=None, adam_eps=1e-15,
+               adam_weight_decay=1e-5)
+    cfg.update(overrides)
+    return cfg
+
+
+def check_config(config: dict) -> None:
+    """Fail loudly on what the reference requires and on what is not built (loss modes of losses.py:10-75)."""
+    missing = [k for k in REQUIRED_CONFIG_KEYS if k not in config]
+    if missing:
+        raise KeyError(f"config lacks {missing}: NeuralGraphMap._read_config reads them unconditionally (rm.py:116-220)")
+    if config["photometric_loss"] not in K.PHOTO:
+        raise NotImplementedError(f"photometric_loss {config['photometric_loss']!r} is not built (built: {sorted(K.PHOTO)}; "
+                                  "gaussian_nll, losses.py:30-36, needs gradients through the rendered colour variances)")
+    if config["depth_loss"] not in K.DEPTH:
+        raise NotImplementedError(f"depth_loss {config['depth_loss']!r} is not built (built: {sorted(K.DEPTH)}; gaussian_nll / "
+                                  "laplacian_nll, losses.py:64-75, need gradients through the rendered depth variance)")
+    if config["geometry_mode"] not in K.GEO:
+        raise ValueError(f"Unsupported geometry mode {config['geometry_mode']}")        # rm.py:760 wording
+
+
 def make_render_cfg(camera: Camera, config: dict, guided: bool = True) -> K.RenderCfg:
-    """Reference config keys (rm.py:116-220) -> ngm_render_cfg."""
+    """Reference config keys (rm.py:116-220) -> ngm_render_cfg.  Optional keys keep the reference's `.get` defaults
+    (tsdf_weight 0.0, color / geometry factor 1.0, range_depth_guided -> truncation_distance)."""
+    check_config(config)
     fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
     tau = config.get("truncation_distance", 0.1)
     rho = config.get("range_depth_guided") or tau
     return K.render_cfg(
-        geometry_mode=config.get("geometry_mode", "nrgbd"), num_samples_coarse=config["num_samples_coarse"],
-        num_samples_guided=config.get("num_samples_depth_guided", 0) if guided else 0,
+        geometry_mode=config["geometry_mode"], num_samples_coarse=config["num_samples_coarse"],
+        num_samples_guided=config["num_samples_depth_guided"] if guided else 0,
         geometry_factor=config.get("geometry_factor", 1.0), color_factor=config.get("color_factor", 1.0),
         truncation_distance=tau, range_depth_guided=rho, fx=fx, fy=fy, cx=cx, cy=cy,
-        w_termination=config.get("termination_weight", 0.0), w_photometric=config.get("photometric_weight", 1.0),
-        w_depth=config.get("depth_weight", 1.0), w_freespace=config.get("freespace_weight", 0.0),
-        w_tsdf=config.get("tsdf_weight", 0.0))
+        w_termination=config["termination_weight"], w_photometric=config["photometric_weight"],
+        w_depth=config["depth_weight"], w_freespace=config["freespace_weight"],
+        w_tsdf=config.get("tsdf_weight", 0.0), photometric_loss=config["photometric_loss"], depth_loss=config["depth_loss"])
 
 
 class NeuralGraphRenderer:
@@ -255,16 +291,18 @@ class NeuralGraphRenderer:
         return out
 
     def compute_losses(self, target: Target, prediction: Prediction) -> dict:
-        """_compute_losses (rm.py:1769-1872) on torch tensors (l1 photometric, huber depth)."""
+        """_compute_losses (rm.py:1769-1872) on torch tensors; loss dict keys carry the mode like rm.py:1827, 1837."""
         rc = self._rc_train
+        pk = "photometric_" + self._config["photometric_loss"]
         m = target.depth_mask & (prediction.term_probs > rc.term_threshold)
         loss = {}
         tm = target.term_mask
         loss["termination"] = ((prediction.term_probs[tm] - target.term_probs[tm]) ** 2).mean()
-        loss["photometric_l1"] = (target.rgbds[m][:, :3] - prediction.rgbds[m][:, :3]).abs().mean()
+        diff = target.rgbds[m][:, :3] - prediction.rgbds[m][:, :3]
+        loss[pk] = diff.abs().mean() if rc.photometric_mode == K.PHOTO["l1"] else (diff ** 2).mean()   # losses.py:26-29
         loss["depth_huber"] = torch.nn.functional.huber_loss(prediction.rgbds[m][:, 3], target.rgbds[m][:, 3],
                                                              delta=rc.huber_delta)
-        total = (rc.w_termination * loss["termination"] + rc.w_photometric * loss["photometric_l1"]
+        total = (rc.w_termination * loss["termination"] + rc.w_photometric * loss[pk]
                  + rc.w_depth * loss["depth_huber"])
         if prediction.freespace_geometry is not None:
             loss["freespace"] = ((prediction.freespace_geometry - rc.truncation_distance) ** 2).mean()
@@ -474,7 +512,8 @@ class NeuralGraphRenderer:
         if self.process_group is not None:
             torch.distributed.all_reduce(sums, group=self.process_group)
         rc = self._rc_train
-        loss = D.loss_values_from_sums(sums, rc.w_termination, rc.w_photometric, rc.w_depth, rc.w_freespace, rc.w_tsdf)
+        loss = D.loss_values_from_sums(sums, rc.w_termination, rc.w_photometric, rc.w_depth, rc.w_freespace, rc.w_tsdf,
+                                       self._config["photometric_loss"], self._config["depth_loss"])
         if update:
             self._step += 1
             if self._step_dev is None:
@@ -572,7 +611,8 @@ class NeuralGraphRenderer:
                                      sums_ptr, C.byref(gs), w["loss"].data_ptr(), w["ws"].data_ptr(), w["wsb"],
                                      st), "ngm_render_bwd")
         lv = w["loss"]
-        loss = {"combined": lv[0], "termination": lv[1], "photometric_l1": lv[2], "depth_huber": lv[3],
+        loss = {"combined": lv[0], "termination": lv[1], "photometric_" + self._config["photometric_loss"]: lv[2],
+                "depth_" + self._config["depth_loss"]: lv[3],
                 "freespace": lv[4], "tsdf": lv[5]}
         if not update:
             loss["grads"] = grads

@@ -128,6 +128,7 @@ class RenderSpec:
     photometric_weight: float = 1.0
     depth_weight: float = 1.0
     huber_delta: float = 0.05                       # losses.py:63
+    photometric_loss: str = "l1"                    # losses.py:26-29 ("l1" | "l2"; gaussian_nll not restated)
 
     def __post_init__(self):
         if self.range_depth_guided is None:
@@ -626,15 +627,23 @@ def sample_target_sv(cam: CameraSpec, rgbd_image, c2w, positions, active_field_i
 
 
 def compute_losses(pred, target_rgbds, depth_mask, term_mask, term_target, rs: RenderSpec):
-    """Global masked means over all fields (rm.py:1787-1872); l1 photometric + huber depth."""
+    """Global masked means over all fields (rm.py:1787-1872); l1 / l2 photometric (losses.py:26-29) + huber depth
+    (losses.py:60-63); the loss dict key carries the mode like rm.py:1827."""
     m = depth_mask & (pred["term_probs"] > 0.8)                     # rm.py:1787-1788
     loss = {}
     loss["termination"] = ((pred["term_probs"][term_mask] - term_target[term_mask]) ** 2).mean()
-    loss["photometric_l1"] = (target_rgbds[m][:, :3] - pred["rgbds"][m][:, :3]).abs().mean()
+    pk = "photometric_" + rs.photometric_loss
+    diff = target_rgbds[m][:, :3] - pred["rgbds"][m][:, :3]
+    if rs.photometric_loss == "l1":
+        loss[pk] = diff.abs().mean()
+    elif rs.photometric_loss == "l2":
+        loss[pk] = (diff ** 2).mean()
+    else:
+        raise NotImplementedError(rs.photometric_loss)
     loss["depth_huber"] = torch.nn.functional.huber_loss(
         pred["rgbds"][m][:, 3], target_rgbds[m][:, 3], delta=rs.huber_delta)
     total = (rs.termination_weight * loss["termination"]
-             + rs.photometric_weight * loss["photometric_l1"]
+             + rs.photometric_weight * loss[pk]
              + rs.depth_weight * loss["depth_huber"])
     if pred["freespace_geometry"] is not None:
         loss["freespace"] = ((pred["freespace_geometry"] - rs.truncation_distance) ** 2).mean()

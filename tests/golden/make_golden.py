@@ -196,14 +196,14 @@ def g5_quadrature():
 
 
 def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, dim_enc=64,
-                termination_weight=0.0, perturb=True, save_samples=False, inside=False):
+                termination_weight=0.0, perturb=True, save_samples=False, inside=False, photometric_loss="l1"):
     cam = camera.Camera(**NRGBD_CAMERA)
     gen = torch.Generator().manual_seed(seed)
     pos = 0.5 * torch.randn(F, 3, generator=gen)
     quat = rand_quats(F, gen)
     cfg = make_config(encoding=encoding, dim_enc=dim_enc, num_layers=num_layers,
                       num_samples_coarse=n_c, num_samples_depth_guided=n_g,
-                      termination_weight=termination_weight)
+                      termination_weight=termination_weight, photometric_loss=photometric_loss)
     ngm = build_map(rm, cfg, F, pos, quat, seed=seed)
     ngm._camera = cam
     model = ngm._model
@@ -239,6 +239,11 @@ def g6_train():
     _train_case("g6_train_3field", F=3, R=24, n_c=8, n_g=16, seed=61, termination_weight=0.5)
     _train_case("g6_train_nerf_l1", F=2, R=16, n_c=8, n_g=8, seed=62, encoding="nerf",
                 num_layers=1)
+
+
+def g18_train_l2():
+    """photometric_loss: l2 (losses.py:28-29) -- the one non-default loss mode the fused kernels build"""
+    _train_case("g18_train_l2", F=2, R=24, n_c=8, n_g=8, seed=180, termination_weight=0.5, photometric_loss="l2")
 
 
 def g11_target_sampler():
@@ -618,7 +623,7 @@ def g9_render_image():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g18_train_l2]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

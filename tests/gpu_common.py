@@ -50,6 +50,9 @@ CASES = {
     "g6_train_3field": (dict(encoding="fourier", dim_enc=64, num_layers=2),
                         dict(num_samples_coarse=8, num_samples_depth_guided=16, termination_weight=0.5)),
     "g6_train_nerf_l1": (dict(encoding="nerf", num_octaves=8, num_layers=1), dict(num_samples_coarse=8, num_samples_depth_guided=8)),
+    # photometric_loss: l2 (losses.py:28-29), fixture G18 from the real reference
+    "g18_train_l2": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                     dict(num_samples_coarse=8, num_samples_depth_guided=8, termination_weight=0.5, photometric_loss="l2")),
     # cameras inside the field, near < 0: geometry of samples behind the camera overwritten (rm.py:614-622)
     "g10_train_behind_camera": (dict(encoding="fourier", dim_enc=64, num_layers=2),
                                 dict(num_samples_coarse=12, num_samples_depth_guided=8, termination_weight=0.5)),
@@ -78,7 +81,8 @@ def make_renderer(fkw, ckw, num_fields, params=None):
         distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube",
         weight_dtype=fkw.get("weight_dtype")).to(DEV)
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
-               termination_weight=0.0, photometric_weight=1.0, depth_weight=1.0, freespace_weight=40.0, tsdf_weight=50.0,
+               termination_weight=0.0, photometric_weight=1.0, photometric_loss="l1", depth_weight=1.0, depth_loss="huber",
+               freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0)
     cfg.update(ckw)
     cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5, pixel_center=0.0)

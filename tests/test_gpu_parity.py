@@ -520,7 +520,7 @@ def test_fused_train_step_golden(name):
         grad_close(res["grads"][k], v, 1e-2 if nerf else 2e-3, k)
 
 
-@pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field"])
+@pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field", "g18_train_l2"])
 def test_render_ijs_autograd_path_golden(name):
     """reference-style call sequence: render_ijs -> compute_losses -> backward (rm.py:1164-1186)."""
     g = load_golden(name)
@@ -826,9 +826,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
         encoding_kwargs=dict(pos_dim=3, log2_hashmap_size=12, nr_levels=16, nr_feat_per_level=2, coarsest_scale=1,
                              finest_scale=0.0001, init_scale=0.00001), num_layers=1, dim_out=4, neus_initial_sd=1.0),
         num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
-    cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, truncation_distance=0.1, field_radius=1.0,
-               freespace_weight=40.0, tsdf_weight=50.0, num_samples_coarse=n_c, num_samples_depth_guided=n_g,
-               learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5)
+    cfg = Rr.shipped_config(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
     cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5)
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=DEV)
     r.add_fields(F)

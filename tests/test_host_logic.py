@@ -2,6 +2,9 @@
 import torch
 
 from conftest import load_golden, split_prefix
+import pytest
+
+from neural_graph_mapping_amd import _capi as K
 from neural_graph_mapping_amd import distributed as D
 from neural_graph_mapping_amd import models as M
 from neural_graph_mapping_amd import renderer as Rr
@@ -55,8 +58,7 @@ def test_camera_effective_principal_point():
     cam = Rr.Camera(640, 480, 554.25, 554.25, 319.5, 239.5, pixel_center=0.0)
     fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
     assert (cx, cy) == (319.5, 239.5)
-    rc = Rr.make_render_cfg(cam, dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_factor=20.0,
-                                      truncation_distance=0.1, freespace_weight=40.0, tsdf_weight=50.0))
+    rc = Rr.make_render_cfg(cam, Rr.shipped_config())
     assert rc.num_samples_guided == 16 and abs(rc.range_depth_guided - 0.1) < 1e-7 and rc.w_tsdf == 50.0
 
 
@@ -109,7 +111,7 @@ def _cpu_renderer(num_fields):
         encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
         encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4,
         neus_initial_sd=1.0), num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube")
-    r = Rr.NeuralGraphRenderer(model, Rr.Camera(32, 24, 27.7, 27.7, 15.5, 11.5), dict(num_samples_coarse=8), device="cpu")
+    r = Rr.NeuralGraphRenderer(model, Rr.Camera(32, 24, 27.7, 27.7, 15.5, 11.5), Rr.shipped_config(), device="cpu")
     if num_fields:
         r.add_fields(num_fields)
     return r
@@ -144,3 +146,39 @@ def test_checkpoint_layout_matches_the_reference_and_round_trips(tmp_path):
     r2 = _cpu_renderer(1)                                    # a map that already holds fields is replaced, not merged
     r2.load_model(str(out))
     assert r2._model.all_fields_params["_linears.0.weight"].shape[0] == 3
+
+
+def test_config_fails_loudly_like_the_reference():
+    """_read_config reads the loss weights and modes unconditionally (rm.py:116-220): a config it would refuse with a
+    KeyError is refused here; loss modes of losses.py that the fused kernels do not build raise instead of silently
+    training with l1 / huber."""
+    cam = Rr.Camera(640, 480, 554.25, 554.25, 319.5, 239.5)
+    good = Rr.shipped_config()
+    rc = Rr.make_render_cfg(cam, good)
+    assert rc.photometric_mode == K.PHOTO["l1"] and rc.depth_mode == K.DEPTH["huber"] and rc.w_freespace == 40.0
+    assert Rr.make_render_cfg(cam, {**good, "photometric_loss": "l2"}).photometric_mode == K.PHOTO["l2"]
+    for key in ("termination_weight", "photometric_weight", "photometric_loss", "depth_weight", "depth_loss", "freespace_weight",
+                "geometry_mode", "num_samples_coarse", "num_samples_depth_guided"):
+        bad = {k: v for k, v in good.items() if k != key}
+        with pytest.raises(KeyError):
+            Rr.make_render_cfg(cam, bad)
+    no_tsdf = {k: v for k, v in good.items() if k != "tsdf_weight"}
+    assert Rr.make_render_cfg(cam, no_tsdf).w_tsdf == 0.0                 # config.get("tsdf_weight", 0.0), rm.py:135
+    with pytest.raises(NotImplementedError):
+        Rr.make_render_cfg(cam, {**good, "photometric_loss": "gaussian_nll"})
+    for mode in ("gaussian_nll", "laplacian_nll"):
+        with pytest.raises(NotImplementedError):
+            Rr.make_render_cfg(cam, {**good, "depth_loss": mode})
+    with pytest.raises(ValueError):
+        Rr.make_render_cfg(cam, {**good, "geometry_mode": "sdf"})
+    with pytest.raises(KeyError):                                          # the renderer's constructor goes through the same check
+        _cpu_renderer_cfg({"num_samples_coarse": 8})
+
+
+def _cpu_renderer_cfg(cfg):
+    from neural_graph_mapping_amd import models as M
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4,
+        neus_initial_sd=1.0), num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube")
+    return Rr.NeuralGraphRenderer(model, Rr.Camera(32, 24, 27.7, 27.7, 15.5, 11.5), cfg, device="cpu")

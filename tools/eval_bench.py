@@ -28,8 +28,7 @@ def main():
             encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
             encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
             num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=0.5, scale_mode="unit_cube").to(dev)
-        cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, truncation_distance=0.1, field_radius=0.5, num_samples_coarse=8,
-                   num_samples_depth_guided=16, eval_near_distance=0.0, eval_far_distance=8.0, eval_num_samples=S)
+        cfg = Rr.shipped_config(field_radius=0.5, eval_near_distance=0.0, eval_far_distance=8.0, eval_num_samples=S)
         r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
         r.add_fields(NF)
         r.set_field_poses(pos.to(dev), quat.to(dev))

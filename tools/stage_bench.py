@@ -115,8 +115,7 @@ def main():
         encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
         num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(dev)
     cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
-    r = Rr.NeuralGraphRenderer(model, cam, dict(geometry_mode="nrgbd", geometry_factor=20.0, truncation_distance=0.1,
-                                                field_radius=1.0, num_samples_coarse=S2, num_samples_depth_guided=0), device=dev)
+    r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(num_samples_coarse=S2, num_samples_depth_guided=0), device=dev)
     r.add_fields(F2)
     r.set_field_poses(torch.zeros(F2, 3, device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(F2, 1))
     ijs2 = torch.stack([torch.randint(0, 480, (F2, R2), device=dev), torch.randint(0, 640, (F2, R2), device=dev)], -1)

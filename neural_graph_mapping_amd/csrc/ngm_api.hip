@@ -91,7 +91,7 @@ static int fail(int code, const char* msg) {
 // prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
 #define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
-static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile
+static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_prefer_paired_bwd = 0;
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
@@ -109,6 +109,7 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   int e = (force32 || no_b3 || !try_b3p || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3p(a, blocks, st);
   g_last_bwd_variant = 4;
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
+  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
   if (e == NGM_E_UNSUPPORTED && !force32 && a.act) { e = ngm_launch_field_bwd16s(a, blocks, st); g_last_bwd_variant = 2; }
   if (e == NGM_E_UNSUPPORTED && !force32) { e = ngm_launch_field_bwd16(a, blocks, st); g_last_bwd_variant = 1; }
   if (e == NGM_E_UNSUPPORTED) { e = ngm_launch_field_bwd(a, blocks, st); g_last_bwd_variant = 0; }
@@ -683,20 +684,22 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
     sb.counter = (rays->philox_offset_autoinc && rays->philox_offset_dev)
                      ? reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(rays->philox_offset_dev)) : nullptr;
   }
+  FieldBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
+  carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
+  sb.xyz_out = a.hash_xyz;                 // permutohedral encoding: positions for the table-gradient kernel
+  a.hash_xyz_ready = a.hash_xyz != nullptr;
   int e = ngm_launch_stash_bwd(sb, st);
   if (e) return fail(e, "render_bwd: unsupported geometry mode");
   e = check_launch("ngm_stash_bwd");
   if (e) return e;
-  FieldBwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
   if (neus && grads->neus_sd)
     ngm_launch_neus_sd_grad(sb.d_isd_rays, rays->F, rays->R, params->neus_sd, params->neus_sd_stride, params->field_index,
                             grads->neus_sd, st);
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
-  carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
   if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;

@@ -422,6 +422,12 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
       c0 = sa.x; c1 = sa.y; c2 = sa.z; geom = sa.w; t = sb.x; T = sb.y;
       const float4 r1 = reinterpret_cast<const float4*>(a.raytab)[2 * ray + 1];
       dzc = r1.z; gt = r1.w;
+      if (a.xyz_out) {             // hash encoding: the position k_hash_grad searches the simplex of (the forward's own fmaf)
+        const float4 r0 = reinterpret_cast<const float4*>(a.raytab)[2 * ray];
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f p = {fmaf(t, r0.w, r0.x), fmaf(t, r1.x, r0.y), fmaf(t, r1.y, r0.z), 0.f};
+        __builtin_nontemporal_store(p, reinterpret_cast<v4f*>(a.xyz_out + g));
+      }
       if (a.seed_mode == 0) {
         const float4 pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
         const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];

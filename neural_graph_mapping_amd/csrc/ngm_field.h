@@ -750,10 +750,10 @@ __device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, 
 //     act[layer][tile = g >> 5][chunk c = feature >> 2][position][4 floats],   g = global flat sample index
 // i.e. 16-byte granules (4 consecutive features of one sample); the 32 lanes of a C-layout half-wave hold
 // one chunk of 32 consecutive samples = 512 contiguous bytes per store instruction and half.
-// 64-wide layers (MH = 2): sample r = g & 31 sits at position r ^ (c & 7) -- the image k_field_bwd_b3 wants in LDS
-// (bank-conflict-free column reads), so that its HBM -> LDS transfers are plain linear copies: a transfer whose lanes
+// Sample r = g & 31 of chunk c sits at position r ^ (c & 7) -- the image k_field_bwd_b3 / k_hash_mlp_bwd want in LDS
+// (bank-conflict-free column reads), so that their HBM -> LDS transfers are plain linear copies: a transfer whose lanes
 // gather a permutation costs the issuing wave ~240 clocks, a linear one ~30 (the permutation moves inside 128-byte
-// groups, so the stores here stay whole lines).  Other widths (the hash encoding's 32 features): position = r.
+// groups, so the stores here stay whole lines).
 struct ActStash {
   float* base;            // NULL: nothing is stored
   int64_t layer_stride;   // floats between layers
@@ -781,7 +781,7 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
         {
           typedef float v4f __attribute__((ext_vector_type(4)));
           const v4f val = {H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]};
-          const int pos = (MH == 2) ? (r ^ ((2 * g4 + hi) & 7)) : r;     // chunk = 8 m + 2 g4 + hi
+          const int pos = r ^ ((2 * g4 + hi) & 7);                       // chunk = 8 m + 2 g4 + hi
           __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));   // streamed: read once, by the backward
         }
     }

@@ -40,8 +40,9 @@ __device__ __forceinline__ RawIn16 fetch_inputs16(const FieldBwdArgs& a, int f, 
     if constexpr (E_STASH) {
       if (a.act) {
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f* tile = reinterpret_cast<const v4f*>(a.act) + (g >> 5) * (8 * 32) + (g & 31);
-        const v4f e0 = __builtin_nontemporal_load(tile + q * 32), e1 = __builtin_nontemporal_load(tile + (4 + q) * 32);
+        const v4f* tile = reinterpret_cast<const v4f*>(a.act) + (g >> 5) * (8 * 32);
+        const int r = (int)(g & 31);                      // chunk c holds sample r at position r ^ (c & 7) (ActStash)
+        const v4f e0 = __builtin_nontemporal_load(tile + q * 32 + (r ^ q)), e1 = __builtin_nontemporal_load(tile + (4 + q) * 32 + (r ^ (4 + q)));
         in.e[0] = make_float4(e0.x, e0.y, e0.z, e0.w);
         in.e[1] = make_float4(e1.x, e1.y, e1.z, e1.w);
       }
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(B16_THREADS) void k_field_bwd16(FieldBwdArgs a) {
                 const int level = 8 * m + 2 * q + p;
                 if (level < hc.nlev) a.hash_dE[level * NP + g] = make_float2(dE[m][2 * p], dE[m][2 * p + 1]);
               }
-            if (q == 0) a.hash_xyz[g] = make_float4(x, y, z, 0.f);
+            if (q == 0 && !a.hash_xyz_ready) a.hash_xyz[g] = make_float4(x, y, z, 0.f);
           }
         }
         if (ENC_GRAD) {

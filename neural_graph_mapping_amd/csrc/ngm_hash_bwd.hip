@@ -1,0 +1,336 @@
+// k_hash_mlp_bwd: backward of the reference's DEFAULT network (config/neural_graph_map.yaml:6-20: permutohedral hash
+// encoding, 16 levels x 2 features, one hidden layer of 32 units) in the fused training step, on the bf16 matrix pipe with
+// the exact three-way split of ngm_field.h (fp32-exact products, fp32 accumulate) -- the arithmetic of k_field_bwd_b3
+// for 32-wide layers, selected by the same ngm_field_cfg.matmul_mode.
+//
+// The generic kernel that served this shape (k_field_bwd16: 16-sample tiles, fp32 MFMA, every operand through LDS
+// staging tiles, five wave barriers per tile) took 66 us for 7x less arithmetic than the Fourier network's backward.
+// Here a tile is 32 samples on one wave and 36 MFMAs:
+//   * the encoding E (32 features per sample) comes from the forward's stash (no simplex search, no table gathers) by
+//     HBM -> LDS DMA, in the [16-byte chunk][sample ^ (chunk & 7)] image that serves both orientations an MFMA operand
+//     can ask for: rows (lane = sample, two ds_read_b128 per k-block) and columns (lane = feature, ds_read_b32,
+//     bank-conflict free);
+//   * H^T = relu(E W0^T + b) is recomputed TRANSPOSED (A = rows of E, B = planes of W0): its C fragment has lane = hidden
+//     unit, registers = 16 of the samples -- the orientation in which the output-layer gradient, the ReLU mask, the bias
+//     and output-weight gradients are lane-local and in which dY is directly the weight gradient's A operand (no stash of
+//     H: 12 MFMAs are cheaper than 2 x 67 MB of HBM traffic);
+//   * dY goes through a 4 KB scratch tile once to be read as rows, the B operand of dE^T = W0^T dY^T, whose C fragment has
+//     lane = sample, registers = features: each lane stores its sample's (level, 2 features) pairs as float2 into the
+//     level-major dL/dE array k_hash_grad reads -- 256 contiguous bytes per half-wave and level;
+//   * the scaled sample positions k_hash_grad needs are written by k_stash_bwd, which has the ray entry and the distance
+//     in registers anyway (bit-identical: the same fmaf of the same operands as the forward), not here.
+// Registers: one 32x32 accumulator (16) + ~120 -> two waves per SIMD (8 per workgroup), so the hardware overlaps one
+// wave's splits with the other's MFMAs and nothing has to be software-pipelined.  Deterministic: fixed tile lists, fixed
+// summation order in the epilogue.
+//
+// Supported: permutohedral encoding with dim_enc <= 32, one hidden layer of <= 32 units, skip_mode no, ray mode with the
+// forward's encoding stash, matmul_mode auto / bf16x3.  Everything else keeps k_field_bwd16.
+#include "ngm_bwd_b3.h"
+
+#define HB_WAVES 8
+#define HB_THREADS 512
+#define HB_PG 128                 // 16-byte granules of one weight plane: [kb 2][kh 2][n 32]
+
+struct LdsHB {
+  static constexpr int PLANES = 2 * 3 * HB_PG * 4;          // floats: planes of W0 for the recompute, then for the data gradient
+  static constexpr int CONSTS = PLANES;                      // float4 wout[32], float b0[32]
+  static constexpr int WAVES = CONSTS + 192;
+  static constexpr int ET = 0, DT = 1024, OB = 2048;         // per wave: encoding tile, dY scratch tile, d_out rows (64 x float4: the
+  static constexpr int WAVE_TOTAL = 2048 + 256;              // DMA instruction moves 64 x 16 bytes)
+  static constexpr int BODY = WAVES + HB_WAVES * WAVE_TOTAL;
+  static constexpr int EPI = HB_WAVES * 1024 + HB_WAVES * 9 * 64;
+  static constexpr int TOTAL = BODY > EPI ? BODY : EPI;
+};
+
+// one 32-feature encoding tile, samples [n0, n0 + 32) of the field (clamped to end - 1): 4 transfers of two chunks each
+__device__ __forceinline__ void hb_issue_tile(const char* sbase, uint32_t gb, uint32_t n0, uint32_t end, int lane, uint32_t lds_tile) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t c = 2 * k + (lane >> 5);
+    uint32_t n = n0 + (((uint32_t)lane & 31u) ^ (c & 7u));
+    if (n >= end) n = end - 1;
+    const uint32_t u = n + gb;
+    dma16_so(sbase, (((u >> 5) * 8u + c) * 32u + ((u & 31u) ^ (c & 7u))) * 16u, lds_tile + k * 1024);
+  }
+}
+
+__global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  using LY = LdsHB;
+  const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, hi = lane >> 5;
+  const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
+  ngm_u32x4* Pf = reinterpret_cast<ngm_u32x4*>(sm);          // B operand of the recompute: lane (o, kh) holds W0[o][16 kb + 8 kh + e]
+  ngm_u32x4* Pd = Pf + 3 * HB_PG;                              // A operand of the data gradient: lane (i, kh) holds W0[16 kb + 8 kh + e][i]
+  float4* cwout = reinterpret_cast<float4*>(sm + LY::CONSTS);
+  float* cb0 = sm + LY::CONSTS + 128;
+  float* wl = sm + LY::WAVES + wave * LY::WAVE_TOTAL;
+  float* Et = wl + LY::ET;
+  float* Dt = wl + LY::DT;
+  float* ob = wl + LY::OB;
+  const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wl);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float dbh = 0.f, dwo[4] = {0.f, 0.f, 0.f, 0.f}, dbo[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
+  const uint32_t first = beg + 32u * (uint32_t)wave;
+  constexpr uint32_t TSTRIDE = 32 * HB_WAVES;
+  const int64_t g0 = (int64_t)f * a.P;
+  const uint32_t gb = (uint32_t)(g0 & 31);
+  const char* act = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 1024);
+  const char* dout = reinterpret_cast<const char*>(a.d_out + g0);
+  auto issue = [&](uint32_t n0) __attribute__((always_inline)) {
+    uint32_t n = n0 + (uint32_t)i;                                     // both halves fetch the 32 rows: the transfer is 64 x 16 bytes
+    if (n >= end) n = end - 1;
+    dma16(dout + 16 * (size_t)n, wl_lds + LY::OB * 4);
+    const uint32_t u0 = n0 + gb;
+    if (((u0 & 31u) == 0u) && (n0 + 32u <= end)) {                     // whole tile, aligned with the stash tiles: one linear 4 KB copy
+      const char* b0 = act + (size_t)__builtin_amdgcn_readfirstlane(u0 >> 5) * 4096;
+      dma16_x4(b0, (uint32_t)lane * 16u, wl_lds + LY::ET * 4);
+    } else {
+      hb_issue_tile(act, gb, n0, end, lane, wl_lds + LY::ET * 4);
+    }
+  };
+  if (first < end) issue(first);
+  // weight planes + per-unit constants while the first tile travels
+  {
+    const float* W = a.pr.w[0];
+    const int64_t w0 = row * a.pr.w_stride[0];
+    if (threadIdx.x < 2 * HB_PG) {
+      const bool dg = threadIdx.x >= HB_PG;
+      const int g = threadIdx.x & (HB_PG - 1);
+      const int n = g & 31, kh = (g >> 5) & 1, kb = g >> 6;
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * kb + 8 * kh + e;
+        const int o = dg ? k : n, c = dg ? n : k;
+        x[e] = (o < H && c < D) ? ngm_ldp(W, w0 + (int64_t)o * D + c, a.pr.dtype) : 0.f;
+      }
+      ngm_bf16x8 h, m, lo;
+      b3_split8(x, h, m, lo);
+      ngm_u32x4* P = dg ? Pd : Pf;
+      P[g] = __builtin_bit_cast(ngm_u32x4, h);
+      P[HB_PG + g] = __builtin_bit_cast(ngm_u32x4, m);
+      P[2 * HB_PG + g] = __builtin_bit_cast(ngm_u32x4, lo);
+    } else if (threadIdx.x < 2 * HB_PG + 32) {
+      const int ft = threadIdx.x - 2 * HB_PG;
+      const float* Wo = a.pr.w[1];
+      const int64_t wo0 = row * a.pr.w_stride[1];
+      cwout[ft] = (ft < H) ? make_float4(ngm_ldp(Wo, wo0 + ft, a.pr.dtype), ngm_ldp(Wo, wo0 + H + ft, a.pr.dtype),
+                                         ngm_ldp(Wo, wo0 + 2 * H + ft, a.pr.dtype), ngm_ldp(Wo, wo0 + 3 * H + ft, a.pr.dtype))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      cb0[ft] = (ft < H) ? ngm_ldp(a.pr.b[0], row * a.pr.b_stride[0] + ft, a.pr.dtype) : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // lane-constant LDS offsets (floats): element (feature i, sample frow(r, hi)) of a tile sits at
+  //   (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))
+  int col[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
+#define COL_OFF(r) (col[(r) & 3] + 32 * ((r) >> 2))
+  const float4 wout = cwout[i];
+  const float bias = cb0[i];
+  const int64_t NP = (int64_t)a.F * a.P;
+  const int nlev = a.fc.nr_levels;
+
+  DMA_WAIT(0);
+  WAVE_SYNC();
+  for (uint32_t base = first; base < end; base += TSTRIDE) {
+    const uint32_t nxt = base + TSTRIDE;
+    if (base + 32u > end) {                     // last, partial tile: rows past the end carry no gradient
+      if (base + (uint32_t)lane >= end && lane < 32) {
+        float z = 0.f;
+        asm volatile("" : "+v"(z));              // materialised here (hoisted out of the loop it was spilled to scratch)
+        *reinterpret_cast<float4*>(ob + 4 * lane) = make_float4(z, z, z, z);
+      }
+      WAVE_SYNC();
+    }
+    // ---- the rows of E and the first k-block's planes; the rest is fetched where its latency hides behind arithmetic
+    float4 er[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int c0 = 4 * kb + 2 * hi;
+      er[kb][0] = *reinterpret_cast<const float4*>(Et + tile_chunk(c0, i));
+      er[kb][1] = *reinterpret_cast<const float4*>(Et + tile_chunk(c0 + 1, i));
+    }
+    ngm_u32x4 wf[2][3];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[kb][p] = Pf[p * HB_PG + (kb * 2 + hi) * 32 + i];
+    const float4 drow = *reinterpret_cast<const float4*>(ob + 4 * i);
+    dbo[0] += drow.x; dbo[1] += drow.y; dbo[2] += drow.z; dbo[3] += drow.w;
+    // ---- H^T = E W0^T + b, transposed: lane = hidden unit, register r <-> sample frow(r, hi)
+    f32x16 Hc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Hc[r] = bias;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const B3Op A = b3_rows(er[kb][0], er[kb][1]);
+      const ngm_bf16x8 wh = __builtin_bit_cast(ngm_bf16x8, wf[kb][0]), wm = __builtin_bit_cast(ngm_bf16x8, wf[kb][1]),
+                       wlo = __builtin_bit_cast(ngm_bf16x8, wf[kb][2]);
+      Hc = mfma_bf16(A.l, wh, Hc);
+      Hc = mfma_bf16(A.h, wlo, Hc);
+      Hc = mfma_bf16(A.m, wm, Hc);
+      Hc = mfma_bf16(A.m, wh, Hc);
+      Hc = mfma_bf16(A.h, wm, Hc);
+      Hc = mfma_bf16(A.h, wh, Hc);
+    }
+    // ---- output layer, lane = hidden unit: dY = relu'(.) (Wout^T d_out); output-weight and hidden-bias gradients
+    float dY[16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 dO[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dO[e] = *reinterpret_cast<const float4*>(ob + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * half + e;
+        const float4 d = dO[e];
+        const float pre = Hc[r];
+        const float h = fmaxf(pre, 0.f);
+        const float dh = fmaf(wout.w, d.w, fmaf(wout.z, d.z, fmaf(wout.y, d.y, wout.x * d.x)));
+        const float g = (pre > 0.f) ? dh : 0.f;
+        dY[r] = g;
+        dbh += g;
+        dwo[0] = fmaf(d.x, h, dwo[0]); dwo[1] = fmaf(d.y, h, dwo[1]); dwo[2] = fmaf(d.z, h, dwo[2]); dwo[3] = fmaf(d.w, h, dwo[3]);
+      }
+    }
+    // ---- dY through the scratch tile: written as columns, read as rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Dt[COL_OFF(r)] = dY[r];
+    WAVE_SYNC();
+    float4 dr[2][2];
+    ngm_u32x4 wd[2][3];
+    float Ec[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ec[r] = Et[COL_OFF(r)];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int c0 = 4 * kb + 2 * hi;
+      dr[kb][0] = *reinterpret_cast<const float4*>(Dt + tile_chunk(c0, i));
+      dr[kb][1] = *reinterpret_cast<const float4*>(Dt + tile_chunk(c0 + 1, i));
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wd[kb][p] = Pd[p * HB_PG + (kb * 2 + hi) * 32 + i];
+    }
+    WAVE_SYNC();
+    // ---- the next tile's transfers: every landing buffer has been read, no LDS instruction follows until the wait
+    if (nxt < end) issue(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- weight gradient: dW0[o][i] += sum_s dY[s][o] E[s][i], both operands lane = feature
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float ya[8], xa[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ya[e] = dY[8 * b + e]; xa[e] = Ec[8 * b + e]; }
+      const B3Op A = b3_arr(ya), Bx = b3_arr(xa);
+      acc = mfma_bf16(A.l, Bx.h, acc);
+      acc = mfma_bf16(A.h, Bx.l, acc);
+      acc = mfma_bf16(A.m, Bx.m, acc);
+      acc = mfma_bf16(A.m, Bx.h, acc);
+      acc = mfma_bf16(A.h, Bx.m, acc);
+      acc = mfma_bf16(A.h, Bx.h, acc);
+    }
+    // ---- data gradient dE^T[i][s] = sum_o W0[o][i] dY[s][o]: lane = sample, register r <-> feature frow(r, hi)
+    f32x16 dE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dE[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const B3Op Bd = b3_rows(dr[kb][0], dr[kb][1]);
+      const ngm_bf16x8 wh = __builtin_bit_cast(ngm_bf16x8, wd[kb][0]), wm = __builtin_bit_cast(ngm_bf16x8, wd[kb][1]),
+                       wlo = __builtin_bit_cast(ngm_bf16x8, wd[kb][2]);
+      dE = mfma_bf16(wlo, Bd.h, dE);
+      dE = mfma_bf16(wh, Bd.l, dE);
+      dE = mfma_bf16(wm, Bd.m, dE);
+      dE = mfma_bf16(wm, Bd.h, dE);
+      dE = mfma_bf16(wh, Bd.m, dE);
+      dE = mfma_bf16(wh, Bd.h, dE);
+    }
+    if (base + (uint32_t)i < end) {
+      // lane-dependent part of the address once (sample, the half's first level); the eight (q, p) offsets are wave-uniform
+      float2* dst = a.hash_dE + (g0 + base + i) + (int64_t)(2 * hi) * NP;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int lv = 4 * q + p;                        // level = lv + 2 hi: features 2 level, 2 level + 1 = frow(4 q + 2 p, hi), + 1
+          if (lv + 2 * hi < nlev) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f v = {dE[4 * q + 2 * p], dE[4 * q + 2 * p + 1]};
+            __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(dst + (int64_t)lv * NP));      // read once, by k_hash_grad
+          }
+        }
+    }
+    DMA_WAIT(0);
+    WAVE_SYNC();
+  }
+#undef COL_OFF
+  __syncthreads();
+
+  // ---- epilogue: the eight waves' accumulators in fixed wave order (all of LDS is free now)
+  float* stage = sm;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(stage + ((wave * 4 + q) * 64 + lane) * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  float* vec = stage + HB_WAVES * 1024 + wave * 9 * 64;
+  vec[lane] = dbh;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vec[(1 + c) * 64 + lane] = dwo[c];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vec[(5 + c) * 64 + lane] = wave_sum(dbo[c]);
+  __syncthreads();
+  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
+  (void)ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
+  float* dstp = a.partials + (int64_t)blockIdx.x * a.p_pad;
+  if (threadIdx.x < 256) {
+    const int e4 = threadIdx.x;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < HB_WAVES; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(stage + (w * 256 + e4) * 4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    const int q = e4 >> 6, ln = e4 & 63;
+    const int o0 = 8 * q + 4 * (ln >> 5), c = ln & 31;        // rows frow(4 q + j, hi) = o0 + j
+    if (c < D) {
+      float* d = dstp + w_off[0] + (int64_t)o0 * D + c;
+      if (o0 < H) d[0] = s4.x;
+      if (o0 + 1 < H) d[D] = s4.y;
+      if (o0 + 2 < H) d[2 * D] = s4.z;
+      if (o0 + 3 < H) d[3 * D] = s4.w;
+    }
+  } else for (int e = threadIdx.x - 256; e < 9 * 32; e += HB_THREADS - 256) {
+    const int k = e >> 5, ii = e & 31;
+    const float* v0 = stage + HB_WAVES * 1024;
+    float s0 = 0.f;
+#pragma unroll
+    for (int w = 0; w < HB_WAVES; ++w) s0 += v0[(w * 9 + k) * 64 + ii] + v0[(w * 9 + k) * 64 + 32 + ii];
+    if (k == 0) { if (ii < H) dstp[b_off[0] + ii] = s0; }
+    else if (k < 5) { if (ii < H) dstp[w_off[1] + (int64_t)(k - 1) * H + ii] = s0; }
+    else if (ii == 0) dstp[b_off[1] + (k - 5)] = 0.25f * s0;     // both halves of a wave added the same 32 rows, and wave_sum put
+                                                                 // the wave's total into both lanes read here
+  }
+}
+
+// returns NGM_E_UNSUPPORTED when this kernel does not apply (caller falls back to k_field_bwd16)
+int ngm_launch_hash_mlp_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  if (a.fc.encoding != NGM_ENC_PERMUTO || !a.act || a.points || !a.raytab || !a.stashB || a.fc.skip_mode != NGM_SKIP_NO ||
+      a.fc.matmul_mode == NGM_MATMUL_F32 || a.fc.num_layers != 1 || a.fc.dim_enc > 32 || a.fc.dim_hidden > 32 || a.fc.dim_enc <= 16 ||
+      a.fc.dim_out != 4 || !a.hash_dE || !a.hash_xyz_ready)
+    return NGM_E_UNSUPPORTED;
+  if ((a.P + 64) * 128 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
+  NgmProfScope prof_(NGM_K_FIELD_BWD, st);
+  const size_t lds = (size_t)LdsHB::TOTAL * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)k_hash_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_hash_mlp_bwd, dim3(blocks), dim3(HB_THREADS), lds, st, a);
+  return 0;
+}

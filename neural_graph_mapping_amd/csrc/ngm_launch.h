@@ -77,6 +77,8 @@ struct FieldBwdArgs {
   float2* hash_dE;        // permutohedral: [L][F*P] dL/d(level features) per sample (level-major: coalesced)
   float4* hash_xyz;       // permutohedral: [F*P] scaled field-local sample positions
   float* hash_part;       // permutohedral: [F][L][8][2T] partial gradient tables
+  int hash_xyz_ready;     // ray mode: k_stash_bwd already wrote hash_xyz (one fmaf triple per sample where ray entry and distance
+                          // are in registers anyway), the MLP backward must not
   long long* tri_acc;     // triplane: [F][3 C res res] Q23.40 gradient accumulators (zeroed by the API before the launch)
   int64_t tri_numel;      // 3 C res res
   float* planes_grad;     // triplane: caller's (F, 3, C, res, res) gradient, stride between fields
@@ -142,6 +144,7 @@ struct StashBwdArgs {
   int n_partials;
   float* sums_out;            // (16) optional copy of the reduced sums
   unsigned long long* counter;// optional iteration counter to advance (what k_loss_reduce does otherwise)
+  float4* xyz_out;            // (F*R*S) optional: scaled field-local sample positions for k_hash_grad (permutohedral encoding)
 };
 
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
@@ -150,6 +153,7 @@ int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_tri_finish(const FieldBwdArgs& a, hipStream_t st);
 int ngm_launch_field_bwd_b3p(const FieldBwdArgs& a, int blocks, hipStream_t st);  // the same with a tile's two hidden layers on two waves (2 hidden layers)
 int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 32-sample tiles on the bf16 matrix pipe (three-way split), activation stash
+int ngm_launch_hash_mlp_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);          // hash encoding + 1 x 32 MLP (the reference's default network), bf16 split, encoding stash
 int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st);  // 16-sample tiles, activations from the forward's stash
 int ngm_launch_field_bwd16(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 16-sample tiles, 8 waves; NGM_E_UNSUPPORTED -> fall back
 int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);

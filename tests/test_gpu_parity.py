@@ -805,10 +805,12 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("mm", ["auto", "f32"])
 @pytest.mark.parametrize("F,R,n_c,n_g", [(3, 40, 8, 16), (1, 9, 4, 4), (2, 33, 3, 2), (5, 7, 8, 16), (3, 130, 20, 4)])
-def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
+def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g, mm):
     """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP; ragged shapes put
-    field starts in the middle of the 32-sample tiles of the encoding stash and leave partial 16-sample tiles."""
+    field starts in the middle of the 32-sample tiles of the encoding stash and leave partial tiles.  Both backward
+    kernels: k_hash_mlp_bwd (bf16 split, `auto`) and k_field_bwd16 (fp32 MFMA, `mlp_matmul: f32`)."""
     torch.manual_seed(5)
     fs = O.FieldSpec(num_layers=1, **PERMUTO)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
@@ -826,7 +828,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
         encoding_kwargs=dict(pos_dim=3, log2_hashmap_size=12, nr_levels=16, nr_feat_per_level=2, coarsest_scale=1,
                              finest_scale=0.0001, init_scale=0.00001), num_layers=1, dim_out=4, neus_initial_sd=1.0),
         num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube").to(DEV)
-    cfg = Rr.shipped_config(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
+    cfg = Rr.shipped_config(num_samples_coarse=n_c, num_samples_depth_guided=n_g, mlp_matmul=mm)
     cam = Rr.Camera(640, 480, NRGBD_KW["fx"], NRGBD_KW["fy"], 319.5, 239.5)
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=DEV)
     r.add_fields(F)
@@ -835,6 +837,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
         model.all_fields_params[k].copy_(v.to(DEV))
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    assert K.lib().ngm_debug_last_bwd_variant() == (5 if mm == "auto" else 1)     # no silent fallback either way
     close(res["prediction"].rgbds, pred["rgbds"].detach(), rtol=2e-3, atol=2e-4)
     n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
     if min(n_m, pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())) == 0:
@@ -843,6 +846,10 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g):
     for k in po:
         if po[k].grad is not None:
             grad_close(res["grads"][k], po[k].grad, 1e-2, k)          # hash: fp32 lattice coordinates at sigma = 1e-4
+    first = {k: v.clone() for k, v in res["grads"].items()}            # (the renderer reuses its gradient buffers)
+    again = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    for k in first:
+        assert torch.equal(again["grads"][k], first[k]), k             # fixed orders + fixed-point scatter: bitwise reproducible
     before = model.all_fields_params["_encoding.random_shift_per_level"].clone()
     r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
     assert torch.equal(before, model.all_fields_params["_encoding.random_shift_per_level"])   # no grad -> untouched

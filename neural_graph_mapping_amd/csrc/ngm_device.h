@@ -388,6 +388,33 @@ __device__ __forceinline__ float seg_scan_add(float v, int k, int lane) {
   o = dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(0.f, v); v += (k > lane - 32) ? o : 0.f;   // rows 2,3 += total of lanes 0..31
   return v;
 }
+// N segmented sum scans over the same segmentation at once.  A step of seg_scan_add is v_mov_dpp + v_cndmask + v_add per
+// value; here it is ONE v_fmac_f32_dpp: v += dpp(v) * m with the step's condition as a 1.0 / 0.0 factor shared by the N
+// values (same single rounding as the add; values must be finite).  The compiler does not fold a DPP move into an fmac,
+// hence the asm; its hazard recognizer does not look into asm either, so the two wait states a DPP read needs after a VALU
+// write of the same register are supplied by hand: an s_nop in front of every step, and value-minor order inside a step.
+template <int N>
+__device__ __forceinline__ void seg_scan_add_n(float (&v)[N], int k, int lane) {
+  static_assert(N >= 3, "value-minor order must put two instructions between a register's write and its next DPP read");
+  const int pr = lane & 15;
+  const float m[6] = {(k >= 1) ? 1.f : 0.f, (k >= 2) ? 1.f : 0.f, (k >= 4) ? 1.f : 0.f, (k >= 8) ? 1.f : 0.f,
+                      (k > pr) ? 1.f : 0.f, (k > lane - 32) ? 1.f : 0.f};
+  // volatile asm statements keep their program order: one s_nop per step (covers the compiler's own VALU write in front
+  // of the first step), then the N values in turn
+#define NGM_SSA_STEP(CTRL, M)                                                                       \
+  do {                                                                                              \
+    asm volatile("s_nop 1");                                                                        \
+    _Pragma("unroll") for (int c_ = 0; c_ < N; ++c_)                                                \
+      asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL : "+v"(v[c_]) : "v"(M));                       \
+  } while (0)
+  NGM_SSA_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", m[0]);
+  NGM_SSA_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", m[1]);
+  NGM_SSA_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", m[2]);
+  NGM_SSA_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", m[3]);
+  NGM_SSA_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", m[4]);             // rows 1, 3 += total of rows 0, 2
+  NGM_SSA_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", m[5]);             // rows 2, 3 += total of lanes 0..31
+#undef NGM_SSA_STEP
+}
 __device__ __forceinline__ float seg_scan_mul(float v, int k, int lane) {
   const int pr = lane & 15;
   float o;

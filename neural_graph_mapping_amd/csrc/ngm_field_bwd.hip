@@ -676,12 +676,15 @@ int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 // instructions per value): |v| * 2^9 = hi + rem, hi = floor, rem in [0,1), both exact for a non-negative operand;
 // magnitude = hi * 2^31 + trunc(rem * 2^31), then the sign.  |v| < 2^22; error < 2^-40 (truncation toward zero).
 __device__ __forceinline__ unsigned long long to_fix(float v) {
-  const float s = fabsf(v) * 512.0f;
-  const float fl = floorf(s);
-  const unsigned int hi = (unsigned int)fl;
-  const unsigned int lo = (unsigned int)((s - fl) * 2147483648.0f);     // < 2^31
-  const unsigned long long mag = ((unsigned long long)(hi >> 1) << 32) | ((hi << 31) | lo);
-  return (v < 0.f) ? (0ull - mag) : mag;
+  // signed throughout (truncation toward zero in both stages = truncation of the magnitude: the same bits as the
+  // sign-magnitude form this replaces, without its abs / 64-bit negate): v 2^9 = hi + rem, hi = trunc (exact), |rem| < 1
+  // with the sign of v; value = hi 2^31 + trunc(rem 2^31) as a 64-bit integer.
+  const float s = v * 512.0f;
+  const float tr = truncf(s);
+  const int hi = (int)tr;                                               // |hi| < 2^31
+  const int lo = (int)((s - tr) * 2147483648.0f);                       // |lo| < 2^31, sign of v
+  const long long r = (long long)hi * 2147483648ll + (long long)lo;
+  return (unsigned long long)r;
 }
 
 struct HashGradArgs {
@@ -701,7 +704,24 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
   // Q23.40 fixed point in LDS: integer LDS atomics run at full bank rate (fp32 LDS atomics measured ~2.5
   // cycles per LANE regardless of address) and make the table gradient order-independent -> deterministic.
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
-  const int chunk = blockIdx.x, level = blockIdx.y, f = blockIdx.z;
+  // 1-D grid, decoded so that blocks id and id + total / 2 -- which share a CU when total / 2 = the number of CUs, two
+  // blocks being resident per CU -- work on levels l and L - 1 - l: a coarse level (long runs: the segmented scans run)
+  // costs ~1.5x a fine one, and two coarse blocks on one CU set the kernel's time
+  int chunk, level, f;
+  {
+    const int nlev = a.fc.nr_levels, total = gridDim.x, id = blockIdx.x;
+    if ((nlev & 1) == 0) {
+      const int half = id >= total / 2, j = id - half * (total / 2);
+      chunk = j % a.chunks;
+      const int r = j / a.chunks, lh = r % (nlev / 2);
+      f = r / (nlev / 2);
+      level = half ? nlev - 1 - lh : lh;
+    } else {
+      chunk = id % a.chunks;
+      level = (id / a.chunks) % nlev;
+      f = id / (a.chunks * nlev);
+    }
+  }
   const int T = 1 << a.fc.log2_hashmap_size;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) tab[i] = 0ull;
@@ -716,15 +736,28 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
   const int64_t beg = (int64_t)chunk * a.per_chunk, end = min(a.P, beg + a.per_chunk);
   const uint32_t mask = (uint32_t)T - 1u;
   const int lane = threadIdx.x & 63;
+  // the next iteration's position and gradient travel while this one is worked on (few waves per SIMD: a load issued
+  // where it is used exposes the whole HBM latency once per iteration)
+  float4 p_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 d_nx = make_float2(0.f, 0.f);
+  if (beg + threadIdx.x < end) {
+    const int64_t g = (int64_t)f * a.P + beg + threadIdx.x;
+    p_nx = a.xyz[g];
+    d_nx = a.dE[level * NP + g];
+  }
   for (int64_t s0 = beg; s0 < end; s0 += blockDim.x) {      // trip count uniform across the wave (shuffles inside)
     const int64_t s = s0 + threadIdx.x;
     const bool valid = s < end;
     uint32_t idx[4] = {0u, 0u, 0u, 0u}; float bw[4] = {0.f, 0.f, 0.f, 0.f};
     float2 d = make_float2(0.f, 0.f);
+    const float4 p = p_nx;
+    if (valid) d = d_nx;
+    if (s + blockDim.x < end) {
+      const int64_t g = (int64_t)f * a.P + s + blockDim.x;
+      p_nx = a.xyz[g];
+      d_nx = a.dE[level * NP + g];
+    }
     if (valid) {
-      const int64_t g = (int64_t)f * a.P + s;
-      const float4 p = a.xyz[g];
-      d = a.dE[level * NP + g];
 #ifdef NGM_ABLH_NOSIMPLEX   // timing ablations of k_hash_grad (results meaningless when defined)
       idx[0] = (uint32_t)(p.x * 1000.f) & mask; idx[1] = (idx[0] + 1) & mask; idx[2] = (idx[0] + 2) & mask; idx[3] = (idx[0] + 3) & mask;
       bw[0] = p.x; bw[1] = p.y; bw[2] = p.z; bw[3] = 1.f - p.x;
@@ -755,8 +788,7 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
     if (__popcll(hm) <= 40) {                                   // wave-uniform
       const unsigned long long below = hm & ((2ull << lane) - 1ull);
       const int k = lane - (63 - __clzll(below));
-#pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = seg_scan_add(v[c], k, lane);
+      seg_scan_add_n<8>(v, k, lane);
       issue = valid && ((lane == 63) || ((hm >> (lane + 1)) & 1ull));
     }
     if (issue) {
@@ -815,10 +847,19 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
   const int T = 1 << fb.fc.log2_hashmap_size;
   const size_t lds = (size_t)2 * T * sizeof(unsigned long long);
   if (lds > 150 * 1024) return NGM_E_UNSUPPORTED;
-  // ~3 blocks per CU (two are resident at a time, 64 KB of LDS each): every block zeroes and flushes a whole level
-  // table, so fewer, longer blocks win until the levels' unequal cost unbalances the CUs (M1 hash batch: 8 chunks
-  // 0.305 ms/step, 6: 0.299, 4: 0.306)
-  int chunks = (int)((3 * 256 + (int64_t)fb.F * fb.fc.nr_levels - 1) / ((int64_t)fb.F * fb.fc.nr_levels));
+  // 2 blocks per CU = exactly what is resident at a time (64 KB of LDS each), one round: with the coarse / fine level
+  // pairing of k_hash_grad's block decoding the CUs finish together (M1 hash batch, kernel time: 4 chunks 99 us, 6: 100,
+  // 8: 102, 5: 115; before the pairing 4 chunks cost 118 -- two coarse levels on one CU)
+  int ncu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cached = prop.multiProcessorCount;
+    if (cached) ncu = cached;
+  }
+  int chunks = (int)((2 * ncu + (int64_t)fb.F * fb.fc.nr_levels - 1) / ((int64_t)fb.F * fb.fc.nr_levels));
   const int64_t max_chunks = (fb.P + 4095) / 4096;
   if (chunks > max_chunks) chunks = (int)max_chunks;
   if (chunks < 1) chunks = 1;
@@ -844,7 +885,7 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
   (void)hipFuncSetAttribute((const void*)k_hash_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   {
     NgmProfScope prof_(NGM_K_HASH_GRAD, st);
-    hipLaunchKernelGGL(k_hash_grad, dim3(chunks, fb.fc.nr_levels, fb.F), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k_hash_grad, dim3(chunks * fb.fc.nr_levels * fb.F), dim3(512), lds, st, a);
   }
   {
     NgmProfScope prof_(NGM_K_HASH_REDUCE, st);

@@ -258,9 +258,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
           __builtin_nontemporal_store(sb, reinterpret_cast<v2f*>(a.stashB + gs));
         }
       }
-      const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
-                  s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * depth, k, lane),
-                  s4 = seg_scan_add(w, k, lane);
+      float sc[5] = {w * c0, w * c1, w * c2, w * depth, w};      // five segmented sums over the same rays: one fused scan
+      seg_scan_add_n<5>(sc, k, lane);
+      const float s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3], s4 = sc[4];
       const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
       if (tail) {
         float* ra = wl.ra[rl];
@@ -376,8 +376,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float depth = -(wl.rt[rl][6] * t);
       float e0 = ra[0] - (valid ? q0 : 0.f), e1 = ra[1] - (valid ? q1 : 0.f),
             e2 = ra[2] - (valid ? q2 : 0.f), e3 = ra[3] - depth;
-      const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
-                  v2 = seg_scan_add(w * (e2 * e2), k, lane), v3 = seg_scan_add(w * (e3 * e3), k, lane);
+      float vv[4] = {w * (e0 * e0), w * (e1 * e1), w * (e2 * e2), w * (e3 * e3)};
+      seg_scan_add_n<4>(vv, k, lane);
+      const float v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
       const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
       WAVE_SYNC();   // all lanes have read ra[] means before tails update the variance slots
       if (tail) {

@@ -99,10 +99,11 @@ def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, ma
     return r
 
 
-def cpu_baseline(budget_s=15.0):
-    """Oracle (CPU restatement of the reference path) on a bounded sample: 1 field x 512 rays x 128 samples."""
+def cpu_baseline(budget_s=12.0, F=F_PER_GPU):
+    """Oracle (CPU restatement of the reference path, pinned to the real reference by the committed fixtures) on the
+    SAME batch as the GPU line: F = 8 fields x 512 rays x 128 samples per step, best thread count of the box; the
+    1-field sample of earlier rounds rides along as `one_field` (cpu_baseline(F=1))."""
     from oracle import ngm_oracle as O
-    F = 1
     fs = O.FieldSpec(encoding="fourier", dim_enc=D_ENC, num_layers=N_LAYERS)
     rs = O.RenderSpec(num_samples_coarse=S_C, num_samples_depth_guided=S_G, geometry_factor=20.0)
     cam = O.CameraSpec(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5)
@@ -134,14 +135,74 @@ def cpu_baseline(budget_s=15.0):
             best = (one, nt)
     one, nt = best
     torch.set_num_threads(nt)
-    n = max(3, min(200, int(budget_s / max(one, 1e-3))))
+    n = max(2, min(200, int(budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
-    return dict(value=F * R * (S_C + S_G) * n / dt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps (fwd+loss+bwd) of 1 field x {R} rays x {S_C + S_G} samples, "
-                       f"oracle/ngm_oracle.py on torch CPU fp32, {dt:.1f} s")
+    res = dict(value=F * R * (S_C + S_G) * n / dt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"{n} train steps (fwd+loss+bwd) of {F} field(s) x {R} rays x {S_C + S_G} samples"
+                      + (" = the GPU line's batch" if F == F_PER_GPU else "") + ", oracle/ngm_oracle.py (a restatement pinned "
+                      f"to the reference, NOT the reference itself) on torch CPU fp32, {dt:.1f} s")
+    if F == F_PER_GPU:
+        one_f = cpu_baseline(budget_s=4.0, F=1)
+        res["one_field"] = dict(value=one_f["value"], cores=one_f["cores"], sample=one_f["sample"])
+    return res
+
+
+def time_steps(r, tgt, steps, warmup, spin_up, use_graph=True):
+    """K timed steps of the captured iteration (single GPU) + the per-kernel eager pass; -> (seconds, kernels_us, loss, bwd variant)"""
+    from neural_graph_mapping_amd import _capi as K
+    L = K.lib()
+    rep = r.capture_iteration(tgt, seed=7) if use_graph else (lambda: r.optimization_iteration(tgt, seed=7, update=True))
+    for _ in range(spin_up + warmup):
+        out = rep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = rep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.ngm_profile_reset()
+    L.ngm_profile_enable(1)
+    for _ in range(steps):
+        r.optimization_iteration(tgt, seed=7, update=True)
+    torch.cuda.synchronize()
+    L.ngm_profile_enable(0)
+    kern = {}
+    for name, kid in K.KERNEL_IDS.items():
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.ngm_profile_read(kid, C.byref(ms), C.byref(n))
+        if n.value:
+            kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
+    return dt, kern, float(out["combined"]), L.ngm_debug_last_bwd_variant()
+
+
+def hash_rooflines(kern, n_local):
+    """roofline objects of the hash variant's two dominant kernels (512 B of gathers / of scatter per sample)"""
+    out = {}
+    hg, ff = kern.get("hash_grad"), kern.get("render_fwd")
+    algo = 512 * n_local
+    if hg:
+        ach = algo / (hg["avg_us"] * 1e-6) / 1e9
+        out["roofline"] = dict(bound="hbm", kernel="k_hash_grad (simplex search + per-level table in LDS, Q23.40 integer atomics)",
+                               achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                               avg_launch_us=hg["avg_us"], launches_timed=hg["launches"], algorithmic_bytes_per_launch=algo,
+                               timing="HIP events on the launch stream, instrumented pass of the same steps",
+                               note="priced against the HBM scatter it replaces (512 B/sample, SURVEY 8d); the kernel itself "
+                                    "accumulates in LDS and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
+    if ff:
+        ach = algo / (ff["avg_us"] * 1e-6) / 1e9
+        out["roofline_fwd"] = dict(bound="hbm", kernel="k_render_fwd<1,1,1,hash> (64 table gathers of 8 B per sample through the "
+                                                        "vector L1 / the XCD's L2; fp32 MFMA 32x32x2 for the 32-wide layer)",
+                                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                                   avg_launch_us=ff["avg_us"], launches_timed=ff["launches"], algorithmic_bytes_per_launch=algo,
+                                   note="algorithmic gather bytes (512 B/sample, SURVEY 8d) against the HBM peak as the survey asks; "
+                                        "the tables (512 KB per field) are L2-resident, so the path actually used is L2 -> L1: "
+                                        "tools/micro/gather_rate.hip measures 2.2 TB/s of useful bytes chip-wide for such gathers "
+                                        "(69 clocks per wave instruction and CU), 7.1 TB/s from an L1-resident 32 KB table, "
+                                        "35 TB/s from LDS")
+    return out
 
 
 def launch_ranks(n):
@@ -261,6 +322,9 @@ def main():
                     help="hidden layers of the forward kernels: auto (library default) = the exact three-way bf16 split with fp32 "
                          "accumulation where it is compiled (this workload), f32 = exact-fp32 MFMA everywhere; the line's `dtype` "
                          "says which ran, and the other one is measured next to it (`matmul_alternative`)")
+    ap.add_argument("--no-aux-hash", action="store_true",
+                    help="skip the auxiliary measurement of the reference's default network (hash encoding + 1x32 MLP) that the "
+                         "default line carries as `aux_hash`")
     ap.add_argument("--scene-sim", action="store_true",
                     help="auxiliary strong-scaling measurement of a realistic mapping iteration (200 fields, 32 active per "
                          "iteration, sharded id %% world) instead of the headline line; see scene_sim()")
@@ -359,6 +423,8 @@ def main():
     kern = {}
     L.ngm_profile_enable(0)
     bwd_variant = L.ngm_debug_last_bwd_variant()     # of the measured path (read before the side measurement below runs the other one)
+    # the arithmetic the library resolved `auto` to for THIS batch shape (not the host-side expectation)
+    resolved = r.last_matmul("forward") or r.mlp_matmul
     for name, kid in K.KERNEL_IDS.items():
         ms, n = C.c_double(0), C.c_int64(0)
         L.ngm_profile_read(kid, C.byref(ms), C.byref(n))
@@ -369,7 +435,7 @@ def main():
     # layers' matrix products (exact-fp32 MFMA <-> exact three-way bf16 split, forward and backward), so that one line carries both
     side = None
     if world == 1 and args.variant == "fourier" and args.matmul == "auto" and not strong:
-        other = "f32" if r.mlp_matmul == "bf16x3" else "bf16x3"
+        other = "f32" if resolved == "bf16x3" else "bf16x3"
         r3 = build_renderer(dev, F_PER_GPU, args.variant, matmul=other)
         r3.set_field_poses(pos.to(dev), quat.to(dev))
         rep3 = r3.capture_iteration(tgt, seed=7) if use_graph else (lambda: r3.optimization_iteration(tgt, seed=7, update=True))
@@ -392,13 +458,29 @@ def main():
         dv[rank] = dev_index
         torch.distributed.all_reduce(dv)
         devs = dv.tolist()
+    if args.variant == "hash" and bwd_variant == 5:
+        resolved_note = "hidden layer: fp32 MFMA in the fused forward, three-way bf16 split in the backward (k_hash_mlp_bwd)"
+    else:
+        resolved_note = None
+    # auxiliary: the reference's DEFAULT network (hash 16x2 + 1x32 MLP) on the same batch, in the same run
+    aux_hash = None
+    if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_hash:
+        rh = build_renderer(dev, F_PER_GPU, "hash", matmul=args.matmul)
+        rh.set_field_poses(pos.to(dev), quat.to(dev))
+        dth, kh, lh, bvh = time_steps(rh, tgt, args.steps, args.warmup, 20, use_graph)
+        n_h = F_PER_GPU * R * (S_C + S_G)
+        aux_hash = dict(workload="same M1 batch, permutohedral hash (16 levels x 2 features, 2^12 entries) + 1x32 MLP = the network of "
+                                 "config/neural_graph_map.yaml (parity unpinned: third-party CUDA package absent)",
+                        value=n_h * args.steps / dth, unit="ray-samples/s", ms_per_step=1e3 * dth / args.steps, final_loss=lh,
+                        bwd_variant=bvh, kernels_us={k: round(v["avg_us"], 2) for k, v in kh.items()}, **hash_rooflines(kh, n_h))
+        del rh
     if rank == 0:
         n_local = F_PER_GPU * R * (S_C + S_G)
         value = world * n_local * args.steps / dt
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
                    value=value, unit="ray-samples/s", n_gpus=ranks_seen, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
-                   dtype=DTYPE_LABEL[r.mlp_matmul], data="synthetic",
+                   dtype=DTYPE_LABEL[resolved], data="synthetic",
                    config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
                                            "permutohedral hash (16 levels x 2, 2^12 entries)+1x32 MLP [auxiliary variant]")
@@ -441,7 +523,7 @@ def main():
                 res["roofline_fwd"] = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (v_mfma_f32_32x32x2_f32)", achieved=a_f,
                                            peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=a_f / PEAK_F32_MFMA_TF,
                                            avg_launch_us=ff["avg_us"], algorithmic_flop_per_launch=FLOP_FWD * n_local)
-                if r.mlp_matmul == "bf16x3":     # both fractions: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
+                if resolved == "bf16x3":     # both fractions: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
                     issued = 6 * 2 * (64 * 64 + 64 * 64) * n_local         # six bf16 products per fp32 product, hidden layers
                     res["roofline_fwd"].update(kernel="k_render_fwd<2,2,2,bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)",
                                                issued_bf16_tflops=issued / (ff["avg_us"] * 1e-6) / 1e12, peak_bf16=2500.0,
@@ -450,21 +532,15 @@ def main():
             res["roofline_step"] = dict(bound="mfma", achieved=a_s, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                                         frac=a_s / PEAK_F32_MFMA_TF, note="whole timed step (all kernels + launch gaps), "
                                         "algorithmic MLP flops fwd 16 896 + bwd 33 792 per sample")
-        hg = kern.get("hash_grad")
-        if hg and args.variant == "hash":
-            # the table-gradient scatter is 16 levels x 4 vertices x 2 features x 4 B = 512 B per sample
-            algo = 512 * n_local
-            ach = algo / (hg["avg_us"] * 1e-6) / 1e9
-            res["roofline"] = dict(bound="hbm", kernel="k_hash_grad (simplex search + per-level table in LDS, Q23.40 integer atomics)",
-                                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
-                                   avg_launch_us=hg["avg_us"], launches_timed=hg["launches"],
-                                   algorithmic_bytes_per_launch=algo,
-                                   timing="HIP events on the launch stream, instrumented pass of the same steps",
-                                   note="priced against the HBM scatter it replaces (512 B/sample, SURVEY 8d); the kernel "
-                                        "itself accumulates in LDS and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
+        if args.variant == "hash":
+            res.update(hash_rooflines(kern, n_local))
+            if resolved_note:
+                res["dtype"] = DTYPE_LABEL["f32"] + "; " + resolved_note
         res["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in kern.items()}
         if side:
             res["matmul_alternative"] = side
+        if aux_hash:
+            res["aux_hash"] = aux_hash
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -355,12 +355,15 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
  * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4; N_f <= 4096 (the assignment kernel
- * keeps 36 B per field in the 160 KiB LDS; more: NGM_E_UNSUPPORTED). */
+ * keeps 36 B per field in the 160 KiB LDS; more: NGM_E_UNSUPPORTED).
+ * mask_radius: the `field_radius` ARGUMENT of NeuralFieldSet.forward (models.py:293, 368): a point is evaluated when its
+ * nearest field centre is closer than this; the local coordinates are still scaled with fcfg->field_radius
+ * (models.py:278-285, 378) -- _extract_mesh colours its vertices with radius + 0.1 (rm.py:2324-2336).  <= 0: fcfg->field_radius. */
 int64_t ngm_field_eval_knn_workspace(int32_t num_fields, int64_t P, int32_t num_knn);
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields,
                        int64_t P, const float* points, const float* field_pos,
                        const float* field_quat, int32_t num_knn, float distance_factor,
-                       float outside_value, float* out, void* workspace, int64_t workspace_bytes,
+                       float outside_value, float mask_radius, float* out, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
 /* ---- training-target sampler -------------------------------------------------------
@@ -449,7 +452,9 @@ enum ngm_kernel_id {
   NGM_K_HASH_GRAD = 8,   /* hash-table gradient: simplex search + LDS fixed-point scatter (one level per workgroup) */
   NGM_K_HASH_REDUCE = 9, /* sum of the per-workgroup partial tables (+ fused sparse Adam on the tables)             */
   NGM_K_LOSS_REDUCE = 10,
-  NGM_K_COUNT = 11
+  NGM_K_KNN_ASSIGN = 11, /* evaluation path: exact K nearest fields per point                                       */
+  NGM_K_KNN_EVAL = 12,   /* evaluation path: per-field MLP tiles over the (point, neighbour) pairs (dominant there) */
+  NGM_K_COUNT = 13
 };
 int ngm_profile_enable(int32_t on);
 int ngm_profile_reset(void);
@@ -467,8 +472,13 @@ int ngm_debug_fwd_phase_cycles(unsigned long long* out528);   /* 16 summary slot
 /* Debug: which MLP backward kernel the last ngm_render_bwd* / ngm_field_eval_bwd call launched:
  * 0 = k_field_bwd (32-sample tiles, forward recompute), 1 = k_field_bwd16 (16-sample tiles, recompute),
  * 2 = k_field_bwd16s (16-sample tiles, hidden activations read from the forward's stash), 3 = k_field_bwd_b3 (three-way
- * bf16 split, 32-sample tiles, stash), 4 = k_field_bwd_b3p (the same on two waves per tile), -1 = none yet. */
+ * bf16 split, 32-sample tiles, stash), 4 = k_field_bwd_b3p (the same on two waves per tile), 5 = k_hash_mlp_bwd (hash
+ * encoding + one hidden layer of <= 32 units, three-way bf16 split, encoding stash), -1 = none yet. */
 int ngm_debug_last_bwd_variant(void);
+/* Debug: the arithmetic the last launch of a forward-type kernel resolved ngm_field_cfg.matmul_mode to (AUTO is resolved
+ * per kernel and batch shape): which = 0 fused render forward (ngm_render_fwd), 1 point evaluation (ngm_field_eval_fwd),
+ * 2 kNN evaluation (ngm_field_eval_knn).  Returns NGM_MATMUL_F32 or NGM_MATMUL_BF16X3, -1 before the first launch. */
+int ngm_debug_last_matmul(int which);
 /* Experiments: 1 = try k_field_bwd_b3p (a tile's two hidden layers on two waves; correct, ~9 % slower than k_field_bwd_b3
  * as measured in round 2) before the default order; 0 = default.  Returns the previous setting. */
 int ngm_debug_prefer_paired_bwd(int on);

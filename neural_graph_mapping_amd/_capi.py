@@ -151,7 +151,7 @@ def lib():
     L.ngm_step_advance.argtypes = [vp, vp, vp]
     L.ngm_adam_sparse_multi.restype = C.c_int
     L.ngm_step_advance.restype = C.c_int
-    L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, vp, vp, i64, vp]
+    L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, f32, vp, vp, i64, vp]
     L.ngm_field_eval_knn_workspace.argtypes = [i32, i64, i32]
     L.ngm_field_eval_knn_workspace.restype = i64
     L.ngm_target_visibility.argtypes = [P(Keyframes), i32, vp, i32, vp, f32, vp, vp, vp]
@@ -187,7 +187,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_prefer_paired_bwd", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
+            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_last_matmul", "ngm_debug_prefer_paired_bwd", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
             "ngm_marching_cubes_workspace", "ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;
@@ -195,7 +195,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
 NO_GRAD_PARAMS = frozenset({"_encoding.random_shift_per_level"})
 
 KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
-                  composite_bwd=7, hash_grad=8, hash_reduce=9, loss_reduce=10)
+                  composite_bwd=7, hash_grad=8, hash_reduce=9, loss_reduce=10, knn_assign=11, knn_eval=12)
 
 
 class NgmError(RuntimeError):

@@ -29,8 +29,8 @@ int ngm_launch_mc_emit(const float* vol, int nx, int ny, int nz, float iso, floa
                        int64_t* faces, int64_t max_faces, void* workspace, int64_t workspace_bytes, hipStream_t st);
 int ngm_mc_copy_tables(int8_t* tri_table, int32_t* tri_count);
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
-                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
-                   void* workspace, int64_t workspace_bytes, hipStream_t st);
+                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
+                   float* out, void* workspace, int64_t workspace_bytes, hipStream_t st);
 int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K);
 
 #include <mutex>
@@ -91,6 +91,7 @@ static int fail(int code, const char* msg) {
 // prefer the 8-wave / 16-sample-tile backward; fall back to the 4-wave / 32-sample-tile kernel
 #define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
+int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_prefer_paired_bwd = 0;
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
@@ -275,6 +276,7 @@ int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float r
 }
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
+int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_last_matmul[which] : -1; }
 int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 
 static unsigned long long* g_debug_cycles_fwd = nullptr;
@@ -835,7 +837,7 @@ int64_t ngm_field_eval_knn_workspace(int32_t num_fields, int64_t P, int32_t num_
 
 int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t num_fields, int64_t P,
                        const float* points, const float* field_pos, const float* field_quat, int32_t num_knn,
-                       float distance_factor, float outside_value, float* out, void* workspace,
+                       float distance_factor, float outside_value, float mask_radius, float* out, void* workspace,
                        int64_t workspace_bytes, void* stream) {
   int e = check_field_cfg(fcfg);
   if (e) return e;
@@ -845,8 +847,8 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   if (P == 0) return NGM_OK;
   const int K = num_knn < num_fields ? num_knn : num_fields;
   if (K < 1 || K > 4) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_knn: K must be in [1,4]");
-  e = ngm_launch_knn(fcfg, params, num_fields, P, points, field_pos, field_quat, K, distance_factor, outside_value, out,
-                     workspace, workspace_bytes, (hipStream_t)stream);
+  e = ngm_launch_knn(fcfg, params, num_fields, P, points, field_pos, field_quat, K, distance_factor, outside_value,
+                     mask_radius > 0.f ? mask_radius : fcfg->field_radius, out, workspace, workspace_bytes, (hipStream_t)stream);
   if (e == NGM_E_WORKSPACE) return fail(e, "ngm_field_eval_knn: workspace too small");
   if (e) return fail(e, "ngm_field_eval_knn: not available for this configuration");
   return check_launch("ngm_field_eval_knn");

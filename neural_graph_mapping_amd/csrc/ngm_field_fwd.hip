@@ -489,6 +489,7 @@ static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
   const dim3 blk(NGM_BLOCK);
   if constexpr (b3_shape<MI, MH, L>()) {
     if (b3_wanted(a.fc)) {       // standalone evaluation: the mode is a preference here (fp32 MFMA where not compiled)
+      g_ngm_last_matmul[1] = NGM_MATMUL_BF16X3;
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
       (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, 0, 0, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -496,6 +497,7 @@ static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
       return 0;
     }
   }
+  g_ngm_last_matmul[1] = NGM_MATMUL_F32;
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
     if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_field_points_fwd, false, 1, blocks, blk, 0, 0);
     else return NGM_E_UNSUPPORTED;
@@ -507,6 +509,7 @@ template <int MI, int MH, int L>
 static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   const size_t wave_lds = (size_t)a.waves_per_block * RenderWaveLds::floats(a.maxs);
   const dim3 blk(64 * a.waves_per_block);
+  g_ngm_last_matmul[0] = NGM_MATMUL_F32;
   if (a.rc.geometry_mode == NGM_GEO_NEUS) {
     // neus in the fused kernel (two-pass compositing over the wave's LDS planes): Fourier / no encoding, skip no, fp32 MFMA
     if (a.fc.skip_mode != NGM_SKIP_NO || (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NONE) || !a.neus_sd)
@@ -523,6 +526,7 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
       if (a.fc.skip_mode == NGM_SKIP_NO && (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
         const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
         if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;
+        g_ngm_last_matmul[0] = NGM_MATMUL_BF16X3;
         (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 0, 0, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 0, 0, true>), dim3(blocks), blk, lds, st, a);

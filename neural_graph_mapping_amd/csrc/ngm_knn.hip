@@ -295,9 +295,11 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((k_knn_eval<MI, MH, L, NC, HS, SK>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);                  \
   } while (0)
   const int sk = a.fc.skip_mode;
+  g_ngm_last_matmul[2] = NGM_MATMUL_F32;
   if constexpr (MI == 2 && MH == 2 && L <= 2) {
     if ((a.fc.matmul_mode == NGM_MATMUL_BF16X3 || a.fc.matmul_mode == NGM_MATMUL_AUTO) && sk == NGM_SKIP_NO &&
         (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
+      g_ngm_last_matmul[2] = NGM_MATMUL_BF16X3;
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
       (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, 0, 0, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -322,14 +324,14 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
 }
 
 int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
-                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float* out,
-                   void* workspace, int64_t workspace_bytes, hipStream_t st) {
+                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
+                   float* out, void* workspace, int64_t workspace_bytes, hipStream_t st) {
   if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
   // k_knn_assign keeps centres + histogram + 4 candidate lists of every field in LDS: 36 B per field of the 160 KiB
   if (num_fields > 4096 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
   KnnArgs a;
   a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.P = P; a.points = points; a.pos = pos; a.quat = quat;
-  a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = fc->field_radius; a.out = out;
+  a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = mask_radius; a.out = out;
   const int64_t n = P * K;
   char* w = reinterpret_cast<char*>(((int64_t)workspace + 255) / 256 * 256);
   auto carve = [&](int64_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
@@ -349,7 +351,10 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36);
     if (attr != hipSuccess) return NGM_E_HIP;
   }
-  hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
+  {
+    NgmProfScope prof_(NGM_K_KNN_ASSIGN, st);
+    hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
+  }
   if (hipGetLastError() != hipSuccess) return NGM_E_HIP;      // an over-sized LDS request fails here, not four launches later
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
@@ -357,13 +362,16 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
   const FieldShape s = field_shape(fc);
   int le = NGM_E_UNSUPPORTED;
-  if (s.MI == 2 && s.MH == 2 && s.L == 2) le = launch_eval<2, 2, 2>(a, max_tiles, st);
+  {
+    NgmProfScope prof_eval_(NGM_K_KNN_EVAL, st);
+    if (s.MI == 2 && s.MH == 2 && s.L == 2) le = launch_eval<2, 2, 2>(a, max_tiles, st);
 #ifndef NGM_FAST_BUILD
-  else if (s.MI == 2 && s.MH == 2 && s.L == 1) le = launch_eval<2, 2, 1>(a, max_tiles, st);
-  else if (s.MI == 1 && s.MH == 1 && s.L == 1) le = launch_eval<1, 1, 1>(a, max_tiles, st);
-  else if (s.MI == 1 && s.MH == 1 && s.L == 2) le = launch_eval<1, 1, 2>(a, max_tiles, st);
-  else if (s.MI == 2 && s.MH == 2 && s.L == 3) le = launch_eval<2, 2, 3>(a, max_tiles, st);
+    else if (s.MI == 2 && s.MH == 2 && s.L == 1) le = launch_eval<2, 2, 1>(a, max_tiles, st);
+    else if (s.MI == 1 && s.MH == 1 && s.L == 1) le = launch_eval<1, 1, 1>(a, max_tiles, st);
+    else if (s.MI == 1 && s.MH == 1 && s.L == 2) le = launch_eval<1, 1, 2>(a, max_tiles, st);
+    else if (s.MI == 2 && s.MH == 2 && s.L == 3) le = launch_eval<2, 2, 3>(a, max_tiles, st);
 #endif
+  }
   if (le) return le;
   hipLaunchKernelGGL(k_knn_blend, dim3(std::max(pb, 1)), dim3(256), 0, st, a);
   return 0;

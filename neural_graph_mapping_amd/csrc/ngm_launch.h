@@ -147,6 +147,9 @@ struct StashBwdArgs {
   float4* xyz_out;            // (F*R*S) optional: scaled field-local sample positions for k_hash_grad (permutohedral encoding)
 };
 
+// which arithmetic the last launch of each forward-type kernel resolved to (ngm_debug_last_matmul): 0 = the fused render
+// forward, 1 = the point evaluation, 2 = the kNN evaluation; values NGM_MATMUL_F32 / NGM_MATMUL_BF16X3, -1 = none yet
+extern int g_ngm_last_matmul[3];
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);

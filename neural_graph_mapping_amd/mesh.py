@@ -55,7 +55,8 @@ def marching_cubes(volume: torch.Tensor, isolevel: float):
 def save_ply(path_or_file, verts: torch.Tensor, faces: torch.Tensor, verts_colors: Optional[torch.Tensor] = None) -> None:
     """Binary little-endian PLY as pytorch3d.io.save_ply(f, verts, faces, verts_colors, ascii=False,
     colors_as_uint8=False) lays it out (the call of rm.py:2375-2384): float x y z [red green blue] per vertex,
-    `list uchar int vertex_indices` per face."""
+    `list uchar int vertex_index` per face (pytorch3d's header spelling, as far as its public documentation shows; the
+    reader below accepts either -- a file is data-identical whichever name the list carries)."""
     v = verts.detach().cpu().numpy().astype("<f4")
     f = faces.detach().cpu().numpy().astype("<i4")
     header = ["ply", "format binary_little_endian 1.0", f"element vertex {len(v)}", "property float x", "property float y",
@@ -64,7 +65,7 @@ def save_ply(path_or_file, verts: torch.Tensor, faces: torch.Tensor, verts_color
         c = verts_colors.detach().cpu().numpy().astype("<f4")
         header += ["property float red", "property float green", "property float blue"]
         v = np.concatenate([v, c], 1)
-    header += [f"element face {len(f)}", "property list uchar int vertex_indices", "end_header"]
+    header += [f"element face {len(f)}", "property list uchar int vertex_index", "end_header"]
     rec = np.empty(len(f), dtype=[("n", "u1"), ("idx", "<i4", (3,))])
     rec["n"] = 3
     rec["idx"] = f
@@ -125,14 +126,34 @@ def _quat_mul(a, b):
                         aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
 
 
+def grid_axes(pos: torch.Tensor, field_radius: float, resolution: float):
+    """rm.py:2222-2231: bounding box of the field centres +- 2 r, three torch.arange axes of spacing `resolution`"""
+    lo = pos.min(0)[0] - 2 * field_radius
+    hi = pos.max(0)[0] + 2 * field_radius
+    return [torch.arange(float(lo[i]), float(hi[i]), step=resolution, device=pos.device) for i in range(3)]
+
+
+def grid_to_world(v: torch.Tensor, bx: torch.Tensor, by: torch.Tensor, bz: torch.Tensor) -> torch.Tensor:
+    """Marching-cubes vertices in grid-index coordinates (ix, iy, iz) of one block -> world.  The reference maps
+    pytorch3d's local coordinates l = 2 i / (n - 1) - 1 back with (0.5 l + 0.5) (last - first) + first per axis
+    (rm.py:2304-2317, then the zyx -> xyz swap of :2320-2322); the block's axes are uniform, so this is the same affine
+    map without the detour through [-1, 1]."""
+    org = torch.stack([bx[0], by[0], bz[0]])
+    span = torch.stack([bx[-1] - bx[0], by[-1] - by[0], bz[-1] - bz[0]])
+    n1 = torch.tensor([len(bx) - 1, len(by) - 1, len(bz) - 1], device=v.device, dtype=torch.float32)
+    return v / n1 * span + org
+
+
 @torch.no_grad()
 def extract_mesh(renderer, mesh_file_path=None, resolution: Optional[float] = None, threshold: Optional[float] = None,
-                 transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200):
+                 transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200,
+                 debug: Optional[dict] = None):
     """NeuralGraphMap._extract_mesh (rm.py:2186-2384): bounding box of the field centres +- 2 r, grid of spacing
     `resolution` (default: the training sample spacing, rm.py:199-207), blocks of `block`^3 cells evaluated with the
     kNN-blended fields, marching cubes per block, vertex colours from a second evaluation with radius + 0.1
     (rm.py:2320-2340), one PLY + `<stem>_fields.txt`.  Returns (verts (V,3) world, faces (T,3), colours (V,3) in
-    [0,255] as the reference stores them) or None when no block crosses the iso-surface."""
+    [0,255] as the reference stores them) or None when no block crosses the iso-surface.
+    Vertex and face ORDER are this build's (oracle/mesh_oracle.py), not pytorch3d's: compare meshes as surfaces."""
     m = renderer._model
     dev = renderer._device
     gmd = renderer._global_map_dict
@@ -151,26 +172,25 @@ def extract_mesh(renderer, mesh_file_path=None, resolution: Optional[float] = No
             return None
         pos, quat, fidx = pos[field_ids].contiguous(), quat[field_ids].contiguous(), field_ids.contiguous()
     r = renderer._field_radius
-    lo = pos.min(0)[0] - 2 * r
-    hi = pos.max(0)[0] + 2 * r
     if resolution is None:
         cfg = renderer._config
         n_g = cfg.get("num_samples_depth_guided", 0)
         rho = cfg.get("range_depth_guided") or cfg.get("truncation_distance", 0.1)
         resolution = 2 * rho / n_g if n_g > 0 else 2 * r / cfg["num_samples_coarse"]
-    axes = [torch.arange(float(lo[i]), float(hi[i]), step=resolution, device=dev) for i in range(3)]
+    axes = grid_axes(pos, r, resolution)
     mode = renderer._rc_train.geometry_mode
     isolevel, low_is_inside = {K.GEO["occupancy"]: (0.5, False), K.GEO["density"]: (30.0, False),
                                K.GEO["neus"]: (0.0, True), K.GEO["nrgbd"]: (0.0, True)}[mode]     # rm.py:2268-2289
     if threshold is not None:
         isolevel = threshold
     gfac, cfac = renderer._rc_train.geometry_factor, renderer._rc_train.color_factor
-    fc_color = m.field_cfg(r + 0.1)                                  # "avoid black colors on field boundaries"
+    color_radius = r + 0.1          # "avoid black colors on field boundaries" (rm.py:2332-2333): widens the inside test only,
+                                    # the local coordinates keep the model's own scaling (models.py:278-285, 368-378)
     big = int(renderer._config.get("block_size", 3000000))
 
-    def evaluate(fc, pts):
-        outs = [ops.field_eval_knn(fc, params, pts[s:s + big], pos, quat, m._num_knn, m._distance_factor, m._outside_value,
-                                   fidx) for s in range(0, pts.shape[0], big)]
+    def evaluate(pts, mask_radius=None):
+        outs = [ops.field_eval_knn(renderer._fc, params, pts[s:s + big], pos, quat, m._num_knn, m._distance_factor,
+                                   m._outside_value, fidx, mask_radius) for s in range(0, pts.shape[0], big)]
         return torch.cat(outs) if len(outs) > 1 else outs[0]
 
     all_v, all_f, all_c, offset = [], [], [], 0
@@ -178,21 +198,19 @@ def extract_mesh(renderer, mesh_file_path=None, resolution: Optional[float] = No
     for xs, ys, zs in itertools.product(*starts):
         bx, by, bz = axes[0][xs:xs + block + 1], axes[1][ys:ys + block + 1], axes[2][zs:zs + block + 1]
         xyz = torch.cartesian_prod(bx, by, bz)
-        vol = evaluate(renderer._fc, xyz)[:, 3].reshape(len(bx), len(by), len(bz))
+        vol = evaluate(xyz)[:, 3].reshape(len(bx), len(by), len(bz))
         if mode == K.GEO["occupancy"]:
             vol = torch.sigmoid(gfac * vol)
         if low_is_inside:
             vol = -vol
         v, f = marching_cubes(vol.contiguous(), isolevel)
+        if debug is not None:      # tests: what was handed to marching cubes and what came back, per block (fixture G17)
+            debug.setdefault("blocks", []).append(dict(axes=(bx, by, bz), volume=vol, isolevel=isolevel, verts_grid=v, faces=f))
+            debug["color_fn"] = lambda pts: torch.clamp(cfac * evaluate(pts, color_radius)[:, :3], 0, 1) * 255
         if len(v) == 0:
             continue
-        # grid-index coordinates -> world: the block's axes are uniform, so this is the reference's affine map of the
-        # normalised coordinates (rm.py:2304-2317) without the detour through [-1, 1]
-        org = torch.stack([bx[0], by[0], bz[0]])
-        span = torch.stack([bx[-1] - bx[0], by[-1] - by[0], bz[-1] - bz[0]])
-        n1 = torch.tensor([len(bx) - 1, len(by) - 1, len(bz) - 1], device=dev, dtype=torch.float32)
-        vw = v / n1 * span + org
-        col = torch.clamp(cfac * evaluate(fc_color, vw)[:, :3], 0, 1) * 255
+        vw = grid_to_world(v, bx, by, bz)
+        col = torch.clamp(cfac * evaluate(vw, color_radius)[:, :3], 0, 1) * 255
         all_v.append(vw)
         all_f.append(f + offset)
         all_c.append(col)

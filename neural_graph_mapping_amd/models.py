@@ -200,6 +200,10 @@ class NeuralFieldSet(torch.nn.Module):
         self._scale_mode, self._field_radius, self._dim_points = scale_mode, field_radius, dim_points
         self._num_knn, self._distance_factor, self._outside_value = num_knn, distance_factor, outside_value
         self._prototype_field = str_to_object(field_type)(**field_kwargs)
+        if self._weight_dtype is not None and isinstance(getattr(self._prototype_field, "_encoding", None), TriplaneEncoding):
+            # the plane gradient is a fixed-point scatter into fp32 planes and their Adam launch has no 16-bit copy to
+            # refresh: fail here, not at the first kernel call
+            raise NotImplementedError("weight_dtype (16-bit weight storage) is not built for the triplane encoding")
         self.all_fields_params: Optional[Dict[str, torch.Tensor]] = None
         self.vmap_fields_params: Optional[Dict[str, torch.Tensor]] = None
 

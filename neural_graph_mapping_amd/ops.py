@@ -21,16 +21,34 @@ from . import _capi as K
 NS = "ngm355"
 
 
+_BLOBS: Dict[bytes, torch.Tensor] = {}       # struct bytes -> its uint8 CPU tensor (a renderer uses a handful of distinct structs)
+_STRUCTS: Dict[int, object] = {}             # id(blob tensor) -> decoded ctypes struct (the blobs above live for the process)
+
+
 def cfg_blob(struct) -> torch.Tensor:
-    return torch.frombuffer(bytearray(bytes(struct)), dtype=torch.uint8)
+    raw = bytes(struct)
+    t = _BLOBS.get(raw)
+    if t is None:
+        if len(_BLOBS) > 4096:
+            _BLOBS.clear(); _STRUCTS.clear()
+        t = _BLOBS[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        _STRUCTS[id(t)] = type(struct).from_buffer_copy(raw)
+    return t
+
+
+def _decode(blob: torch.Tensor, cls):
+    s = _STRUCTS.get(id(blob))
+    if s is not None and isinstance(s, cls):
+        return s                             # read-only use below: the cached struct is never mutated
+    return cls.from_buffer_copy(blob.numpy().tobytes())
 
 
 def _field_cfg(blob: torch.Tensor) -> "K.FieldCfg":
-    return K.FieldCfg.from_buffer_copy(blob.numpy().tobytes())
+    return _decode(blob, K.FieldCfg)
 
 
 def _render_cfg(blob: torch.Tensor) -> "K.RenderCfg":
-    return K.RenderCfg.from_buffer_copy(blob.numpy().tobytes())
+    return _decode(blob, K.RenderCfg)
 
 
 def _op(name, mutates_args=()):
@@ -171,7 +189,7 @@ def _field_eval_bwd_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[t
 
 @_field_eval_bwd_op.register_fake
 def _(fcfg, points, pos, quat, d_out, params):
-    return [torch.empty_like(p) for p in params]
+    return [torch.empty_like(p, dtype=torch.float32) for p in params]      # gradients are fp32 whatever the storage dtype
 
 
 def _field_eval_setup(ctx, inputs, output):
@@ -203,7 +221,7 @@ def field_eval(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None
 @_op("field_eval_knn")
 def _field_eval_knn_op(fcfg: torch.Tensor, points: torch.Tensor, pos: torch.Tensor, quat: torch.Tensor,
                        params: List[torch.Tensor], num_knn: int, distance_factor: float, outside_value: float,
-                       field_index: Optional[torch.Tensor]) -> torch.Tensor:
+                       field_index: Optional[torch.Tensor], mask_radius: float) -> torch.Tensor:
     fc = _field_cfg(fcfg)
     P, NF = points.shape[0], pos.shape[0]
     out = torch.empty(P, 4, device=points.device, dtype=torch.float32)
@@ -214,24 +232,27 @@ def _field_eval_knn_op(fcfg: torch.Tensor, points: torch.Tensor, pos: torch.Tens
     wsb = L.ngm_field_eval_knn_workspace(NF, P, num_knn)
     ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
     K.check(L.ngm_field_eval_knn(C.byref(fc), C.byref(ps), NF, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)),
-                                 num_knn, distance_factor, outside_value, _ptr(out), _ptr(ws), wsb, _stream()),
+                                 num_knn, distance_factor, outside_value, mask_radius, _ptr(out), _ptr(ws), wsb, _stream()),
             "ngm_field_eval_knn")
     return out
 
 
 @_field_eval_knn_op.register_fake
-def _(fcfg, points, pos, quat, params, num_knn, distance_factor, outside_value, field_index):
+def _(fcfg, points, pos, quat, params, num_knn, distance_factor, outside_value, field_index, mask_radius):
     return points.new_empty(points.shape[0], 4)
 
 
 def field_eval_knn(fc, params, points, pos, quat, num_knn=2, distance_factor=10.0, outside_value=1.0,
-                   field_index=None):
+                   field_index=None, mask_radius=None):
     """models.py:347-405: kNN-blended evaluation of world points (P,3) over all fields -> (P,4).
+    `mask_radius` = the `field_radius` argument of the reference's forward (models.py:293, 368): which points count as
+    inside a field; the local coordinates are scaled with the model's own radius (fc.field_radius) either way.
     Dispatches through torch.ops.ngm355.field_eval_knn."""
     plist = [params[n] for n in K.param_names(fc)]
     _require_gpu(points, pos, quat, *plist)
     return torch.ops.ngm355.field_eval_knn(cfg_blob(fc), _f32c(points.reshape(-1, 3)), pos, quat, plist, int(num_knn),
-                                           float(distance_factor), float(outside_value), field_index)
+                                           float(distance_factor), float(outside_value), field_index,
+                                           float(mask_radius) if mask_radius else 0.0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -370,7 +391,8 @@ def _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed
 def _render_ijs_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2ws: torch.Tensor, near: Optional[torch.Tensor],
                    far: Optional[torch.Tensor], gt: Optional[torch.Tensor], pos: torch.Tensor, quat: torch.Tensor,
                    u_coarse: Optional[torch.Tensor], u_guided: Optional[torch.Tensor], seed: int, near_const: float,
-                   far_const: float, save: bool, num_samples: int, params: List[torch.Tensor]) -> List[torch.Tensor]:
+                   far_const: float, save: bool, num_samples: int, workspace_bytes: int,
+                   params: List[torch.Tensor]) -> List[torch.Tensor]:
     """[rgbds (F,R,4), color_vars (F,R,3), depth_vars (F,R), term_probs (F,R), geoms (F,R,S) | empty, dists (F,R,S) | empty,
     workspace (bytes) | empty]; geoms / dists / workspace are filled when `save` (needed for a backward or for the
     free-space / TSDF vectors of the Prediction)."""
@@ -387,6 +409,8 @@ def _render_ijs_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2
     L = K.lib()
     ps = params_struct(fc, dict(zip(K.param_names(fc), params)))
     wsb = L.ngm_render_workspace(C.byref(fc), C.byref(rc), F, R, 1) if save else 0
+    if wsb != workspace_bytes:
+        raise ValueError(f"render_ijs: workspace_bytes {workspace_bytes} != ngm_render_workspace {wsb}")
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), None, C.byref(pred), None,
                              _ptr(ws) if save else None, wsb, _stream()), "ngm_render_fwd")
@@ -400,11 +424,12 @@ def _render_ijs_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2
 
 @_render_ijs_op.register_fake
 def _(fcfg, rcfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, save, num_samples,
-      params):
+      workspace_bytes, params):
     F, R, S = ijs.shape[0], ijs.shape[1], num_samples
     f = lambda *shape: torch.empty(*shape, device=ijs.device, dtype=torch.float32)
     n = (F, R, S) if save else (0,)
-    return [f(F, R, 4), f(F, R, 3), f(F, R), f(F, R), f(*n), f(*n), torch.empty(0, device=ijs.device, dtype=torch.uint8)]
+    return [f(F, R, 4), f(F, R, 3), f(F, R), f(F, R), f(*n), f(*n),
+            torch.empty(workspace_bytes, device=ijs.device, dtype=torch.uint8)]
 
 
 @_op("render_ijs_bwd", mutates_args=("workspace",))
@@ -430,7 +455,7 @@ def _render_ijs_bwd_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor
 @_render_ijs_bwd_op.register_fake
 def _(fcfg, rcfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, d_rgbds, d_term,
       d_geoms, workspace, params):
-    return [torch.empty_like(p) for p in params]
+    return [torch.empty_like(p, dtype=torch.float32) for p in params]      # gradients are fp32 whatever the storage dtype
 
 
 _RAY_SLOTS = ("ijs", "c2ws", "near", "far", "gt", "pos", "quat", "u_coarse", "u_guided")
@@ -438,7 +463,7 @@ _RAY_SLOTS = ("ijs", "c2ws", "near", "far", "gt", "pos", "quat", "u_coarse", "u_
 
 def _render_ijs_setup(ctx, inputs, output):
     fcfg, rcfg, *rest = inputs
-    ray_t, (seed, near_const, far_const, save, _), params = rest[:9], rest[9:14], rest[14]
+    ray_t, (seed, near_const, far_const, save, _, _), params = rest[:9], rest[9:15], rest[15]
     ctx.fcfg, ctx.rcfg, ctx.scalars, ctx.save = fcfg, rcfg, (seed, near_const, far_const), save
     ctx.present = [t is not None for t in ray_t]
     ctx.consumed = False
@@ -462,7 +487,7 @@ def _render_ijs_backward(ctx, grads):
     seed, near_const, far_const = ctx.scalars
     g = torch.ops.ngm355.render_ijs_bwd(ctx.fcfg, ctx.rcfg, *ray_t, seed, near_const, far_const, d_rgbds.contiguous(),
                                         d_term.contiguous(), d_geoms.contiguous() if d_geoms.numel() else None, ws, params)
-    return (None,) * 16 + (g,)
+    return (None,) * 17 + (g,)
 
 
 _render_ijs_op.register_autograd(_render_ijs_backward, setup_context=_render_ijs_setup)
@@ -480,7 +505,9 @@ def render_ijs_fused(fc: K.FieldCfg, rc: K.RenderCfg, params: Dict[str, torch.Te
     out = torch.ops.ngm355.render_ijs(cfg_blob(fc), cfg_blob(rc), ijs.contiguous(), _f32c(c2ws), _f32c(near), _f32c(far),
                                       _f32c(gt), _f32c(pos), _f32c(quat), _f32c(u_coarse), _f32c(u_guided), int(seed),
                                       float(near_const), float(far_const), save,
-                                      rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0), plist)
+                                      rc.num_samples_coarse + (rc.num_samples_guided if gt is not None else 0),
+                                      int(K.lib().ngm_render_workspace(C.byref(fc), C.byref(rc), ijs.shape[0], ijs.shape[1], 1)) if save else 0,
+                                      plist)
     rgbds, cvars, dvars, term, geoms, dists, _ = out
     return (rgbds, cvars.detach(), dvars.detach(), term, geoms if save else None, dists.detach() if save else None)
 
@@ -698,9 +725,17 @@ def target_sv_intersect(pos_c, points, radius):
 def target_sv_rays(pos_c, radius, pts_ijs, segments, image, fx, fy, cx, cy):
     """Per-ray targets of the single-view sampler (rm.py:1536-1561), keyed like the reference's Target record."""
     pos_c, image = _f32c(pos_c), _f32c(image)
+    _require_gpu(pos_c, image, pts_ijs, segments)
+    if pts_ijs.dtype != torch.int64 or segments.dtype != torch.int64:
+        raise TypeError(f"target_sv_rays: pts_ijs / segments must be int64 (got {pts_ijs.dtype}, {segments.dtype})")
     pts_ijs, segments = pts_ijs.contiguous(), segments.contiguous()
     F, R = segments.shape
     H, W = image.shape[0], image.shape[1]
+    if segments.numel() and (int(segments.min()) < 0 or int(segments.max()) >= pts_ijs.shape[0]):
+        raise IndexError("target_sv_rays: segment index outside the point list")
+    if pts_ijs.numel() and (int(pts_ijs[:, 0].min()) < 0 or int(pts_ijs[:, 0].max()) >= H or int(pts_ijs[:, 1].min()) < 0
+                            or int(pts_ijs[:, 1].max()) >= W):
+        raise IndexError("target_sv_rays: pixel index outside the frame")
     dev = pos_c.device
     o = dict(ijs=torch.empty(F, R, 2, dtype=torch.int64, device=dev), near=torch.empty(F, R, device=dev),
              far=torch.empty(F, R, device=dev), gt=torch.empty(F, R, device=dev), rgbds=torch.empty(F, R, 4, device=dev),

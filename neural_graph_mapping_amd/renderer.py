@@ -126,6 +126,14 @@ class NeuralGraphRenderer:
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
 
+    def last_matmul(self, kernel: str = "forward") -> Optional[str]:
+        """The arithmetic the library resolved `mlp_matmul` to in the LAST launch of the fused forward ("forward"), the
+        point evaluation ("points") or the kNN evaluation ("knn"): "f32" | "bf16x3" (None before the first launch).
+        `auto` is resolved per kernel and batch shape (LDS plan), so this -- not `self.mlp_matmul`, the host-side
+        expectation -- is what a measurement should be labelled with."""
+        v = K.lib().ngm_debug_last_matmul({"forward": 0, "points": 1, "knn": 2}[kernel])
+        return {K.MATMUL["f32"]: "f32", K.MATMUL["bf16x3"]: "bf16x3"}.get(v)
+
     # -- map bookkeeping supplied by the caller ------------------------------------------------
     def set_field_poses(self, positions: torch.Tensor, orientations: torch.Tensor):
         self._global_map_dict = {"positions": positions, "orientations": orientations, "num": positions.shape[0]}
@@ -176,10 +184,11 @@ class NeuralGraphRenderer:
         return torch.cat(outs).reshape(*lead, 4)
 
     def extract_mesh(self, mesh_file_path=None, resolution: Optional[float] = None, threshold: Optional[float] = None,
-                     transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200):
+                     transform: Optional[torch.Tensor] = None, field_ids: Optional[torch.Tensor] = None, block: int = 200,
+                     debug: Optional[dict] = None):
         """_extract_mesh (rm.py:2186-2384): dense grid -> HIP marching cubes -> vertex colours -> PLY (see mesh.py)."""
         from . import mesh
-        return mesh.extract_mesh(self, mesh_file_path, resolution, threshold, transform, field_ids, block)
+        return mesh.extract_mesh(self, mesh_file_path, resolution, threshold, transform, field_ids, block, debug)
 
     # -- reference-compatible API --------------------------------------------------------------
     def quadrature(self, sample_colors, sample_geometries, sample_distances, sample_depths, neus_isds=None):

@@ -383,14 +383,15 @@ def field_set_forward_vmap(query_points, pos, quat, params, fs: FieldSpec, radiu
 
 def field_set_forward_knn(points, pos, quat, params, fs: FieldSpec, radius=1.0,
                           scale_mode="unit_cube", num_knn=2, distance_factor=10.0,
-                          outside_value=1.0):
-    """NeuralFieldSet.forward(use_vmap=False) (models.py:347-405). points (P,3)."""
+                          outside_value=1.0, mask_radius=None):
+    """NeuralFieldSet.forward(use_vmap=False) (models.py:347-405). points (P,3).  `mask_radius` = the forward's
+    `field_radius` argument (models.py:293, 368: the inside test only); `radius` = the model's own (scaling, :278-285)."""
     P = points.shape[0]
     K = min(num_knn, pos.shape[0])
     d2 = ((points[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
     d2k, idx = torch.topk(d2, K, dim=-1, largest=False, sorted=True)
     dist = torch.sqrt(d2k)
-    inside = dist[:, 0] < radius
+    inside = dist[:, 0] < (radius if mask_radius is None else mask_radius)
     out = torch.full((P, fs.dim_out), outside_value, dtype=points.dtype)
     if inside.any():
         pi, di, ii = points[inside], dist[inside], idx[inside]

@@ -44,6 +44,31 @@ def _quaternion_apply(q, p):
     return out[..., 1:]
 
 
+def _matrix_to_quaternion(m):
+    """real-first unit quaternion of a rotation matrix (textbook: largest of w, x, y, z as the pivot); the sign is
+    irrelevant for rotating points, which is all utils.transform_quaternions' result is used for"""
+    m = m.double()
+    lead = m.shape[:-2]
+    m = m.reshape(-1, 3, 3)
+    out = []
+    for r in m:
+        t = r.trace()
+        if t > 0:
+            s = torch.sqrt(t + 1.0) * 2
+            q = torch.stack([0.25 * s, (r[2, 1] - r[1, 2]) / s, (r[0, 2] - r[2, 0]) / s, (r[1, 0] - r[0, 1]) / s])
+        else:
+            i = int(torch.argmax(torch.diagonal(r)))
+            j, k = (i + 1) % 3, (i + 2) % 3
+            s = torch.sqrt(1.0 + r[i, i] - r[j, j] - r[k, k]) * 2
+            q = torch.zeros(4, dtype=torch.float64)
+            q[0] = (r[k, j] - r[j, k]) / s
+            q[1 + i] = 0.25 * s
+            q[1 + j] = (r[j, i] + r[i, j]) / s
+            q[1 + k] = (r[k, i] + r[i, k]) / s
+        out.append(q / q.norm())
+    return torch.stack(out).reshape(*lead, 4).float()
+
+
 def _knn_points(p1, p2, K=1, return_sorted=True, **kw):
     d2 = torch.cdist(p1.double(), p2.double()).float() ** 2
     # exact squared distances (cdist may use the mm trick): recompute directly
@@ -73,6 +98,7 @@ def import_reference():
     tr.quaternion_apply = _quaternion_apply
     tr.quaternion_raw_multiply = _quaternion_raw_multiply
     tr.quaternion_multiply = _quaternion_raw_multiply
+    tr.matrix_to_quaternion = _matrix_to_quaternion
     sys.modules["pytorch3d.transforms"] = tr
     sys.modules["pytorch3d"].transforms = tr
     knn = types.ModuleType("pytorch3d.ops.knn")

@@ -620,10 +620,94 @@ def g9_render_image():
          eval_far=np.float32(5.0), eval_num_samples=np.int64(48), **arrays)
 
 
+def g17_extract_mesh():
+    """NeuralGraphMap._extract_mesh (rm.py:2186-2384) run for real, with the two un-vendored pytorch3d calls replaced:
+    `marching_cubes` by oracle/mesh_oracle.py behind pytorch3d's documented interface (volume (N, D, H, W) -> per batch
+    element vertices in LOCAL coordinates, x <-> W, y <-> H, z <-> D, normalised to [-1, 1]; faces), `save_ply` by a
+    recorder.  What the fixture pins is everything the reference does itself: bounding box and grid axes, the block
+    loop (BLOCK_SIZE = 200 with one shared plane, two blocks along x here), the volume handed to marching cubes (sign:
+    low_is_inside), the isolevel, the affine map of the local vertices back to the world, the second evaluation with
+    radius + 0.1 for the colours, the concatenation / face offsets, and what is handed to save_ply / np.savetxt.
+    Stored subsampled (the volume has 2.4 M entries): seeded index sets + values, and totals."""
+    import pathlib
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import mesh_oracle as MO
+    gen = torch.Generator().manual_seed(17)
+    NF, radius, res = 4, 0.5, 0.016
+    pos = torch.tensor([[0.0, 0.0, 0.0], [0.8, 0.05, -0.04], [1.6, -0.06, 0.03], [2.4, 0.02, 0.05]])
+    quat = rand_quats(NF, gen)
+    cfg = make_config(field_radius=radius)
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=170)
+    model = ngm._model
+    for k, v in model.all_fields_params.items():
+        if v.dim() > 1:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    model.all_fields_params["_linears.2.weight"].mul_(3.0)
+    model.all_fields_params["_linears.2.bias"][:, 3] = -0.02            # geometry crosses zero inside the fields
+    ngm.eval()
+    rec = dict(volumes=[], isolevels=[], raw=[], ply=None)
+
+    def mc_stub(volume, isolevel):
+        vol = volume[0].numpy()
+        v, f = MO.marching_cubes(vol, float(isolevel))
+        n1 = np.array(vol.shape, np.float32) - 1.0
+        loc = v / n1 * 2.0 - 1.0                                                   # (ix, iy, iz) -> [-1, 1] per axis
+        p3d = np.stack((loc[:, 2], loc[:, 1], loc[:, 0]), -1).astype(np.float32)    # pytorch3d: x <-> last volume axis
+        rec["volumes"].append(volume[0].clone()); rec["isolevels"].append(float(isolevel))
+        rec["raw"].append(torch.from_numpy(v.copy()))
+        return [torch.from_numpy(p3d)], [torch.from_numpy(f)]
+
+    def ply_stub(fp, verts, faces, verts_colors, ascii, colors_as_uint8, verts_normals):
+        rec["ply"] = dict(verts=verts.clone(), faces=faces.clone(), colors=verts_colors.clone(), ascii=ascii,
+                          colors_as_uint8=colors_as_uint8, normals=verts_normals)
+
+    old_mc, old_ply = rm.marching_cubes, rm.save_ply
+    rm.marching_cubes, rm.save_ply = mc_stub, ply_stub
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = pathlib.Path(d) / "mesh.ply"
+            ngm._extract_mesh(path, resolution=res)
+            fields_txt = np.loadtxt(str(pathlib.Path(d) / "mesh_fields.txt")).reshape(-1, 3)
+    finally:
+        rm.marching_cubes, rm.save_ply = old_mc, old_ply
+    assert rec["ply"] is not None and len(rec["volumes"]) >= 2, "expected a surface and at least two blocks"
+    out = {}
+    rng = np.random.default_rng(170)
+    v_all, c_all = rec["ply"]["verts"], rec["ply"]["colors"]
+    off = 0
+    for b, (vol, raw) in enumerate(zip(rec["volumes"], rec["raw"])):
+        flat = vol.reshape(-1)
+        sel = np.sort(rng.choice(flat.numel(), size=4096, replace=False))
+        out[f"b{b}_shape"] = np.array(vol.shape, np.int64)
+        out[f"b{b}_vol_idx"] = sel.astype(np.int64)
+        out[f"b{b}_vol_val"] = flat[sel]
+        out[f"b{b}_vol_sum"] = np.float64(flat.double().sum())
+        out[f"b{b}_vol_inside"] = np.int64((flat > rec["isolevels"][b]).sum())
+        nvb = raw.shape[0]
+        vs = np.sort(rng.choice(nvb, size=min(2048, nvb), replace=False))
+        out[f"b{b}_num_verts"] = np.int64(nvb)
+        out[f"b{b}_vert_idx"] = vs.astype(np.int64)
+        out[f"b{b}_vert_grid"] = raw[vs]                       # marching-cubes output: grid-index coordinates (ix, iy, iz)
+        out[f"b{b}_vert_world"] = v_all[off + vs]              # what the reference made of them (xyz, world)
+        out[f"b{b}_vert_color"] = c_all[off + vs]
+        off += nvb
+    assert off == v_all.shape[0]
+    faces = rec["ply"]["faces"]
+    save("g17_extract_mesh", pos=pos, quat=quat, field_radius=np.float32(radius), resolution=np.float64(res),
+         isolevel=np.float32(rec["isolevels"][0]), num_blocks=np.int64(len(rec["volumes"])),
+         num_verts=np.int64(v_all.shape[0]), num_faces=np.int64(faces.shape[0]), faces_max=np.int64(faces.max()),
+         verts_min=v_all.min(0)[0], verts_max=v_all.max(0)[0], verts_sum=v_all.double().sum(0),
+         colors_sum=c_all.double().sum(0), fields_txt=fields_txt.astype(np.float64),
+         ply_ascii=np.int64(bool(rec["ply"]["ascii"])), ply_colors_as_uint8=np.int64(bool(rec["ply"]["colors_as_uint8"])),
+         **{"p::" + k: v for k, v in model.all_fields_params.items()}, **out)
+
+
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g18_train_l2]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

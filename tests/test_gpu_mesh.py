@@ -97,3 +97,50 @@ def test_extract_mesh_of_a_trained_field(tmp_path):
     _, _, _, area_b, _ = MO.mesh_stats(vb.cpu().numpy(), fb.cpu().numpy())
     assert abs(area_b - area) / area < 1e-4
     assert r.extract_mesh(None, resolution=0.2, threshold=1e9) is None  # no crossing -> None (rm.py:2343-2345)
+
+
+def test_extract_mesh_reproduces_the_reference_run_g17(tmp_path):
+    """G17: the REAL NeuralGraphMap._extract_mesh (rm.py:2186-2384) with pytorch3d's marching cubes stubbed by
+    oracle/mesh_oracle.py and save_ply by a recorder.  The build must hand marching cubes the same blocks and the same
+    volume (sign convention included), map its vertices to the same world points, colour them the same, and write the same
+    side files.  Tolerances: volume 3e-4, vertices 1e-5, colours +-1 level of 255; vertex / face ORDER is the build's."""
+    g = load_golden("g17_extract_mesh")
+    radius, res = float(g["field_radius"]), float(g["resolution"])
+    NF = g["pos"].shape[0]
+    r = make_renderer(dict(encoding="fourier", dim_enc=64, num_layers=2), dict(field_radius=radius, num_samples_coarse=8, num_samples_depth_guided=16), NF, split_prefix(g, "p::"))
+    r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
+    dbg = {}
+    path = tmp_path / "mesh.ply"
+    verts, faces, cols = r.extract_mesh(path, resolution=res, debug=dbg)
+    assert len(dbg["blocks"]) == int(g["num_blocks"])
+    for b, blk in enumerate(dbg["blocks"]):
+        vol = blk["volume"]
+        assert tuple(vol.shape) == tuple(int(v) for v in g[f"b{b}_shape"])            # block loop, shared planes (rm.py:2232-2246)
+        assert blk["isolevel"] == float(g["isolevel"])
+        got = vol.reshape(-1)[g[f"b{b}_vol_idx"].to(DEV)].cpu()
+        assert float((got - g[f"b{b}_vol_val"]).abs().max()) < 3e-4                   # incl. the low_is_inside negation
+        n_in = int((vol > blk["isolevel"]).sum())
+        assert abs(n_in - int(g[f"b{b}_vol_inside"])) <= 2e-3 * int(g[f"b{b}_vol_inside"]) + 4
+        nv_ref = int(g[f"b{b}_num_verts"])
+        assert abs(len(blk["verts_grid"]) - nv_ref) <= 5e-3 * nv_ref + 8
+        if nv_ref == 0:
+            continue
+        axes = blk["axes"]
+        vw = Mh.grid_to_world(g[f"b{b}_vert_grid"].to(DEV), *axes).cpu()               # rm.py:2304-2322
+        assert float((vw - g[f"b{b}_vert_world"]).abs().max()) < 1e-5
+        col = dbg["color_fn"](g[f"b{b}_vert_world"].to(DEV)).cpu()                     # radius + 0.1 evaluation, clamp, x255 (rm.py:2324-2340)
+        assert float((col - g[f"b{b}_vert_color"]).abs().max()) <= 1.0
+        # same surface: every sampled reference vertex has a vertex of the build next to it
+        mine = Mh.grid_to_world(blk["verts_grid"], *axes)
+        d = torch.cdist(g[f"b{b}_vert_world"].to(DEV), mine).min(1)[0]
+        assert float(d.max()) < 0.5 * res and float(d.median()) < 1e-4
+    assert abs(len(verts) - int(g["num_verts"])) <= 5e-3 * int(g["num_verts"]) + 8
+    assert abs(len(faces) - int(g["num_faces"])) <= 5e-3 * int(g["num_faces"]) + 16
+    assert int(faces.max()) == len(verts) - 1 and int(faces.min()) == 0                # block face offsets (rm.py:2319)
+    assert float((verts.min(0)[0].cpu() - g["verts_min"]).abs().max()) < res and float((verts.max(0)[0].cpu() - g["verts_max"]).abs().max()) < res
+    assert float((verts.double().sum(0).cpu() / len(verts) - g["verts_sum"] / int(g["num_verts"])).abs().max()) < 2e-3
+    assert float((cols.double().sum(0).cpu() / len(cols) - g["colors_sum"] / int(g["num_verts"])).abs().max()) < 0.5
+    txt = np.loadtxt(str(tmp_path / "mesh_fields.txt")).reshape(-1, 3)
+    assert np.abs(txt - g["fields_txt"].numpy()).max() < 1e-6
+    v2, f2, c2 = Mh.load_ply(path)
+    assert torch.equal(v2, verts.cpu()) and torch.equal(f2, faces.cpu()) and torch.equal(c2, cols.cpu())

@@ -701,13 +701,21 @@ def test_stash_backward_bf16_split_other_encodings(enc):
 
 
 # ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)
-def test_knn_blend_golden():
+@pytest.mark.parametrize("mm", ["auto", "f32", "bf16x3"])
+def test_knn_blend_golden(mm):
+    """G8 through each arithmetic of the evaluation kernels' hidden layers; which one really ran is read back from the
+    library (ngm_debug_last_matmul), so a silent fallback to the other would fail here"""
     g = load_golden("g8_knn")
-    fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+    fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, matmul_mode=mm)
     params = cu({k: v for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"})
     out = ops.field_eval_knn(fc, params, g["points"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV), 2, 10.0, 1.0)
+    assert K.lib().ngm_debug_last_matmul(2) == K.MATMUL["f32" if mm == "f32" else "bf16x3"]
     close(out, g["out"], rtol=2e-4, atol=3e-5)
     assert torch.equal(out[:5].cpu(), torch.ones(5, 4))
+    pts = g["points"][:64].to(DEV)
+    one = {k: v[:1] for k, v in params.items()}
+    ops.field_eval(fc, one, pts[None], g["pos"][:1].to(DEV), g["quat"][:1].to(DEV))
+    assert K.lib().ngm_debug_last_matmul(1) == K.MATMUL["f32" if mm == "f32" else "bf16x3"]       # the point evaluation too
 
 
 @pytest.mark.parametrize("NF,K_,P", [(1, 2, 300), (7, 3, 5000), (40, 2, 70000)])
@@ -941,83 +949,8 @@ def test_target_sampler_single_view_golden():
     assert bool((t2.gt_distances > 0).all())                               # only pixels with depth are sampled
 
 
-# ------------------------------------------------------------------ trained-parameter / PSNR parity over a training run
-def _smooth_scene_batch(F, R, pos, quat_unused, seed):
-    """rays of synth_target with a LEARNABLE supervision: colour = smooth function of the hit point."""
-    _, _, t = synth_target(F, R, seed=seed)
-    # same field poses for every batch: re-derive near/far/gt for the fixed positions
-    d = O.ijs_to_directions(t["ijs"], NRGBD)
-    pos_c = torch.einsum("...kd,...k->...d", t["c2ws"][..., :3, :3], pos[:, None] - t["c2ws"][..., :3, 3])
-    center = (pos_c * d).sum(-1)
-    near, far = (center - 1).clamp_min(0), (center + 1).clamp_min(0)
-    gen = torch.Generator().manual_seed(seed + 7)
-    gt = near + (far - near) * (0.35 + 0.3 * torch.rand(F, R, generator=gen))
-    dw = torch.einsum("...ij,...j->...i", t["c2ws"][..., :3, :3], d)
-    hit = t["c2ws"][..., :3, 3] + gt[..., None] * dw
-    rgb = 0.5 + 0.4 * torch.sin(2.0 * hit + torch.tensor([0.0, 1.0, 2.0]))
-    t.update(near=near, far=far, gt=gt, rgbds=torch.cat([rgb, (gt * d[..., 2].abs())[..., None]], -1),
-             depth_mask=torch.ones(F, R, dtype=torch.bool), term_probs=torch.ones(F, R),
-             term_mask=torch.ones(F, R, dtype=torch.bool))
-    return t
-
-
-@pytest.mark.parametrize("seed", [0])
-def test_training_run_psnr_matches_oracle(seed):
-    """200 identical iterations (same batches, same jitter draws, same initial parameters) through the oracle on the
-    CPU and through the fused kernels + sparse Adam; then both parameter sets render the same 2048 held-out rays.
-    The loss is discontinuous in the prediction (the mask term > 0.8 of rm.py:1787, ReLU), so fp32 round-off makes the
-    two trajectories drift apart like two runs of the reference with different summation orders would; what must
-    agree is where they are heading: same loss level (no bias in the gradients or in Adam), held-out PSNR improving
-    alike (the 10-step golden run G7 checks the trajectory itself against the real reference)."""
-    F, R, n_c, n_g, iters = 1, 128, 16, 16, 200
-    fs = O.FieldSpec(encoding="fourier", dim_enc=64, num_layers=2)
-    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
-    fkw, ckw = dict(encoding="fourier", dim_enc=64, num_layers=2), dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g,
-                                                                       learning_rate=5e-3)
-    pos, quat, _ = synth_target(F, R, seed=1 + seed)
-    quat = torch.tensor([[1.0, 0, 0, 0]]).repeat(F, 1)
-    p0 = O.init_params(fs, F, seed=2 + seed, sigma=2.0)
-    r = make_renderer(fkw, ckw, F, {k: v.clone() for k, v in p0.items()})
-    r.set_field_poses(pos.to(DEV), quat.to(DEV))
-    po = {k: v.clone() for k, v in p0.items()}
-    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in po.items()}
-    lr, eps, wd = r._learning_rate, r._adam_eps, r._adam_weight_decay
-    assert lr == 5e-3
-    lo, lg = [], []
-    for it in range(iters):
-        t = _smooth_scene_batch(F, R, pos, quat, seed=1000 + it)
-        g = torch.Generator().manual_seed(5000 + it)
-        u_c, u_g = torch.rand(F, R, n_c, generator=g), torch.rand(F, R, n_g, generator=g)
-        pr = {k: v.clone().requires_grad_(True) for k, v in po.items()}
-        pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, pr, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
-        loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
-        loss["combined"].backward()
-        for k in po:
-            gk = pr[k].grad if pr[k].grad is not None else torch.zeros_like(po[k])
-            po[k], m, v = O.adam_step(po[k], gk, mom[k][0], mom[k][1], it + 1, lr=lr, eps=eps, weight_decay=wd)
-            mom[k] = (m, v)
-        res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)
-        if it == 0:
-            close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
-        lo.append(float(loss["combined"].detach())); lg.append(float(res["combined"]))
-    lo_end, lg_end = sum(lo[-30:]) / 30, sum(lg[-30:]) / 30
-    assert lo_end < 0.5 * lo[0], (lo[0], lo_end)                    # the run did train
-    assert abs(lg_end - lo_end) < 0.1 * lo_end, (lo_end, lg_end)    # same loss level at the end
-    t = _smooth_scene_batch(F, 2048, pos, quat, seed=99)
-    g = torch.Generator().manual_seed(77)
-    u_c, u_g = torch.rand(F, 2048, n_c, generator=g), torch.rand(F, 2048, n_g, generator=g)
-    with torch.no_grad():
-        ref = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
-        ini = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, p0, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
-    out = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
-    psnr_ini = O.psnr(ini["rgbds"][..., :3], t["rgbds"][..., :3])
-    psnr_ref = O.psnr(ref["rgbds"][..., :3], t["rgbds"][..., :3])
-    psnr_gpu = O.psnr(out["prediction"].rgbds[..., :3].cpu(), t["rgbds"][..., :3])
-    print("psnr: initial %.3f, oracle-trained %.3f, kernel-trained %.3f; loss level %.4f / %.4f (start %.4f)"
-          % (psnr_ini, psnr_ref, psnr_gpu, lo_end, lg_end, lo[0]))
-    # mid-training PSNR of a 128-ray problem is a noisy observable (measured: 0.05 dB apart after 300 iterations, 0.6 dB
-    # after 200), so only its direction is asserted; the loss level above is the drift check
-    assert psnr_ref > psnr_ini + 1.0 and psnr_gpu > psnr_ini + 1.0, (psnr_ini, psnr_ref, psnr_gpu)
+# (the 200-iteration "both trajectories improve" comparison that stood here is superseded by the G13 runs of
+# tests/test_gpu_training_run.py: trained parameters against the real reference's trajectory, ensemble PSNR within 0.1 dB)
 
 
 # ------------------------------------------------------------------ end to end: sampler -> train -> kNN render

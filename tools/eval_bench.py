@@ -41,7 +41,43 @@ def main():
             r.render_image(c2w)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        out[f"S{S}"] = dict(ms_per_image=round(dt * 1e3, 2), ray_samples_per_s=640 * 480 * S / dt, fields=NF)
+        out[f"S{S}"] = dict(ms_per_image=round(dt * 1e3, 2), ray_samples_per_s=640 * 480 * S / dt, fields=NF,
+                            knn_matmul=r.last_matmul("knn"))
+        if S == 640:
+            # roofline of the dominant kernel (k_knn_eval: per-field MLP tiles over the (point, neighbour) pairs): HIP events
+            # around its launches (C-ABI hooks) + the number of pairs it evaluates, counted here with torch on the same
+            # sample points (a point is evaluated for its K nearest fields when the nearest is closer than the radius)
+            from neural_graph_mapping_amd import _capi as K
+            from neural_graph_mapping_amd import ops
+            import ctypes as C
+            L = K.lib()
+            L.ngm_profile_reset(); L.ngm_profile_enable(1)
+            r.render_image(c2w)
+            torch.cuda.synchronize()
+            L.ngm_profile_enable(0)
+            kern = {}
+            for name in ("knn_assign", "knn_eval"):
+                ms, n = C.c_double(0), C.c_int64(0)
+                L.ngm_profile_read(K.KERNEL_IDS[name], C.byref(ms), C.byref(n))
+                kern[name] = dict(total_ms=ms.value, launches=n.value)
+            rc = Rr.make_render_cfg(cam, {**cfg, "num_samples_coarse": S, "num_samples_depth_guided": 0}, guided=False)
+            pairs = 0
+            idx = torch.arange(0, 640 * 480, device=dev)
+            ijs = torch.stack((idx // 640, idx % 640), -1)
+            posd = pos.to(dev)
+            for s0 in range(0, ijs.shape[0], 8192):
+                _, pw, _ = ops.sample_rays_world(rc, ijs[s0:s0 + 8192], c2w, None, None, None, None, None, s0, near_const=0.0, far_const=8.0)
+                pts = pw.reshape(-1, 3)
+                for c0 in range(0, pts.shape[0], 1 << 20):
+                    d2 = ((pts[c0:c0 + (1 << 20), None, :] - posd[None]) ** 2).sum(-1).min(-1)[0]
+                    pairs += 2 * int((d2 < 0.25).sum())
+            flop = 16896.0 * pairs
+            t = kern["knn_eval"]["total_ms"] * 1e-3
+            out["roofline_eval"] = dict(bound="mfma", kernel="k_knn_eval<2,2,2> (" + (r.last_matmul("knn") or "?") + ")", pairs=pairs,
+                                        algorithmic_flop=flop, kernel_ms=round(t * 1e3, 3), achieved=flop / t / 1e12, peak=157.3,
+                                        unit="TFLOP/s", frac=flop / t / 1e12 / 157.3, knn_assign_ms=round(kern["knn_assign"]["total_ms"], 3),
+                                        note="jitter differs between the counted pass and the timed pass (Philox offsets): the pair "
+                                             "count is exact to ~1e-3")
     print(json.dumps(dict(workload="render_image 640x480, Fourier(64)+2x64 fields, kNN blend K=2", **out)))
 
 

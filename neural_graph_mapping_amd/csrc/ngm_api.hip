@@ -161,7 +161,6 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
     if (fc->tri_resolution < 2 || fc->tri_resolution > 4096 || fc->tri_mode < NGM_TRI_SUM || fc->tri_mode > NGM_TRI_CONCAT ||
         (fc->tri_mode == NGM_TRI_CONCAT && fc->dim_enc % 3))
       return fail(NGM_E_INVALID, "triplane: resolution / mode / dim_enc inconsistent");
-    if (fc->skip_mode != NGM_SKIP_NO) return fail(NGM_E_UNSUPPORTED, "triplane: skip connections are not compiled");
   }
   if (fc->encoding == NGM_ENC_NONE && fc->dim_enc != 3) return fail(NGM_E_INVALID, "no encoding: dim_enc must be 3");
   if (fc->dim_enc < 1 || fc->dim_enc > 64 || fc->dim_hidden < 1 || fc->dim_hidden > 64)
@@ -170,10 +169,10 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
     return fail(NGM_E_UNSUPPORTED, "dim_enc and dim_hidden must pad to the same multiple of 32");
   if (fc->skip_mode != NGM_SKIP_NO && fc->skip_mode != NGM_SKIP_ADD && fc->skip_mode != NGM_SKIP_CONCAT)
     return fail(NGM_E_UNSUPPORTED, "skip_mode: no / add / concat");
-  if (fc->skip_mode == NGM_SKIP_CONCAT && fc->encoding != NGM_ENC_FOURIER && fc->encoding != NGM_ENC_NONE)
-    return fail(NGM_E_UNSUPPORTED, "skip_mode concat: compiled for the Fourier encoding and for no encoding");
-  if (fc->skip_mode == NGM_SKIP_ADD && (fc->dim_hidden < fc->dim_enc || fc->encoding == NGM_ENC_PERMUTO))
-    return fail(NGM_E_UNSUPPORTED, "skip_mode add: needs dim_hidden >= dim_enc and a non-hash encoding");
+  // skip connections are encoding-agnostic like models.py:159-169 (every encoding x {no, add, concat}); "add" needs room for
+  // the encoding in the hidden units (the reference adds out[..., :D] += encoding: D <= H)
+  if (fc->skip_mode == NGM_SKIP_ADD && fc->dim_hidden < fc->dim_enc)
+    return fail(NGM_E_UNSUPPORTED, "skip_mode add: needs dim_hidden >= dim_enc");
   return NGM_OK;
 }
 static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
@@ -484,7 +483,7 @@ static int act_stash_kind(const ngm_field_cfg* fc) {
   static const bool off = getenv("NGM_NO_ACT_STASH") != nullptr;
   if (off) return 0;
   const int th = (fc->dim_hidden + 15) / 16, ti = (fc->dim_enc + 15) / 16;
-  if (fc->encoding == NGM_ENC_PERMUTO) return (ti == 2 && fc->dim_hidden <= 32) ? 2 : 0;
+  if (fc->encoding == NGM_ENC_PERMUTO) return (ti == 2 && fc->dim_hidden <= 32 && fc->skip_mode == NGM_SKIP_NO) ? 2 : 0;   // the stash's consumers (k_hash_mlp_bwd, k_field_bwd16) are skip-less
   if (fc->encoding == NGM_ENC_TRIPLANE) return 0;      // 32-sample-tile backward (recompute: it needs the taps anyway)
   // with a skip connection the stashed activation no longer tells the ReLU mask
   return (fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2) ? 1 : 0;

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
 
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, HASH == 1 ? a.lattice_grad + (int64_t)f * a.lattice_grad_stride : nullptr);
   const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, HASH == 2 ? a.tri_acc + (int64_t)f * a.tri_numel : nullptr);
-  const bool add_enc = HASH == 0 && MI <= MH && a.fc.skip_mode == NGM_SKIP_ADD;
+  const bool add_enc = MI <= MH && a.fc.skip_mode == NGM_SKIP_ADD;
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
   for (int64_t base = beg + wave * 32; base < end; base += 32 * NGM_WAVES_PER_BLOCK) {
     const int64_t n = base + j;
@@ -365,11 +365,21 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
           // triplane: d loss / d planes scattered straight from the lane's dE registers (fixed-point atomics)
           f32x16 dE[MI];
           layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
+          if (add_enc || CAT) {          // what reached the encoding through the skip connections of the later layers
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dE[mi][r] += dEsum[mi][r];
+          }
           scatter_triplane_grad<MI>(tc, hi, x, y, z, dE, valid);
         }
         if constexpr (HASH == 1) {
           f32x16 dE[MI];
           layer_dgrad<MI, MH>(sm + LY::w_off(0), lane, dY, dE);
+          if (add_enc || CAT) {          // what reached the encoding through the skip connections of the later layers
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dE[0][r] += dEsum[0][r];
+          }
           // hand dL/dE to k_hash_grad (level-major, coalesced); table scatter happens there in LDS
           if (valid) {
             const int64_t g = (int64_t)f * a.P + n, NP = (int64_t)a.F * a.P;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_bwd(FieldBwdArgs a) {
                 const int level = 4 * q + 2 * hi + p;
                 if (level < hc.nlev) a.hash_dE[level * NP + g] = make_float2(dE[0][4 * q + 2 * p], dE[0][4 * q + 2 * p + 1]);
               }
-            if (hi == 0) a.hash_xyz[g] = make_float4(x, y, z, 0.f);
+            if (hi == 0 && !a.hash_xyz_ready) a.hash_xyz[g] = make_float4(x, y, z, 0.f);
           }
         }
         if (ENC_GRAD) {
@@ -626,16 +636,15 @@ static int launch_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
                               (int)lds);                                                                                \
     hipLaunchKernelGGL((k_field_bwd<MI, MH, L, NC, EG, HS, CT>), dim3(blocks), dim3(NGM_BLOCK), lds, st, a);            \
   } while (0)
-  const bool cat = a.fc.skip_mode == NGM_SKIP_CONCAT;      // compiled for the Fourier encoding and for no encoding
+  const bool cat = a.fc.skip_mode == NGM_SKIP_CONCAT;      // every encoding (models.py:159-161 is encoding-agnostic)
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if (cat) return NGM_E_UNSUPPORTED;
-    if constexpr (MI == 1) NGM_LB(false, false, 1, false);
+    if constexpr (MI == 1) { if (cat) NGM_LB(false, false, 1, true); else NGM_LB(false, false, 1, false); }
     else return NGM_E_UNSUPPORTED;
   } else if (a.fc.encoding == NGM_ENC_TRIPLANE) {
-    if (a.fc.skip_mode != NGM_SKIP_NO || !a.tri_acc) return NGM_E_UNSUPPORTED;
-    NGM_LB(false, false, 2, false);
+    if (!a.tri_acc) return NGM_E_UNSUPPORTED;
+    if (cat) NGM_LB(false, false, 2, true); else NGM_LB(false, false, 2, false);
   } else if (a.fc.encoding == NGM_ENC_FOURIER) { if (cat) NGM_LB(false, true, 0, true); else NGM_LB(false, true, 0, false); }
-  else if (a.fc.encoding == NGM_ENC_NERF) { if (cat) return NGM_E_UNSUPPORTED; NGM_LB(true, false, 0, false); }
+  else if (a.fc.encoding == NGM_ENC_NERF) { if (cat) NGM_LB(true, false, 0, true); else NGM_LB(true, false, 0, false); }
   else { if (cat) NGM_LB(false, false, 0, true); else NGM_LB(false, false, 0, false); }
 #undef NGM_LB
   return 0;

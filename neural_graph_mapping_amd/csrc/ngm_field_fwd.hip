@@ -453,7 +453,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-// the skip variants exist for the non-hash encodings only; concat (SKIP = 2) for Fourier / no encoding
+// every encoding x skip_mode {no, add, concat} (models.py:159-169 is encoding-agnostic)
 #define NGM_LAUNCH_ONE(KERNEL, NC, HS, SK, GRID, BLK, LDSW, LDSX)                                                       \
   do {                                                                                                                 \
     const size_t lds_ = (FieldLds<MI, MH, L, (SK) == 2>::TOTAL + (LDSX)) * sizeof(float);                              \
@@ -464,16 +464,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   } while (0)
 #define NGM_LAUNCH_VARIANT(KERNEL, NC, HS, GRID, BLK, LDSW, LDSX)                               \
   do {                                                                                          \
-    if constexpr ((HS) == 0) {                                                                  \
-      if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, 1, GRID, BLK, LDSW, LDSX); \
-      else if (a.fc.skip_mode == NGM_SKIP_CONCAT) {                                             \
-        if constexpr (!(NC)) NGM_LAUNCH_ONE(KERNEL, NC, HS, 2, GRID, BLK, LDSW, LDSX);          \
-        else return NGM_E_UNSUPPORTED;                                                          \
-      } else NGM_LAUNCH_ONE(KERNEL, NC, HS, 0, GRID, BLK, LDSW, LDSX);                          \
-    } else {                                                                                    \
-      if (a.fc.skip_mode != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;                              \
-      NGM_LAUNCH_ONE(KERNEL, NC, HS, 0, GRID, BLK, LDSW, LDSX);                                 \
-    }                                                                                           \
+    if (a.fc.skip_mode == NGM_SKIP_ADD) NGM_LAUNCH_ONE(KERNEL, NC, HS, 1, GRID, BLK, LDSW, LDSX);   \
+    else if (a.fc.skip_mode == NGM_SKIP_CONCAT) NGM_LAUNCH_ONE(KERNEL, NC, HS, 2, GRID, BLK, LDSW, LDSX); \
+    else NGM_LAUNCH_ONE(KERNEL, NC, HS, 0, GRID, BLK, LDSW, LDSX);                              \
   } while (0)
 
 // the bf16 split path (ngm_matmul_mode) is compiled for 49..64-wide layers, <= 2 hidden layers, Fourier / no encoding, skip no

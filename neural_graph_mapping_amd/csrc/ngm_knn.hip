@@ -308,14 +308,12 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
     }
   }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
-    if constexpr (MI == 1) NGM_KE(false, 1, 0);
+    if constexpr (MI == 1) { if (sk == NGM_SKIP_ADD) NGM_KE(false, 1, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, 1, 2); else NGM_KE(false, 1, 0); }
     else return NGM_E_UNSUPPORTED;
   } else if (a.fc.encoding == NGM_ENC_TRIPLANE) {
-    if (sk != NGM_SKIP_NO) return NGM_E_UNSUPPORTED;
-    NGM_KE(false, 2, 0);
+    if (sk == NGM_SKIP_ADD) NGM_KE(false, 2, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, 2, 2); else NGM_KE(false, 2, 0);
   } else if (a.fc.encoding == NGM_ENC_NERF) {
-    if (sk == NGM_SKIP_ADD) NGM_KE(true, 0, 1); else if (sk == NGM_SKIP_NO) NGM_KE(true, 0, 0); else return NGM_E_UNSUPPORTED;
+    if (sk == NGM_SKIP_ADD) NGM_KE(true, 0, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(true, 0, 2); else NGM_KE(true, 0, 0);
   } else {
     if (sk == NGM_SKIP_ADD) NGM_KE(false, 0, 1); else if (sk == NGM_SKIP_CONCAT) NGM_KE(false, 0, 2); else NGM_KE(false, 0, 0);
   }

@@ -385,6 +385,44 @@ def g12_skip_modes():
              dim_hidden=np.int64(dim_mlp or dim_enc), **arrays)
 
 
+def g19_skip_other_encodings():
+    """skip connections with the encodings that are pure torch in the reference (models.py:159-169 is encoding-agnostic):
+    NeRF octaves (D = 48) and the triplane encoding (sum, C = 32), add and concat, two hidden layers; vmapped forward
+    and every parameter gradient of sum(out * seed)."""
+    for enc in ("nerf", "triplane"):
+        for mode in ("add", "concat"):
+            gen = torch.Generator().manual_seed(190 + len(enc) + len(mode))
+            F, P = 2, 48
+            torch.manual_seed(19)
+            if enc == "nerf":
+                ek = dict(encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingNeRF",
+                          encoding_kwargs=dict(dim_in=3, num_octaves=8, start_octave=0))
+                scale_mode, spread = "unit_cube", 0.8
+            else:
+                ek = dict(encoding_type="neural_graph_mapping.positional_encodings.TriplaneEncoding",
+                          encoding_kwargs=dict(resolution=12, num_components=32, init_scale=0.5, mode="sum"))
+                scale_mode, spread = "unit_ball", 2.3
+            fs = models.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+                **ek, num_layers=2, dim_out=4, dim_mlp_out=None, skip_mode=mode, initial_geometry_bias=0.0, neus_initial_sd=1.0),
+                num_knn=2, distance_factor=10.0, field_radius=1.0, scale_mode=scale_mode, outside_value=1.0)
+            fs.add_fields(F)
+            for k, v in fs.all_fields_params.items():
+                if v.dim() > 1:
+                    v.add_(0.1 * torch.randn(v.shape, generator=gen))
+            fs.set_vmap_fields(None)
+            for v in fs.vmap_fields_params.values():
+                v.requires_grad_()
+            pos = 0.3 * torch.randn(F, 3, generator=gen)
+            quat = rand_quats(F, gen)
+            q = pos[:, None] + spread * (torch.rand(F, P, 3, generator=gen) - 0.5)
+            seed = torch.randn(F, P, 4, generator=gen)
+            out = fs(q, pos, quat, None, True)
+            (out * seed).sum().backward()
+            vp = fs.vmap_fields_params
+            save(f"g19_skip_{mode}_{enc}", query=q, pos=pos, quat=quat, out=out, seed=seed,
+                 **{"p::" + k: v for k, v in vp.items()}, **{"g::" + k: v.grad for k, v in vp.items() if v.grad is not None})
+
+
 def g15_triplane():
     """TriplaneEncoding (positional_encodings.py:69-161) in all three modes: vmapped field forward and every parameter
     gradient of sum(out * seed), points in and slightly outside [-1,1]^3 (border padding), scale_mode unit_ball."""
@@ -707,7 +745,7 @@ def g17_extract_mesh():
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

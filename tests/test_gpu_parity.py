@@ -464,6 +464,75 @@ def test_triplane_golden(name):
     close(a, b, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["g19_skip_add_nerf", "g19_skip_concat_nerf", "g19_skip_add_triplane", "g19_skip_concat_triplane"])
+def test_skip_with_other_encodings_golden(name):
+    """models.py:159-169 is encoding-agnostic: skip add / concat with NeRF octaves and with the triplane encoding against
+    the real reference (G19): forward, every parameter gradient (planes included), the kNN evaluation path."""
+    g = load_golden(name)
+    mode, enc = name.split("_")[2], name.split("_")[3]
+    if enc == "nerf":
+        fc = K.field_cfg(encoding="nerf", num_octaves=8, num_layers=2, skip_mode=mode)
+        ftol, gtol = dict(rtol=2e-3, atol=3e-4), 1e-2             # arguments up to 2^7 pi: the NeRF tolerances of G4 / G6
+    else:
+        fc = K.field_cfg(encoding="triplane", resolution=12, num_components=32, tri_mode="sum", num_layers=2, skip_mode=mode,
+                         scale_mode="unit_ball")
+        ftol, gtol = dict(rtol=2e-4, atol=3e-5), 2e-3
+    assert K.param_shapes(fc)["_linears.1.weight"] == tuple(g["p::_linears.1.weight"].shape[1:])
+    params = {k: v.to(DEV).requires_grad_() for k, v in split_prefix(g, "p::").items() if k != "_neus_sd"}
+    out = ops.field_eval(fc, params, g["query"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV))
+    close(out, g["out"], **ftol)
+    (out * g["seed"].to(DEV)).sum().backward()
+    assert K.lib().ngm_debug_last_bwd_variant() == 0              # skip connections run on the 32-sample-tile kernel
+    for k, gr in split_prefix(g, "g::").items():
+        grad_close(params[k].grad, gr, gtol, k)
+    pts = g["pos"][:1] + 0.4 * (torch.rand(200, 3) - 0.5)
+    one = {k: v[:1].detach() for k, v in params.items()}
+    a = ops.field_eval_knn(fc, one, pts.to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV), 1, 10.0, 1.0)
+    b = ops.field_eval(fc, one, pts[None].to(DEV), g["pos"][:1].to(DEV), g["quat"][:1].to(DEV))[0]
+    close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["add", "concat"])
+@pytest.mark.parametrize("enc", ["permuto", "nerf", "triplane"])
+def test_skip_other_encodings_fused_train_step_vs_oracle(enc, mode):
+    """the fused render / train step with skip connections on every encoding the Fourier-only build refused
+    (hash: 1x32 MLP, W_out becomes (4, 32 + 32) with concat; parity of the hash encoding itself is unpinned)"""
+    F, R, n_c, n_g = 2, 33, 6, 10
+    torch.manual_seed(8)
+    fkw = dict(permuto=dict(encoding="permuto", num_layers=1, nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4),
+               nerf=dict(encoding="nerf", num_octaves=8, num_layers=2),
+               triplane=dict(encoding="triplane", resolution=16, num_components=32, tri_mode="sum", num_layers=2))[enc]
+    fkw = dict(fkw, skip_mode=mode)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos, quat, t = synth_target(F, R, seed=4)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params = O.init_params(fs, F, seed=11)
+    params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    if mode == "concat":
+        assert r._model.all_fields_params[f"_linears.{fkw['num_layers']}.weight"].shape[-1] == fs.dim_hidden + fs.dim_enc
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    loose = enc != "triplane"            # hash: lattice coordinates up to 1e4; NeRF: arguments up to 2^7 pi
+    # "add" puts the encoding itself (fp32 error ~1e-3 absolute at these frequencies / lattice scales, in the oracle as in the
+    # kernels) straight into the hidden units of every layer: a single ray in 264 sat 5e-4 off at atol 2e-4
+    close(res["prediction"].rgbds, pred["rgbds"].detach(),
+          **(dict(rtol=2e-3, atol=1e-3 if mode == "add" else 2e-4) if loose else {}))
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=2e-3 if loose else 3e-4, atol=1e-5)
+    loss["combined"].backward()
+    for k in po:
+        if po[k].grad is not None:
+            grad_close(res["grads"][k], po[k].grad, 1e-2 if loose else 2e-3, k)
+    out = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)   # fused Adam
+    assert torch.isfinite(out["combined"])
+
+
 @pytest.mark.parametrize("tri_mode,comps", [("sum", 64), ("product", 32), ("concat", 20)])
 def test_triplane_fused_train_step_vs_oracle(tri_mode, comps):
     F, R, n_c, n_g = 2, 33, 6, 10

@@ -267,6 +267,10 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4;
       }
   };
+#ifdef NGM_FWD_STAGGER   // experiment: offset the second wave of every SIMD by a fraction of a step so that its matrix
+  // phases meet the first wave's VALU phases instead of its matrix phases (NGM_FWD_STAGGER x 64 clocks)
+  if (wave >= nwaves / 2) __builtin_amdgcn_s_sleep(NGM_FWD_STAGGER);
+#endif
   for (int rb = r_beg; rb < r_end; rb += BR) {
     const int nb = min(BR, r_end - rb);
     const int nsamp = nb * S;

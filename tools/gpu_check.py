@@ -290,7 +290,7 @@ def init_params_np(fc, F, seed=0, sigma=4.0):
 
 def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
     L = K.lib()
-    fc = (K.field_cfg(encoding="permuto", num_layers=1) if hash_enc
+    fc = (K.field_cfg(encoding="permuto", num_layers=1, matmul_mode=os.environ.get("NGM_MATMUL", "f32")) if hash_enc
           else K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, matmul_mode=os.environ.get("NGM_MATMUL", "f32")))
     rc = K.render_cfg(num_samples_coarse=S_c, num_samples_guided=S_g, **NRGBD)
     b = synth_batch(F, R, S_c, S_g)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-end measurement on the GPU box: bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
+# Round-end measurement on the GPU box: bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes,
+# SQ counters, the hash variant, the evaluation path, the scene simulation and the micro-benchmarks.
 # Outputs land under gpurun_out/final/ (copy what should be judged into profiles/).
 set -u
 O=$GRAFT_REPO_ROOT/gpurun_out/final; mkdir -p $O
@@ -10,3 +11,20 @@ NGM_MATMUL=auto NGM_CHECK=time bash tools/pmc_pass.sh fetch FETCH_SIZE
 NGM_MATMUL=auto NGM_CHECK=time bash tools/pmc_pass.sh write WRITE_SIZE
 python tools/pmc_traffic.py $(find gpurun_out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_write -name "*counter_collection.csv" | head -1) > $O/pmc_field_bwd.json
 find $O -name "*kernel_stats.csv" | head -2
+cd $GRAFT_REPO_ROOT
+NGM_MATMUL=auto NGM_CHECK=time bash tools/pmc_pass.sh sq1 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+NGM_MATMUL=auto NGM_CHECK=time bash tools/pmc_pass.sh sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT
+NGM_MATMUL=auto NGM_CHECK=time bash tools/pmc_pass.sh sq3 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM
+python tools/pmc_summary.py $(find gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 -name "*counter_collection.csv") > $O/sq_counters.txt 2>&1
+# the hash variant: SQ counters of its kernels + HBM bytes
+NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h1 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT
+NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h2 FETCH_SIZE
+NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h3 WRITE_SIZE
+python tools/pmc_summary.py $(find gpurun_out/pmc_h1 gpurun_out/pmc_h2 gpurun_out/pmc_h3 -name "*counter_collection.csv") > $O/sq_counters_hash.txt 2>&1
+python bench.py --variant hash --no-cpu-baseline > $O/bench_line_hash.json 2>> $O/bench.err
+python bench.py --matmul f32 --no-cpu-baseline --no-aux-hash > $O/bench_line_f32.json 2>> $O/bench.err
+python bench.py --scene-sim > $O/scene_sim.json 2>> $O/bench.err
+python tools/eval_bench.py > $O/eval_bench.json 2>> $O/bench.err
+timeout 120 tools/micro/gather_rate > $O/gather_rate.txt 2>&1
+timeout 120 tools/micro/dot2c_split > $O/dot2c_split.txt 2>&1
+head -30 $O/sq_counters.txt

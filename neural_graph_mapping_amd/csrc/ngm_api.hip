@@ -105,9 +105,9 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   // order of preference: stashed activations (no forward recompute) -> 16-sample-tile recompute ->
   // 32-sample-tile recompute
   static const bool no_b3 = getenv("NGM_NO_BWD_B3") != nullptr;
-  static const bool env_b3p = getenv("NGM_BWD_B3P") != nullptr;
-  const bool try_b3p = env_b3p || g_prefer_paired_bwd;
-  int e = (force32 || no_b3 || !try_b3p || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3p(a, blocks, st);
+  static const bool env_b3q = getenv("NGM_BWD_B3Q") != nullptr;
+  const bool try_b3q = env_b3q || g_prefer_paired_bwd;
+  int e = (force32 || no_b3 || !try_b3q || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3q(a, blocks, st);
   g_last_bwd_variant = 4;
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
@@ -472,6 +472,7 @@ struct RenderPlan {
   int64_t p_pad;
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
   int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
+  int64_t off_xyz; int has_xyz;    // 64-wide stash backward: scaled field-local sample positions (16 B per sample) written by k_stash_bwd
 };
 // The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
 // has a kernel that consumes them: 49..64-wide hidden layers, 1-2 layers, non-hash encoding.  The
@@ -560,6 +561,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     if (kind == 1) {
       p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
       p.off_act = o; o = align_up(o + fc->num_layers * p.act_layer_stride * 4 + 64, 256);
+      p.has_xyz = 1; p.off_xyz = o; o = align_up(o + NS * 16, 256);
     } else if (kind == 2) {
       p.act_layer_stride = align_up(NS, 32) * 32 + 1024;      // one "layer": the 32-feature encoding
       p.off_act = o; o = align_up(o + p.act_layer_stride * 4 + 64, 256);
@@ -689,7 +691,8 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
-  sb.xyz_out = a.hash_xyz;                 // permutohedral encoding: positions for the table-gradient kernel
+  if (!a.hash_xyz && p.has_xyz) a.hash_xyz = reinterpret_cast<float4*>(ws + p.off_xyz);   // 64-wide stash backward (k_field_bwd_b3q)
+  sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash) / the paired MLP backward
   a.hash_xyz_ready = a.hash_xyz != nullptr;
   int e = ngm_launch_stash_bwd(sb, st);
   if (e) return fail(e, "render_bwd: unsupported geometry mode");

@@ -1,5 +1,5 @@
 // Shared pieces of the backward kernels on the bf16 matrix pipe (ngm_field_bwd_b3.hip: one wave per tile;
-// ngm_field_bwd_b3p.hip: a pair of waves per tile): tile layout in LDS, DMA issue, three-way splits, MFMA blocks.
+// ngm_field_bwd_b3q.hip: a pair of waves per tile, both on one SIMD): tile layout in LDS, DMA issue, three-way splits, MFMA blocks.
 #pragma once
 #include "ngm_bwd16.h"
 

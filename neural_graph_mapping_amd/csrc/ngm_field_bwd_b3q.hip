@@ -181,6 +181,9 @@ __global__ __launch_bounds__(B3Q_THREADS) void k_field_bwd_b3q(FieldBwdArgs a) {
   __syncthreads();
 
 #define COL_OFF(m, r) ((m) * 1024 + col[(r) & 3] + 32 * ((r) >> 2))
+#ifdef NGM_B3Q_PRIO   // experiment: role A is the longer role (role B idles at the step barrier): let it win VALU arbitration
+  if (!roleB) __builtin_amdgcn_s_setprio(NGM_B3Q_PRIO);
+#endif
   const int lane0 = lane;
 #ifdef NGM_B3Q_TIMING   // per-wave clocks: slots 0..5 phases of the role, 6 transfer wait, 7 barrier wait, 8 total (waves 0 and 4 of the middle block)
   unsigned long long tq_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_readcyclecounter();

@@ -323,6 +323,9 @@ __device__ __forceinline__ void encode_hash(const float* sm_lvl, const HashCtx& 
     }
 }
 
+// (Staging one level's table at a time in LDS for these gathers was measured and dropped: 196 us against 111 us for the fused
+// forward, profiles/r03a_hash_lds_experiment.txt and DESIGN.md 3.14.)
+
 // scatter dL/dE of the lane's 8 levels into the gradient table (float atomics in L2)
 __device__ __forceinline__ void scatter_hash_grad(const float* sm_lvl, const HashCtx& hc, int hi, float x, float y, float z,
                                                   const f32x16& dE, bool valid) {

@@ -230,77 +230,115 @@ def scene_sim(args, rank, world, dev):
     NF, FA, Rn, NB = 200, 32, 512, 8
     out = dict(mode="scene-sim", n_gpus=world, fields_total=NF, active_per_iteration=FA, rays_per_field=Rn,
                launch="eager (the active set and with it the per-rank batch shape change every iteration)", configs={})
-    gen = torch.Generator().manual_seed(2024)
-    active_sets = [torch.randperm(NF, generator=gen)[:FA].sort().values for _ in range(NB)]
-    for label, (s_c, s_g) in dict(default_8p16=(8, 16), metric_64p64=(64, 64)).items():
-        owned = D.local_field_slots(NF, rank, world)
-        r = build_renderer(dev, len(owned), args.variant, s_c, s_g)
-        pos_all, quat_all, _ = synth_target(NF, 1, seed=77)
-        r.set_field_poses(pos_all[owned].to(dev), quat_all[owned].to(dev))
-        if world > 1:
-            r.process_group = torch.distributed.group.WORLD
-        batches, counts = [], []
-        for b, ids in enumerate(active_sets):
-            _, _, t = synth_target(FA, Rn, seed=500 + b)
-            shift = (pos_all[ids] - synth_target(FA, 1, seed=500 + b)[0])[:, None]     # rays around the map's field centres
-            c2w = t.c2ws.clone()
-            c2w[..., :3, 3] += shift
-            t = t._replace(c2ws=c2w, field_ids=ids)
-            tl = D.shard_target(t, rank, world)
-            tl = tl._replace(field_ids=D.global_to_local(tl.field_ids, world))
-            batches.append(type(tl)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tl]))
-            counts.append(int(tl.ijs.shape[0]))
-
-        def run(n):
-            for i in range(n):
-                r.optimization_iteration(batches[i % NB], seed=3, update=True)
-        # the clocks of an idle GPU take ~0.1 s to ramp up: a generous, FIXED number of untimed iterations (the same on
-        # every rank: each iteration contains a collective)
-        run(max(args.warmup, 256))
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        t0 = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        dt = time.perf_counter() - t0
-        cnt = torch.tensor(counts, device=dev, dtype=torch.float32)
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tt.item())
-            allc = [torch.empty_like(cnt) for _ in range(world)]
-            torch.distributed.all_gather(allc, cnt)
-            cnt = torch.stack(allc)                                           # (world, NB)
-        else:
-            cnt = cnt[None]
-        S = s_c + s_g
-        res = dict(ms_per_iteration=1e3 * dt / args.steps, ray_samples_per_s=FA * Rn * S * args.steps / dt,
-                   active_fields_per_rank=dict(mean=float(cnt.mean()), min=float(cnt.min()), max=float(cnt.max()),
-                                               max_over_ranks_mean=float(cnt.max(0).values.mean())))
-        if world == 1:                         # fixed cost vs batch size: what a rank with few active fields pays
-            sweep = {}
-            for Fa in (1, 2, 4, 8, 32):
-                _, _, t = synth_target(Fa, Rn, seed=900 + Fa)
-                ids = torch.arange(Fa)
-                t = t._replace(c2ws=t.c2ws + 0, field_ids=ids)
+    cur = torch.arange(NF - 50, NF)                 # the observed fields: the 50 most recent ones
+    # spread of the active set over 8 owner ranks under both sampler policies (host arithmetic, 1000 draws each)
+    spread = {}
+    for pol in ("reference", "balanced_by_owner"):
+        g8 = torch.Generator().manual_seed(7)
+        mx = []
+        for _ in range(1000):
+            ids = (D.draw_fields_reference(cur, NF, FA, generator=g8)[0] if pol == "reference"
+                   else D.draw_fields_balanced(cur, NF, FA, 8, generator=g8))
+            mx.append(int(torch.bincount(ids % 8, minlength=8).max()))
+        spread[pol] = dict(mean_per_rank=FA / 8, max_over_ranks_mean=sum(mx) / len(mx), max_over_ranks_worst=max(mx))
+    out["active_fields_per_rank_at_world8"] = spread
+    policies = ("reference", "balanced_by_owner") if world > 1 else ("reference",)
+    peer = None
+    out["exchange"] = args.exchange
+    for policy in policies:
+        gen = torch.Generator().manual_seed(2024)
+        active_sets = [(D.draw_fields_reference(cur, NF, FA, generator=gen)[0] if policy == "reference"
+                        else D.draw_fields_balanced(cur, NF, FA, world, generator=gen)) for _ in range(NB)]
+        for label0, (s_c, s_g) in dict(default_8p16=(8, 16), metric_64p64=(64, 64)).items():
+            label = label0 if policy == "reference" else label0 + "_balanced_by_owner"
+            owned = D.local_field_slots(NF, rank, world)
+            r = build_renderer(dev, len(owned), args.variant, s_c, s_g)
+            pos_all, quat_all, _ = synth_target(NF, 1, seed=77)
+            r.set_field_poses(pos_all[owned].to(dev), quat_all[owned].to(dev))
+            if world > 1:
+                r.process_group = torch.distributed.group.WORLD
+                if args.exchange == "peer":
+                    if peer is None:
+                        peer = D.PeerExchange.try_create(torch.distributed.group.WORLD, dev)
+                    r.peer_exchange = peer
+            batches, counts = [], []
+            for b, ids in enumerate(active_sets):
+                _, _, t = synth_target(FA, Rn, seed=500 + b)
+                shift = (pos_all[ids] - synth_target(FA, 1, seed=500 + b)[0])[:, None]     # rays around the map's field centres
                 c2w = t.c2ws.clone()
-                c2w[..., :3, 3] += (pos_all[ids] - synth_target(Fa, 1, seed=900 + Fa)[0])[:, None]
-                tb = type(t)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in t._replace(c2ws=c2w)])
-                for graph in (False, True):
-                    step = r.capture_iteration(tb, seed=3) if graph else (lambda: r.optimization_iteration(tb, seed=3, update=True))
-                    for _ in range(10):
-                        step()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
+                c2w[..., :3, 3] += shift
+                t = t._replace(c2ws=c2w, field_ids=ids)
+                tl = D.shard_target(t, rank, world)
+                tl = tl._replace(field_ids=D.global_to_local(tl.field_ids, world))
+                batches.append(type(tl)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tl]))
+                counts.append(int(tl.ijs.shape[0]))
+
+            def run(n):
+                for i in range(n):
+                    r.optimization_iteration(batches[i % NB], seed=3, update=True)
+            # the clocks of an idle GPU take ~0.1 s to ramp up: a generous, FIXED number of untimed iterations (the same on
+            # every rank: each iteration contains a collective)
+            run(max(args.warmup, 256))
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            dt = time.perf_counter() - t0
+            cnt = torch.tensor(counts, device=dev, dtype=torch.float32)
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                dt = float(tt.item())
+                allc = [torch.empty_like(cnt) for _ in range(world)]
+                torch.distributed.all_gather(allc, cnt)
+                cnt = torch.stack(allc)                                           # (world, NB)
+            else:
+                cnt = cnt[None]
+            S = s_c + s_g
+            res = dict(ms_per_iteration=1e3 * dt / args.steps, ray_samples_per_s=FA * Rn * S * args.steps / dt,
+                       active_fields_per_rank=dict(mean=float(cnt.mean()), min=float(cnt.min()), max=float(cnt.max()),
+                                                   max_over_ranks_mean=float(cnt.max(0).values.mean())))
+            if world == 1:                         # fixed cost vs batch size: what a rank with few active fields pays
+                sweep = {}
+                for Fa in (1, 2, 4, 8, 32):
+                    _, _, t = synth_target(Fa, Rn, seed=900 + Fa)
+                    ids = torch.arange(Fa)
+                    t = t._replace(c2ws=t.c2ws + 0, field_ids=ids)
+                    c2w = t.c2ws.clone()
+                    c2w[..., :3, 3] += (pos_all[ids] - synth_target(Fa, 1, seed=900 + Fa)[0])[:, None]
+                    tb = type(t)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in t._replace(c2ws=c2w)])
+                    for graph in (False, True):
+                        step = r.capture_iteration(tb, seed=3) if graph else (lambda: r.optimization_iteration(tb, seed=3, update=True))
+                        for _ in range(10):
+                            step()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(50):
+                            step()
+                        torch.cuda.synchronize()
+                        sweep[f"F={Fa},{'graph' if graph else 'eager'}"] = round(1e3 * (time.perf_counter() - t0) / 50, 4)
+                    # where the fixed cost sits: HIP-event time of every kernel of the step at this batch size
+                    from neural_graph_mapping_amd import _capi as K
+                    L = K.lib()
+                    L.ngm_profile_reset()
+                    L.ngm_profile_enable(1)
                     for _ in range(50):
-                        step()
+                        r.optimization_iteration(tb, seed=3, update=True)
                     torch.cuda.synchronize()
-                    sweep[f"F={Fa},{'graph' if graph else 'eager'}"] = round(1e3 * (time.perf_counter() - t0) / 50, 4)
-            res["ms_per_step_vs_active_fields"] = sweep
-        out["configs"][label] = res
+                    L.ngm_profile_enable(0)
+                    kk = {}
+                    for name, kid in K.KERNEL_IDS.items():
+                        ms, n = C.c_double(0), C.c_int64(0)
+                        L.ngm_profile_read(kid, C.byref(ms), C.byref(n))
+                        if n.value:
+                            kk[name] = round(1e3 * ms.value / n.value, 2)
+                    sweep[f"F={Fa},kernels_us"] = kk
+                res["ms_per_step_vs_active_fields"] = sweep
+            out["configs"][label] = res
     if rank == 0:
         print(json.dumps(out))
 
@@ -325,6 +363,10 @@ def main():
     ap.add_argument("--no-aux-hash", action="store_true",
                     help="skip the auxiliary measurement of the reference's default network (hash encoding + 1x32 MLP) that the "
                          "default line carries as `aux_hash`")
+    ap.add_argument("--exchange", choices=["rccl", "peer"], default="rccl",
+                    help="multi-GPU: how the 64-byte loss sums are exchanged.  rccl (default): torch.distributed.all_reduce "
+                         "between two hipGraphs; peer: ngm_loss_exchange, one kernel of xGMI peer writes inside ONE graph "
+                         "(distributed.PeerExchange; falls back to rccl when its set-up self-test fails)")
     ap.add_argument("--scene-sim", action="store_true",
                     help="auxiliary strong-scaling measurement of a realistic mapping iteration (200 fields, 32 active per "
                          "iteration, sharded id %% world) instead of the headline line; see scene_sim()")
@@ -378,6 +420,8 @@ def main():
     tgt = tgt._replace(field_ids=torch.arange(F_PER_GPU, device=dev))      # local slots of this rank's fields
     if world > 1 or torch.distributed.is_initialized():
         r.process_group = torch.distributed.group.WORLD
+        if args.exchange == "peer":
+            r.peer_exchange = D.PeerExchange.try_create(torch.distributed.group.WORLD, dev)
 
     # the whole iteration (6 kernels) is captured once into a hipGraph and replayed;
     # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
@@ -489,7 +533,9 @@ def main():
                                sharding=f"field-per-GPU x{world}", ranks_seen=ranks_seen, spin_up_steps=SPIN_UP,
                                devices=sorted(set(devs)), jitter="in-kernel Philox",
                                launch=("eager" if (not use_graph or getattr(replay, "graph", None) is None) else
-                                       "hipGraph replay" if r.process_group is None else "2 hipGraphs + all-reduce"), final_loss=loss))
+                                       "hipGraph replay" if r.process_group is None else
+                                       "1 hipGraph incl. the peer loss exchange" if r.peer_exchange is not None else
+                                       "2 hipGraphs + all-reduce"), final_loss=loss))
         fb, ff = kern.get("field_bwd"), kern.get("render_fwd")
         if fb and args.variant == "fourier":
             achieved = FLOP_BWD * n_local / (fb["avg_us"] * 1e-6) / 1e12

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 3
+#define NGM_ABI_VERSION 4
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -484,6 +484,32 @@ int ngm_debug_last_matmul(int which);
  * correct, measured equal to k_field_bwd_b3 within the pool's noise in round 3: DESIGN 3.10) before the default order;
  * 0 = default.  Returns the previous setting.  Environment: NGM_BWD_B3Q=1. */
 int ngm_debug_prefer_paired_bwd(int on);
+
+/* ---- one-shot exchange of the loss sums between the ranks of one node ---------------
+ * Replaces torch.distributed.all_reduce (RCCL) on the 16 floats between ngm_render_fwd and ngm_render_bwd* by ONE small
+ * kernel that can be captured in the same hipGraph as the two: every rank writes its 16 values into every rank's
+ * mailbox (peer memory mapped through hipIpc: xGMI stores), polls its own mailbox and sums in rank order -- bit-identical
+ * sums on all ranks.  The reference has no counterpart (rm.py is single-process); the values are the sums / counts the
+ * means of rm.py:1803-1871 are taken from.  Set-up (once per process group, host side, see distributed.PeerExchange):
+ *   ngm_peer_alloc(ngm_peer_mailbox_bytes(), &mailbox)  ->  ngm_ipc_export(mailbox, handle)  ->  exchange the 64-byte
+ *   handles by any means  ->  ngm_ipc_open(handle_of_rank_p, &px.mailbox[p]) for p != rank, px.mailbox[rank] = mailbox;
+ *   px.seq / px.status: 8 + 4 bytes of zeroed device memory of this rank (ngm_peer_alloc works for them too).
+ * Every rank must call ngm_loss_exchange the same number of times (idle ranks with zeros), like the collective it replaces.
+ * A rank that waits ~2 s for a peer sets *status = 1 (sticky) and returns the partial sum: check it after synchronising. */
+#define NGM_MAX_PEERS 8
+typedef struct ngm_peer_exchange {
+  int32_t world, rank;
+  void* mailbox[NGM_MAX_PEERS];   /* [p] = rank p's mailbox as mapped into THIS process; [rank] = the own allocation   */
+  unsigned long long* seq;        /* device counter of this rank, advanced by every exchange (starts at 0)             */
+  int32_t* status;                /* device word of this rank: 0 = ok, 1 = a peer did not arrive in time (sticky)       */
+} ngm_peer_exchange;
+int64_t ngm_peer_mailbox_bytes(void);
+int ngm_peer_alloc(int64_t bytes, void** ptr);              /* zeroed fine-grained (uncached) device memory              */
+int ngm_peer_free(void* ptr);
+int ngm_ipc_export(void* ptr, unsigned char handle[64]);    /* hipIpcGetMemHandle                                        */
+int ngm_ipc_open(const unsigned char handle[64], void** ptr);   /* hipIpcOpenMemHandle (lazy peer access)               */
+int ngm_ipc_close(void* ptr);
+int ngm_loss_exchange(const ngm_peer_exchange* px, float* loss_sums /* (16) device, summed in place */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,11 @@ class AdamTensor(C.Structure):
                 ("param_lp", C.c_void_p), ("lp_dtype", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class PeerExchange(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("mailbox", C.c_void_p * 8), ("seq", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
 class Targets(C.Structure):
     _fields_ = [("rgbds", f32p), ("depth_mask", C.c_void_p), ("term_mask", C.c_void_p),
                 ("term_probs", f32p)]
@@ -149,6 +154,13 @@ def lib():
     L.ngm_adam_sparse.argtypes = [vp, vp, vp, i64, vp, i64, vp, i32, i64, i64, f32, f32, f32, f32, f32, vp]
     L.ngm_adam_sparse_multi.argtypes = [P(AdamTensor), i32, vp, i32, i64, vp, f32, f32, f32, f32, f32, i32, vp, vp]
     L.ngm_step_advance.argtypes = [vp, vp, vp]
+    L.ngm_peer_mailbox_bytes.restype = i64
+    L.ngm_peer_alloc.argtypes = [i64, P(C.c_void_p)]
+    L.ngm_peer_free.argtypes = [vp]
+    L.ngm_ipc_export.argtypes = [vp, C.c_char_p]
+    L.ngm_ipc_open.argtypes = [C.c_char_p, P(C.c_void_p)]
+    L.ngm_ipc_close.argtypes = [vp]
+    L.ngm_loss_exchange.argtypes = [P(PeerExchange), vp, vp]
     L.ngm_adam_sparse_multi.restype = C.c_int
     L.ngm_step_advance.restype = C.c_int
     L.ngm_field_eval_knn.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, i32, f32, f32, f32, vp, vp, i64, vp]
@@ -188,6 +200,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
             "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_last_matmul", "ngm_debug_prefer_paired_bwd", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
+            "ngm_peer_mailbox_bytes", "ngm_peer_alloc", "ngm_peer_free", "ngm_ipc_export", "ngm_ipc_open", "ngm_ipc_close", "ngm_loss_exchange",
             "ngm_marching_cubes_workspace", "ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"]
 
 # parameters that never receive a gradient (the CUDA package gives none to the per-level shifts either;

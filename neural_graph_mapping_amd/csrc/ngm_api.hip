@@ -886,4 +886,52 @@ int ngm_marching_cubes_tables(int8_t* tri_table, int32_t* tri_count) {
   return e ? fail(e, "marching cubes: table derivation failed") : NGM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// one-shot loss exchange between the ranks of a node (ngm_peer.hip)
+// ------------------------------------------------------------------------------------------------
+static int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  return NGM_E_HIP;
+}
+int64_t ngm_peer_mailbox_bytes(void) { return 2 * NGM_MAX_PEERS * 16 * 8; }
+int ngm_peer_alloc(int64_t bytes, void** ptr) {
+  if (!ptr || bytes <= 0) return fail(NGM_E_INVALID, "ngm_peer_alloc: bad argument");
+  const int e = ngm_peer_alloc_impl(bytes, ptr);
+  return e ? hip_fail((hipError_t)e, "ngm_peer_alloc") : NGM_OK;
+}
+int ngm_peer_free(void* ptr) {
+  const hipError_t e = hipFree(ptr);
+  return e == hipSuccess ? NGM_OK : hip_fail(e, "ngm_peer_free");
+}
+int ngm_ipc_export(void* ptr, unsigned char handle[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!ptr || !handle) return fail(NGM_E_INVALID, "ngm_ipc_export: NULL");
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, ptr);
+  if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle");
+  memcpy(handle, &h, 64);
+  return NGM_OK;
+}
+int ngm_ipc_open(const unsigned char handle[64], void** ptr) {
+  if (!ptr || !handle) return fail(NGM_E_INVALID, "ngm_ipc_open: NULL");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+  return e == hipSuccess ? NGM_OK : hip_fail(e, "hipIpcOpenMemHandle");
+}
+int ngm_ipc_close(void* ptr) {
+  const hipError_t e = hipIpcCloseMemHandle(ptr);
+  return e == hipSuccess ? NGM_OK : hip_fail(e, "hipIpcCloseMemHandle");
+}
+int ngm_loss_exchange(const ngm_peer_exchange* px, float* loss_sums, void* stream) {
+  if (!px || !loss_sums || !px->seq || !px->status) return fail(NGM_E_INVALID, "ngm_loss_exchange: NULL");
+  if (px->world < 1 || px->world > NGM_MAX_PEERS || px->rank < 0 || px->rank >= px->world)
+    return fail(NGM_E_INVALID, "ngm_loss_exchange: 1 <= world <= 8, 0 <= rank < world");
+  for (int p = 0; p < px->world; ++p)
+    if (!px->mailbox[p]) return fail(NGM_E_INVALID, "ngm_loss_exchange: mailbox of a rank not mapped");
+  ngm_launch_loss_exchange(*px, loss_sums, (hipStream_t)stream);
+  return check_launch("ngm_loss_exchange");
+}
+
 }  // extern "C"

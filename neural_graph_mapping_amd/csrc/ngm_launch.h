@@ -163,6 +163,8 @@ int ngm_launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st);
+int ngm_launch_loss_exchange(const ngm_peer_exchange& px, float* sums, hipStream_t st);   // ngm_peer.hip
+int ngm_peer_alloc_impl(int64_t bytes, void** out);
 
 int ngm_launch_target_visibility(const ngm_keyframes& kf, int F, const float* field_pos, int num_offsets, const float* offsets,
                                  float radius, uint8_t* kf_mask, float* bbox, hipStream_t st);

@@ -1,0 +1,68 @@
+// One-shot exchange of the 16 loss sums / counts between the ranks of one node: the path's only collective
+// (rm.py has no distributed code -- the exchange exists because the per-loss means of rm.py:1803-1871 are
+// taken over ALL fields of the iteration and the fields are sharded).  RCCL's all-reduce of 64 bytes is a host-side
+// call between two captured graphs; this kernel sits INSIDE the captured iteration instead:
+//   every rank owns a mailbox of [2 parities][world][16] 8-byte words in fine-grained device memory, mapped into every
+//   other rank's address space (hipIpc); word = (float value, 32-bit sequence number) written with ONE 64-bit store, so
+//   that a reader never sees a value without its sequence number (the "LL" idea of the collective libraries);
+//   rank r stores its 16 values into slot r of EVERY mailbox (its own included: 8 x 16 stores over xGMI, one per lane),
+//   then polls its own mailbox until all `world` slots carry the current sequence number and sums them in rank order --
+//   the same order on every rank, so all ranks hold bit-identical sums.
+// Two parities: a rank can be at most one exchange ahead of the slowest (it cannot finish exchange k + 1 before every
+// rank has written k + 1, i.e. read all of k), so exchange k + 2 never overwrites unread data of exchange k.
+// The sequence number lives on the device and advances with every launch: graph replays need no host update.
+// The poll is bounded (~2 s); on expiry the kernel raises a sticky status word and returns what it has.
+#include "ngm_launch.h"
+
+__global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, float* sums) {
+  const int t = threadIdx.x, slot = t & 15, peer = t >> 4;
+  const uint32_t seq = (uint32_t)(*px.seq) + 1u;
+  const int par = seq & 1u;
+  const int W = px.world;
+  if (peer < W) {
+    const uint32_t bits = __float_as_uint(sums[slot]);
+    unsigned long long* mb = reinterpret_cast<unsigned long long*>(px.mailbox[peer]);
+    const unsigned long long word = ((unsigned long long)seq << 32) | bits;
+    __hip_atomic_store(mb + ((size_t)par * NGM_MAX_PEERS + px.rank) * 16 + slot, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();          // this rank's `sums` are read before they are overwritten below
+  if (t < 16) {
+    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(px.mailbox[px.rank]) + (size_t)par * NGM_MAX_PEERS * 16;
+    float total = 0.f;
+    bool late = false;
+    for (int p = 0; p < W; ++p) {
+      unsigned long long w = 0;
+      int spins = 0;
+      for (;;) {
+        w = __hip_atomic_load(mine + p * 16 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((uint32_t)(w >> 32) == seq) break;
+        if (++spins > (1 << 21)) { late = true; break; }     // x ~1 us of s_sleep: about two seconds
+        __builtin_amdgcn_s_sleep(32);
+      }
+      total += __uint_as_float((uint32_t)w);
+    }
+    if (late) atomicExch(px.status, 1);
+    sums[t] = total;
+  }
+  if (t == 0) *px.seq = (unsigned long long)seq;
+}
+
+int ngm_launch_loss_exchange(const ngm_peer_exchange& px, float* sums, hipStream_t st) {
+  hipLaunchKernelGGL(k_loss_exchange, dim3(1), dim3(128), 0, st, px, sums);
+  return 0;
+}
+
+// Mailbox memory: uncached / fine-grained device memory where the runtime offers it (stores of a RUNNING kernel on another
+// GPU must become visible to the polling loads; coarse-grained memory only promises that at kernel boundaries), zeroed.
+int ngm_peer_alloc_impl(int64_t bytes, void** out) {
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); }
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+  *out = p;
+  return 0;
+}

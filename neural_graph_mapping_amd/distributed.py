@@ -44,12 +44,156 @@ def global_to_local(field_ids: torch.Tensor, world_size: int) -> torch.Tensor:
     return field_ids // world_size
 
 
+def draw_fields_reference(current_field_ids: torch.Tensor, num_fields: int, num_train_fields: int, generator=None):
+    """The reference's draw (rm.py:1280-1319): half of `num_train_fields` among the currently observed fields, the rest
+    uniformly among all others, union sorted.  -> (field_ids, subset_observed, subset_random)"""
+    dev = current_field_ids.device
+    n_obs = min(num_train_fields // 2, len(current_field_ids))
+    if n_obs > 0:
+        sub_obs = torch.multinomial(torch.ones(len(current_field_ids), device=dev), n_obs, generator=generator)
+    else:
+        sub_obs = torch.empty(0, dtype=torch.int64, device=dev)
+    obs_ids = current_field_ids[sub_obs]
+    n_rand = min(num_train_fields - len(obs_ids), num_fields - len(obs_ids))
+    if n_rand <= 0:
+        return obs_ids, sub_obs, None
+    w = torch.ones(num_fields, device=dev)
+    w[obs_ids] = 0.0
+    sub_rand = torch.multinomial(w, n_rand, generator=generator)
+    return torch.unique(torch.cat((sub_rand, obs_ids))), sub_obs, sub_rand
+
+
+def draw_fields_balanced(current_field_ids: torch.Tensor, num_fields: int, num_train_fields: int, world_size: int,
+                         generator=None) -> torch.Tensor:
+    """Opt-in sampler policy `field_draw: balanced_by_owner` (NOT the reference's distribution): the reference's draw
+    made once PER OWNER RANK with a quota of num_train_fields / world (the first `num_train_fields % world` owners get one
+    more), over that owner's fields only -- half of the quota among its currently observed fields, the rest uniformly
+    among its other fields.  Every rank then trains the same number of fields in every iteration (as far as it owns
+    that many), where the reference's global draw puts 7 of 32 on the worst of 8 ranks against a mean of 4.
+    Same generator state on every rank -> same set everywhere.  With world_size 1 this is the reference's draw."""
+    if world_size <= 1:
+        return draw_fields_reference(current_field_ids, num_fields, num_train_fields, generator)[0]
+    dev = current_field_ids.device
+    chosen = []
+    base, extra = divmod(num_train_fields, world_size)
+    for owner in range(world_size):
+        quota = base + (1 if owner < extra else 0)
+        mine = torch.arange(owner, num_fields, world_size, device=dev)
+        if quota == 0 or len(mine) == 0:
+            continue
+        cur_o = current_field_ids[current_field_ids % world_size == owner]
+        # local indices (slot = id // world) so that the per-owner draw is the reference's draw on the owner's sub-map
+        ids_local, _, _ = draw_fields_reference(cur_o // world_size, len(mine), quota, generator)
+        chosen.append(ids_local * world_size + owner)
+    return torch.sort(torch.cat(chosen)).values if chosen else torch.empty(0, dtype=torch.int64, device=dev)
+
+
 def allreduce_loss_sums(loss_sums: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the per-rank loss sums / counts in place.  Ranks without active fields pass zeros but
     MUST still call this."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(loss_sums, op=dist.ReduceOp.SUM, group=group)
     return loss_sums
+
+
+class PeerExchange:
+    """The 64-byte loss exchange as ONE small kernel inside the captured iteration instead of an RCCL call between two
+    graphs (include/ngm_hip.h, ngm_loss_exchange; csrc/ngm_peer.hip): every rank writes its 16 sums into every rank's
+    mailbox (peer memory mapped through hipIpc, xGMI stores), polls its own and sums in rank order -- bit-identical on
+    all ranks.  One node, world <= 8.  Set-up is collective over `group` (handles travel by all_gather_object) and ends
+    with a self-test exchange; any failure raises, so that a caller can keep the RCCL path (`try_create`).
+    Every rank must call `allreduce` the same number of times (idle ranks with zeros)."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from . import _capi as K
+        self._K, self._C = K, C
+        L = K.lib()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > 8:
+            raise NotImplementedError("PeerExchange: one node, at most 8 ranks")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._opened = []
+        with torch.cuda.device(self.device):
+            own = C.c_void_p()
+            K.check(L.ngm_peer_alloc(L.ngm_peer_mailbox_bytes(), C.byref(own)), "ngm_peer_alloc")
+            self._own = own
+            state = C.c_void_p()
+            K.check(L.ngm_peer_alloc(64, C.byref(state)), "ngm_peer_alloc")      # seq (8 bytes) + status (4 bytes)
+            self._state = state
+            handle = C.create_string_buffer(64)
+            K.check(L.ngm_ipc_export(own, handle), "ngm_ipc_export")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, (self.rank, handle.raw), group=group)
+            px = K.PeerExchange()
+            px.world, px.rank = self.world, self.rank
+            for r, raw in handles:
+                if r == self.rank:
+                    px.mailbox[r] = own.value
+                else:
+                    ptr = C.c_void_p()
+                    K.check(L.ngm_ipc_open(raw, C.byref(ptr)), f"ngm_ipc_open(rank {r})")
+                    self._opened.append(ptr)
+                    px.mailbox[r] = ptr.value
+            px.seq = state.value
+            px.status = state.value + 16
+            self._px = px
+            # self-test: every rank contributes rank + 1 in slot 0 -> world (world + 1) / 2 everywhere
+            probe = torch.zeros(16, device=self.device)
+            probe[0] = self.rank + 1.0
+            self.allreduce(probe)
+            torch.cuda.synchronize(self.device)
+            ok = self.status() == 0 and float(probe[0]) == self.world * (self.world + 1) / 2
+        verdict = [None] * self.world
+        dist.all_gather_object(verdict, bool(ok), group=group)
+        if not all(verdict):
+            self.close()
+            raise RuntimeError(f"PeerExchange self-test failed (per rank: {verdict})")
+
+    @classmethod
+    def try_create(cls, group=None, device=None):
+        """-> PeerExchange or None (the caller keeps torch.distributed.all_reduce).  Collective: the set-up either
+        succeeds on every rank or fails on every rank, except when the handle exchange itself breaks."""
+        try:
+            return cls(group, device)
+        except Exception as e:                                   # noqa: BLE001 - any failure means "use RCCL"
+            ok = [None] * dist.get_world_size(group)
+            try:
+                dist.all_gather_object(ok, False, group=group)   # pairs with the verdict gather of the ranks that got that far
+            except Exception:                                    # noqa: BLE001
+                pass
+            import warnings
+            warnings.warn(f"PeerExchange unavailable, using the process group's all_reduce: {e}")
+            return None
+
+    def allreduce(self, loss_sums: torch.Tensor) -> torch.Tensor:
+        """Sum the (16,) float32 device tensor over the ranks, in place, on the current stream (capturable)."""
+        assert loss_sums.dtype == torch.float32 and loss_sums.numel() == 16 and loss_sums.is_contiguous()
+        K, C = self._K, self._C
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        K.check(K.lib().ngm_loss_exchange(C.byref(self._px), loss_sums.data_ptr(), st), "ngm_loss_exchange")
+        return loss_sums
+
+    def status(self) -> int:
+        """0 = every exchange so far completed; 1 = some exchange waited ~2 s for a peer and gave up (sticky).
+        Synchronises with the device."""
+        from . import hiprt as H
+        torch.cuda.synchronize(self.device)
+        out = self._C.c_int32(-1)
+        with torch.cuda.device(self.device):
+            H._chk(H.hip().hipMemcpy(self._C.byref(out), self._px.status, 4, 2), "hipMemcpy D2H")
+        return int(out.value)
+
+    def close(self):
+        L = self._K.lib()
+        for p in self._opened:
+            L.ngm_ipc_close(p)
+        self._opened = []
+        for name in ("_own", "_state"):
+            p = getattr(self, name, None)
+            if p is not None:
+                L.ngm_peer_free(p)
+                setattr(self, name, None)
 
 
 def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsdf, photometric_loss="l1",

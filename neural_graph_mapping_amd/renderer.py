@@ -125,6 +125,7 @@ class NeuralGraphRenderer:
         self._step_dev = None
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
+        self.peer_exchange = None          # distributed.PeerExchange: the same sum as one kernel inside the captured iteration
 
     def last_matmul(self, kernel: str = "forward") -> Optional[str]:
         """The arithmetic the library resolved `mlp_matmul` to in the LAST launch of the fused forward ("forward"), the
@@ -325,30 +326,40 @@ class NeuralGraphRenderer:
     # -- training-target sampler (rm.py:1259-1459) ------------------------------------------------
     @torch.no_grad()
     def sample_target_mv(self, current_field_ids, c_c2w, nc_rgbd, frame_cid_to_ncid, num_train_fields, num_rays_per_field,
-                         num_fields=None, camera: Optional[Camera] = None, draws: Optional[dict] = None) -> Target:
+                         num_fields=None, camera: Optional[Camera] = None, draws: Optional[dict] = None,
+                         field_draw: str = "reference", world_size: int = 1) -> Target:
         """NeuralGraphMap._sample_target_mv: choose the fields to train, find the keyframes that see them, sample
         keyframes and pixels, collect the RGB-D supervision.  State that the reference keeps on `self` is passed in:
         c_c2w (Nc,4,4) = _c_c2w_tensor, nc_rgbd (N,H,W,4) = _nc_rgbd_tensor, frame_cid_to_ncid (Nc,).
         The random draws are made with torch on this device in the reference's order (multinomial, multinomial,
         randn, multinomial, rand); `draws` (dict: subset_observed, subset_random, offsets, frame_cids, u_xy)
-        replays recorded ones.  The geometry between the draws runs in two HIP kernels."""
+        replays recorded ones.  The geometry between the draws runs in two HIP kernels.
+        field_draw="balanced_by_owner" (opt-in, with world_size) replaces the choice of fields by
+        distributed.draw_fields_balanced: the same draw per owner rank with a quota of num_train_fields / world -- every
+        rank trains equally many fields per iteration; not the reference's distribution, see DESIGN 5."""
+        if field_draw not in ("reference", "balanced_by_owner"):
+            raise NotImplementedError(f"field_draw={field_draw!r}: 'reference' or 'balanced_by_owner'")
         cam = camera or self._camera
         dev = self._device
         radius = self._field_radius + 0.0
         num_fields = self._global_map_dict["num"] if num_fields is None else num_fields
         d = draws or {}
         cur = current_field_ids.to(dev)
-        n_obs = min(num_train_fields // 2, len(cur))
-        sub_obs = d["subset_observed"].to(dev) if draws else torch.multinomial(torch.ones(len(cur), device=dev), n_obs)
-        obs_ids = cur[sub_obs]
-        n_rand = min(num_train_fields - len(obs_ids), num_fields - len(obs_ids))
-        if n_rand > 0:
-            dist = torch.ones(num_fields, device=dev)
-            dist[obs_ids] = 0.0
-            sub_rand = d["subset_random"].to(dev) if draws else torch.multinomial(dist, n_rand)
-            field_ids = torch.unique(torch.cat((torch.arange(num_fields, device=dev)[sub_rand], obs_ids)))
-        else:
-            field_ids = obs_ids
+        if field_draw == "balanced_by_owner" and world_size > 1 and not draws:
+            from . import distributed as D
+            field_ids = D.draw_fields_balanced(cur, num_fields, num_train_fields, world_size)
+        else:                                                      # rm.py:1280-1319
+            n_obs = min(num_train_fields // 2, len(cur))
+            sub_obs = d["subset_observed"].to(dev) if draws else torch.multinomial(torch.ones(len(cur), device=dev), n_obs)
+            obs_ids = cur[sub_obs]
+            n_rand = min(num_train_fields - len(obs_ids), num_fields - len(obs_ids))
+            if n_rand > 0:
+                dist = torch.ones(num_fields, device=dev)
+                dist[obs_ids] = 0.0
+                sub_rand = d["subset_random"].to(dev) if draws else torch.multinomial(dist, n_rand)
+                field_ids = torch.unique(torch.cat((torch.arange(num_fields, device=dev)[sub_rand], obs_ids)))
+            else:
+                field_ids = obs_ids
         pos_w = self._global_map_dict["positions"][field_ids].contiguous()
         if draws:
             offsets = d["offsets"].to(dev)
@@ -503,8 +514,14 @@ class NeuralGraphRenderer:
         ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=update)
         if self.process_group is not None:
             # the only cross-GPU exchange of the path: global loss sums / counts (64 bytes)
-            torch.distributed.all_reduce(ctx["w"]["sums"], group=self.process_group)
+            self._exchange(ctx["w"]["sums"])
         return self._iteration_backward(ctx, update)
+
+    def _exchange(self, sums: torch.Tensor):
+        if self.peer_exchange is not None:
+            self.peer_exchange.allreduce(sums)       # one kernel on the current stream: xGMI peer writes, capturable
+        else:
+            torch.distributed.all_reduce(sums, group=self.process_group)
 
     def _neus_fused(self) -> bool:
         """the neus geometry mode runs in the fused kernels for the Fourier / no encoding without skip connections
@@ -519,7 +536,7 @@ class NeuralGraphRenderer:
         from . import distributed as D
         sums = torch.zeros(16, device=self._device)
         if self.process_group is not None:
-            torch.distributed.all_reduce(sums, group=self.process_group)
+            self._exchange(sums)
         rc = self._rc_train
         loss = D.loss_values_from_sums(sums, rc.w_termination, rc.w_photometric, rc.w_depth, rc.w_freespace, rc.w_tsdf,
                                        self._config["photometric_loss"], self._config["depth_loss"])
@@ -632,7 +649,8 @@ class NeuralGraphRenderer:
         """Capture optimization_iteration(target) into hipGraphs (torch.cuda.CUDAGraph); the returned callable
         replays it.  Tensors of `target` are read in place at every replay; the Adam step counter and the Philox
         jitter offset live on the device and advance inside the graph.  With a process group the iteration becomes
-        two graphs (before / after the loss all-reduce) and the 64-byte collective is issued between the replays."""
+        two graphs (before / after the loss all-reduce) and the 64-byte collective is issued between the replays --
+        unless `peer_exchange` is set: then the exchange is a kernel of the ONE captured graph."""
         if self._rc_train.geometry_mode == K.GEO["neus"] and not self._neus_fused():
             raise NotImplementedError("capture_iteration: the staged (neus) iteration allocates under autograd; call "
                                       "optimization_iteration directly")
@@ -642,7 +660,8 @@ class NeuralGraphRenderer:
             for _ in range(2):                                # warm-up on a side stream (allocations, lazy init)
                 out = self.optimization_iteration(target, u_coarse, u_guided, seed=seed)
         torch.cuda.current_stream().wait_stream(s)
-        if self.process_group is None:
+        if self.process_group is None or self.peer_exchange is not None:
+            # one graph: single GPU, or the loss exchange is a kernel of the iteration (distributed.PeerExchange)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.optimization_iteration(target, u_coarse, u_guided, seed=seed)

@@ -194,3 +194,95 @@ def test_two_ranks_render_image_sharded(tmp_path):
     r, cam = _g9_renderer(g)
     rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
     assert torch.equal(res["rgbd"], rgbd.cpu()) and torch.equal(res["dvar"], dvar.cpu())   # pixels are independent
+
+
+# ------------------------------------------------------------------------------------------ one-shot peer exchange
+def _expected_sum(vs):
+    """the kernel's order: 0 + v_0 + v_1 + ... in fp32"""
+    tot = torch.zeros(16)
+    for v in vs:
+        tot = tot + v
+    return tot
+
+
+def _peer_worker(rank, world, port, out):
+    _init(rank, world, port)
+    px = D.PeerExchange(dist.group.WORLD)                 # set-up incl. the self-test exchange
+    vals = lambda it, r: torch.randn(16, generator=torch.Generator().manual_seed(1000 * it + r)) * 10.0 ** (it % 5 - 2)  # noqa: E731
+    eager = []
+    for it in range(40):                                  # plain launches; both parities, many sequence numbers
+        x = vals(it, rank).to(DEV)
+        px.allreduce(x)
+        eager.append(x.cpu())
+    # captured: a graph of (copy the staged input, exchange) replayed with fresh inputs
+    stage, buf = torch.zeros(16, device=DEV), torch.zeros(16, device=DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        buf.copy_(stage)
+        px.allreduce(buf)                                 # warm-up outside the capture keeps the ranks' counts equal
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        buf.copy_(stage)
+        px.allreduce(buf)
+    replayed = []
+    for it in range(40, 60):
+        stage.copy_(vals(it, rank))
+        graph.replay()
+        replayed.append(buf.cpu())
+    status = px.status()
+    torch.save(dict(eager=eager, replayed=replayed, status=status), os.path.join(out, f"peer{rank}.pt"))
+    dist.barrier()
+    px.close()
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_two_ranks_bitwise(tmp_path):
+    """ngm_loss_exchange (csrc/ngm_peer.hip) between two processes sharing GPU 0 through hipIpc-mapped mailboxes: every
+    exchange returns, on BOTH ranks, exactly 0 + v_0 + v_1 (rank order, fp32) -- eager launches and hipGraph replays
+    (the sequence number lives on the device), no time-out."""
+    world = 2
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"peer{r}.pt")) for r in range(world)]
+    vals = lambda it, r: torch.randn(16, generator=torch.Generator().manual_seed(1000 * it + r)) * 10.0 ** (it % 5 - 2)  # noqa: E731
+    for r in range(world):
+        assert res[r]["status"] == 0
+        for it in range(40):
+            assert torch.equal(res[r]["eager"][it], _expected_sum([vals(it, q) for q in range(world)])), (r, it)
+        for j, it in enumerate(range(40, 60)):
+            assert torch.equal(res[r]["replayed"][j], _expected_sum([vals(it, q) for q in range(world)])), (r, it)
+
+
+def _train_peer_worker(rank, world, port, out):
+    _init(rank, world, port)
+    g = load_golden(NAME)
+    r, tgt, uc, ug, gids = _local_renderer(g, rank, world)
+    r.peer_exchange = D.PeerExchange(dist.group.WORLD)
+    replay = r.capture_iteration(tgt, u_coarse=uc, u_guided=ug)
+    for _ in range(N_REPLAY):
+        last = replay()
+    torch.cuda.synchronize()
+    one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
+    rec = dict(ids=gids, one_graph=one_graph, status=r.peer_exchange.status(), step=r._step, step_dev=int(r._step_dev.item()),
+               last_loss=last["combined"].cpu(), params={k: v.cpu().clone() for k, v in r._model.all_fields_params.items()})
+    torch.save(rec, os.path.join(out, f"trainpx{rank}.pt"))
+    dist.barrier()
+    r.peer_exchange.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_peer_exchange_inside_one_graph(tmp_path):
+    """The sharded iteration with `peer_exchange` set: forward, loss exchange and backward + Adam in ONE hipGraph per rank
+    (no host-side collective between replays); trained parameters after 5 updates = the one-process run."""
+    world = 2
+    mp.spawn(_train_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(NAME)
+    _, last, params1 = _single_process(g, 2 + N_REPLAY)
+    for rank in range(world):
+        res = torch.load(os.path.join(tmp_path, f"trainpx{rank}.pt"))
+        assert res["one_graph"] and res["status"] == 0
+        assert res["step"] == 2 + N_REPLAY == res["step_dev"]
+        close(res["last_loss"], last["combined"], rtol=1e-4, atol=1e-6)
+        for k, v in res["params"].items():
+            close(v, params1[k][res["ids"]], rtol=1e-4, atol=1e-6)

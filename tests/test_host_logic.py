@@ -182,3 +182,38 @@ def _cpu_renderer_cfg(cfg):
         encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4,
         neus_initial_sd=1.0), num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube")
     return Rr.NeuralGraphRenderer(model, Rr.Camera(32, 24, 27.7, 27.7, 15.5, 11.5), cfg, device="cpu")
+
+
+def test_balanced_by_owner_field_draw():
+    """Opt-in sampler policy of DESIGN 5: every owner rank gets num_train_fields / world fields per iteration, half of them
+    among its observed fields; same generator state -> same set on every rank; world 1 = the reference's draw."""
+    from neural_graph_mapping_amd import distributed as D
+    NF, FA, W = 200, 32, 8
+    cur = torch.arange(150, 200)                       # the 50 most recent fields are observed
+    for seed in range(5):
+        g = torch.Generator().manual_seed(seed)
+        ids = D.draw_fields_balanced(cur, NF, FA, W, generator=g)
+        assert len(ids) == FA and len(torch.unique(ids)) == FA and bool((ids[1:] > ids[:-1]).all())
+        per_owner = torch.bincount(ids % W, minlength=W)
+        assert per_owner.tolist() == [FA // W] * W
+        for o in range(W):                             # half of each quota among the owner's observed fields (it has 6-7)
+            assert int(((ids % W == o) & (ids >= 150)).sum()) >= (FA // W) // 2
+        ids2 = D.draw_fields_balanced(cur, NF, FA, W, generator=torch.Generator().manual_seed(seed))
+        assert torch.equal(ids, ids2)
+    # quota remainder goes to the first owners; an owner with fewer fields than its quota trains all it has
+    ids = D.draw_fields_balanced(torch.arange(0, 4), 10, 7, 4, generator=torch.Generator().manual_seed(0))
+    assert torch.bincount(ids % 4, minlength=4).tolist() == [2, 2, 2, 1]
+    ids = D.draw_fields_balanced(torch.empty(0, dtype=torch.int64), 5, 8, 4, generator=torch.Generator().manual_seed(0))
+    assert ids.tolist() == [0, 1, 2, 3, 4]
+    # the reference's global draw for comparison: the worst rank of an iteration gets well over the mean
+    worst = []
+    g = torch.Generator().manual_seed(1)
+    for _ in range(200):
+        r = D.draw_fields_reference(cur, NF, FA, generator=g)[0]
+        assert len(r) == FA
+        worst.append(int(torch.bincount(r % W, minlength=W).max()))
+    assert sum(worst) / len(worst) > 6.0
+    # world 1: the reference's draw itself
+    a = D.draw_fields_balanced(cur, NF, FA, 1, generator=torch.Generator().manual_seed(3))
+    b = D.draw_fields_reference(cur, NF, FA, generator=torch.Generator().manual_seed(3))[0]
+    assert torch.equal(a, b)

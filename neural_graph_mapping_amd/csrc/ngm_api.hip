@@ -521,6 +521,9 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   int64_t lds = 0;
   shape(8, 0, &lds);                                    // exact-fp32 plan first: 8 waves unless its LDS does not fit
   if (lds > LDS_MAX || R < 8) shape(4, 0, &lds);
+  // a grid of 8-wave workgroups that leaves CUs idle (a rank with one or two active fields): 4 waves per
+  // workgroup on twice as many CUs -- one wave per SIMD runs a step in about half the time (F = 1: 29 -> 25.5 us, split path)
+  const bool few = R >= 8 && (int64_t)F * ((R + 7) / 8) < ncu;
   p.b3 = 0;
   // The split path's weight planes (48 KB for two 64-wide layers) compete with the per-wave sample planes for LDS: a
   // batch of many samples per ray (8192 x 256: 1024 samples buffered per wave) leaves no room at 8 waves.  Smaller ray
@@ -539,7 +542,10 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   } else if (fc->matmul_mode == NGM_MATMUL_AUTO && b3_compiled && rc->geometry_mode != NGM_GEO_NEUS) {
     const int64_t lds_f32 = lds;
     const RenderPlan keep = p;
-    if (fit_b3() && p.waves_fwd == 8) p.b3 = 1;                       // auto: the planes next to an 8-wave plan, else exact-fp32 MFMA
+    bool ok = false;
+    if (few) { shape(4, b3_bytes, &lds); ok = lds <= LDS_MAX; }
+    if (!ok) ok = fit_b3() && p.waves_fwd == 8;                       // auto: the planes next to an 8-wave plan, else exact-fp32 MFMA
+    if (ok) p.b3 = 1;
     else { p = keep; lds = lds_f32; }
   }
   p.p_pad = param_pad(fc);

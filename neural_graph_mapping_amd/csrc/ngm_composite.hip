@@ -369,6 +369,36 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   const float inv_s = 1.0f / (float)S;
   const float tau = a.rc.truncation_distance, gamma = a.rc.geometry_factor, cf = a.rc.color_factor;
   const int mode = a.rc.geometry_mode;
+  // The streams of a step (stash, ray table, per-ray predictions / targets) are fetched ONE STEP AHEAD: the first step's
+  // loads travel under the loss-partial reduction below, the next step's under this step's scans (a wave runs its
+  // steps back to front with a carried suffix value, so nothing else overlaps them at one or two steps per wave).
+  const int64_t nsamp_all = (r_end - r_beg) * S;
+  const int64_t nsteps = (nsamp_all + 63) / 64;
+  struct StepIn {
+    float4 sa, r0, r1, pr, tg; float2 sb; float term, tprob; unsigned char dm, tm;
+  };
+  auto fetch = [&](int64_t st, StepIn& in) __attribute__((always_inline)) {
+    const int64_t idx = st * 64 + lane;
+    in.sa = in.r0 = in.r1 = in.pr = in.tg = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.sb = make_float2(0.f, 0.f); in.term = in.tprob = 0.f; in.dm = in.tm = 0;
+    if (st >= 0 && idx < nsamp_all) {
+      const int64_t rl = idx / S;
+      const int64_t ray = r_beg + rl, g = ray * S + (idx - rl * S);
+      in.sa = a.stashA[g];
+      in.sb = a.stashB[g];
+      in.r1 = reinterpret_cast<const float4*>(a.raytab)[2 * ray + 1];
+      if (a.xyz_out) in.r0 = reinterpret_cast<const float4*>(a.raytab)[2 * ray];
+      if (a.seed_mode == 0) {
+        in.pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
+        in.tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
+        in.term = a.pred.term_probs[ray];
+        in.dm = a.tg.depth_mask[ray];
+        if (a.tg.term_mask) { in.tm = a.tg.term_mask[ray]; in.tprob = a.tg.term_probs[ray]; }
+      }
+    }
+  };
+  StepIn cur;
+  fetch(nsteps - 1, cur);
   // global loss normalisers (after the caller's all-reduce, or -- deferred reduction -- summed here by every workgroup
   // from the forward's partials in k_loss_reduce's fixed order: identical in all workgroups, deterministic)
   __shared__ float s_red[16][17];
@@ -403,9 +433,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   }
   // the loss scalars ride along (one thread; saves a launch in the training step)
   if (a.loss_out && a.seed_mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) loss_values_from_sums(a.rc, sums, a.loss_out);
-  const int64_t nsamp_all = (r_end - r_beg) * S;
   float carryQ = 0.f;
-  const int64_t nsteps = (nsamp_all + 63) / 64;
   for (int64_t st = nsteps - 1; st >= 0; --st) {
     const int64_t idx = st * 64 + lane;
     const bool valid = idx < nsamp_all;
@@ -416,23 +444,25 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     const int64_t ray = r_beg + rl, g = ray * S + k;
     float c0 = 0, c1 = 0, c2 = 0, geom = 0, t = 0, T = 0, dzc = 0, gt = 0;
     float dC0 = 0, dC1 = 0, dC2 = 0, dD = 0, dT = 0;
+    const StepIn in = cur;
+    fetch(st - 1, cur);                                  // no-op for st == 0
     if (valid) {
-      const float4 sa = a.stashA[g];
-      const float2 sb = a.stashB[g];
+      const float4 sa = in.sa;
+      const float2 sb = in.sb;
       c0 = sa.x; c1 = sa.y; c2 = sa.z; geom = sa.w; t = sb.x; T = sb.y;
-      const float4 r1 = reinterpret_cast<const float4*>(a.raytab)[2 * ray + 1];
+      const float4 r1 = in.r1;
       dzc = r1.z; gt = r1.w;
       if (a.xyz_out) {             // hash encoding: the position k_hash_grad searches the simplex of (the forward's own fmaf)
-        const float4 r0 = reinterpret_cast<const float4*>(a.raytab)[2 * ray];
+        const float4 r0 = in.r0;
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f p = {fmaf(t, r0.w, r0.x), fmaf(t, r1.x, r0.y), fmaf(t, r1.y, r0.z), 0.f};
         __builtin_nontemporal_store(p, reinterpret_cast<v4f*>(a.xyz_out + g));
       }
       if (a.seed_mode == 0) {
-        const float4 pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
-        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
-        const float term = a.pred.term_probs[ray];
-        const bool m = a.tg.depth_mask[ray] && (term > a.rc.term_threshold);
+        const float4 pr = in.pr;
+        const float4 tg = in.tg;
+        const float term = in.term;
+        const bool m = in.dm && (term > a.rc.term_threshold);
         if (m) {
           const float e0 = pr.x - tg.x, e1 = pr.y - tg.y, e2 = pr.z - tg.z;
           if (a.rc.photometric_mode == NGM_PHOTO_L2) {      // d mean(e^2) (losses.py:28-29)
@@ -444,7 +474,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
           const float e = pr.w - tg.w, dl = a.rc.huber_delta;
           dD = k_depth * ((fabsf(e) < dl) ? e : dl * ((e > 0.f) - (e < 0.f)));
         }
-        if (a.tg.term_mask && a.tg.term_mask[ray]) dT = k_term * (term - a.tg.term_probs[ray]);
+        if (a.tg.term_mask && in.tm) dT = k_term * (term - in.tprob);
       } else {
         const float4 d = reinterpret_cast<const float4*>(a.d_rgbds)[ray];
         dC0 = d.x; dC1 = d.y; dC2 = d.z; dD = d.w;
@@ -533,7 +563,7 @@ int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
     if (a.d_isd_rays) (void)hipMemsetAsync(a.d_isd_rays, 0, sizeof(float) * (size_t)a.F * a.R, st);
   }
   int rpw;
-  const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);
+  const int blocks = comp_grid((int64_t)a.F * a.R, a.S, &rpw);   // one ray per wave up to 6144 rays (2 and 4 rays per wave: +3 / +9 us at M1)
   hipLaunchKernelGGL(k_stash_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
   return 0;
 }

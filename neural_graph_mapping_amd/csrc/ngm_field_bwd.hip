@@ -802,12 +802,15 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
     }
     if (issue) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { atomicAdd(&tab[2 * idx[r]], to_fix(v[2 * r])); atomicAdd(&tab[2 * idx[r] + 1], to_fix(v[2 * r + 1])); }
+      for (int r = 0; r < 4; ++r) { atomicAdd(&tab[idx[r]], to_fix(v[2 * r])); atomicAdd(&tab[T + idx[r]], to_fix(v[2 * r + 1])); }
     }
   }
   __syncthreads();
   float* dst = a.part + (((int64_t)f * a.fc.nr_levels + level) * a.chunks + chunk) * 2 * T;
-  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) dst[i] = (float)((double)(long long)tab[i] * (1.0 / 1099511627776.0));
+  // LDS holds one plane per feature (8-byte stride: the 64 lanes of an atomic spread over 32 bank pairs; interleaved, 16-byte
+  // entries reach only 16); the partial table is written in the parameter layout [entry][feature]
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x)
+    dst[i] = (float)((double)(long long)tab[(i & 1) * T + (i >> 1)] * (1.0 / 1099511627776.0));
 }
 
 // gtab[f][level][i] = sum over chunks (fixed order): overwrites -> no zero-fill of the gradient needed

@@ -484,6 +484,11 @@ int ngm_debug_last_matmul(int which);
  * correct, measured equal to k_field_bwd_b3 within the pool's noise in round 3: DESIGN 3.10) before the default order;
  * 0 = default.  Returns the previous setting.  Environment: NGM_BWD_B3Q=1. */
 int ngm_debug_prefer_paired_bwd(int on);
+/* Debug: 1 when the last ngm_render_bwd / ngm_render_bwd_adam ran the compositing backward inside k_field_bwd_b3 (loss
+ * seeds, pointwise geometry modes, ray-aligned wave ranges; no k_stash_bwd launch, the forward's colour / geometry stash
+ * stays intact), 0 when k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */
+int ngm_debug_last_comp_fused(void);
+int ngm_debug_disable_fused_comp(int on);   /* 1 = always launch k_stash_bwd (as NGM_NO_FUSED_COMP=1); returns the previous setting */
 
 /* ---- one-shot exchange of the loss sums between the ranks of one node ---------------
  * Replaces torch.distributed.all_reduce (RCCL) on the 16 floats between ngm_render_fwd and ngm_render_bwd* by ONE small

@@ -94,6 +94,13 @@ static unsigned long long* g_debug_cycles = nullptr;
 int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_prefer_paired_bwd = 0;
+static int g_no_fused_comp = 0;       // ngm_debug_disable_fused_comp
+static int g_last_comp_fused = 0;     // the last training backward did the compositing backward inside k_field_bwd_b3 (no k_stash_bwd launch)
+// true when launch_bwd_any's first candidate is k_field_bwd_b3 (no experiment switch in the way)
+static bool bwd_b3_is_default() {
+  static const bool off = getenv("NGM_BWD32") != nullptr || getenv("NGM_NO_BWD_B3") != nullptr || getenv("NGM_BWD_B3Q") != nullptr;
+  return !off && !g_prefer_paired_bwd;
+}
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
   static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
@@ -110,6 +117,8 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   int e = (force32 || no_b3 || !try_b3q || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3q(a, blocks, st);
   g_last_bwd_variant = 4;
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
+  g_last_comp_fused = (a.fused_comp && e == 0) ? 1 : 0;
+  if (a.fused_comp && e) return e ? e : NGM_E_UNSUPPORTED;      // no other kernel composites: never fall through
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
   if (e == NGM_E_UNSUPPORTED && !force32 && a.act) { e = ngm_launch_field_bwd16s(a, blocks, st); g_last_bwd_variant = 2; }
   if (e == NGM_E_UNSUPPORTED && !force32) { e = ngm_launch_field_bwd16(a, blocks, st); g_last_bwd_variant = 1; }
@@ -276,6 +285,8 @@ int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float r
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_last_matmul[which] : -1; }
+int ngm_debug_last_comp_fused(void) { return g_last_comp_fused; }
+int ngm_debug_disable_fused_comp(int on) { const int old = g_no_fused_comp; g_no_fused_comp = on ? 1 : 0; return old; }
 int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 
 static unsigned long long* g_debug_cycles_fwd = nullptr;
@@ -345,11 +356,22 @@ int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   return check_launch("ngm_field_eval_fwd");
 }
 
-static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf) {
+// S > 0 (ray mode): a workgroup's range is a multiple of 4 lcm(32, S) samples where that unit is small -- every wave's quarter
+// of it then begins and ends with a ray AND a 32-sample tile, which is what the fused compositing backward of
+// k_field_bwd_b3 needs (*ray_aligned says whether it holds); other kernels only need the multiple of 128.
+static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int S = 0, int* ray_aligned = nullptr) {
   const int ncu = num_cus();
   int64_t b = (ncu + F - 1) / F;
-  int64_t per = align_up((P + b - 1) / b, 32 * NGM_WAVES_PER_BLOCK);
-  if (per < 32 * NGM_WAVES_PER_BLOCK) per = 32 * NGM_WAVES_PER_BLOCK;
+  int64_t unit = 32 * NGM_WAVES_PER_BLOCK;
+  if (ray_aligned) *ray_aligned = 0;
+  if (S > 0) {
+    int64_t g = 32, s = S;
+    while (s) { const int64_t r = g % s; g = s; s = r; }          // gcd(32, S)
+    const int64_t u = 4 * (32 / g) * S;                             // 4 lcm(32, S)
+    if (u <= 4096) { unit = u; if (ray_aligned) *ray_aligned = 1; }
+  }
+  int64_t per = align_up((P + b - 1) / b, unit);
+  if (per < unit) per = unit;
   *per_block = per;
   *bpf = (int)((P + per - 1) / per);
 }
@@ -469,7 +491,9 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 struct RenderPlan {
   int S, rays_per_block, blocks_fwd, waves_fwd, maxs, b3;
   int64_t per_block_bwd; int blocks_per_field_bwd;
+  int ray_aligned_bwd;             // the backward's wave ranges begin and end with a ray (plan_bwd)
   int64_t p_pad;
+  int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
   int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
   int64_t off_xyz; int has_xyz;    // 64-wide stash backward: scaled field-local sample positions (16 B per sample) written by k_stash_bwd
@@ -553,6 +577,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
   if (train) {
     const int64_t NR = (int64_t)F * R, NS = NR * p.S;
     p.off_raytab = o; o = align_up(o + NR * 8 * 4, 256);
+    p.off_rayseed = o; o = align_up(o + NR * 8 * 4, 256);
     p.off_stashA = o; o = align_up(o + NS * 16, 256);
     p.off_stashB = o; o = align_up(o + NS * 8, 256);
     p.off_losspart = o; o = align_up(o + (int64_t)p.blocks_fwd * NGM_NUM_LOSS_SUMS * 4, 256);
@@ -560,7 +585,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
       p.off_dout = o; o = align_up(o + NS * 16, 256);
       p.off_disd = o; o = align_up(o + NR * 4, 256);
     }
-    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd);
+    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd, p.S, &p.ray_aligned_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
     const int kind = act_stash_kind(fc);
@@ -647,6 +672,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   a.S = p.S; a.rays_per_block = p.rays_per_block; a.waves_per_block = p.waves_fwd; a.maxs = p.maxs;
   if (save) {
     a.raytab = reinterpret_cast<float*>(ws + p.off_raytab);
+    if (has_tg) a.rayseed = reinterpret_cast<float*>(ws + p.off_rayseed);
     a.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
     a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
     a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
@@ -698,19 +724,36 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
   if (!a.hash_xyz && p.has_xyz) a.hash_xyz = reinterpret_cast<float4*>(ws + p.off_xyz);   // 64-wide stash backward (k_field_bwd_b3q)
-  sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash) / the paired MLP backward
-  a.hash_xyz_ready = a.hash_xyz != nullptr;
-  int e = ngm_launch_stash_bwd(sb, st);
-  if (e) return fail(e, "render_bwd: unsupported geometry mode");
-  e = check_launch("ngm_stash_bwd");
-  if (e) return e;
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
+  a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
+  if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
+  // Compositing backward inside the MLP backward (k_field_bwd_b3<.., FC>): loss seeds, pointwise geometry modes, wave ranges
+  // that begin and end with a ray, and the kernel that implements it about to be chosen.  Otherwise k_stash_bwd runs first
+  // and leaves dL/d(raw outputs) in place of the forward's stash.  NGM_NO_FUSED_COMP=1: never.
+  static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
+  const bool no_fuse = no_fuse_env || g_no_fused_comp;
+  const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
+  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_aligned_bwd && bwd_b3_is_default() && a.P < (1 << 24) &&
+                    ngm_field_bwd_b3_applies(a);
+  int e = 0;
+  if (fuse) {
+    a.fused_comp = 1; a.rc = *rcfg;
+    a.rayseed = reinterpret_cast<const float*>(ws + p.off_rayseed);
+    a.loss_sums = sb.loss_sums; a.loss_partials = sb.loss_partials; a.n_partials = sb.n_partials;
+    a.sums_out = sb.sums_out; a.loss_out = sb.loss_out; a.counter = sb.counter;
+    a.hash_xyz = nullptr;
+  } else {
+    sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash) / the paired MLP backward
+    a.hash_xyz_ready = a.hash_xyz != nullptr;
+    e = ngm_launch_stash_bwd(sb, st);
+    if (e) return fail(e, "render_bwd: unsupported geometry mode");
+    e = check_launch("ngm_stash_bwd");
+    if (e) return e;
+  }
   if (neus && grads->neus_sd)
     ngm_launch_neus_sd_grad(sb.d_isd_rays, rays->F, rays->R, params->neus_sd, params->neus_sd_stride, params->field_index,
                             grads->neus_sd, st);
-  a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
-  if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;
   e = launch_bwd_any(a, a.blocks_per_field * a.F, st);

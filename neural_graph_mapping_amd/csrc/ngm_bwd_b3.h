@@ -35,8 +35,8 @@ struct LdsB3b {
   // Single buffers: the next tile's transfers are issued when all of them are free (see the tile loop).
   static constexpr int HL = 0;
   static constexpr int H1 = HT;
-  static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16]
-  static constexpr int PB = INB + 512;                               // float4 [32]
+  static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16] + (fused compositing) [2 pieces][32]
+  static constexpr int PB = INB + 768;                               // float4 [32]
   static constexpr int OB = PB + 128;                                // float4 [32]
   static constexpr int WAVE_TOTAL = OB + 128;
   static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave

@@ -358,8 +358,6 @@ int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
 // Backward of compositing + losses on the fused forward's stash.  Reads (colour, geometry | t, T),
 // overwrites stashA with dL/d(raw MLP outputs) for the MFMA backward kernel.
 // ================================================================================================
-__device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out);
-
 __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int rays_per_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t N = (int64_t)a.F * a.R;
@@ -572,18 +570,6 @@ int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
 // loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination,
 // photometric, depth, freespace, tsdf.  Empty selections contribute 0 (the reference yields NaN).
 // ================================================================================================
-__device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out) {
-  const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
-              n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
-  const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
-  const float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
-  const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : 0.f;
-  const float lf = n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : 0.f;
-  const float ls = n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : 0.f;
-  out[1] = lt; out[2] = lp; out[3] = ld; out[4] = lf; out[5] = ls;
-  out[0] = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld + rc.w_freespace * lf + rc.w_tsdf * ls;
-  out[6] = 0.f; out[7] = 0.f;
-}
 __global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   loss_values_from_sums(rc, sums, out);

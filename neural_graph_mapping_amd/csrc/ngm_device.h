@@ -440,6 +440,33 @@ __device__ __forceinline__ void seg_rscan_affine(float& A, float& B, int kr, int
   }
 }
 
+// idx / S for 0 <= idx < 2^24 by reciprocal multiplication, corrected at the segment borders
+__device__ __forceinline__ int fdiv_idx32(int idx, float inv_s, int S) {
+  int q = (int)(((float)idx + 0.5f) * inv_s);
+  if (q * S > idx) --q;
+  if ((q + 1) * S <= idx) ++q;
+  return q;
+}
+// The same over the 32 samples of a tile held by lanes 0..31 (lanes 32..63 must hold the identity A = 0, B = 1), lane
+// exchange by DPP only: row_shl inside the two 16-lane rows, then row 0 composes with lane 16's map where its segment runs
+// past lane 15.  For a wave that has its SIMD to itself (k_field_bwd_b3): five dependent ds_bpermute round trips would
+// be ~500 clocks of nothing per tile.
+#define NGM_DPP_ROW_SHL(d) (0x100 + (d))
+#define NGM_DPP_WAVE_SHL1 0x130
+__device__ __forceinline__ void seg_rscan_affine32(float& A, float& B, int kr, int lane) {
+#define NGM_RS32_STEP(d)                                                                  \
+  {                                                                                       \
+    const float oA = dpp_take<NGM_DPP_ROW_SHL(d), 0xf>(0.f, A), oB = dpp_take<NGM_DPP_ROW_SHL(d), 0xf>(1.f, B); \
+    if (kr >= (d)) { A = fmaf(B, oA, A); B = B * oB; }                                    \
+  }
+  NGM_RS32_STEP(1) NGM_RS32_STEP(2) NGM_RS32_STEP(4) NGM_RS32_STEP(8)
+#undef NGM_RS32_STEP
+  const float A16 = lane_value(A, 16), B16 = lane_value(B, 16);
+  if (lane < 16 && kr >= 16 - lane) { A = fmaf(B, A16, A); B = B * B16; }
+}
+// value of lane + 1 (lane 63 keeps `ident`)
+__device__ __forceinline__ float lane_next(float v, float ident) { return dpp_take<NGM_DPP_WAVE_SHL1, 0xf>(ident, v); }
+
 // sum over the 64 lanes (uniform result): DPP row scans, row totals carried by row_bcast, lane 63 read back
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(0.f, v);
@@ -449,6 +476,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(0.f, v);
   v += dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(0.f, v);
   return lane_value(v, 63);
+}
+
+// loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination, photometric, depth, freespace,
+// tsdf.  Empty selections contribute 0 (the reference yields NaN).
+__device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out) {
+  const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
+              n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
+  const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
+  const float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
+  const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : 0.f;
+  const float lf = n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : 0.f;
+  const float ls = n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : 0.f;
+  out[1] = lt; out[2] = lp; out[3] = ld; out[4] = lf; out[5] = ls;
+  out[0] = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld + rc.w_freespace * lf + rc.w_tsdf * ls;
+  out[6] = 0.f; out[7] = 0.f;
 }
 
 // geometry value written over samples behind the camera (rm.py:614-622)

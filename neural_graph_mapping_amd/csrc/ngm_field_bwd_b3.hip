@@ -29,7 +29,10 @@
 #include "ngm_bwd_b3.h"
 
 // ------------------------------------------------------------------------------------------------
-template <int L, bool NEED_COS, bool ENC_GRAD>
+// FC: the compositing backward of k_stash_bwd fused into the input phase (FieldBwdArgs::fused_comp): the d_out stream then
+// carries the forward's (colour, geometry) stash, every wave walks a contiguous ray-aligned range of tiles BACK TO FRONT
+// and carries the suffix value Q of the per-ray recursion Q_{k-1} = a_k o_k + (1 - o_k) Q_k from tile to tile.
+template <int L, bool NEED_COS, bool ENC_GRAD, bool FC = false>
 __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = LdsB3b<L, ENC_GRAD>;
@@ -64,9 +67,24 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   }
   dbo[0] = dbo[1] = dbo[2] = dbo[3] = 0.f;
 
-  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
-  const uint32_t first = beg + 32u * (uint32_t)wave;
+  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, bend = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
   constexpr uint32_t TSTRIDE = 32 * B3B_WAVES;
+  // this wave's tiles: tile it of ntiles starts at first + it * tstep (FC: a contiguous quarter of the block's range, last
+  // tile first; else every fourth tile of the block); samples at or beyond `end` do not exist
+  uint32_t first, end, ntiles;
+  int32_t tstep;
+  if constexpr (FC) {
+    const uint32_t wr = (uint32_t)a.per_block / B3B_WAVES, wb = min(bend, beg + (uint32_t)wave * wr);
+    end = min(bend, wb + wr);
+    ntiles = (end - wb + 31u) >> 5;
+    first = wb + 32u * (ntiles - 1u);          // unused when ntiles == 0
+    tstep = -32;
+  } else {
+    end = bend;
+    first = beg + 32u * (uint32_t)wave;
+    ntiles = first < end ? (end - first + TSTRIDE - 1u) / TSTRIDE : 0u;
+    tstep = (int32_t)TSTRIDE;
+  }
   FieldStreams fs;
   {
     const int64_t g0 = (int64_t)f * a.P;
@@ -78,10 +96,18 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     fs.act[0] = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 2048);
     fs.act[1] = reinterpret_cast<const char*>(a.act + a.act_layer_stride + (g0 >> 5) * 2048);
   }
+  const char* seeds = FC ? reinterpret_cast<const char*>(a.rayseed) + 32 * (((int64_t)f * a.P) / a.S) : nullptr;
+  // FC: the per-ray loss seeds of the tile's 32 samples, pieces 0 / 1 on the two half-waves (one more transfer per tile)
+  auto issue_seeds = [&](uint32_t n0) __attribute__((always_inline)) {
+    uint32_t n = n0 + (uint32_t)(lane & 31);
+    if (n >= end) n = end - 1;
+    dma16(seeds + 32 * (size_t)(n / (uint32_t)a.S) + 16 * (lane >> 5), wl_lds + LY::INB * 4 + 2048);
+  };
   // first tile's transfers, then the per-lane constants and the weight planes while they are in flight
-  if (first < end) {
+  if (ntiles) {
     issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
     issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+    if constexpr (FC) issue_seeds(first);
     issue_tile32(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::HL * 4);
     if (L == 2) issue_tile32(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::H1 * 4);
   }
@@ -98,9 +124,52 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
                          : make_float4(0.f, 0.f, 0.f, 0.f);
     cenc[ft] = enc_row_of(a.fc, a.pr, row, ft);
   }
+  // FC: the global loss normalisers, as in k_stash_bwd (from the all-reduced sums, or summed here by every workgroup from
+  // the forward's per-workgroup partials in k_loss_reduce's fixed order: identical everywhere, deterministic)
+  __shared__ float s_red[FC ? 16 : 1][17];
+  __shared__ float s_sums[NGM_NUM_LOSS_SUMS];
+  if constexpr (FC) {
+    if (a.loss_partials) {
+      const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
+      float s = 0.f;
+      for (int b = part; b < a.n_partials; b += 16) s += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
+      s_red[part][slot] = s;
+    }
+  }
   if (ENC_GRAD) build_dgrad_planes(a.fc, a.pr, row, 0, planes + LY::plane_slot(0) * 3 * PLANE_G);
   if (L == 2) build_dgrad_planes(a.fc, a.pr, row, 1, planes + LY::plane_slot(1) * 3 * PLANE_G);
   __syncthreads();
+  __shared__ __attribute__((aligned(16))) float s_k[8];   // FC: the five normalisers, re-read per tile (loop-long registers would spill)
+  if constexpr (FC) {
+    if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
+      float t = 0.f;
+      if (a.loss_partials) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += s_red[p][threadIdx.x];
+      } else t = a.loss_sums[threadIdx.x];
+      s_sums[threadIdx.x] = t;
+      if (blockIdx.x == 0 && a.sums_out) a.sums_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float n_m = s_sums[NGM_LS_PHOTO_CNT], n_d = s_sums[NGM_LS_DEPTH_CNT], n_t = s_sums[NGM_LS_TERM_CNT],
+                  n_fs = s_sums[NGM_LS_FS_CNT], n_ts = s_sums[NGM_LS_TSDF_CNT];
+      float k_photo = n_m > 0 ? a.rc.w_photometric / (3.0f * n_m) : 0.f;
+      if (a.rc.photometric_mode == NGM_PHOTO_L2) k_photo = 2.0f * k_photo;    // d mean(e^2): the seed carries e, not sign(e)
+      s_k[0] = k_photo;
+      s_k[1] = n_d > 0 ? a.rc.w_depth / n_d : 0.f;
+      s_k[2] = n_t > 0 ? a.rc.w_termination * 2.0f / n_t : 0.f;
+      s_k[3] = n_fs > 0 ? a.rc.w_freespace * 2.0f / n_fs : 0.f;
+      s_k[4] = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
+      if (blockIdx.x == 0) {
+        if (a.loss_partials && a.counter) *a.counter += 1ull;
+        if (a.loss_out) loss_values_from_sums(a.rc, s_sums, a.loss_out);
+      }
+    }
+    __syncthreads();
+  }
+  const float inv_s = 1.0f / (float)a.S;
+  float carryQ = 0.f;                 // FC: suffix value of the ray that continues into the next (= previous in memory) tile
 
   // lane-constant LDS offsets (floats): column element (feature 32 m + i, sample frow(r, hi)) of a tile sits at
   //   m * 1024 + (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))
@@ -112,9 +181,10 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   DMA_WAIT(0);
   TICK_DECL;
   TICK(0);
-  for (uint32_t base = first; base < end; base += TSTRIDE) {
-    const uint32_t nxt = base + TSTRIDE;
-    const bool more = nxt < end;
+  for (uint32_t it = 0; it < ntiles; ++it) {
+    const uint32_t base = first + (uint32_t)((int32_t)it * tstep);
+    const uint32_t nxt = base + (uint32_t)tstep;
+    const bool more = it + 1u < ntiles;
     float* HLb = wl + LY::HL;
     float* H1b = wl + LY::H1;
     // ---- inputs: lane = sample (both halves compute, half 0 stores)
@@ -127,7 +197,41 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       const uint32_t nc = valid ? n : end - 1;
       const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
       const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
-      const float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (FC) {
+        // k_stash_bwd's arithmetic on this tile (pointwise geometry modes, loss seeds): dd = (colour, geometry) of the
+        // forward, q0 / q1 = the ray's loss derivatives without the normalisers.  Lanes 32..63 mirror 0..31 as for the
+        // positions; in the scan they are the identity map, so a look-ahead past lane 31 composes with nothing.
+        const float4* ins = reinterpret_cast<const float4*>(inb) + 128;
+        const float4 q0 = ins[j], q1 = ins[32 + j];
+        const float4 kn = *reinterpret_cast<const float4*>(s_k);
+        const float k_photo = kn.x, k_depth = kn.y, k_term = kn.z, k_fs = kn.w, k_ts = s_k[4];
+        const float T = ((nc + fs.par) & 1u) ? sp.w : sp.y;
+        const int rayi = fdiv_idx32((int)nc, inv_s, a.S);      // nc < 2^24 (the API fuses only then)
+        const int k = (int)nc - rayi * a.S, kr = a.S - 1 - k;
+        const float dzc = r1.z, gt = r1.w, geom = dd.w;
+        const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
+        const float depth = -(dzc * t);
+        float dodg = 0.f;
+        const float occ = occ_pointwise(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
+        const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * depth + dT;
+        const bool live = valid && hi == 0;
+        float A = live ? ak * occ : 0.f, B = live ? 1.0f - occ : 1.0f;
+        seg_rscan_affine32(A, B, live ? kr : 0, lane);
+        const float Qend = (live && kr > 31 - j) ? carryQ : 0.f;
+        const float nA = lane_next(A, 0.f), nB = lane_next(B, 1.f);
+        const float Qk = (kr >= 1) ? fmaf(nB, Qend, nA) : Qend;
+        carryQ = lane_value(fmaf(B, Qend, A), 0);
+        const float tau = a.rc.truncation_distance, cf = a.rc.color_factor;
+        const float w = occ * T;
+        float dg = T * (ak - Qk) * dodg;
+        const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);
+        if (t < thr) dg += k_fs * (geom * tau - tau) * tau;
+        const float dl = gt - t;
+        if (fabsf(dl) < tau && gt != 0.0f) dg += k_ts * (geom * tau - dl) * tau;
+        if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;      // overwritten sample: no gradient reaches the MLP output
+        dout = valid ? make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       WAVE_SYNC();
       if (hi == 0) {
         *reinterpret_cast<float4*>(pbuf + 4 * j) = make_float4(x, y, z, 0.f);
@@ -279,6 +383,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     if (more) {
       issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
       issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+      if constexpr (FC) issue_seeds(nxt);
       const uint32_t u0 = nxt + fs.gb;
       if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
         issue_tile32_fast(fs.act[L - 1], u0 >> 5, lane, wl_lds + LY::HL * 4);
@@ -402,9 +507,15 @@ static int launch_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   do {                                                                                                                \
     const size_t lds = (size_t)LdsB3b<L, EG>::TOTAL * sizeof(float);                                                  \
     if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;                                                                   \
-    (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                              (int)lds);                                                                              \
-    hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);                     \
+    if (a.fused_comp) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                            \
+      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG, true>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);             \
+    } else {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                            \
+      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);                   \
+    }                                                                                                                 \
   } while (0)
   if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LBB3(false, true);
   else if (a.fc.encoding == NGM_ENC_NERF) NGM_LBB3(true, false);
@@ -413,13 +524,22 @@ static int launch_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   return 0;
 }
 
-// returns NGM_E_UNSUPPORTED when this variant does not apply (caller falls back to the fp32-MFMA kernels)
-int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a) {
   const int MI = (a.fc.dim_enc + 31) / 32, MH = (a.fc.dim_hidden + 31) / 32, L = a.fc.num_layers;
   if (!a.act || a.points || a.fc.skip_mode != NGM_SKIP_NO || a.fc.matmul_mode == NGM_MATMUL_F32 || MI != 2 || MH != 2 || L < 1 || L > 2)
-    return NGM_E_UNSUPPORTED;
-  if (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NERF && a.fc.encoding != NGM_ENC_NONE) return NGM_E_UNSUPPORTED;
-  if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
+    return false;
+  if (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NERF && a.fc.encoding != NGM_ENC_NONE) return false;
+  if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return false;   // 32-bit byte offsets inside a field
+#ifdef NGM_FAST_BUILD
+  if (L != 2) return false;
+#endif
+  return true;
+}
+// returns NGM_E_UNSUPPORTED when this variant does not apply (caller falls back to the fp32-MFMA kernels)
+int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  const int L = a.fc.num_layers;
+  if (!ngm_field_bwd_b3_applies(a)) return NGM_E_UNSUPPORTED;
+  if (a.fused_comp && (a.per_block % (4 * 32) || !a.rayseed)) return NGM_E_INVALID;
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   if (L == 2) return launch_bwd_b3<2>(a, blocks, st);
 #ifndef NGM_FAST_BUILD

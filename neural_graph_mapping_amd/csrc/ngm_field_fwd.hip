@@ -418,6 +418,21 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
           const float e = term - ra[11];
           ls[NGM_LS_TERM_SUM] += e * e; cnt_r += 1u << 20;
         }
+        if (a.rayseed) {
+          // what k_stash_bwd derives per ray from prediction and target, minus the global normalisers: e = prediction -
+          // target; L1: sign(e), L2: e (the backward multiplies by 2 k); Huber'(depth error); termination error
+          const float e0 = ra[0] - tg.x, e1 = ra[1] - tg.y, e2 = ra[2] - tg.z, ed = ra[3] - tg.w, dlt = a.rc.huber_delta;
+          const bool l2 = a.rc.photometric_mode == NGM_PHOTO_L2;
+          float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m) {
+            s0.x = l2 ? e0 : (float)((e0 > 0.f) - (e0 < 0.f)); s0.y = l2 ? e1 : (float)((e1 > 0.f) - (e1 < 0.f));
+            s0.z = l2 ? e2 : (float)((e2 > 0.f) - (e2 < 0.f));
+            s0.w = (fabsf(ed) < dlt) ? ed : dlt * (float)((ed > 0.f) - (ed < 0.f));
+          }
+          float4* o = reinterpret_cast<float4*>(a.rayseed + ray * 8);
+          o[0] = s0;
+          o[1] = make_float4((ra[10] != 0.f) ? term - ra[11] : 0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
     WAVE_SYNC();

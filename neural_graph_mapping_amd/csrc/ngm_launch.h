@@ -38,6 +38,9 @@ struct RenderFwdArgs {
   float4* stashA;         // (F*R*S): colour(3), geometry                      (train) or NULL
   float2* stashB;         // (F*R*S): t, T_exclusive
   float* loss_partials;   // (blocks, 16)
+  float* rayseed;         // (F*R, 8) train + targets: per-ray loss derivatives before the global normalisers -- d photometric /
+                          // d colour (3), d depth loss / d depth, d termination loss / d termination probability, 3 x unused --
+                          // read by the fused compositing backward (k_field_bwd_b3, FieldBwdArgs::fused_comp)
   float* act;             // hidden-activation stash [L][F*R*S][64] (train, 64-wide hidden layers) or NULL
   int64_t act_layer_stride;  // floats
   const float* neus_sd;   // neus: "_neus_sd" (N,) rows like the other parameters (field_index), else NULL
@@ -87,7 +90,18 @@ struct FieldBwdArgs {
   int64_t act_layer_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
   GradAdam lattice_adam;              // optional (tensors != NULL, num == 1): k_hash_reduce applies Adam to the hash tables
+  // Fused compositing backward (k_field_bwd_b3 only, pointwise geometry modes, loss seeds): d_out then holds the forward's
+  // (colour, geometry) stash untouched, and the kernel does what k_stash_bwd does -- per-ray reverse scan, loss derivatives,
+  // the loss bookkeeping of its block 0 -- on the tile it is about to back-propagate.  Every wave walks a contiguous,
+  // ray-aligned range of tiles back to front (per_block is a multiple of 4 lcm(32, S)).
+  int fused_comp;
+  ngm_render_cfg rc;
+  const float* rayseed;               // (F*R, 8) from the forward
+  const float* loss_sums;             // global (all-reduced) sums, or NULL -> loss_partials
+  const float* loss_partials; int n_partials;
+  float* sums_out; float* loss_out; unsigned long long* counter;   // as StashBwdArgs
 };
+bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a);   // would ngm_launch_field_bwd_b3 take this problem
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr);
 
 struct GradReduceArgs {

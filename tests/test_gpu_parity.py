@@ -742,6 +742,17 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
     ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
     from neural_graph_mapping_amd import _capi
     assert _capi.lib().ngm_debug_last_bwd_variant() == variant
+    # the split kernel also does the compositing backward (no k_stash_bwd launch) -- rays of 2, 7, 24, 31 and 128 samples
+    # against its 32-sample tiles; the fp32 kernels leave it to k_stash_bwd
+    assert _capi.lib().ngm_debug_last_comp_fused() == (1 if variant == 3 else 0)
+    if variant == 3:                                 # and the same kernel behind k_stash_bwd
+        L = _capi.lib()
+        L.ngm_debug_disable_fused_comp(1)
+        try:
+            ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
+            assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 0
+        finally:
+            L.ngm_debug_disable_fused_comp(0)
     if variant == 3 and layers == 2:                 # the experimental two-waves-per-tile kernel: same cases, same tolerances
         L = _capi.lib()
         L.ngm_debug_prefer_paired_bwd(1)
@@ -750,6 +761,42 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
             assert L.ngm_debug_last_bwd_variant() == 4
         finally:
             L.ngm_debug_prefer_paired_bwd(0)
+
+
+@pytest.mark.parametrize("geom", ["nrgbd", "occupancy", "density"])
+@pytest.mark.parametrize("photo", ["l1", "l2"])
+def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
+    """The compositing backward inside k_field_bwd_b3 against k_stash_bwd + the same kernel on one batch (8 + 16 samples,
+    rays straddling the 32-sample tiles): same loss scalars bit for bit (same sums), gradients to 1e-5 of their scale (the
+    per-ray suffix recursion is composed over 32-lane tiles instead of 64-lane steps); the density mode is not fused."""
+    from neural_graph_mapping_amd import _capi
+    L = _capi.lib()
+    F, R = 3, 40
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_mode=geom, photometric_loss=photo,
+               termination_weight=0.3, mlp_matmul="auto")
+    pos, quat, t = synth_target(F, R, seed=11)
+    r = make_renderer(fkw, ckw, F)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    tgt = make_target(t, torch.arange(F))
+    out = {}
+    for fused in (1, 0):
+        L.ngm_debug_disable_fused_comp(0 if fused else 1)
+        try:
+            res = r.optimization_iteration(tgt, seed=5, update=False)
+            torch.cuda.synchronize()
+            assert L.ngm_debug_last_bwd_variant() == 3
+            assert L.ngm_debug_last_comp_fused() == (1 if fused and geom != "density" else 0)
+            out[fused] = ({k: v.clone() for k, v in res.items() if k not in ("grads", "prediction")},
+                          {k: v.clone() for k, v in res["grads"].items()})
+        finally:
+            L.ngm_debug_disable_fused_comp(0)
+    for k, v in out[1][0].items():
+        assert torch.equal(v, out[0][0][k]), k
+    for k, v in out[1][1].items():
+        scale = float(out[0][1][k].abs().max()) + 1e-30
+        assert float((v - out[0][1][k]).abs().max()) / scale < 1e-5, k
+        assert float(v.abs().max()) > 0, k
 
 
 @pytest.mark.parametrize("enc", ["nerf", "fourier61"])

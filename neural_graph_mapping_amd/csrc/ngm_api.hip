@@ -84,6 +84,7 @@ static void prof_drain() {
   }
 }
 
+static int g_force_fused_comp = 0;    // ngm_debug_force_fused_comp: ray-aligned backward ranges whatever they cost in parallelism (tests)
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
@@ -286,6 +287,7 @@ int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float r
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_last_matmul[which] : -1; }
 int ngm_debug_last_comp_fused(void) { return g_last_comp_fused; }
+int ngm_debug_force_fused_comp(int on) { const int old = g_force_fused_comp; g_force_fused_comp = on ? 1 : 0; return old; }
 int ngm_debug_disable_fused_comp(int on) { const int old = g_no_fused_comp; g_no_fused_comp = on ? 1 : 0; return old; }
 int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 
@@ -356,22 +358,31 @@ int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   return check_launch("ngm_field_eval_fwd");
 }
 
-// S > 0 (ray mode): a workgroup's range is a multiple of 4 lcm(32, S) samples where that unit is small -- every wave's quarter
-// of it then begins and ends with a ray AND a 32-sample tile, which is what the fused compositing backward of
-// k_field_bwd_b3 needs (*ray_aligned says whether it holds); other kernels only need the multiple of 128.
-static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int S = 0, int* ray_aligned = nullptr) {
+// S > 0 (ray mode): where it costs no parallelism (at most a quarter fewer workgroups than the plain multiple of 128), a
+// workgroup's range is a multiple of 8 lcm(32, S) samples -- every wave's quarter / eighth of it then begins and ends with a
+// ray AND a 32-sample tile, which is what the compositing backward fused into k_field_bwd_b3 (4 waves) / k_hash_mlp_bwd
+// (8 waves) needs.  *ray_unit = lcm(32, S) if that holds, else 0 (small batches: k_stash_bwd runs, the MLP backward keeps
+// its fine-grained split -- F = 1 x 512 rays x 24 samples: 96 workgroups against 16).
+static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int S = 0, int* ray_unit = nullptr) {
   const int ncu = num_cus();
   int64_t b = (ncu + F - 1) / F;
-  int64_t unit = 32 * NGM_WAVES_PER_BLOCK;
-  if (ray_aligned) *ray_aligned = 0;
+  const int64_t unit = 32 * NGM_WAVES_PER_BLOCK;
+  int64_t per = align_up((P + b - 1) / b, unit);
+  if (per < unit) per = unit;
+  if (ray_unit) *ray_unit = 0;
   if (S > 0) {
     int64_t g = 32, s = S;
     while (s) { const int64_t r = g % s; g = s; s = r; }          // gcd(32, S)
-    const int64_t u = 4 * (32 / g) * S;                             // 4 lcm(32, S)
-    if (u <= 4096) { unit = u; if (ray_aligned) *ray_aligned = 1; }
+    const int64_t lcm = (32 / g) * S;
+    for (int waves : {8, 4}) {
+      const int64_t per_ray = align_up(per, waves * lcm);
+      if (waves * lcm <= 8192 && (per_ray * 4 <= per * 5 || g_force_fused_comp)) {
+        per = per_ray;
+        if (ray_unit) *ray_unit = (int)lcm;
+        break;
+      }
+    }
   }
-  int64_t per = align_up((P + b - 1) / b, unit);
-  if (per < unit) per = unit;
   *per_block = per;
   *bpf = (int)((P + per - 1) / per);
 }
@@ -491,7 +502,7 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 struct RenderPlan {
   int S, rays_per_block, blocks_fwd, waves_fwd, maxs, b3;
   int64_t per_block_bwd; int blocks_per_field_bwd;
-  int ray_aligned_bwd;             // the backward's wave ranges begin and end with a ray (plan_bwd)
+  int ray_unit_bwd;                // lcm(32, S) when per_block_bwd is a multiple of 4 (or 8) of it, else 0 (plan_bwd)
   int64_t p_pad;
   int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
@@ -585,7 +596,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
       p.off_dout = o; o = align_up(o + NS * 16, 256);
       p.off_disd = o; o = align_up(o + NR * 4, 256);
     }
-    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd, p.S, &p.ray_aligned_bwd);
+    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd, p.S, &p.ray_unit_bwd);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
     const int kind = act_stash_kind(fc);
@@ -734,7 +745,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
   const bool no_fuse = no_fuse_env || g_no_fused_comp;
   const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
-  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_aligned_bwd && bwd_b3_is_default() && a.P < (1 << 24) &&
+  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_unit_bwd && p.per_block_bwd % (4 * p.ray_unit_bwd) == 0 && bwd_b3_is_default() && a.P < (1 << 24) &&
                     ngm_field_bwd_b3_applies(a);
   int e = 0;
   if (fuse) {

@@ -662,6 +662,20 @@ def test_full_size_properties_m1():
     assert torch.equal(b["prediction"].rgbds, pred_a)
     for k in pa:
         assert torch.equal(b["grads"][k], pa[k]), k
+    # at this size the default plan is ray-aligned: the split backward did the compositing backward itself (no k_stash_bwd
+    # launch); the same step behind k_stash_bwd: same loss scalars bit for bit, gradients to 1e-5 of their scale
+    from neural_graph_mapping_amd import _capi
+    Lc = _capi.lib()
+    assert Lc.ngm_debug_last_bwd_variant() == 3 and Lc.ngm_debug_last_comp_fused() == 1
+    Lc.ngm_debug_disable_fused_comp(1)
+    try:
+        u = r.optimization_iteration(tgt, seed=11, update=False)
+        assert Lc.ngm_debug_last_bwd_variant() == 3 and Lc.ngm_debug_last_comp_fused() == 0
+        assert torch.equal(u["combined"], b["combined"]) and torch.equal(u["prediction"].rgbds, pred_a)
+        for k in pa:
+            grad_close(u["grads"][k], pa[k], 1e-5, "separate compositing backward " + k)
+    finally:
+        Lc.ngm_debug_disable_fused_comp(0)
     # field permutation equivariance (fields are independent; only the global loss counts couple them)
     perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
     tp = {k: v[perm] for k, v in t.items()}
@@ -742,17 +756,19 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
     ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
     from neural_graph_mapping_amd import _capi
     assert _capi.lib().ngm_debug_last_bwd_variant() == variant
-    # the split kernel also does the compositing backward (no k_stash_bwd launch) -- rays of 2, 7, 24, 31 and 128 samples
-    # against its 32-sample tiles; the fp32 kernels leave it to k_stash_bwd
-    assert _capi.lib().ngm_debug_last_comp_fused() == (1 if variant == 3 else 0)
-    if variant == 3:                                 # and the same kernel behind k_stash_bwd
+    # batches this small keep k_stash_bwd where ray-aligned ranges would leave fewer workgroups (all but the 1 + 1-sample case,
+    # whose rays tile 32 samples anyway)
+    assert _capi.lib().ngm_debug_last_comp_fused() == (1 if (variant == 3 and n_c + n_g == 2) else 0)
+    if variant == 3:
+        # ... unless told otherwise: the split kernel doing the compositing backward itself -- rays of 2, 7, 24, 31 and 128
+        # samples against its 32-sample tiles, partial last tiles, fields starting in the middle of a stash tile
         L = _capi.lib()
-        L.ngm_debug_disable_fused_comp(1)
+        L.ngm_debug_force_fused_comp(1)
         try:
             ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
-            assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 0
+            assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 1
         finally:
-            L.ngm_debug_disable_fused_comp(0)
+            L.ngm_debug_force_fused_comp(0)
     if variant == 3 and layers == 2:                 # the experimental two-waves-per-tile kernel: same cases, same tolerances
         L = _capi.lib()
         L.ngm_debug_prefer_paired_bwd(1)
@@ -768,7 +784,8 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
 def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
     """The compositing backward inside k_field_bwd_b3 against k_stash_bwd + the same kernel on one batch (8 + 16 samples,
     rays straddling the 32-sample tiles): same loss scalars bit for bit (same sums), gradients to 1e-5 of their scale (the
-    per-ray suffix recursion is composed over 32-lane tiles instead of 64-lane steps); the density mode is not fused."""
+    per-ray suffix recursion is composed over 32-lane tiles instead of 64-lane steps); the density mode is not fused.
+    A batch large enough for the default plan to fuse is covered by the M1 train-step tests below."""
     from neural_graph_mapping_amd import _capi
     L = _capi.lib()
     F, R = 3, 40
@@ -780,17 +797,19 @@ def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     tgt = make_target(t, torch.arange(F))
     out = {}
-    for fused in (1, 0):
-        L.ngm_debug_disable_fused_comp(0 if fused else 1)
-        try:
+    L.ngm_debug_force_fused_comp(1)                  # a small batch: the default plan would keep k_stash_bwd
+    try:
+        for fused in (1, 0):
+            L.ngm_debug_disable_fused_comp(0 if fused else 1)
             res = r.optimization_iteration(tgt, seed=5, update=False)
             torch.cuda.synchronize()
             assert L.ngm_debug_last_bwd_variant() == 3
             assert L.ngm_debug_last_comp_fused() == (1 if fused and geom != "density" else 0)
             out[fused] = ({k: v.clone() for k, v in res.items() if k not in ("grads", "prediction")},
                           {k: v.clone() for k, v in res["grads"].items()})
-        finally:
-            L.ngm_debug_disable_fused_comp(0)
+    finally:
+        L.ngm_debug_disable_fused_comp(0)
+        L.ngm_debug_force_fused_comp(0)
     for k, v in out[1][0].items():
         assert torch.equal(v, out[0][0][k]), k
     for k, v in out[1][1].items():

@@ -118,9 +118,9 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   int e = (force32 || no_b3 || !try_b3q || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3q(a, blocks, st);
   g_last_bwd_variant = 4;
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
-  g_last_comp_fused = (a.fused_comp && e == 0) ? 1 : 0;
-  if (a.fused_comp && e) return e ? e : NGM_E_UNSUPPORTED;      // no other kernel composites: never fall through
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
+  g_last_comp_fused = (a.fused_comp && e == 0) ? 1 : 0;
+  if (a.fused_comp && e) return e;                              // no other kernel composites: never fall through
   if (e == NGM_E_UNSUPPORTED && !force32 && a.act) { e = ngm_launch_field_bwd16s(a, blocks, st); g_last_bwd_variant = 2; }
   if (e == NGM_E_UNSUPPORTED && !force32) { e = ngm_launch_field_bwd16(a, blocks, st); g_last_bwd_variant = 1; }
   if (e == NGM_E_UNSUPPORTED) { e = ngm_launch_field_bwd(a, blocks, st); g_last_bwd_variant = 0; }
@@ -745,15 +745,16 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
   const bool no_fuse = no_fuse_env || g_no_fused_comp;
   const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
-  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_unit_bwd && p.per_block_bwd % (4 * p.ray_unit_bwd) == 0 && bwd_b3_is_default() && a.P < (1 << 24) &&
-                    ngm_field_bwd_b3_applies(a);
+  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_unit_bwd && bwd_b3_is_default() && a.P < (1 << 24) &&
+                    ((p.per_block_bwd % (4 * p.ray_unit_bwd) == 0 && ngm_field_bwd_b3_applies(a)) ||
+                     (p.per_block_bwd % (8 * p.ray_unit_bwd) == 0 && ngm_hash_mlp_bwd_applies(a)));
   int e = 0;
   if (fuse) {
     a.fused_comp = 1; a.rc = *rcfg;
     a.rayseed = reinterpret_cast<const float*>(ws + p.off_rayseed);
     a.loss_sums = sb.loss_sums; a.loss_partials = sb.loss_partials; a.n_partials = sb.n_partials;
     a.sums_out = sb.sums_out; a.loss_out = sb.loss_out; a.counter = sb.counter;
-    a.hash_xyz = nullptr;
+    // (hash encoding: k_hash_mlp_bwd writes the positions k_hash_grad needs into a.hash_xyz itself)
   } else {
     sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash) / the paired MLP backward
     a.hash_xyz_ready = a.hash_xyz != nullptr;

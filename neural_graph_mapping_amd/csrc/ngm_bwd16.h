@@ -74,6 +74,19 @@ __device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint3
       : "v"(voff), "s"(sbase), "s"(lds_base)
       : "memory");
 }
+// the same without the non-temporal hint: rows many lanes (and neighbouring tiles) read again
+__device__ __forceinline__ void dma16_so_c(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
 #define DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 // Per-field bases (wave-uniform) of everything the tile loop streams in; sample indices inside the loop are

@@ -97,11 +97,12 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     fs.act[1] = reinterpret_cast<const char*>(a.act + a.act_layer_stride + (g0 >> 5) * 2048);
   }
   const char* seeds = FC ? reinterpret_cast<const char*>(a.rayseed) + 32 * (((int64_t)f * a.P) / a.S) : nullptr;
+  const float inv_s = 1.0f / (float)a.S;
   // FC: the per-ray loss seeds of the tile's 32 samples, pieces 0 / 1 on the two half-waves (one more transfer per tile)
   auto issue_seeds = [&](uint32_t n0) __attribute__((always_inline)) {
     uint32_t n = n0 + (uint32_t)(lane & 31);
     if (n >= end) n = end - 1;
-    dma16(seeds + 32 * (size_t)(n / (uint32_t)a.S) + 16 * (lane >> 5), wl_lds + LY::INB * 4 + 2048);
+    dma16_so_c(seeds, 32u * (uint32_t)fdiv_idx32((int)n, inv_s, a.S) + 16u * (uint32_t)(lane >> 5), wl_lds + LY::INB * 4 + 2048);
   };
   // first tile's transfers, then the per-lane constants and the weight planes while they are in flight
   if (ntiles) {
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     }
     __syncthreads();
   }
-  const float inv_s = 1.0f / (float)a.S;
   float carryQ = 0.f;                 // FC: suffix value of the ray that continues into the next (= previous in memory) tile
 
   // lane-constant LDS offsets (floats): column element (feature 32 m + i, sample frow(r, hi)) of a tile sits at

@@ -36,7 +36,8 @@ struct LdsHB {
   static constexpr int CONSTS = PLANES;                      // float4 wout[32], float b0[32]
   static constexpr int WAVES = CONSTS + 192;
   static constexpr int ET = 0, DT = 1024, OB = 2048;         // per wave: encoding tile, dY scratch tile, d_out rows (64 x float4: the
-  static constexpr int WAVE_TOTAL = 2048 + 256;              // DMA instruction moves 64 x 16 bytes)
+  static constexpr int WAVE_TOTAL = 2048 + 768;              // DMA instruction moves 64 x 16 bytes); fused compositing: three such
+                                                             // blocks [stash row | (t, T) pair], [ray entry 0 | 1], [loss seeds 0 | 1]
   static constexpr int BODY = WAVES + HB_WAVES * WAVE_TOTAL;
   static constexpr int EPI = HB_WAVES * 1024 + HB_WAVES * 9 * 64;
   static constexpr int TOTAL = BODY > EPI ? BODY : EPI;
@@ -54,6 +55,10 @@ __device__ __forceinline__ void hb_issue_tile(const char* sbase, uint32_t gb, ui
   }
 }
 
+// FC: the compositing backward of k_stash_bwd fused in (FieldBwdArgs::fused_comp, as in k_field_bwd_b3): d_out carries the
+// forward's (colour, geometry) stash, every wave walks a contiguous ray-aligned range of tiles back to front carrying the
+// suffix value of the per-ray recursion, and writes the scaled sample positions k_hash_grad searches the simplices of.
+template <bool FC>
 __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = LdsHB;
@@ -77,17 +82,44 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float dbh = 0.f, dwo[4] = {0.f, 0.f, 0.f, 0.f}, dbo[4] = {0.f, 0.f, 0.f, 0.f};
 
-  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, end = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
-  const uint32_t first = beg + 32u * (uint32_t)wave;
+  const uint32_t beg = (uint32_t)chunk * (uint32_t)a.per_block, bend = (uint32_t)min(a.P, (int64_t)beg + a.per_block);
   constexpr uint32_t TSTRIDE = 32 * HB_WAVES;
+  uint32_t first, end, ntiles;
+  int32_t tstep;
+  if constexpr (FC) {
+    const uint32_t wr = (uint32_t)a.per_block / HB_WAVES, wb = min(bend, beg + (uint32_t)wave * wr);
+    end = min(bend, wb + wr);
+    ntiles = (end - wb + 31u) >> 5;
+    first = wb + 32u * (ntiles - 1u);
+    tstep = -32;
+  } else {
+    end = bend;
+    first = beg + 32u * (uint32_t)wave;
+    ntiles = first < end ? (end - first + TSTRIDE - 1u) / TSTRIDE : 0u;
+    tstep = (int32_t)TSTRIDE;
+  }
   const int64_t g0 = (int64_t)f * a.P;
   const uint32_t gb = (uint32_t)(g0 & 31);
   const char* act = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 1024);
   const char* dout = reinterpret_cast<const char*>(a.d_out + g0);
+  const char* tpair = reinterpret_cast<const char*>(a.stashB + (g0 & ~(int64_t)1));
+  const uint32_t par = (uint32_t)(g0 & 1);
+  const char* raytab = reinterpret_cast<const char*>(a.raytab) + 32 * (g0 / a.S);
+  const char* seeds = FC ? reinterpret_cast<const char*>(a.rayseed) + 32 * (g0 / a.S) : nullptr;
+  const float inv_s = 1.0f / (float)a.S;
   auto issue = [&](uint32_t n0) __attribute__((always_inline)) {
     uint32_t n = n0 + (uint32_t)i;                                     // both halves fetch the 32 rows: the transfer is 64 x 16 bytes
     if (n >= end) n = end - 1;
-    dma16(dout + 16 * (size_t)n, wl_lds + LY::OB * 4);
+    if constexpr (FC) {
+      // wave-uniform bases + 32-bit lane offsets (per-lane 64-bit pointers kept across the loop were spilled, and a scratch
+      // reload between two transfers waits for the first to land)
+      const uint32_t ray = (uint32_t)fdiv_idx32((int)n, inv_s, a.S);
+      dma16(hi ? tpair + 8 * (size_t)((n + par) & ~1u) : dout + 16 * (size_t)n, wl_lds + LY::OB * 4);
+      dma16_so_c(raytab, 32u * ray + 16u * (uint32_t)hi, wl_lds + LY::OB * 4 + 1024);
+      dma16_so_c(seeds, 32u * ray + 16u * (uint32_t)hi, wl_lds + LY::OB * 4 + 2048);
+    } else {
+      dma16(dout + 16 * (size_t)n, wl_lds + LY::OB * 4);
+    }
     const uint32_t u0 = n0 + gb;
     if (((u0 & 31u) == 0u) && (n0 + 32u <= end)) {                     // whole tile, aligned with the stash tiles: one linear 4 KB copy
       const char* b0 = act + (size_t)__builtin_amdgcn_readfirstlane(u0 >> 5) * 4096;
@@ -96,7 +128,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
       hb_issue_tile(act, gb, n0, end, lane, wl_lds + LY::ET * 4);
     }
   };
-  if (first < end) issue(first);
+  if (ntiles) issue(first);
   // weight planes + per-unit constants while the first tile travels
   {
     const float* W = a.pr.w[0];
@@ -128,7 +160,48 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
       cb0[ft] = (ft < H) ? ngm_ldp(a.pr.b[0], row * a.pr.b_stride[0] + ft, a.pr.dtype) : 0.f;
     }
   }
+  // FC: the global loss normalisers, as in k_stash_bwd / k_field_bwd_b3
+  __shared__ float s_red[FC ? 16 : 1][17];
+  __shared__ float s_sums[NGM_NUM_LOSS_SUMS];
+  __shared__ __attribute__((aligned(16))) float s_k[8];
+  if constexpr (FC) {
+    if (a.loss_partials && threadIdx.x < 256) {
+      const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
+      float sacc = 0.f;
+      for (int b = part; b < a.n_partials; b += 16) sacc += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
+      s_red[part][slot] = sacc;
+    }
+  }
   __syncthreads();
+  if constexpr (FC) {
+    if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
+      float t = 0.f;
+      if (a.loss_partials) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += s_red[p][threadIdx.x];
+      } else t = a.loss_sums[threadIdx.x];
+      s_sums[threadIdx.x] = t;
+      if (blockIdx.x == 0 && a.sums_out) a.sums_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float n_m = s_sums[NGM_LS_PHOTO_CNT], n_d = s_sums[NGM_LS_DEPTH_CNT], n_t = s_sums[NGM_LS_TERM_CNT],
+                  n_fs = s_sums[NGM_LS_FS_CNT], n_ts = s_sums[NGM_LS_TSDF_CNT];
+      float k_photo = n_m > 0 ? a.rc.w_photometric / (3.0f * n_m) : 0.f;
+      if (a.rc.photometric_mode == NGM_PHOTO_L2) k_photo = 2.0f * k_photo;
+      s_k[0] = k_photo;
+      s_k[1] = n_d > 0 ? a.rc.w_depth / n_d : 0.f;
+      s_k[2] = n_t > 0 ? a.rc.w_termination * 2.0f / n_t : 0.f;
+      s_k[3] = n_fs > 0 ? a.rc.w_freespace * 2.0f / n_fs : 0.f;
+      s_k[4] = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
+      if (blockIdx.x == 0) {
+        if (a.loss_partials && a.counter) *a.counter += 1ull;
+        if (a.loss_out) loss_values_from_sums(a.rc, s_sums, a.loss_out);
+      }
+    }
+    __syncthreads();
+  }
+  float carryQ = 0.f;
 
   // lane-constant LDS offsets (floats): element (feature i, sample frow(r, hi)) of a tile sits at
   //   (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))
@@ -143,9 +216,57 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
 
   DMA_WAIT(0);
   WAVE_SYNC();
-  for (uint32_t base = first; base < end; base += TSTRIDE) {
-    const uint32_t nxt = base + TSTRIDE;
-    if (base + 32u > end) {                     // last, partial tile: rows past the end carry no gradient
+  for (uint32_t it = 0; it < ntiles; ++it) {
+    const uint32_t base = first + (uint32_t)((int32_t)it * tstep);
+    const uint32_t nxt = base + (uint32_t)tstep;
+    const bool more = it + 1u < ntiles;
+    if constexpr (FC) {
+      // ---- k_stash_bwd's arithmetic on this tile, lane = sample (lanes 32..63 mirror 0..31 and are the identity of the
+      // scan); the stash rows in `ob` are replaced by dL/d(raw outputs), which is what the rest of the tile reads there
+      const float4* blk = reinterpret_cast<const float4*>(ob);
+      const float4 dd = blk[i], sp = blk[32 + i], r0 = blk[64 + i], r1 = blk[96 + i], q0 = blk[128 + i], q1 = blk[160 + i];
+      const uint32_t n = base + (uint32_t)i;
+      const bool valid = n < end;
+      const uint32_t nc = valid ? n : end - 1;
+      const bool odd = ((nc + par) & 1u) != 0u;
+      const float t = odd ? sp.z : sp.x, T = odd ? sp.w : sp.y;
+      const int rayi = fdiv_idx32((int)nc, inv_s, a.S);
+      const int k = (int)nc - rayi * a.S, kr = a.S - 1 - k;
+      const float4 kn = *reinterpret_cast<const float4*>(s_k);
+      const float k_photo = kn.x, k_depth = kn.y, k_term = kn.z, k_fs = kn.w, k_ts = s_k[4];
+      const float dzc = r1.z, gt = r1.w, geom = dd.w;
+      const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
+      const float depth = -(dzc * t);
+      float dodg = 0.f;
+      const float occ = occ_pointwise(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
+      const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * depth + dT;
+      const bool live = valid && hi == 0;
+      float A = live ? ak * occ : 0.f, B = live ? 1.0f - occ : 1.0f;
+      seg_rscan_affine32(A, B, live ? kr : 0, lane);
+      const float Qend = (live && kr > 31 - i) ? carryQ : 0.f;
+      const float nA = lane_next(A, 0.f), nB = lane_next(B, 1.f);
+      const float Qk = (kr >= 1) ? fmaf(nB, Qend, nA) : Qend;
+      carryQ = lane_value(fmaf(B, Qend, A), 0);
+      const float tau = a.rc.truncation_distance, cf = a.rc.color_factor;
+      const float w = occ * T;
+      float dg = T * (ak - Qk) * dodg;
+      const float thr = (gt - tau) * (gt != 0.0f ? 1.0f : 0.0f);
+      if (t < thr) dg += k_fs * (geom * tau - tau) * tau;
+      const float dl = gt - t;
+      if (fabsf(dl) < tau && gt != 0.0f) dg += k_ts * (geom * tau - dl) * tau;
+      if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;
+      const float4 dv = valid ? make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      WAVE_SYNC();                               // every lane has read its rows
+      if (hi == 0) {
+        *reinterpret_cast<float4*>(ob + 4 * i) = dv;
+        if (valid) {                             // the position k_hash_grad searches the simplex of (the forward's own fmaf)
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          const v4f pxyz = {fmaf(t, r0.w, r0.x), fmaf(t, r1.x, r0.y), fmaf(t, r1.y, r0.z), 0.f};
+          __builtin_nontemporal_store(pxyz, reinterpret_cast<v4f*>(a.hash_xyz + g0 + n));
+        }
+      }
+      WAVE_SYNC();
+    } else if (base + 32u > end) {              // last, partial tile: rows past the end carry no gradient
       if (base + (uint32_t)lane >= end && lane < 32) {
         float z = 0.f;
         asm volatile("" : "+v"(z));              // materialised here (hoisted out of the loop it was spilled to scratch)
@@ -223,7 +344,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
     }
     WAVE_SYNC();
     // ---- the next tile's transfers: every landing buffer has been read, no LDS instruction follows until the wait
-    if (nxt < end) issue(nxt);
+    if (more) issue(nxt);
     __builtin_amdgcn_sched_barrier(0);
     // ---- weight gradient: dW0[o][i] += sum_s dY[s][o] E[s][i], both operands lane = feature
 #pragma unroll
@@ -257,7 +378,10 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
     }
     if (base + (uint32_t)i < end) {
       // lane-dependent part of the address once (sample, the half's first level); the eight (q, p) offsets are wave-uniform
-      float2* dst = a.hash_dE + (g0 + base + i) + (int64_t)(2 * hi) * NP;
+      int li = i, lh = hi;
+      asm volatile("" : "+v"(li), "+v"(lh));       // re-derived per tile: hoisted, the 64-bit lane part of the address was
+                                                    // spilled and its reload waited for the transfers issued above
+      float2* dst = a.hash_dE + (g0 + base + li) + (int64_t)(2 * lh) * NP;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -321,16 +445,25 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
   }
 }
 
-// returns NGM_E_UNSUPPORTED when this kernel does not apply (caller falls back to k_field_bwd16)
-int ngm_launch_hash_mlp_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+bool ngm_hash_mlp_bwd_applies(const FieldBwdArgs& a) {
   if (a.fc.encoding != NGM_ENC_PERMUTO || !a.act || a.points || !a.raytab || !a.stashB || a.fc.skip_mode != NGM_SKIP_NO ||
       a.fc.matmul_mode == NGM_MATMUL_F32 || a.fc.num_layers != 1 || a.fc.dim_enc > 32 || a.fc.dim_hidden > 32 || a.fc.dim_enc <= 16 ||
-      a.fc.dim_out != 4 || !a.hash_dE || !a.hash_xyz_ready)
-    return NGM_E_UNSUPPORTED;
-  if ((a.P + 64) * 128 >= ((int64_t)1 << 32)) return NGM_E_UNSUPPORTED;   // 32-bit byte offsets inside a field
+      a.fc.dim_out != 4 || !a.hash_dE)
+    return false;
+  return (a.P + 64) * 128 < ((int64_t)1 << 32);     // 32-bit byte offsets inside a field
+}
+// returns NGM_E_UNSUPPORTED when this kernel does not apply (caller falls back to k_field_bwd16)
+int ngm_launch_hash_mlp_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st) {
+  if (!ngm_hash_mlp_bwd_applies(a)) return NGM_E_UNSUPPORTED;
+  if (a.fused_comp ? (!a.rayseed || !a.hash_xyz || a.per_block % (HB_WAVES * 32)) : !a.hash_xyz_ready) return NGM_E_UNSUPPORTED;
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   const size_t lds = (size_t)LdsHB::TOTAL * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)k_hash_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_hash_mlp_bwd, dim3(blocks), dim3(HB_THREADS), lds, st, a);
+  if (a.fused_comp) {
+    (void)hipFuncSetAttribute((const void*)k_hash_mlp_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_hash_mlp_bwd<true>, dim3(blocks), dim3(HB_THREADS), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_hash_mlp_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_hash_mlp_bwd<false>, dim3(blocks), dim3(HB_THREADS), lds, st, a);
+  }
   return 0;
 }

@@ -102,6 +102,7 @@ struct FieldBwdArgs {
   float* sums_out; float* loss_out; unsigned long long* counter;   // as StashBwdArgs
 };
 bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a);   // would ngm_launch_field_bwd_b3 take this problem
+bool ngm_hash_mlp_bwd_applies(const FieldBwdArgs& a);   // would ngm_launch_hash_mlp_bwd (given positions, or fused_comp)
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr);
 
 struct GradReduceArgs {

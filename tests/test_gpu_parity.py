@@ -948,12 +948,26 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("mm", ["auto", "f32"])
+@pytest.mark.parametrize("mm", ["auto", "f32", "auto-fused"])
 @pytest.mark.parametrize("F,R,n_c,n_g", [(3, 40, 8, 16), (1, 9, 4, 4), (2, 33, 3, 2), (5, 7, 8, 16), (3, 130, 20, 4)])
 def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g, mm):
     """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP; ragged shapes put
     field starts in the middle of the 32-sample tiles of the encoding stash and leave partial tiles.  Both backward
-    kernels: k_hash_mlp_bwd (bf16 split, `auto`) and k_field_bwd16 (fp32 MFMA, `mlp_matmul: f32`)."""
+    kernels: k_hash_mlp_bwd (bf16 split, `auto`) and k_field_bwd16 (fp32 MFMA, `mlp_matmul: f32`); `auto-fused`:
+    k_hash_mlp_bwd doing the compositing backward and the positions of k_hash_grad itself (no k_stash_bwd launch), which
+    the default plan reserves for batches where ray-aligned ranges cost no parallelism."""
+    forced = mm == "auto-fused"
+    if forced:
+        mm = "auto"
+        K.lib().ngm_debug_force_fused_comp(1)
+    try:
+        _permuto_train_case(F, R, n_c, n_g, mm)
+        assert K.lib().ngm_debug_last_comp_fused() == (1 if forced else 0)
+    finally:
+        K.lib().ngm_debug_force_fused_comp(0)
+
+
+def _permuto_train_case(F, R, n_c, n_g, mm):
     torch.manual_seed(5)
     fs = O.FieldSpec(num_layers=1, **PERMUTO)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)

@@ -423,7 +423,8 @@ def main():
         if args.exchange == "peer":
             r.peer_exchange = D.PeerExchange.try_create(torch.distributed.group.WORLD, dev)
 
-    # the whole iteration (6 kernels) is captured once into a hipGraph and replayed;
+    # the whole iteration (3 kernels on the split path: fused forward, MLP backward incl. the compositing backward,
+    # gradient reduction + Adam) is captured once into a hipGraph and replayed;
     # the Adam step counter and the Philox jitter offset advance on the device inside the graph.
     # multi-GPU: two graphs around the loss all-reduce (renderer.capture_iteration); --eager launches every kernel
     use_graph = not args.eager
@@ -551,7 +552,11 @@ def main():
                      3: "k_field_bwd_b3<2> (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash)",
                      4: "k_field_bwd_b3p (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash, "
                         "a tile's two hidden layers on two waves)"}.get(variant, "?")
-            res["roofline"] = dict(bound="mfma", kernel=kname, achieved=achieved,
+            fused_comp = bool(L.ngm_debug_last_comp_fused())
+            if fused_comp:
+                kname += " + the compositing backward of each tile (what k_stash_bwd did in a launch of its own: +7 % kernel time, " \
+                         "-17 us per step)"
+            res["roofline"] = dict(bound="mfma", kernel=kname, fused_compositing_backward=fused_comp, achieved=achieved,
                                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
                                    traffic=traffic, traffic_source=traffic_src, avg_launch_us=fb["avg_us"],
                                    launches_timed=fb["launches"],

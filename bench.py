@@ -549,9 +549,7 @@ def main():
             kname = {0: "k_field_bwd<2,2,2> (v_mfma_f32_32x32x2_f32, forward recompute)",
                      1: "k_field_bwd16<4,4,2> (v_mfma_f32_16x16x4_f32, forward recompute)",
                      2: "k_field_bwd16s<2> (v_mfma_f32_16x16x4_f32, activations from the forward's stash)",
-                     3: "k_field_bwd_b3<2> (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash)",
-                     4: "k_field_bwd_b3p (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash, "
-                        "a tile's two hidden layers on two waves)"}.get(variant, "?")
+                     3: "k_field_bwd_b3<2> (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash)"}.get(variant, "?")
             fused_comp = bool(L.ngm_debug_last_comp_fused())
             if fused_comp:
                 kname += " + the compositing backward of each tile (what k_stash_bwd did in a launch of its own: +7 % kernel time, " \
@@ -562,7 +560,7 @@ def main():
                                    launches_timed=fb["launches"],
                                    timing="HIP events on the launch stream, instrumented pass of the same steps",
                                    algorithmic_flop_per_launch=FLOP_BWD * n_local)
-            if variant in (3, 4):    # both fractions, as for the forward: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
+            if variant == 3:    # both fractions, as for the forward: algorithmic fp32 flops / fp32 peak, issued bf16 flops / bf16 peak
                 issued_b = 6 * 2 * 4 * (64 * 64) * n_local         # weight + data gradient of both 64x64 layers, six bf16 products each
                 res["roofline"].update(issued_bf16_tflops=issued_b / (fb["avg_us"] * 1e-6) / 1e12, peak_bf16=2500.0,
                                        frac_bf16=issued_b / (fb["avg_us"] * 1e-6) / 1e12 / 2500.0,

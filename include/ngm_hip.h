@@ -472,18 +472,13 @@ int ngm_debug_fwd_phase_cycles(unsigned long long* out528);   /* 16 summary slot
 /* Debug: which MLP backward kernel the last ngm_render_bwd* / ngm_field_eval_bwd call launched:
  * 0 = k_field_bwd (32-sample tiles, forward recompute), 1 = k_field_bwd16 (16-sample tiles, recompute),
  * 2 = k_field_bwd16s (16-sample tiles, hidden activations read from the forward's stash), 3 = k_field_bwd_b3 (three-way
- * bf16 split, 32-sample tiles, stash), 4 = k_field_bwd_b3q (the same with a tile's two hidden layers on the two waves of
- * a SIMD; opt-in), 5 = k_hash_mlp_bwd (hash
+ * bf16 split, 32-sample tiles, stash), 5 = k_hash_mlp_bwd (hash
  * encoding + one hidden layer of <= 32 units, three-way bf16 split, encoding stash), -1 = none yet. */
 int ngm_debug_last_bwd_variant(void);
 /* Debug: the arithmetic the last launch of a forward-type kernel resolved ngm_field_cfg.matmul_mode to (AUTO is resolved
  * per kernel and batch shape): which = 0 fused render forward (ngm_render_fwd), 1 point evaluation (ngm_field_eval_fwd),
  * 2 kNN evaluation (ngm_field_eval_knn).  Returns NGM_MATMUL_F32 or NGM_MATMUL_BF16X3, -1 before the first launch. */
 int ngm_debug_last_matmul(int which);
-/* Experiments: 1 = try k_field_bwd_b3q (a tile's two hidden layers on the two waves of a SIMD, 8 waves per workgroup;
- * correct, measured equal to k_field_bwd_b3 within the pool's noise in round 3: DESIGN 3.10) before the default order;
- * 0 = default.  Returns the previous setting.  Environment: NGM_BWD_B3Q=1. */
-int ngm_debug_prefer_paired_bwd(int on);
 /* Debug: 1 when the last ngm_render_bwd / ngm_render_bwd_adam ran the compositing backward inside k_field_bwd_b3 (loss
  * seeds, pointwise geometry modes, ray-aligned wave ranges; no k_stash_bwd launch, the forward's colour / geometry stash
  * stays intact), 0 when k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */

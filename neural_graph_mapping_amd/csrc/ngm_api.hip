@@ -94,13 +94,12 @@ static int fail(int code, const char* msg) {
 static unsigned long long* g_debug_cycles = nullptr;
 int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile, 5: hash encoding + 1x32 MLP on the bf16 split
-static int g_prefer_paired_bwd = 0;
 static int g_no_fused_comp = 0;       // ngm_debug_disable_fused_comp
 static int g_last_comp_fused = 0;     // the last training backward did the compositing backward inside k_field_bwd_b3 (no k_stash_bwd launch)
 // true when launch_bwd_any's first candidate is k_field_bwd_b3 (no experiment switch in the way)
 static bool bwd_b3_is_default() {
-  static const bool off = getenv("NGM_BWD32") != nullptr || getenv("NGM_NO_BWD_B3") != nullptr || getenv("NGM_BWD_B3Q") != nullptr;
-  return !off && !g_prefer_paired_bwd;
+  static const bool off = getenv("NGM_BWD32") != nullptr || getenv("NGM_NO_BWD_B3") != nullptr;
+  return !off;
 }
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
@@ -113,10 +112,7 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   // order of preference: stashed activations (no forward recompute) -> 16-sample-tile recompute ->
   // 32-sample-tile recompute
   static const bool no_b3 = getenv("NGM_NO_BWD_B3") != nullptr;
-  static const bool env_b3q = getenv("NGM_BWD_B3Q") != nullptr;
-  const bool try_b3q = env_b3q || g_prefer_paired_bwd;
-  int e = (force32 || no_b3 || !try_b3q || !a.act) ? NGM_E_UNSUPPORTED : ngm_launch_field_bwd_b3q(a, blocks, st);
-  g_last_bwd_variant = 4;
+  int e = NGM_E_UNSUPPORTED;
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
   g_last_comp_fused = (a.fused_comp && e == 0) ? 1 : 0;
@@ -289,7 +285,6 @@ int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_
 int ngm_debug_last_comp_fused(void) { return g_last_comp_fused; }
 int ngm_debug_force_fused_comp(int on) { const int old = g_force_fused_comp; g_force_fused_comp = on ? 1 : 0; return old; }
 int ngm_debug_disable_fused_comp(int on) { const int old = g_no_fused_comp; g_no_fused_comp = on ? 1 : 0; return old; }
-int ngm_debug_prefer_paired_bwd(int on) { const int old = g_prefer_paired_bwd; g_prefer_paired_bwd = on ? 1 : 0; return old; }
 
 static unsigned long long* g_debug_cycles_fwd = nullptr;
 int ngm_debug_fwd_phase_cycles(unsigned long long* out528) {
@@ -507,7 +502,6 @@ struct RenderPlan {
   int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
   int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
-  int64_t off_xyz; int has_xyz;    // 64-wide stash backward: scaled field-local sample positions (16 B per sample) written by k_stash_bwd
 };
 // The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
 // has a kernel that consumes them: 49..64-wide hidden layers, 1-2 layers, non-hash encoding.  The
@@ -603,7 +597,6 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     if (kind == 1) {
       p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
       p.off_act = o; o = align_up(o + fc->num_layers * p.act_layer_stride * 4 + 64, 256);
-      p.has_xyz = 1; p.off_xyz = o; o = align_up(o + NS * 16, 256);
     } else if (kind == 2) {
       p.act_layer_stride = align_up(NS, 32) * 32 + 1024;      // one "layer": the 32-feature encoding
       p.off_act = o; o = align_up(o + p.act_layer_stride * 4 + 64, 256);
@@ -734,7 +727,6 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   memset(&a, 0, sizeof(a));
   a.fc = *fcfg; a.pr = *params; a.F = rays->F; a.P = (int64_t)rays->R * p.S; a.S = p.S;
   carve_hash_scratch(fcfg, rays->F, a.P, ws + p.off_hash, a);
-  if (!a.hash_xyz && p.has_xyz) a.hash_xyz = reinterpret_cast<float4*>(ws + p.off_xyz);   // 64-wide stash backward (k_field_bwd_b3q)
   a.per_block = p.per_block_bwd; a.blocks_per_field = p.blocks_per_field_bwd;
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
@@ -756,7 +748,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
     a.sums_out = sb.sums_out; a.loss_out = sb.loss_out; a.counter = sb.counter;
     // (hash encoding: k_hash_mlp_bwd writes the positions k_hash_grad needs into a.hash_xyz itself)
   } else {
-    sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash) / the paired MLP backward
+    sb.xyz_out = a.hash_xyz;                 // positions for the table-gradient kernel (hash encoding)
     a.hash_xyz_ready = a.hash_xyz != nullptr;
     e = ngm_launch_stash_bwd(sb, st);
     if (e) return fail(e, "render_bwd: unsupported geometry mode");

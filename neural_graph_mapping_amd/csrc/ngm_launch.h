@@ -169,7 +169,6 @@ int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_field_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);
 int ngm_launch_tri_finish(const FieldBwdArgs& a, hipStream_t st);
-int ngm_launch_field_bwd_b3q(const FieldBwdArgs& a, int blocks, hipStream_t st);  // the same with a tile's two hidden layers on the two waves of a SIMD (2 hidden layers)
 int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st);   // 32-sample tiles on the bf16 matrix pipe (three-way split), activation stash
 int ngm_launch_hash_mlp_bwd(const FieldBwdArgs& a, int blocks, hipStream_t st);          // hash encoding + 1 x 32 MLP (the reference's default network), bf16 split, encoding stash
 int ngm_launch_field_bwd16s(const FieldBwdArgs& a, int blocks, hipStream_t st);  // 16-sample tiles, activations from the forward's stash

@@ -256,6 +256,10 @@ def test_peer_exchange_two_ranks_bitwise(tmp_path):
 
 def _train_peer_worker(rank, world, port, out):
     _init(rank, world, port)
+    from neural_graph_mapping_amd import _capi
+    # the compositing backward inside the MLP backward reading the EXCHANGED sums (with a process group the forward's
+    # partials are reduced before the exchange; single-GPU runs take them from the partials): forced, the batch is small
+    _capi.lib().ngm_debug_force_fused_comp(1)
     g = load_golden(NAME)
     r, tgt, uc, ug, gids = _local_renderer(g, rank, world)
     r.peer_exchange = D.PeerExchange(dist.group.WORLD)
@@ -265,6 +269,7 @@ def _train_peer_worker(rank, world, port, out):
     torch.cuda.synchronize()
     one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
     rec = dict(ids=gids, one_graph=one_graph, status=r.peer_exchange.status(), step=r._step, step_dev=int(r._step_dev.item()),
+               fused=_capi.lib().ngm_debug_last_comp_fused(), variant=_capi.lib().ngm_debug_last_bwd_variant(),
                last_loss=last["combined"].cpu(), params={k: v.cpu().clone() for k, v in r._model.all_fields_params.items()})
     torch.save(rec, os.path.join(out, f"trainpx{rank}.pt"))
     dist.barrier()
@@ -282,6 +287,7 @@ def test_two_ranks_peer_exchange_inside_one_graph(tmp_path):
     for rank in range(world):
         res = torch.load(os.path.join(tmp_path, f"trainpx{rank}.pt"))
         assert res["one_graph"] and res["status"] == 0
+        assert res["variant"] == 3 and res["fused"] == 1              # two launches + the exchange kernel per iteration
         assert res["step"] == 2 + N_REPLAY == res["step_dev"]
         close(res["last_loss"], last["combined"], rtol=1e-4, atol=1e-6)
         for k, v in res["params"].items():

@@ -769,14 +769,6 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
             assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 1
         finally:
             L.ngm_debug_force_fused_comp(0)
-    if variant == 3 and layers == 2:                 # the experimental two-waves-per-tile kernel: same cases, same tolerances
-        L = _capi.lib()
-        L.ngm_debug_prefer_paired_bwd(1)
-        try:
-            ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
-            assert L.ngm_debug_last_bwd_variant() == 4
-        finally:
-            L.ngm_debug_prefer_paired_bwd(0)
 
 
 @pytest.mark.parametrize("geom", ["nrgbd", "occupancy", "density"])
@@ -827,12 +819,6 @@ def test_stash_backward_bf16_split_other_encodings(enc):
     from neural_graph_mapping_amd import _capi
     L = _capi.lib()
     assert L.ngm_debug_last_bwd_variant() == 3
-    L.ngm_debug_prefer_paired_bwd(1)                 # and the two-waves-per-tile kernel's instances for these encodings
-    try:
-        ragged_case(3, 41, 9, 5, fkw, mlp_matmul="auto")
-        assert L.ngm_debug_last_bwd_variant() == 4
-    finally:
-        L.ngm_debug_prefer_paired_bwd(0)
 
 
 # ------------------------------------------------------------------ eval path: kNN blend + image (G8, G9)

@@ -327,15 +327,7 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
         tf += e[0].elapsed_ms(e[1]); tb += e[1].elapsed_ms(e[2])
     n = F * R * (S_c + S_g)
     tf /= iters; tb /= iters
-    if os.environ.get("NGM_B3Q_DUMP"):
-        buf = (C.c_ulonglong * (16 + 8 * 64))()
-        L.ngm_debug_phase_cycles.argtypes = [C.c_void_p]
-        if L.ngm_debug_phase_cycles(buf) == 0:
-            na = ["setup", "outlayer", "wgrad1", "dgrad1", "dma+mask", "(idle)", "dma_wait", "barrier", "TOTAL"]
-            nb = ["setup", "dgrad0", "encode", "dY0 load+dma", "wgrad0", "(idle)", "dma_wait", "barrier", "TOTAL"]
-            print("b3q role A (wave 0):", {n: int(buf[k]) for k, n in enumerate(na)})
-            print("b3q role B (wave 4):", {n: int(buf[16 + k]) for k, n in enumerate(nb)})
-    elif os.environ.get("NGM_PHASE_TIMING"):
+    if os.environ.get("NGM_PHASE_TIMING"):
         buf = (C.c_ulonglong * (16 + 8 * 64))()
         L.ngm_debug_phase_cycles.argtypes = [C.c_void_p]
         if L.ngm_debug_phase_cycles(buf) == 0:

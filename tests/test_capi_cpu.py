@@ -123,3 +123,15 @@ def test_ops_are_registered_with_the_dispatcher(capi):
         o = torch.ops.ngm355.field_eval(ops.cfg_blob(fc), torch.empty(1, 8, 3, device="cuda"), None, None,
                                         [torch.empty(p.shape, device="cuda") for p in params])
         assert tuple(o.shape) == (1, 8, 4)
+
+
+def test_graft_entry_build_passes():
+    """the driver's "does it build" check: __graft_entry__.build() compiles (cached here), loads the library and compares
+    its ABI version with the header's -- a hard-coded number there once went stale across two ABI bumps unnoticed"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()

@@ -38,7 +38,12 @@ struct LdsB3b {
   static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16] + (fused compositing) [2 pieces][32]
   static constexpr int PB = INB + 768;                               // float4 [32]
   static constexpr int OB = PB + 128;                                // float4 [32]
-  static constexpr int WAVE_TOTAL = OB + 128;
+  // fused compositing (FC): the inputs of the tile after next, and the position / gradient rows of the next tile (one 64-lane
+  // pass computes two tiles' worth)
+  static constexpr int INB2 = OB + 128;
+  static constexpr int PB2 = INB2 + 768;
+  static constexpr int OB2 = PB2 + 128;
+  static constexpr int WAVE_TOTAL = OB2 + 128;
   static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave
   static constexpr int EPI = B3B_WAVES * NT * 1024;
   static constexpr int BODY = PLANES + B3B_WAVES * WAVE_TOTAL;

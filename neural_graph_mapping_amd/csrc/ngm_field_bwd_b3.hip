@@ -45,6 +45,9 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   float* inb = wl + LY::INB;
   float* pbuf = wl + LY::PB;
   float* obuf = wl + LY::OB;
+  float* inb2 = wl + LY::INB2;
+  float* pbuf2 = wl + LY::PB2;
+  float* obuf2 = wl + LY::OB2;
   const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wl);
 
   f32x16 acc[L][2][2];
@@ -99,16 +102,24 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   const char* seeds = FC ? reinterpret_cast<const char*>(a.rayseed) + 32 * (((int64_t)f * a.P) / a.S) : nullptr;
   const float inv_s = 1.0f / (float)a.S;
   // FC: the per-ray loss seeds of the tile's 32 samples, pieces 0 / 1 on the two half-waves (one more transfer per tile)
-  auto issue_seeds = [&](uint32_t n0) __attribute__((always_inline)) {
+  // FC: a tile's small inputs (ray rows, stash row, (t, T) pair, seeds) into landing buffer 0 (even tiles) or 1 (odd tiles)
+  auto issue_small = [&](uint32_t n0, int which) __attribute__((always_inline)) {
+    const uint32_t dst = wl_lds + (which ? LY::INB2 : LY::INB) * 4;
+    issue_inputs(fs, a.S, n0, end, lane, dst);
+    issue_inputs(fs, a.S, n0 + 16, end, lane, dst + 1024);
     uint32_t n = n0 + (uint32_t)(lane & 31);
     if (n >= end) n = end - 1;
-    dma16_so_c(seeds, 32u * (uint32_t)fdiv_idx32((int)n, inv_s, a.S) + 16u * (uint32_t)(lane >> 5), wl_lds + LY::INB * 4 + 2048);
+    dma16_so_c(seeds, 32u * (uint32_t)fdiv_idx32((int)n, inv_s, a.S) + 16u * (uint32_t)(lane >> 5), dst + 2048);
   };
   // first tile's transfers, then the per-lane constants and the weight planes while they are in flight
   if (ntiles) {
-    issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
-    issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
-    if constexpr (FC) issue_seeds(first);
+    if constexpr (FC) {
+      issue_small(first, 0);
+      if (ntiles > 1u) issue_small(first - 32u, 1);
+    } else {
+      issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
+      issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+    }
     issue_tile32(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::HL * 4);
     if (L == 2) issue_tile32(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::H1 * 4);
   }
@@ -187,40 +198,42 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     const bool more = it + 1u < ntiles;
     float* HLb = wl + LY::HL;
     float* H1b = wl + LY::H1;
-    // ---- inputs: lane = sample (both halves compute, half 0 stores)
-    {
-      const int j = i, h = j >> 4, jj = j & 15;
-      const float4* in4 = reinterpret_cast<const float4*>(inb) + 64 * h;
-      const float4 r0 = in4[jj], r1 = in4[16 + jj], dd = in4[32 + jj], sp = in4[48 + jj];
-      const uint32_t n = base + (uint32_t)j;
-      const bool valid = n < end;
-      const uint32_t nc = valid ? n : end - 1;
-      const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
-      const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
-      float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (FC) {
-        // k_stash_bwd's arithmetic on this tile (pointwise geometry modes, loss seeds): dd = (colour, geometry) of the
-        // forward, q0 / q1 = the ray's loss derivatives without the normalisers.  Lanes 32..63 mirror 0..31 as for the
-        // positions; in the scan they are the identity map, so a look-ahead past lane 31 composes with nothing.
-        const float4* ins = reinterpret_cast<const float4*>(inb) + 128;
-        const float4 q0 = ins[j], q1 = ins[32 + j];
+    // ---- inputs: lane = sample
+    float* pb_c = pbuf;              // where this tile's position / gradient rows are
+    float* ob_c = obuf;
+    if constexpr (FC) {
+      // k_stash_bwd's arithmetic, TWO tiles per pass: lanes 32..63 hold the 32 samples of this tile, lanes 0..31 those of
+      // the next one (lower addresses: the wave walks back to front), i.e. 64 consecutive samples as in k_stash_bwd's
+      // steps; the next tile's rows wait in the second buffers.  Odd tiles only pick those up.
+      if (it & 1u) { pb_c = pbuf2; ob_c = obuf2; }
+      else {
+        const int j = i, h = j >> 4, jj = j & 15;
+        const float4* blk = reinterpret_cast<const float4*>(hi ? inb : inb2);
+        const float4* in4 = blk + 64 * h;
+        const float4 r0 = in4[jj], r1 = in4[16 + jj], dd = in4[32 + jj], sp = in4[48 + jj];
+        const float4 q0 = blk[128 + j], q1 = blk[160 + j];
+        const uint32_t n = (hi ? base : base - 32u) + (uint32_t)j;     // the lower half only counts when there is a next tile
+        const bool valid = hi ? (n < end) : more;
+        const uint32_t nc = (hi && !valid) ? end - 1 : n;
+        const bool odd = ((nc + fs.par) & 1u) != 0u;
+        const float t = odd ? sp.z : sp.x, T = odd ? sp.w : sp.y;
+        const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
         const float4 kn = *reinterpret_cast<const float4*>(s_k);
         const float k_photo = kn.x, k_depth = kn.y, k_term = kn.z, k_fs = kn.w, k_ts = s_k[4];
-        const float T = ((nc + fs.par) & 1u) ? sp.w : sp.y;
-        const int rayi = fdiv_idx32((int)nc, inv_s, a.S);      // nc < 2^24 (the API fuses only then)
+        const int rayi = fdiv_idx32((int)nc, inv_s, a.S);        // nc < 2^24 (the API fuses only then)
         const int k = (int)nc - rayi * a.S, kr = a.S - 1 - k;
         const float dzc = r1.z, gt = r1.w, geom = dd.w;
         const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
         const float depth = -(dzc * t);
         float dodg = 0.f;
-        const float occ = occ_pointwise(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
+        const float occ = occ_pointwise_fast(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
         const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * depth + dT;
-        const bool live = valid && hi == 0;
-        float A = live ? ak * occ : 0.f, B = live ? 1.0f - occ : 1.0f;
-        seg_rscan_affine32(A, B, live ? kr : 0, lane);
-        const float Qend = (live && kr > 31 - j) ? carryQ : 0.f;
+        float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
+        const int krv = valid ? kr : 0;
+        seg_rscan_affine64(A, B, krv, lane);
+        const float Qend = (valid && kr > 63 - lane) ? carryQ : 0.f;
         const float nA = lane_next(A, 0.f), nB = lane_next(B, 1.f);
-        const float Qk = (kr >= 1) ? fmaf(nB, Qend, nA) : Qend;
+        const float Qk = (krv >= 1) ? fmaf(nB, Qend, nA) : Qend;
         carryQ = lane_value(fmaf(B, Qend, A), 0);
         const float tau = a.rc.truncation_distance, cf = a.rc.color_factor;
         const float w = occ * T;
@@ -230,8 +243,24 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
         const float dl = gt - t;
         if (fabsf(dl) < tau && gt != 0.0f) dg += k_ts * (geom * tau - dl) * tau;
         if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;      // overwritten sample: no gradient reaches the MLP output
-        dout = valid ? make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dout = valid ? make_float4(cf * w * dC0, cf * w * dC1, cf * w * dC2, dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        WAVE_SYNC();
+        *reinterpret_cast<float4*>((hi ? pbuf : pbuf2) + 4 * j) = make_float4(x, y, z, 0.f);
+        *reinterpret_cast<float4*>((hi ? obuf : obuf2) + 4 * j) = dout;
+        dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w;
+        WAVE_SYNC();
       }
+    } else {
+      // (both halves compute, half 0 stores)
+      const int j = i, h = j >> 4, jj = j & 15;
+      const float4* in4 = reinterpret_cast<const float4*>(inb) + 64 * h;
+      const float4 r0 = in4[jj], r1 = in4[16 + jj], dd = in4[32 + jj], sp = in4[48 + jj];
+      const uint32_t n = base + (uint32_t)j;
+      const bool valid = n < end;
+      const uint32_t nc = valid ? n : end - 1;
+      const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
+      const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
+      const float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
       WAVE_SYNC();
       if (hi == 0) {
         *reinterpret_cast<float4*>(pbuf + 4 * j) = make_float4(x, y, z, 0.f);
@@ -263,7 +292,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(obuf + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
+        for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pbuf + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+      for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -380,10 +409,16 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     // the wait: under the layer-0 weight gradient (48 MFMAs + operand splits, registers only).
     WAVE_SYNC();
     TICK(3);
+    if constexpr (FC) {
+      // the small inputs of the tile after next: its landing buffer (0 for even tiles, 1 for odd ones) was consumed by the
+      // pass at the top of this tile (even) or of the previous one (odd)
+      if (it + 2u < ntiles) issue_small(base - 64u, (int)(it & 1u));
+    }
     if (more) {
-      issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
-      issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
-      if constexpr (FC) issue_seeds(nxt);
+      if constexpr (!FC) {
+        issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
+        issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+      }
       const uint32_t u0 = nxt + fs.gb;
       if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
         issue_tile32_fast(fs.act[L - 1], u0 >> 5, lane, wl_lds + LY::HL * 4);

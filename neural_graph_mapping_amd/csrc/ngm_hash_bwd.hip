@@ -238,7 +238,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
       const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
       const float depth = -(dzc * t);
       float dodg = 0.f;
-      const float occ = occ_pointwise(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
+      const float occ = occ_pointwise_fast(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
       const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * depth + dT;
       const bool live = valid && hi == 0;
       float A = live ? ak * occ : 0.f, B = live ? 1.0f - occ : 1.0f;

@@ -480,14 +480,11 @@ int ngm_debug_last_bwd_variant(void);
  * 2 kNN evaluation (ngm_field_eval_knn).  Returns NGM_MATMUL_F32 or NGM_MATMUL_BF16X3, -1 before the first launch. */
 int ngm_debug_last_matmul(int which);
 /* Debug: 1 when the last ngm_render_bwd / ngm_render_bwd_adam ran the compositing backward inside k_field_bwd_b3 (loss
- * seeds, pointwise geometry modes, ray-aligned wave ranges; no k_stash_bwd launch, the forward's colour / geometry stash
- * stays intact), 0 when k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */
+ * seeds, pointwise geometry modes; no k_stash_bwd launch, the forward's colour / geometry stash stays intact), 0 when
+ * k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */
 int ngm_debug_last_comp_fused(void);
 int ngm_debug_disable_fused_comp(int on);
-/* 1 = plan ray-aligned backward ranges (the precondition of the fused compositing backward) even where that leaves fewer
- * workgroups than the plain split -- small batches, where the default keeps k_stash_bwd; set BEFORE the workspace of a batch
- * shape is sized (ngm_render_workspace) and keep it until that shape's backward has run.  Returns the previous setting. */
-int ngm_debug_force_fused_comp(int on);   /* 1 = always launch k_stash_bwd (as NGM_NO_FUSED_COMP=1); returns the previous setting */
+  /* 1 = always launch k_stash_bwd (as NGM_NO_FUSED_COMP=1); returns the previous setting */
 
 /* ---- one-shot exchange of the loss sums between the ranks of one node ---------------
  * Replaces torch.distributed.all_reduce (RCCL) on the 16 floats between ngm_render_fwd and ngm_render_bwd* by ONE small

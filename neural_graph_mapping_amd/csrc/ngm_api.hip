@@ -84,7 +84,6 @@ static void prof_drain() {
   }
 }
 
-static int g_force_fused_comp = 0;    // ngm_debug_force_fused_comp: ray-aligned backward ranges whatever they cost in parallelism (tests)
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
@@ -283,7 +282,6 @@ int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float r
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_last_matmul[which] : -1; }
 int ngm_debug_last_comp_fused(void) { return g_last_comp_fused; }
-int ngm_debug_force_fused_comp(int on) { const int old = g_force_fused_comp; g_force_fused_comp = on ? 1 : 0; return old; }
 int ngm_debug_disable_fused_comp(int on) { const int old = g_no_fused_comp; g_no_fused_comp = on ? 1 : 0; return old; }
 
 static unsigned long long* g_debug_cycles_fwd = nullptr;
@@ -353,31 +351,13 @@ int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   return check_launch("ngm_field_eval_fwd");
 }
 
-// S > 0 (ray mode): where it costs no parallelism (at most a quarter fewer workgroups than the plain multiple of 128), a
-// workgroup's range is a multiple of 8 lcm(32, S) samples -- every wave's quarter / eighth of it then begins and ends with a
-// ray AND a 32-sample tile, which is what the compositing backward fused into k_field_bwd_b3 (4 waves) / k_hash_mlp_bwd
-// (8 waves) needs.  *ray_unit = lcm(32, S) if that holds, else 0 (small batches: k_stash_bwd runs, the MLP backward keeps
-// its fine-grained split -- F = 1 x 512 rays x 24 samples: 96 workgroups against 16).
-static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int S = 0, int* ray_unit = nullptr) {
+// unit: samples a workgroup's range is a multiple of -- whole 32-sample tiles for each of its waves (4 waves: 128; the
+// hash network's 8-wave backward: 256)
+static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int64_t unit = 32 * NGM_WAVES_PER_BLOCK) {
   const int ncu = num_cus();
   int64_t b = (ncu + F - 1) / F;
-  const int64_t unit = 32 * NGM_WAVES_PER_BLOCK;
   int64_t per = align_up((P + b - 1) / b, unit);
   if (per < unit) per = unit;
-  if (ray_unit) *ray_unit = 0;
-  if (S > 0) {
-    int64_t g = 32, s = S;
-    while (s) { const int64_t r = g % s; g = s; s = r; }          // gcd(32, S)
-    const int64_t lcm = (32 / g) * S;
-    for (int waves : {8, 4}) {
-      const int64_t per_ray = align_up(per, waves * lcm);
-      if (waves * lcm <= 8192 && (per_ray * 4 <= per * 5 || g_force_fused_comp)) {
-        per = per_ray;
-        if (ray_unit) *ray_unit = (int)lcm;
-        break;
-      }
-    }
-  }
   *per_block = per;
   *bpf = (int)((P + per - 1) / per);
 }
@@ -497,7 +477,6 @@ int ngm_composite_bwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const flo
 struct RenderPlan {
   int S, rays_per_block, blocks_fwd, waves_fwd, maxs, b3;
   int64_t per_block_bwd; int blocks_per_field_bwd;
-  int ray_unit_bwd;                // lcm(32, S) when per_block_bwd is a multiple of 4 (or 8) of it, else 0 (plan_bwd)
   int64_t p_pad;
   int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
@@ -590,7 +569,7 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
       p.off_dout = o; o = align_up(o + NS * 16, 256);
       p.off_disd = o; o = align_up(o + NR * 4, 256);
     }
-    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd, p.S, &p.ray_unit_bwd);
+    plan_bwd(F, (int64_t)R * p.S, &p.per_block_bwd, &p.blocks_per_field_bwd, fc->encoding == NGM_ENC_PERMUTO ? 256 : 128);
     p.off_gradpart = o; o = align_up(o + (int64_t)F * p.blocks_per_field_bwd * p.p_pad * 4, 256);
     p.off_hash = o; o = align_up(o + hash_scratch_bytes(fc, F, (int64_t)R * p.S), 256);
     const int kind = act_stash_kind(fc);
@@ -731,15 +710,14 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
   if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
-  // Compositing backward inside the MLP backward (k_field_bwd_b3<.., FC>): loss seeds, pointwise geometry modes, wave ranges
-  // that begin and end with a ray, and the kernel that implements it about to be chosen.  Otherwise k_stash_bwd runs first
-  // and leaves dL/d(raw outputs) in place of the forward's stash.  NGM_NO_FUSED_COMP=1: never.
+  // Compositing backward inside the MLP backward (k_field_bwd_b3<FC>, k_hash_mlp_bwd<FC>): loss seeds, pointwise geometry
+  // modes, and a kernel that implements it about to be chosen.  Otherwise k_stash_bwd runs first and leaves
+  // dL/d(raw outputs) in place of the forward's stash.  NGM_NO_FUSED_COMP=1: never.
   static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
   const bool no_fuse = no_fuse_env || g_no_fused_comp;
   const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
-  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && p.ray_unit_bwd && bwd_b3_is_default() && a.P < (1 << 24) &&
-                    ((p.per_block_bwd % (4 * p.ray_unit_bwd) == 0 && ngm_field_bwd_b3_applies(a)) ||
-                     (p.per_block_bwd % (8 * p.ray_unit_bwd) == 0 && ngm_hash_mlp_bwd_applies(a)));
+  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && bwd_b3_is_default() && a.P < (1 << 24) &&
+                    (ngm_field_bwd_b3_applies(a) || ngm_hash_mlp_bwd_applies(a));
   int e = 0;
   if (fuse) {
     a.fused_comp = 1; a.rc = *rcfg;

@@ -100,6 +100,41 @@ struct FieldStreams {
   uint32_t par;           // parity of the field's first global sample index
 };
 
+// Fused compositing backward (k_field_bwd_b3<FC>, k_hash_mlp_bwd<FC>): a wave walks its tiles back to front carrying the
+// suffix value Q of the per-ray recursion Q_{k-1} = a_k o_k + (1 - o_k) Q_k.  Its range ends with a tile, not necessarily with
+// a ray: this returns Q at the range's upper end, i.e. the recursion over the m samples of the cut ray that lie BEYOND `end`
+// (they belong to another wave or workgroup, which will compute them again for its own purposes; m < S, same field).
+// Plain loads, once per wave, 64 samples per pass back to front; k = {k_photo, k_depth, k_term} as in the tile passes.
+__device__ __forceinline__ float comp_suffix_beyond(const FieldBwdArgs& a, int64_t g0, uint32_t end, int lane, float inv_s,
+                                                    float k_photo, float k_depth, float k_term) {
+  const int S = a.S;
+  const int last = (int)end - 1;
+  const int ray = fdiv_idx32(last, inv_s, S);
+  const int m = S - 1 - (last - ray * S);                  // samples of that ray at or beyond `end` (wave-uniform)
+  if (m <= 0) return 0.f;
+  const int64_t gray = g0 / S + ray;                       // global ray index
+  const float4 r1 = reinterpret_cast<const float4*>(a.raytab)[2 * gray + 1];
+  const float4 q0 = reinterpret_cast<const float4*>(a.rayseed)[2 * gray], q1 = reinterpret_cast<const float4*>(a.rayseed)[2 * gray + 1];
+  const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
+  float carry = 0.f;
+  for (int p = (m - 1) >> 6; p >= 0; --p) {
+    const int o = 64 * p + lane;                           // offset beyond `end`
+    const bool valid = o < m;
+    const int64_t g = g0 + (int64_t)end + (valid ? o : 0);
+    const float4 dd = a.d_out[g];
+    const float2 tT = a.stashB[g];
+    float dodg;
+    const float occ = occ_pointwise_fast(a.rc.geometry_mode, a.rc.geometry_factor, dd.w, &dodg);
+    const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * (-(r1.z * tT.x)) + dT;
+    float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
+    const int kr = valid ? m - 1 - o : 0;                  // later samples of the ray
+    seg_rscan_affine64(A, B, kr, lane);
+    const float Qend = (valid && kr > 63 - lane) ? carry : 0.f;
+    carry = lane_value(fmaf(B, Qend, A), 0);
+  }
+  return carry;
+}
+
 // inputs of tile [n0, n0+16): lane group q fetches piece q of sample j (0: ray origin + dir.x, 1: rest of the
 // ray entry, 2: d_out, 3: the aligned stash pair holding t).  One instruction, per-lane 64-bit pointers.
 __device__ __forceinline__ void issue_inputs(const FieldStreams& fs, int S, uint32_t n0, uint32_t end, int lane, uint32_t lds) {

@@ -181,6 +181,10 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     __syncthreads();
   }
   float carryQ = 0.f;                 // FC: suffix value of the ray that continues into the next (= previous in memory) tile
+  if constexpr (FC) {
+    // the range ends with a tile, not necessarily with a ray: the recursion over the rest of the cut ray first
+    if (ntiles) carryQ = comp_suffix_beyond(a, (int64_t)f * a.P, end, lane, inv_s, s_k[0], s_k[1], s_k[2]);
+  }
 
   // lane-constant LDS offsets (floats): column element (feature 32 m + i, sample frow(r, hi)) of a tile sits at
   //   m * 1024 + (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))
@@ -574,7 +578,7 @@ bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a) {
 int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   const int L = a.fc.num_layers;
   if (!ngm_field_bwd_b3_applies(a)) return NGM_E_UNSUPPORTED;
-  if (a.fused_comp && (a.per_block % (4 * 32) || !a.rayseed)) return NGM_E_INVALID;
+  if (a.fused_comp && (a.per_block % (B3B_WAVES * 32) || !a.rayseed)) return NGM_E_INVALID;
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
   if (L == 2) return launch_bwd_b3<2>(a, blocks, st);
 #ifndef NGM_FAST_BUILD

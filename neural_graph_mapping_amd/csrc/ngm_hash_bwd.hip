@@ -202,6 +202,9 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
     __syncthreads();
   }
   float carryQ = 0.f;
+  if constexpr (FC) {
+    if (ntiles) carryQ = comp_suffix_beyond(a, g0, end, lane, inv_s, s_k[0], s_k[1], s_k[2]);
+  }
 
   // lane-constant LDS offsets (floats): element (feature i, sample frow(r, hi)) of a tile sits at
   //   (i >> 2) * 128 + (i & 3) + 4 * ((8 (r >> 2) + 4 hi + (r & 3)) ^ (i >> 2))

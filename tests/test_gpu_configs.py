@@ -250,23 +250,8 @@ def test_bf16x3_split_forward_meets_the_fp32_tolerances_and_is_bitwise_determini
         assert torch.equal(o["prediction"].rgbds, ref_p)
     for k in ref_g:
         assert torch.equal(o["grads"][k], ref_g[k]), k
-    # the same ragged batch with the compositing backward inside the MLP backward (rays of 24 samples against 32-sample
-    # tiles, carried suffix values, two tiles per pass)
-    Lc = K.lib()
-    Lc.ngm_debug_force_fused_comp(1)
-    try:
-        r = make_renderer(FOURIER, ckw, F)
-        _perturb(r)
-        r.set_field_poses(pos.to(DEV), quat.to(DEV))
-        first = r.optimization_iteration(tgt, seed=9, update=False)
-        assert Lc.ngm_debug_last_comp_fused() == 1
-        ref_g2 = {k: v.clone() for k, v in first["grads"].items()}
-        for _ in range(300):
-            o = r.optimization_iteration(tgt, seed=9, update=False)
-            for k in ref_g2:
-                assert torch.equal(o["grads"][k], ref_g2[k]), k
-    finally:
-        Lc.ngm_debug_force_fused_comp(0)
+    assert K.lib().ngm_debug_last_comp_fused() == 1     # (the compositing backward ran inside the MLP backward: rays of 24 samples
+                                                         # against 32-sample tiles, carried suffix values, two tiles per pass)
     # full metric batch
     F, R = 8, 512
     r = make_renderer(FOURIER, dict(num_samples_coarse=64, num_samples_depth_guided=64, mlp_matmul="bf16x3"), F)

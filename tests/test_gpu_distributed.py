@@ -257,9 +257,8 @@ def test_peer_exchange_two_ranks_bitwise(tmp_path):
 def _train_peer_worker(rank, world, port, out):
     _init(rank, world, port)
     from neural_graph_mapping_amd import _capi
-    # the compositing backward inside the MLP backward reading the EXCHANGED sums (with a process group the forward's
-    # partials are reduced before the exchange; single-GPU runs take them from the partials): forced, the batch is small
-    _capi.lib().ngm_debug_force_fused_comp(1)
+    # (the compositing backward inside the MLP backward reads the EXCHANGED sums here; single-GPU runs take them from the
+    # forward's partials)
     g = load_golden(NAME)
     r, tgt, uc, ug, gids = _local_renderer(g, rank, world)
     r.peer_exchange = D.PeerExchange(dist.group.WORLD)

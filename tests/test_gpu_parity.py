@@ -756,19 +756,18 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
     ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
     from neural_graph_mapping_amd import _capi
     assert _capi.lib().ngm_debug_last_bwd_variant() == variant
-    # batches this small keep k_stash_bwd where ray-aligned ranges would leave fewer workgroups (all but the 1 + 1-sample case,
-    # whose rays tile 32 samples anyway)
-    assert _capi.lib().ngm_debug_last_comp_fused() == (1 if (variant == 3 and n_c + n_g == 2) else 0)
-    if variant == 3:
-        # ... unless told otherwise: the split kernel doing the compositing backward itself -- rays of 2, 7, 24, 31 and 128
-        # samples against its 32-sample tiles, partial last tiles, fields starting in the middle of a stash tile
+    # the split kernel also does the compositing backward (no k_stash_bwd launch) -- rays of 2, 7, 24, 31 and 128 samples
+    # against its 32-sample tiles, wave ranges that end in the middle of a ray, partial last tiles, fields starting in the
+    # middle of a stash tile; the fp32 kernels leave it to k_stash_bwd
+    assert _capi.lib().ngm_debug_last_comp_fused() == (1 if variant == 3 else 0)
+    if variant == 3:                                 # and the same kernel behind k_stash_bwd
         L = _capi.lib()
-        L.ngm_debug_force_fused_comp(1)
+        L.ngm_debug_disable_fused_comp(1)
         try:
             ragged_case(F, R, n_c, n_g, dict(encoding="fourier", dim_enc=64, num_layers=layers), mlp_matmul=mm)
-            assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 1
+            assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 0
         finally:
-            L.ngm_debug_force_fused_comp(0)
+            L.ngm_debug_disable_fused_comp(0)
 
 
 @pytest.mark.parametrize("geom", ["nrgbd", "occupancy", "density"])
@@ -776,8 +775,7 @@ def test_ragged_shapes_stash_backward(F, R, n_c, n_g, layers, mm, variant):
 def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
     """The compositing backward inside k_field_bwd_b3 against k_stash_bwd + the same kernel on one batch (8 + 16 samples,
     rays straddling the 32-sample tiles): same loss scalars bit for bit (same sums), gradients to 1e-5 of their scale (the
-    per-ray suffix recursion is composed over 32-lane tiles instead of 64-lane steps); the density mode is not fused.
-    A batch large enough for the default plan to fuse is covered by the M1 train-step tests below."""
+    per-ray suffix recursion is composed in a different order); the density mode is not fused."""
     from neural_graph_mapping_amd import _capi
     L = _capi.lib()
     F, R = 3, 40
@@ -789,7 +787,6 @@ def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     tgt = make_target(t, torch.arange(F))
     out = {}
-    L.ngm_debug_force_fused_comp(1)                  # a small batch: the default plan would keep k_stash_bwd
     try:
         for fused in (1, 0):
             L.ngm_debug_disable_fused_comp(0 if fused else 1)
@@ -801,7 +798,6 @@ def test_fused_compositing_backward_equals_stash_bwd(geom, photo):
                           {k: v.clone() for k, v in res["grads"].items()})
     finally:
         L.ngm_debug_disable_fused_comp(0)
-        L.ngm_debug_force_fused_comp(0)
     for k, v in out[1][0].items():
         assert torch.equal(v, out[0][0][k]), k
     for k, v in out[1][1].items():
@@ -934,23 +930,22 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("mm", ["auto", "f32", "auto-fused"])
+@pytest.mark.parametrize("mm", ["auto", "f32", "auto-separate"])
 @pytest.mark.parametrize("F,R,n_c,n_g", [(3, 40, 8, 16), (1, 9, 4, 4), (2, 33, 3, 2), (5, 7, 8, 16), (3, 130, 20, 4)])
 def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g, mm):
     """the reference's DEFAULT field (config/neural_graph_map.yaml:6-20): hash encoding, 1x32 MLP; ragged shapes put
     field starts in the middle of the 32-sample tiles of the encoding stash and leave partial tiles.  Both backward
-    kernels: k_hash_mlp_bwd (bf16 split, `auto`) and k_field_bwd16 (fp32 MFMA, `mlp_matmul: f32`); `auto-fused`:
-    k_hash_mlp_bwd doing the compositing backward and the positions of k_hash_grad itself (no k_stash_bwd launch), which
-    the default plan reserves for batches where ray-aligned ranges cost no parallelism."""
-    forced = mm == "auto-fused"
-    if forced:
+    kernels: k_hash_mlp_bwd (bf16 split, `auto`: it also does the compositing backward and writes the positions of
+    k_hash_grad; `auto-separate`: behind k_stash_bwd) and k_field_bwd16 (fp32 MFMA, `mlp_matmul: f32`)."""
+    separate = mm == "auto-separate"
+    if separate:
         mm = "auto"
-        K.lib().ngm_debug_force_fused_comp(1)
+        K.lib().ngm_debug_disable_fused_comp(1)
     try:
         _permuto_train_case(F, R, n_c, n_g, mm)
-        assert K.lib().ngm_debug_last_comp_fused() == (1 if forced else 0)
+        assert K.lib().ngm_debug_last_comp_fused() == (1 if (mm == "auto" and not separate) else 0)
     finally:
-        K.lib().ngm_debug_force_fused_comp(0)
+        K.lib().ngm_debug_disable_fused_comp(0)
 
 
 def _permuto_train_case(F, R, n_c, n_g, mm):

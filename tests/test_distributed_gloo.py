@@ -112,3 +112,38 @@ def test_two_rank_eval_gather_interleaves_fields_and_pixels(tmp_path):
     assert torch.equal(r0["img"][:, 0], torch.arange(101, dtype=torch.float32))
     assert r0["shard"] == (0, 51) and r1["shard"] == (51, 101)
     assert torch.equal(r0["img"][:, 1], torch.cat([torch.zeros(51), torch.ones(50)]))
+
+
+def _draw_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env(backend="gloo")
+    NF, FA = 41, 12
+    cur = torch.arange(30, 41)
+    sets = []
+    gen = torch.Generator().manual_seed(99)                      # the same seed on every rank, as for the rest of the sampler
+    for _ in range(20):
+        ids = D.draw_fields_balanced(cur, NF, FA, world, generator=gen)
+        mine = ids[D.owned_mask(ids, rank, world)]
+        sets.append((ids, mine))
+    # every rank drew the same sets ...
+    flat = torch.cat([s[0] for s in sets])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], x) for x in gathered)
+    # ... and owns exactly its quota of each
+    counts = torch.tensor([len(s[1]) for s in sets])
+    torch.save(dict(same=same, counts=counts), os.path.join(out, f"draw{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_balanced_field_draw_two_ranks(tmp_path):
+    """the opt-in `balanced_by_owner` draw under two real ranks: identical sets everywhere (same generator state), each rank
+    owning exactly num_train_fields / world of every set"""
+    world = 2
+    mp.spawn(_draw_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        res = torch.load(os.path.join(tmp_path, f"draw{rank}.pt"))
+        assert res["same"]
+        assert res["counts"].tolist() == [6] * 20

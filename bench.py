@@ -552,8 +552,8 @@ def main():
                      3: "k_field_bwd_b3<2> (v_mfma_f32_32x32x16_bf16, 6 products, activations from the forward's stash)"}.get(variant, "?")
             fused_comp = bool(L.ngm_debug_last_comp_fused())
             if fused_comp:
-                kname += " + the compositing backward of each tile (what k_stash_bwd did in a launch of its own: +7 % kernel time, " \
-                         "-17 us per step)"
+                kname += " + the compositing backward of each tile (what k_stash_bwd did in a launch of its own: +4 % kernel time " \
+                         "against the plain kernel, -17 us of launch per step; the algorithmic flops counted here are the MLP's only)"
             res["roofline"] = dict(bound="mfma", kernel=kname, fused_compositing_backward=fused_comp, achieved=achieved,
                                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TF,
                                    traffic=traffic, traffic_source=traffic_src, avg_launch_us=fb["avg_us"],

@@ -339,8 +339,7 @@ __device__ __forceinline__ void encode_hash16(const float* sm_lvl, const HashCtx
         uint32_t idx[4]; float bw[4];
         permuto_simplex(x, y, z, sm_lvl + 8 * level, hc.mask, idx, bw);
         float2 v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = ngm_ldp2(hc.tab, (size_t)level * hc.T + idx[r], hc.dt);
+        ngm_ldp2x4(hc.tab, (size_t)level * hc.T, idx, hc.dt, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
       }

@@ -122,6 +122,23 @@ __device__ __forceinline__ float2 ngm_ldp2(const void* tab, size_t entry, int dt
   const uint32_t raw = reinterpret_cast<const uint32_t*>(tab)[entry];
   return make_float2(ngm_widen(raw & 0xffffu, dt), ngm_widen(raw >> 16, dt));
 }
+// Four table entries at once: ONE storage-type branch around the four loads.  Through ngm_ldp2 every gather sat in a branch
+// diamond of its own and the compiler waited for it (s_waitcnt vmcnt(0)) before issuing the next: the 64 gathers of a
+// 64-sample step of the hash forward were 64 serial L2 round trips.
+__device__ __forceinline__ void ngm_ldp2x4(const void* tab, size_t base, const uint32_t (&idx)[4], int dt, float2 (&v)[4]) {
+  if (dt == NGM_DT_F32) {
+    const float2* t = reinterpret_cast<const float2*>(tab) + base;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+  } else {
+    const uint32_t* t = reinterpret_cast<const uint32_t*>(tab) + base;
+    uint32_t raw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw[r] = t[idx[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = make_float2(ngm_widen(raw[r] & 0xffffu, dt), ngm_widen(raw[r] >> 16, dt));
+  }
+}
 // fp32 -> storage type, round to nearest even (the copy an Adam update leaves for the kernels)
 __device__ __forceinline__ void ngm_stp(void* base, int64_t i, float v, int dt) {
   unsigned short h;

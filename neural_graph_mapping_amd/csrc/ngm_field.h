@@ -311,6 +311,32 @@ __device__ __forceinline__ void permuto_simplex(float x, float y, float z, const
 // tile: register r = 4q + 2p + c holds feature c of level 4q + 2*hi + p.
 __device__ __forceinline__ void encode_hash(const float* sm_lvl, const HashCtx& hc, int hi, float x, float y, float z,
                                             f32x16& E) {
+  if (hc.dt == NGM_DT_F32) {
+    // fp32 tables (the default): straight-line code over the lane's 8 levels -- no branch between one level's gathers and
+    // the next level's simplex search, so the scheduler keeps the next gathers in flight while it consumes these.  Levels
+    // beyond nr_levels (lane-dependent: level = 4 q + 2 hi + p) read level 0's table and are zeroed by a select.
+    const float2* tab = reinterpret_cast<const float2*>(hc.tab);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int level = 4 * q + 2 * hi + p;
+        const bool on = level < hc.nlev;
+        const int lv = on ? level : 0;
+        uint32_t idx[4]; float bw[4];
+        permuto_simplex(x, y, z, sm_lvl + 8 * lv, hc.mask, idx, bw);
+        const float2* t = tab + (size_t)lv * hc.T;
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
+        E[4 * q + 2 * p] = on ? f0 : 0.f;
+        E[4 * q + 2 * p + 1] = on ? f1 : 0.f;
+      }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll

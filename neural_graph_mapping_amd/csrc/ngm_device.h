@@ -92,10 +92,13 @@ __device__ __forceinline__ float ngm_sinf(float x) {
 // reduced-precision parameter STORAGE (ngm_params.dtype): element i of a tensor whose nominal float* base addresses
 // fp32, bf16 or fp16 elements; always widened to fp32 (exact), all arithmetic stays fp32
 // ------------------------------------------------------------------------------------------------
+// Both conversions and a select: as an if / else this put every 16-bit load into a branch diamond, and the compiler waits
+// for a load before leaving the block that issued it -- the weight staging of the 16-bit storage types was a chain of
+// serial memory round trips (section 3.14 of DESIGN.md).
 __device__ __forceinline__ float ngm_widen(uint32_t h16, int dt) {
-  if (dt == NGM_DT_BF16) return __uint_as_float(h16 << 16);
-  const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)h16);
-  return (float)h;
+  const float as_bf16 = __uint_as_float(h16 << 16);
+  const float as_f16 = (float)__builtin_bit_cast(_Float16, (unsigned short)h16);
+  return (dt == NGM_DT_BF16) ? as_bf16 : as_f16;
 }
 __device__ __forceinline__ float ngm_ldp(const float* base, int64_t i, int dt) {
   if (dt == NGM_DT_F32) return base[i];

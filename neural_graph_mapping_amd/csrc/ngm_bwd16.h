@@ -138,6 +138,8 @@ __device__ __forceinline__ float comp_suffix_beyond(const FieldBwdArgs& a, int64
 // inputs of tile [n0, n0+16): lane group q fetches piece q of sample j (0: ray origin + dir.x, 1: rest of the
 // ray entry, 2: d_out, 3: the aligned stash pair holding t).  One instruction, per-lane 64-bit pointers.
 __device__ __forceinline__ void issue_inputs(const FieldStreams& fs, int S, uint32_t n0, uint32_t end, int lane, uint32_t lds) {
+  asm volatile("" : "+v"(lane));     // re-derived per call: hoisted out of the tile loop, the per-lane 64-bit stream base (a select
+                                     // over lane >> 4) was the value the 512-register kernels spilled, reloaded behind the transfers
   const int j = lane & 15, q = lane >> 4;
   uint32_t n = n0 + j;
   if (n >= end) n = end - 1;                       // clamp: finite data, its gradient contribution is zeroed via d_out

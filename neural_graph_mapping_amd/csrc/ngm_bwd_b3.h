@@ -241,11 +241,20 @@ __device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, cons
   for (int g = threadIdx.x; g < PLANE_G; g += B3B_THREADS) {
     const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
     const int c = 32 * nt + n;
+    // the eight loads first, then their use: element by element (ngm_ldp inside a bounds check) every load was waited for
+    // where it was issued -- 32 serial L2 round trips per thread in front of the first tile
     float x[8];
+    int off[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int o = 16 * kb + 8 * kh + e;
-      x[e] = (o < H && c < Din) ? ngm_ldp(W, w0 + (int64_t)o * Din + c, pr.dtype) : 0.f;
+      off[e] = (o < H && c < Din) ? o * Din + c : 0;
+    }
+    ngm_ldp_gather<8>(W, w0, off, pr.dtype, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = 16 * kb + 8 * kh + e;
+      x[e] = (o < H && c < Din) ? x[e] : 0.f;
     }
     ngm_bf16x8 h, m, lo;
     b3_split8(x, h, m, lo);

@@ -104,6 +104,23 @@ __device__ __forceinline__ float ngm_ldp(const float* base, int64_t i, int dt) {
   if (dt == NGM_DT_F32) return base[i];
   return ngm_widen(reinterpret_cast<const unsigned short*>(base)[i], dt);
 }
+// N elements at arbitrary (valid) offsets behind ONE storage-type branch: all loads are issued before any is used (through
+// ngm_ldp every element is a branch diamond of its own and is waited for where it was loaded)
+template <int N>
+__device__ __forceinline__ void ngm_ldp_gather(const float* base0, int64_t first, const int (&off)[N], int dt, float (&x)[N]) {
+  if (dt == NGM_DT_F32) {
+    const float* base = base0 + first;
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = base[off[e]];
+  } else {
+    const unsigned short* b = reinterpret_cast<const unsigned short*>(base0) + first;
+    uint32_t raw[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) raw[e] = b[off[e]];
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = ngm_widen(raw[e], dt);
+  }
+}
 // elements i..i+3; `vec`: one 16-byte (fp32) / 8-byte (16-bit) load is allowed (caller checked alignment and bounds)
 __device__ __forceinline__ float4 ngm_ldp4(const float* base, int64_t i, int dt, bool vec, int n_valid) {
   float4 x = make_float4(0.f, 0.f, 0.f, 0.f);

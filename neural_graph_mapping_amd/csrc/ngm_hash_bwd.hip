@@ -138,11 +138,19 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
       const int g = threadIdx.x & (HB_PG - 1);
       const int n = g & 31, kh = (g >> 5) & 1, kb = g >> 6;
       float x[8];
+      int off[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 16 * kb + 8 * kh + e;
         const int o = dg ? k : n, c = dg ? n : k;
-        x[e] = (o < H && c < D) ? ngm_ldp(W, w0 + (int64_t)o * D + c, a.pr.dtype) : 0.f;
+        off[e] = (o < H && c < D) ? o * D + c : 0;
+      }
+      ngm_ldp_gather<8>(W, w0, off, a.pr.dtype, x);                 // all eight loads in flight together
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * kb + 8 * kh + e;
+        const int o = dg ? k : n, c = dg ? n : k;
+        x[e] = (o < H && c < D) ? x[e] : 0.f;
       }
       ngm_bf16x8 h, m, lo;
       b3_split8(x, h, m, lo);

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from gpu_common import DEV, make_renderer, make_target, synth_target
 from neural_graph_mapping_amd import _capi as K
 FOURIER = dict(encoding="fourier", dim_enc=64, num_layers=2)
+if os.environ.get("NGM_BENCH_WDT"):                 # weight storage type of BASELINE configs 1 / 4: bfloat16 | float16
+    FOURIER["weight_dtype"] = os.environ["NGM_BENCH_WDT"]
 import ctypes as C
 for F, R, sc, sg in ((16, 512, 128, 128), (8, 512, 64, 64), (32, 512, 8, 16), (4, 512, 8, 16)):
     for mm in ("f32", "auto"):

@@ -316,25 +316,31 @@ __device__ __forceinline__ void encode_hash(const float* sm_lvl, const HashCtx& 
     // the next level's simplex search, so the scheduler keeps the next gathers in flight while it consumes these.  Levels
     // beyond nr_levels (lane-dependent: level = 4 q + 2 hi + p) read level 0's table and are zeroed by a select.
     const float2* tab = reinterpret_cast<const float2*>(hc.tab);
+    // software-pipelined by hand: the gathers of level k + 1 are issued before the features of level k are formed
+    uint32_t idx[4]; float bw[4]; float2 v[4]; bool on;
+    auto fetch = [&](int k) __attribute__((always_inline)) {
+      const int level = 4 * (k >> 1) + 2 * hi + (k & 1);
+      on = level < hc.nlev;
+      const int lv = on ? level : 0;
+      permuto_simplex(x, y, z, sm_lvl + 8 * lv, hc.mask, idx, bw);
+      const float2* t = tab + (size_t)lv * hc.T;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
+    };
+    fetch(0);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int level = 4 * q + 2 * hi + p;
-        const bool on = level < hc.nlev;
-        const int lv = on ? level : 0;
-        uint32_t idx[4]; float bw[4];
-        permuto_simplex(x, y, z, sm_lvl + 8 * lv, hc.mask, idx, bw);
-        const float2* t = tab + (size_t)lv * hc.T;
-        float2 v[4];
+    for (int k = 0; k < 8; ++k) {
+      float2 vc[4]; float bc[4];
+      const bool onc = on;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = t[idx[r]];
-        float f0 = 0.f, f1 = 0.f;
+      for (int r = 0; r < 4; ++r) { vc[r] = v[r]; bc[r] = bw[r]; }
+      if (k < 7) fetch(k + 1);
+      float f0 = 0.f, f1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { f0 = fmaf(v[r].x, bw[r], f0); f1 = fmaf(v[r].y, bw[r], f1); }
-        E[4 * q + 2 * p] = on ? f0 : 0.f;
-        E[4 * q + 2 * p + 1] = on ? f1 : 0.f;
-      }
+      for (int r = 0; r < 4; ++r) { f0 = fmaf(vc[r].x, bc[r], f0); f1 = fmaf(vc[r].y, bc[r], f1); }
+      E[2 * k] = onc ? f0 : 0.f;
+      E[2 * k + 1] = onc ? f1 : 0.f;
+    }
     return;
   }
 #pragma unroll

@@ -29,7 +29,7 @@ template <int L, bool EG>
 struct LdsB3b {
   static constexpr int NPL = (L - 1) + (EG ? 1 : 0);                 // layers whose data gradient is needed
   static constexpr int plane_slot(int l) { return EG ? l : l - 1; }  // 16-byte units: slot * 3 * PLANE_G
-  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512 + 768 + 512;   // floats; + per-feature constants: float4 wout[64], enc[64], uint2 woutp[3][2][64], u32x4 id[2][64]
+  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512;         // floats; + per-feature constants: float4 wout[64], enc[64]
   static constexpr int CONSTS = NPL * 3 * PLANE_G * 4;
   // per wave: the output layer's input tile, (L = 2) layer 1's input tile, the input landing buffer, points, d_out.
   // Single buffers: the next tile's transfers are issued when all of them are free (see the tile loop).
@@ -160,6 +160,17 @@ __device__ __forceinline__ B3Op b3_arr(const float (&x)[8]) {
 // float offset of the 16-byte chunk c of sample s inside a tile
 __device__ __forceinline__ int tile_chunk(int c, int s) { return (c * 32 + (s ^ (c & 7))) * 4; }
 
+// rows of a tile for the data gradient's A operand (lane = sample n, k-half kh): chunks 4 kb + 2 kh, + 1 of every k-block
+struct RowRegs { float4 g[4][2]; };
+__device__ __forceinline__ void load_rows(const float* __restrict__ tile, int lane, RowRegs& R) {
+  const int n = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int c0 = 4 * kb + 2 * kh;
+    R.g[kb][0] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0, n));
+    R.g[kb][1] = *reinterpret_cast<const float4*>(tile + tile_chunk(c0 + 1, n));
+  }
+}
 struct PlaneRegs { ngm_u32x4 h[2], m[2], l[2]; };
 __device__ __forceinline__ void load_planes(const ngm_u32x4* __restrict__ P, int kb, int lane, PlaneRegs& W) {
   const int n = lane & 31, kh = lane >> 5;
@@ -186,133 +197,43 @@ __device__ __forceinline__ void dgrad_b3_kb(const B3Op& A, const PlaneRegs& Wk, 
   NGM_DG_PRODUCT(h, h, false);
 #undef NGM_DG_PRODUCT
 }
-// ---- dY in the other orientation, through the matrix pipe --------------------------------------------------------
-// The data gradient's A operand wants lane = sample with eight FEATURES of dY per k-block; the wave holds dY with lane =
-// feature and eight SAMPLES per k-block (the weight gradient's A operand, already split into three bf16 planes).  Instead of
-// a second split of the same numbers read back from LDS in the other orientation (176 VALU per layer and tile + 32 ds_write +
-// 8 ds_read_b128 + two wave barriers), each PLANE is transposed exactly by the pipe that has the slack (0.3 busy):
-//   T[o][s] = sum_k A[o][k] I[k][s],   A = plane operand (row = feature o, k = sample), I = identity (col = sample s),
-// one non-zero product per element, fp32 accumulate -> T holds the plane's bf16 values exactly; its C fragment (lane =
-// column = sample s, register r <-> feature frow(r, hi) of the 32-feature tile) packs pairwise (one v_perm per two values)
-// into the data gradient's A operand when the contraction index of that GEMM is ordered the same way:
-//   k-block kb = 2 m + b, lane half kh, element e  <->  feature 32 m + frow(8 b + e, kh) = 16 kb + 8 (e >> 2) + 4 kh + (e & 3)
-// (build_dgrad_planes stores the weight planes in that order).  2 MFMAs per (plane, feature tile): 12 per layer.
-__host__ __device__ __forceinline__ constexpr int dgrad_k_feature(int kb, int kh, int e) { return 16 * kb + 8 * (e >> 2) + 4 * kh + (e & 3); }
-
-// identity operands of the transposition: lane (s = lane & 31, kh = lane >> 5), k-block b, element e <-> sample
-// 16 b + 8 (e >> 2) + 4 kh + (e & 3) of the tile (the k order of the weight gradient's operands); 1.0 where that is s
-struct IdOps { ngm_u32x4 b[2]; };
-__device__ __forceinline__ IdOps make_id_ops(int lane) {
-  const int s = lane & 31, kh = lane >> 5;
-  IdOps I;
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      uint32_t w = 0;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int e = 2 * d + half;
-        if (16 * b + 8 * (e >> 2) + 4 * kh + (e & 3) == s) w |= 0x3f80u << (16 * half);
-      }
-      I.b[b][d] = w;
-    }
-  return I;
-}
-// One feature tile (32 features) at a time: three planes x two k-blocks of samples = six MFMAs into three accumulators
-// (48 registers live instead of 96: the kernels that use this sit at their register limit).  a0 / a1: the weight gradient's
-// A operands of the feature tile for k-block 0 / 1 (samples 0..15 / 16..31 of the tile).
-struct XposeAcc { f32x16 t[3]; };        // [plane h, m, l]
-// The six MFMAs are ONE inline-asm statement with VGPR destinations.  Through the builtin, a kernel that owns 512 registers
-// gets every MFMA in its AGPR form (LLVM selects the form per function), and each of the 96 transposed values would then cost
-// a v_accvgpr_read before the v_perm that packs it -- as many VALU instructions as the split this replaces.  hipcc pads no
-// hazards inside asm (cdna_hip_programming.md 5.7): `s_nop 1` covers VALU-written operands -> MFMA, the accumulate chains
-// need none, and `s_nop 11` (12 states, 8-pass XDL) ends the string so that any reader of the results may follow.
-__device__ __forceinline__ void xpose_tile(const B3Op& a0, const B3Op& a1, const IdOps& I, XposeAcc& T) {
-#ifdef NGM_B3_XBUILTIN
+__device__ __forceinline__ void dgrad_b3_kb_free(const B3Op& A, const PlaneRegs& Wk, bool first, f32x16 (&dX)[2]) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const ngm_bf16x8 i0 = __builtin_bit_cast(ngm_bf16x8, I.b[0]), i1 = __builtin_bit_cast(ngm_bf16x8, I.b[1]);
-  T.t[0] = mfma_bf16(a0.h, i0, zero);
-  T.t[1] = mfma_bf16(a0.m, i0, zero);
-  T.t[2] = mfma_bf16(a0.l, i0, zero);
-  T.t[0] = mfma_bf16(a1.h, i1, T.t[0]);
-  T.t[1] = mfma_bf16(a1.m, i1, T.t[1]);
-  T.t[2] = mfma_bf16(a1.l, i1, T.t[2]);
-  return;
-#endif
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %3, %9, 0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %1, %4, %9, 0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %2, %5, %9, 0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %6, %10, %0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %1, %7, %10, %1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %2, %8, %10, %2\n\t"
-      "s_nop 11"
-      : "=&v"(T.t[0]), "=&v"(T.t[1]), "=&v"(T.t[2])
-      : "v"(__builtin_bit_cast(ngm_u32x4, a0.h)), "v"(__builtin_bit_cast(ngm_u32x4, a0.m)), "v"(__builtin_bit_cast(ngm_u32x4, a0.l)),
-        "v"(__builtin_bit_cast(ngm_u32x4, a1.h)), "v"(__builtin_bit_cast(ngm_u32x4, a1.m)), "v"(__builtin_bit_cast(ngm_u32x4, a1.l)),
-        "v"(I.b[0]), "v"(I.b[1]));
+#define NGM_DG_PRODUCT(PA, PW, Z) \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) dX[nt] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[nt]), (Z) ? zero : dX[nt])
+  NGM_DG_PRODUCT(l, h, first);
+  NGM_DG_PRODUCT(h, l, false);
+  NGM_DG_PRODUCT(m, m, false);
+  NGM_DG_PRODUCT(m, h, false);
+  NGM_DG_PRODUCT(h, m, false);
+  NGM_DG_PRODUCT(h, h, false);
+#undef NGM_DG_PRODUCT
 }
-// dH^T[s][o] = sum_c d_out[s][c] Wout[c][o] for both feature tiles: six products of the split, two chains, VGPR destinations
-// (the ReLU mask reads them); operands as 128-bit register tuples, upper k half zero
-__device__ __forceinline__ void outlayer_mfma(const ngm_u32x4& ah, const ngm_u32x4& am, const ngm_u32x4& al, const ngm_u32x4 (&wh)[2],
-                                              const ngm_u32x4 (&wm)[2], const ngm_u32x4 (&wl)[2], f32x16 (&dH)[2]) {
-#ifdef NGM_B3_OLBUILTIN
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define NGM_OLB(A, W, Z) _Pragma("unroll") for (int m = 0; m < 2; ++m) dH[m] = mfma_bf16(__builtin_bit_cast(ngm_bf16x8, A), __builtin_bit_cast(ngm_bf16x8, W[m]), (Z) ? zero : dH[m])
-  NGM_OLB(al, wh, true); NGM_OLB(ah, wl, false); NGM_OLB(am, wm, false); NGM_OLB(am, wh, false); NGM_OLB(ah, wm, false); NGM_OLB(ah, wh, false);
-#undef NGM_OLB
-  return;
-#endif
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %4, %5, 0\n\t"      // lo x hi
-      "v_mfma_f32_32x32x16_bf16 %1, %4, %6, 0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %2, %9, %0\n\t"     // hi x lo
-      "v_mfma_f32_32x32x16_bf16 %1, %2, %10, %1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %3, %7, %0\n\t"     // mid x mid
-      "v_mfma_f32_32x32x16_bf16 %1, %3, %8, %1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %3, %5, %0\n\t"     // mid x hi
-      "v_mfma_f32_32x32x16_bf16 %1, %3, %6, %1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %2, %7, %0\n\t"     // hi x mid
-      "v_mfma_f32_32x32x16_bf16 %1, %2, %8, %1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %2, %5, %0\n\t"     // hi x hi
-      "v_mfma_f32_32x32x16_bf16 %1, %2, %6, %1\n\t"
-      "s_nop 11"
-      : "=&v"(dH[0]), "=&v"(dH[1])
-      : "v"(ah), "v"(am), "v"(al), "v"(wh[0]), "v"(wh[1]), "v"(wm[0]), "v"(wm[1]), "v"(wl[0]), "v"(wl[1]));
-}
-// the two k-blocks' A operands of the data gradient this feature tile supplies (k-blocks 2 m, 2 m + 1): 24 v_perm
-__device__ __forceinline__ void xpose_pack(const XposeAcc& T, B3Op& At0, B3Op& At1) {
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    ngm_u32x4 h, mm, l;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      h[d] = b3_pack(__float_as_uint(T.t[0][8 * b + 2 * d]), __float_as_uint(T.t[0][8 * b + 2 * d + 1]));
-      mm[d] = b3_pack(__float_as_uint(T.t[1][8 * b + 2 * d]), __float_as_uint(T.t[1][8 * b + 2 * d + 1]));
-      l[d] = b3_pack(__float_as_uint(T.t[2][8 * b + 2 * d]), __float_as_uint(T.t[2][8 * b + 2 * d + 1]));
-    }
-    B3Op& o = b ? At1 : At0;
-    o.h = __builtin_bit_cast(ngm_bf16x8, h);
-    o.m = __builtin_bit_cast(ngm_bf16x8, mm);
-    o.l = __builtin_bit_cast(ngm_bf16x8, l);
-  }
-}
-// data gradient from ready A operands: only the plane reads of the next k-block travel under this one's MFMAs
-__device__ __forceinline__ void dgrad_b3_t(const ngm_u32x4* __restrict__ P, const B3Op (&At)[4], const PlaneRegs& W0, int lane, f32x16 (&dX)[2]) {
+// k-block kb's 12 MFMAs share their scheduling region with the row split of k-block kb + 1 (and the plane reads of kb + 1)
+__device__ __forceinline__ void dgrad_b3(const ngm_u32x4* __restrict__ P, const RowRegs& R, const PlaneRegs& W0, int lane, f32x16 (&dX)[2]) {
   PlaneRegs Wa, Wb;
+  const B3Op A0 = b3_rows(R.g[0][0], R.g[0][1]);
+  __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 1, lane, Wb);
-  dgrad_b3_kb(At[0], W0, true, dX);
+  const B3Op A1 = b3_rows(R.g[1][0], R.g[1][1]);
+  dgrad_b3_kb_free(A0, W0, true, dX);
+  NGM_INTERLEAVE(12, 4)
+  __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 2, lane, Wa);
-  dgrad_b3_kb(At[1], Wb, false, dX);
+  const B3Op A2 = b3_rows(R.g[2][0], R.g[2][1]);
+  dgrad_b3_kb_free(A1, Wb, false, dX);
+  NGM_INTERLEAVE(12, 4)
+  __builtin_amdgcn_sched_barrier(0);
   load_planes(P, 3, lane, Wb);
-  dgrad_b3_kb(At[2], Wa, false, dX);
-  dgrad_b3_kb(At[3], Wb, false, dX);
+  const B3Op A3 = b3_rows(R.g[3][0], R.g[3][1]);
+  dgrad_b3_kb_free(A2, Wa, false, dX);
+  NGM_INTERLEAVE(12, 4)
+  __builtin_amdgcn_sched_barrier(0);
+  dgrad_b3_kb(A3, Wb, false, dX);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// weight planes of layer l for the data gradient: granule (plane, nt, kb, kh, n) = W[dgrad_k_feature(kb, kh, e)][32 nt + n], e = 0..7
+// weight planes of layer l for the data gradient: granule (plane, nt, kb, kh, n) = W[16 kb + 8 kh + e][32 nt + n], e = 0..7
 __device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int l, ngm_u32x4* P) {
   const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
   const float* W = pr.w[l];
@@ -326,13 +247,13 @@ __device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, cons
     int off[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int o = dgrad_k_feature(kb, kh, e);
+      const int o = 16 * kb + 8 * kh + e;
       off[e] = (o < H && c < Din) ? o * Din + c : 0;
     }
     ngm_ldp_gather<8>(W, w0, off, pr.dtype, x);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int o = dgrad_k_feature(kb, kh, e);
+      const int o = 16 * kb + 8 * kh + e;
       x[e] = (o < H && c < Din) ? x[e] : 0.f;
     }
     ngm_bf16x8 h, m, lo;

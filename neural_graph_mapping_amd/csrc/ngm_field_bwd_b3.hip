@@ -127,30 +127,6 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   // loop-long register residents they were spilled to scratch, and a scratch reload waits on vmcnt, i.e. on the DMA
   float4* cwout = reinterpret_cast<float4*>(sm + LY::CONSTS);
   float4* cenc = cwout + 64;
-  // output layer on the matrix pipe: B operand words of the weight planes, [plane][feature tile m][lane] -> (c0 c1, c2 c3) of
-  // feature 32 m + (lane & 31) for lanes 0..31 (k = 0..3), zero for lanes 32..63 (k = 8..15)
-  uint2* cwoutp = reinterpret_cast<uint2*>(cenc + 64);
-  __shared__ __attribute__((aligned(16))) float s_zero4[4];
-  if (threadIdx.x < 4) s_zero4[threadIdx.x] = 0.f;
-  // identity operands of the matrix-pipe transposition, [k-block][lane]: re-read per use (8 registers the tile loop does not have)
-  ngm_u32x4* cid = reinterpret_cast<ngm_u32x4*>(cwoutp + 3 * 2 * 64);
-  if (threadIdx.x >= 192) {
-    const IdOps io = make_id_ops(lane);
-    cid[lane] = io.b[0]; cid[64 + lane] = io.b[1];
-  }
-  if (threadIdx.x >= 64 && threadIdx.x < 192) {
-    const int t = threadIdx.x - 64, m = t >> 6, ln = t & 63, ft = 32 * m + (ln & 31), H = a.fc.dim_hidden;
-    uint32_t hp0 = 0, mp0 = 0, lp0 = 0, hp1 = 0, mp1 = 0, lp1 = 0;
-    if (ln < 32 && ft < H) {
-      const float* W = a.pr.w[L];
-      const int64_t w0 = row * a.pr.w_stride[L];
-      b3_split2(ngm_ldp(W, w0 + ft, a.pr.dtype), ngm_ldp(W, w0 + H + ft, a.pr.dtype), hp0, mp0, lp0);
-      b3_split2(ngm_ldp(W, w0 + 2 * H + ft, a.pr.dtype), ngm_ldp(W, w0 + 3 * H + ft, a.pr.dtype), hp1, mp1, lp1);
-    }
-    cwoutp[(0 * 2 + m) * 64 + ln] = make_uint2(hp0, hp1);
-    cwoutp[(1 * 2 + m) * 64 + ln] = make_uint2(mp0, mp1);
-    cwoutp[(2 * 2 + m) * 64 + ln] = make_uint2(lp0, lp1);
-  }
   if (threadIdx.x < 64) {
     const int ft = threadIdx.x, H = a.fc.dim_hidden;
     const float* W = a.pr.w[L];
@@ -235,10 +211,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       // steps; the next tile's rows wait in the second buffers.  Odd tiles only pick those up.
       if (it & 1u) { pb_c = pbuf2; ob_c = obuf2; }
       else {
-        int lo = lane;
-        asm volatile("" : "+v"(lo));   // the buffer addresses of this pass re-derived per pass (hoisted, they are spilled)
-        const int hi = lo >> 5;        // (shadows the kernel's: same value, opaque to the loop-invariant code motion)
-        const int j = lo & 31, h = j >> 4, jj = j & 15;
+        const int j = i, h = j >> 4, jj = j & 15;
         const float4* blk = reinterpret_cast<const float4*>(hi ? inb : inb2);
         const float4* in4 = blk + 64 * h;
         const float4 r0 = in4[jj], r1 = in4[16 + jj], dd = in4[32 + jj], sp = in4[48 + jj];
@@ -307,11 +280,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     f32x16 dY[2], Xc[2];
     {
       f32x16 Hc[2];
+      const float4 wout[2] = {cwout[i], cwout[32 + i]};
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Hc[m][r] = HLb[COL_OFF(m, r)];
-#ifdef NGM_B3_OUT_VALU
       if (L == 2) {                  // layer 1's input columns: in flight under the output layer's arithmetic (one wave per SIMD:
                                      // a load issued where it is needed is a stall of a full LDS round trip)
 #pragma unroll
@@ -319,68 +292,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
       }
-#endif
       float4 dOa[2][8];              // both halves' d_out rows up front, as for the positions below
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
-#ifndef NGM_B3_OUT_VALU
-      // dH^T[s][o] = sum_c d_out[s][c] Wout[c][o] on the matrix pipe (K = 4 of 16): A = the tile's d_out rows (lane = sample,
-      // k = channel, split here: 4 values), B = the output layer's weight planes (built once per workgroup, `cwoutp`); its
-      // C fragment is dH in the lane = feature layout.  12 MFMAs for 128 FMAs per lane.
-      f32x16 dH[2];
-      {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // addresses below re-derived per tile: hoisted out of the loop they are spilled (and a
-                                       // scratch reload waits on vmcnt, i.e. on the transfers in flight)
-        const float4 d4 = *reinterpret_cast<const float4*>((ln >> 5) ? s_zero4 : ob_c + 4 * (ln & 31));   // lanes 32..63 carry k = 8..15: zero
-        const uint2* wp = cwoutp + ln;
-        const uint2 wph[2] = {wp[(0 * 2 + 0) * 64], wp[(0 * 2 + 1) * 64]};
-        const uint2 wpm[2] = {wp[(1 * 2 + 0) * 64], wp[(1 * 2 + 1) * 64]};
-        const uint2 wpl[2] = {wp[(2 * 2 + 0) * 64], wp[(2 * 2 + 1) * 64]};
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t hp0, mp0, lp0, hp1, mp1, lp1;
-        b3_split2(d4.x, d4.y, hp0, mp0, lp0);
-        b3_split2(d4.z, d4.w, hp1, mp1, lp1);
-        const ngm_u32x4 ah = {hp0, hp1, 0u, 0u}, am = {mp0, mp1, 0u, 0u}, al = {lp0, lp1, 0u, 0u};
-        const ngm_u32x4 wh[2] = {{wph[0].x, wph[0].y, 0u, 0u}, {wph[1].x, wph[1].y, 0u, 0u}};
-        const ngm_u32x4 wm[2] = {{wpm[0].x, wpm[0].y, 0u, 0u}, {wpm[1].x, wpm[1].y, 0u, 0u}};
-        const ngm_u32x4 wl[2] = {{wpl[0].x, wpl[0].y, 0u, 0u}, {wpl[1].x, wpl[1].y, 0u, 0u}};
-        outlayer_mfma(ah, am, al, wh, wm, wl, dH);
-      }
-      // the output-weight gradient does not depend on dH: it runs while the matrix pipe works
-#pragma unroll
-      for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int r = 8 * half + e;
-          const float4 d = dOa[half][e];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const float h = Hc[m][r];
-            dwo[m][0] = fmaf(d.x, h, dwo[m][0]); dwo[m][1] = fmaf(d.y, h, dwo[m][1]);
-            dwo[m][2] = fmaf(d.z, h, dwo[m][2]); dwo[m][3] = fmaf(d.w, h, dwo[m][3]);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      if (L == 2) {                  // layer 1's input columns: in flight under the ReLU mask (this phase holds 200 registers
-                                     // until the output-weight gradient is done: issued at its top they were spilled)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float g = (Hc[m][r] > 0.f) ? dH[m][r] : 0.f;
-          dY[m][r] = g;
-          dbh[L - 1][m] += g;
-        }
-#else
-      const float4 wout[2] = {cwout[i], cwout[32 + i]};
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -401,54 +317,33 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#endif
-    }
-    TICK(4);
-    // A operands of the weight gradient (lane = feature, eight samples per k-block) of the layer whose output gradient dY is;
-    // the data gradient's A operands (lane = sample) are made from the SAME planes by the matrix pipe (xpose_*, ngm_bwd_b3.h)
-    B3Op Ay0[2], Ay1[2];
-    if constexpr (L == 2) {
-      B3Op At[4];
-      PlaneRegs W0;
-      {
-        Ay0[0] = b3_regs<0>(dY[0]); Ay0[1] = b3_regs<0>(dY[1]);
-        B3Op B0[2] = {b3_regs<0>(Xc[0]), b3_regs<0>(Xc[1])};
-        __builtin_amdgcn_sched_barrier(0);
-        IdOps idops;
-        {
-          int ln = lane;
-          asm volatile("" : "+v"(ln));
-          idops.b[0] = cid[ln]; idops.b[1] = cid[64 + ln];
-        }
-        Ay1[0] = b3_regs<1>(dY[0]); Ay1[1] = b3_regs<1>(dY[1]);
-        B3Op B1[2] = {b3_regs<1>(Xc[0]), b3_regs<1>(Xc[1])};
-        wgrad_b3_block_free(Ay0, B0, acc[1]);
-        NGM_INTERLEAVE(24, 8)
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          XposeAcc T0;
-          xpose_tile(Ay0[0], Ay1[0], idops, T0);
-          xpose_pack(T0, At[0], At[1]);        // (packed before the second tile is transposed: 48 registers less at the peak)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        XposeAcc T1;
-        xpose_tile(Ay0[1], Ay1[1], idops, T1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_planes(planes + LY::plane_slot(1) * 3 * PLANE_G, 0, lane, W0);
-        xpose_pack(T1, At[2], At[3]);          // 24 v_perm in the shadow of the second k-block's MFMAs
-        wgrad_b3_block_free(Ay1, B1, acc[1]);
-        NGM_INTERLEAVE(24, 1)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      TICK(6);
-      // layer 1's input columns again, for the ReLU mask: re-read (they would occupy 32 registers across the three GEMMs
-      // above; the tile is untouched -- dY no longer passes through LDS), in flight under the data gradient's MFMAs
+      WAVE_SYNC();
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
+        for (int r = 0; r < 16; ++r) HLb[COL_OFF(m, r)] = dY[m][r];
+      WAVE_SYNC();
+    }
+    TICK(4);
+    float* Dtile = HLb;              // tile holding, as rows, dY of the layer whose input gradients come next
+    if constexpr (L == 2) {
+      RowRegs R;
+      PlaneRegs W0;
+      {
+        B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, B0[2] = {b3_regs<0>(Xc[0]), b3_regs<0>(Xc[1])};
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(HLb, lane, R);       // consumed after the weight gradient
+        load_planes(planes + LY::plane_slot(1) * 3 * PLANE_G, 0, lane, W0);
+        B3Op A1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, B1[2] = {b3_regs<1>(Xc[0]), b3_regs<1>(Xc[1])};
+        wgrad_b3_block_free(A0, B0, acc[1]);
+        NGM_INTERLEAVE(24, 8)
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad_b3_block(A1, B1, acc[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TICK(6);
       f32x16 dX[2];
-      dgrad_b3_t(planes + LY::plane_slot(1) * 3 * PLANE_G, At, W0, lane, dX);
+      dgrad_b3(planes + LY::plane_slot(1) * 3 * PLANE_G, R, W0, lane, dX);
       TICK(7);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -458,39 +353,25 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
           dY[m][r] = g;
           dbh[0][m] += g;
         }
+      WAVE_SYNC();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1b[COL_OFF(m, r)] = dY[m][r];
+      WAVE_SYNC();
+      Dtile = H1b;
       TICK(9);
     }
-    // ---- layer 0.  Data gradient first, so that cos(.) never has to be kept: the encoding is then evaluated k-block by
-    // k-block, each value feeding the Fourier-matrix gradient and the weight-gradient operand
-    Ay0[0] = b3_regs<0>(dY[0]); Ay0[1] = b3_regs<0>(dY[1]);
+    // ---- layer 0.  Data gradient first (only dY's rows are needed), so that cos(.) never has to be kept: the encoding
+    // is then evaluated k-block by k-block, each value feeding the Fourier-matrix gradient and the weight-gradient operand
     f32x16 dE[2];
     if constexpr (ENC_GRAD) {
-      B3Op At[4];
+      RowRegs R0;
       PlaneRegs W00;
-      IdOps idops;
-      {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        idops.b[0] = cid[ln]; idops.b[1] = cid[64 + ln];
-      }
+      load_rows(Dtile, lane, R0);
+      load_planes(planes + LY::plane_slot(0) * 3 * PLANE_G, 0, lane, W00);
       __builtin_amdgcn_sched_barrier(0);
-      Ay1[0] = b3_regs<1>(dY[0]); Ay1[1] = b3_regs<1>(dY[1]);
-      {
-        XposeAcc T0;
-        xpose_tile(Ay0[0], Ay1[0], idops, T0);
-        xpose_pack(T0, At[0], At[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        XposeAcc T1;
-        xpose_tile(Ay0[1], Ay1[1], idops, T1);
-        load_planes(planes + LY::plane_slot(0) * 3 * PLANE_G, 0, lane, W00);
-        xpose_pack(T1, At[2], At[3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      dgrad_b3_t(planes + LY::plane_slot(0) * 3 * PLANE_G, At, W00, lane, dE);
-    } else {
-      Ay1[0] = b3_regs<1>(dY[0]); Ay1[1] = b3_regs<1>(dY[1]);
+      dgrad_b3(planes + LY::plane_slot(0) * 3 * PLANE_G, R0, W00, lane, dE);
     }
     TICK(8);
     const float4 encw[2] = {cenc[i], cenc[32 + i]};
@@ -554,13 +435,13 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     TICK(5);
     {
-      B3Op B0[2] = {b3_arr(Eb[0][0]), b3_arr(Eb[0][1])};
+      B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}, B0[2] = {b3_arr(Eb[0][0]), b3_arr(Eb[0][1])};
       __builtin_amdgcn_sched_barrier(0);
-      B3Op B1[2] = {b3_arr(Eb[1][0]), b3_arr(Eb[1][1])};
-      wgrad_b3_block_free(Ay0, B0, acc[0]);
-      NGM_INTERLEAVE(24, 4)
+      B3Op A1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}, B1[2] = {b3_arr(Eb[1][0]), b3_arr(Eb[1][1])};
+      wgrad_b3_block_free(A0, B0, acc[0]);
+      NGM_INTERLEAVE(24, 8)
       __builtin_amdgcn_sched_barrier(0);
-      wgrad_b3_block(Ay1, B1, acc[0]);
+      wgrad_b3_block(A1, B1, acc[0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(10);

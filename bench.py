@@ -178,31 +178,108 @@ def time_steps(r, tgt, steps, warmup, spin_up, use_graph=True):
     return dt, kern, float(out["combined"]), L.ngm_debug_last_bwd_variant()
 
 
-def hash_rooflines(kern, n_local):
-    """roofline objects of the hash variant's two dominant kernels (512 B of gathers / of scatter per sample)"""
+PEAK_L2_GBS = 34500.0                            # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs x 4 MiB)
+GATHER_L2_USEFUL_GBS = 2200.0                    # tools/micro/gather_rate.hip: random 8-byte gathers from an L2-resident 512 KB table,
+                                                 # useful bytes chip-wide (every gather pulls a 128-byte line; profiles/r03a_gather_rate_microbench.txt)
+
+
+def hash_rooflines(kern, n_local, scale_note="", pmc_scale=1.0):
+    """roofline objects of the hash variant's two dominant kernels (512 B of gathers / of scatter per sample).
+    `traffic` = HBM bytes per launch from the PMC passes of profiles/pmc_hash.json (FETCH_SIZE doubled, MI355X_MICROARCH.md),
+    `l2_hit_rate` from TCC_HIT_sum / TCC_MISS_sum of the same profile; both belong to the M1 batch (scaled by `pmc_scale`)."""
     out = {}
+    pm = pmc_hash_profile()
+
+    def pmc_of(sub):
+        for k, v in pm.items():
+            if sub in k:
+                return v
+        return {}
     hg, ff = kern.get("hash_grad"), kern.get("render_fwd")
     algo = 512 * n_local
+    src = "profiles/pmc_hash.json: separate rocprofv3 --pmc passes of the hash variant on the M1 batch, NOT this run " + scale_note
     if hg:
         ach = algo / (hg["avg_us"] * 1e-6) / 1e9
+        pv = pmc_of("k_hash_grad")
         out["roofline"] = dict(bound="hbm", kernel="k_hash_grad (simplex search + per-level table in LDS, Q23.40 integer atomics)",
-                               achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                               achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                               traffic=(pv["hbm_bytes"] * pmc_scale) if pv.get("hbm_bytes") is not None else None,
+                               traffic_source=src if pv else None, l2_hit_rate=pv.get("l2_hit_rate"),
                                avg_launch_us=hg["avg_us"], launches_timed=hg["launches"], algorithmic_bytes_per_launch=algo,
                                timing="HIP events on the launch stream, instrumented pass of the same steps",
                                note="priced against the HBM scatter it replaces (512 B/sample, SURVEY 8d); the kernel itself "
-                                    "accumulates in LDS and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
+                                    "accumulates in LDS (its real HBM traffic is `traffic`: positions + dL/dE in, partial tables "
+                                    "out) and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
     if ff:
         ach = algo / (ff["avg_us"] * 1e-6) / 1e9
+        pv = pmc_of("k_render_fwd")
         out["roofline_fwd"] = dict(bound="hbm", kernel="k_render_fwd<1,1,1,hash> (64 table gathers of 8 B per sample through the "
                                                         "vector L1 / the XCD's L2; fp32 MFMA 32x32x2 for the 32-wide layer)",
-                                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                                   traffic=(pv["hbm_bytes"] * pmc_scale) if pv.get("hbm_bytes") is not None else None,
+                                   traffic_source=src if pv else None, l2_hit_rate=pv.get("l2_hit_rate"),
+                                   l2_gather_ceiling=dict(useful_GBs=GATHER_L2_USEFUL_GBS, frac=ach / GATHER_L2_USEFUL_GBS,
+                                                          peak_l2_GBs=PEAK_L2_GBS,
+                                                          note="the tables are L2-resident (l2_hit_rate), so the ceiling of the gathers is "
+                                                               "L2 -> L1, not HBM: a micro-benchmark of random 8-byte gathers from a 512 KB "
+                                                               "table reads 2.2 TB/s of USEFUL bytes (16 x that in 128-byte lines = the L2 "
+                                                               "peak); frac > 1 = the kernel's gathers hit the vector L1 more often than the "
+                                                               "micro-benchmark's (coarse levels: neighbouring samples share vertices)"),
                                    avg_launch_us=ff["avg_us"], launches_timed=ff["launches"], algorithmic_bytes_per_launch=algo,
-                                   note="algorithmic gather bytes (512 B/sample, SURVEY 8d) against the HBM peak as the survey asks; "
-                                        "the tables (512 KB per field) are L2-resident, so the path actually used is L2 -> L1: "
-                                        "tools/micro/gather_rate.hip measures 2.2 TB/s of useful bytes chip-wide for such gathers "
-                                        "(69 clocks per wave instruction and CU), 7.1 TB/s from an L1-resident 32 KB table, "
-                                        "35 TB/s from LDS")
+                                   note="algorithmic gather bytes (512 B/sample, SURVEY 8d) against the HBM peak as the survey asks")
     return out
+
+
+def shader_clock_under_load(step, n=1500):
+    """sclk as rocm-smi reports it WHILE the GPU works through n more (untimed) iterations; None if it cannot be read"""
+    import subprocess
+    try:
+        for i in range(n):
+            step(i)
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        torch.cuda.synchronize()
+        js = json.loads(r.stdout[r.stdout.index("{"):])
+        card = js[sorted(js)[torch.cuda.current_device() if len(js) > torch.cuda.current_device() else 0]]
+        for k, v in card.items():
+            if "sclk" in k.lower():
+                import re
+                m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+                if m:
+                    return int(m.group(1))
+    except Exception:
+        torch.cuda.synchronize()
+    return None
+
+
+def pmc_hash_profile():
+    """profiles/pmc_hash.json: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes) and L2 hit rate
+    (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)) per launch of the hash variant's kernels on the M1 batch -- NOT this run"""
+    pth = os.path.join(ROOT, "profiles", "pmc_hash.json")
+    if not os.path.exists(pth):
+        return {}
+    try:
+        return json.load(open(pth)).get("kernels", {})
+    except Exception:
+        return {}
+
+
+def aux_default_line(dev, args, use_graph):
+    """The iteration the reference actually runs by default (config/neural_graph_map.yaml:6-20, 60-63): 32 active fields x
+    512 rays x (8 coarse + 16 depth-guided) samples, permutohedral hash 16 levels x 2 features + ONE hidden layer of 32."""
+    Fd, Sc, Sg = 32, 8, 16
+    r = build_renderer(dev, Fd, "hash", s_c=Sc, s_g=Sg, matmul=args.matmul)
+    pos, quat, t = synth_target(Fd, R, seed=4242)
+    r.set_field_poses(pos.to(dev), quat.to(dev))
+    tgt = type(t)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in t])
+    tgt = tgt._replace(field_ids=torch.arange(Fd, device=dev))
+    dth, kh, lh, bvh = time_steps(r, tgt, args.steps, args.warmup, 50, use_graph)
+    n = Fd * R * (Sc + Sg)
+    roof = hash_rooflines(kh, n, scale_note="(traffic / L2 hit rate: PMC of the M1 batch scaled by samples)", pmc_scale=n / (8 * 512 * 128))
+    return dict(workload="32 fields x 512 rays x (8 coarse + 16 depth-guided) samples, permutohedral hash (16 levels x 2 features, "
+                         "2^12 entries) + 1x32 MLP: the reference's default iteration (config/neural_graph_map.yaml:6-20, 60-63; "
+                         "parity of the hash encoding unpinned: third-party CUDA package absent)",
+                value=n * args.steps / dth, unit="ray-samples/s", ms_per_step=1e3 * dth / args.steps, final_loss=lh, bwd_variant=bvh,
+                launch="hipGraph replay" if use_graph else "eager", kernels_us={k: round(v["avg_us"], 2) for k, v in kh.items()}, **roof)
 
 
 def launch_ranks(n):
@@ -348,6 +425,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=11,
+                    help="number of consecutive timed windows of --steps steps each (after ONE --warmup phase); the line's "
+                         "ms_per_step / value are the median window, all windows are listed in ms_per_step_windows")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="keep timing windows until this much timed GPU work has run (default 0: exactly --windows)")
+    ap.add_argument("--no-aux-default", action="store_true",
+                    help="skip `aux_default`: the reference's default iteration (32 fields x 512 rays x (8 + 16) samples, "
+                         "hash 16 x 2 + 1 x 32 network: config/neural_graph_map.yaml)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--fields-total", type=int, default=0,
@@ -439,22 +524,41 @@ def main():
         out = step(i)
     for i in range(args.warmup):
         out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+
+    def window():
+        """EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            d = float(tt.item())
+        return d
+
+    # measurement protocol: the contract's timed region (W warm-up steps, then exactly K steps) repeated as `--windows`
+    # consecutive windows; the headline is the MEDIAN window (one 20-step window is 5 ms: +-8 % between boxes and runs).
+    # --min-seconds keeps adding windows until that much timed work has run (lets an external sampler see the load).
+    wins = [window() for _ in range(max(1, args.windows))]
+    while args.min_seconds > 0 and sum(wins) < args.min_seconds:
+        wins.append(window())
+    if world > 1:        # the same count on every rank (each window holds collectives): agree on rank 0's
+        nw = torch.tensor([len(wins)], device=dev)
+        torch.distributed.broadcast(nw, 0)
+        while len(wins) < int(nw.item()):
+            wins.append(window())
+        wins = wins[:int(nw.item())]
+    dt = sorted(wins)[len(wins) // 2] if len(wins) % 2 else 0.5 * (sorted(wins)[len(wins) // 2 - 1] + sorted(wins)[len(wins) // 2])
+    sclk = shader_clock_under_load(step) if rank == 0 else None
     loss = float(out["combined"])
 
     # per-kernel device time: HIP events recorded on the launch stream around every kernel launch
@@ -519,12 +623,20 @@ def main():
                         value=n_h * args.steps / dth, unit="ray-samples/s", ms_per_step=1e3 * dth / args.steps, final_loss=lh,
                         bwd_variant=bvh, kernels_us={k: round(v["avg_us"], 2) for k, v in kh.items()}, **hash_rooflines(kh, n_h))
         del rh
+    aux_default = None
+    if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_default:
+        aux_default = aux_default_line(dev, args, use_graph)
     if rank == 0:
         n_local = F_PER_GPU * R * (S_C + S_G)
         value = world * n_local * args.steps / dt
         res = dict(metric="ray-samples/sec (train step: fwd+loss+bwd+Adam, 4096 rays x 128 samples per GPU)",
                    value=value, unit="ray-samples/s", n_gpus=ranks_seen, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
+                   ms_per_step=1e3 * dt / args.steps,
+                   ms_per_step_windows=dict(n=len(wins), steps_each=args.steps, median=1e3 * dt / args.steps,
+                                            min=1e3 * min(wins) / args.steps, max=1e3 * max(wins) / args.steps,
+                                            first=1e3 * wins[0] / args.steps, all=[round(1e3 * w / args.steps, 5) for w in wins],
+                                            headline="median window"),
+                   sclk_mhz=sclk, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
                    dtype=DTYPE_LABEL[resolved], data="synthetic",
                    config=dict(workload=f"M1: {F_PER_GPU} fields x 512 rays x (64 coarse + 64 depth-guided) samples per GPU, "
                                         + ("Fourier(64,raw)+2x64 MLP" if args.variant == "fourier" else
@@ -590,6 +702,8 @@ def main():
             res["matmul_alternative"] = side
         if aux_hash:
             res["aux_hash"] = aux_hash
+        if aux_default:
+            res["aux_default"] = aux_default
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

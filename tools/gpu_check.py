@@ -423,6 +423,8 @@ if __name__ == "__main__":
              # other shapes of SURVEY 8d: cfg4-like 8192 rays x 256 samples, default-config-like 32 x 512 x 24, one big field
              "time_shapes": lambda: (check_time(F=16, R=512, S_c=128, S_g=128, iters=5), check_time(F=32, R=512, S_c=8, S_g=16),
                                      check_time(F=1, R=4096, S_c=64, S_g=64), check_time(F=64, R=64, S_c=64, S_g=64)), "time_hash": lambda: (check_time(hash_enc=True), check_time(F=32, R=512, S_c=8, S_g=16, hash_enc=True)),
+             "time_hash_m1": lambda: check_time(hash_enc=True),
+             "time_hash_default": lambda: check_time(F=32, R=512, S_c=8, S_g=16, hash_enc=True),
              # what a rank with few active fields pays: the fixed cost
              "time_small": lambda: (check_time(F=1, R=512, S_c=8, S_g=16, iters=20), check_time(F=4, R=512, S_c=8, S_g=16, iters=20),
                                     check_time(F=4, R=512, S_c=64, S_g=64, iters=20)),

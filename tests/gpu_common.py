@@ -202,3 +202,6 @@ def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0
     loss["combined"].backward()
     for k in po:
         grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+
+
+from _philox_host import host_philox_draws, host_philox_uniform  # noqa: E402,F401  (numpy-only: also imported by the CPU tests)

@@ -217,3 +217,21 @@ def test_balanced_by_owner_field_draw():
     a = D.draw_fields_balanced(cur, NF, FA, 1, generator=torch.Generator().manual_seed(3))
     b = D.draw_fields_reference(cur, NF, FA, generator=torch.Generator().manual_seed(3))[0]
     assert torch.equal(a, b)
+
+
+def test_host_philox_restatement_known_answers():
+    """tests/gpu_common.host_philox_uniform (the checker of test_in_kernel_philox_equals_host_philox) IS Philox4x32-10: the
+    known-answer vectors of the Random123 distribution (kat_vectors: philox4x32 10 rounds)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_philox_host", os.path.join(os.path.dirname(__file__), "_philox_host.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    z = m.philox4x32_10((0, 0, 0, 0), (0, 0))
+    assert z == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    f = m.philox4x32_10((0xffffffff,) * 4, (0xffffffff, 0xffffffff))
+    assert f == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    p = m.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0))
+    assert p == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)

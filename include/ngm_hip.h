@@ -354,8 +354,8 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
- * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4; N_f <= 4096 (the assignment kernel
- * keeps 36 B per field in the 160 KiB LDS; more: NGM_E_UNSUPPORTED).
+ * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4; N_f unbounded (the centres are binned into a
+ * uniform grid in the workspace per call; exact K nearest, distance ties to the lower field index).
  * mask_radius: the `field_radius` ARGUMENT of NeuralFieldSet.forward (models.py:293, 368): a point is evaluated when its
  * nearest field centre is closer than this; the local coordinates are still scaled with fcfg->field_radius
  * (models.py:278-285, 378) -- _extract_mesh colours its vertices with radius + 0.1 (rm.py:2324-2336).  <= 0: fcfg->field_radius. */
@@ -496,13 +496,15 @@ int ngm_debug_disable_fused_comp(int on);
  *   handles by any means  ->  ngm_ipc_open(handle_of_rank_p, &px.mailbox[p]) for p != rank, px.mailbox[rank] = mailbox;
  *   px.seq / px.status: 8 + 4 bytes of zeroed device memory of this rank (ngm_peer_alloc works for them too).
  * Every rank must call ngm_loss_exchange the same number of times (idle ranks with zeros), like the collective it replaces.
- * A rank that waits ~2 s for a peer sets *status = 1 (sticky) and returns the partial sum: check it after synchronising. */
+ * A rank that waits ~2 s for a peer sets bit 0 of *status (sticky) and returns the PARTIAL sum; a slot that already carries a
+ * later sequence number (ranks out of step after such a time-out) is accepted and sets bit 1.  A non-zero status is fatal for
+ * the run (the sums of that iteration were wrong): check it after synchronising, as often as a wrong update may go unnoticed. */
 #define NGM_MAX_PEERS 8
 typedef struct ngm_peer_exchange {
   int32_t world, rank;
   void* mailbox[NGM_MAX_PEERS];   /* [p] = rank p's mailbox as mapped into THIS process; [rank] = the own allocation   */
   unsigned long long* seq;        /* device counter of this rank, advanced by every exchange (starts at 0)             */
-  int32_t* status;                /* device word of this rank: 0 = ok, 1 = a peer did not arrive in time (sticky)       */
+  int32_t* status;                /* device word of this rank: 0 = ok, bit 0 = time-out, bit 1 = out of step (sticky)   */
 } ngm_peer_exchange;
 int64_t ngm_peer_mailbox_bytes(void);
 int ngm_peer_alloc(int64_t bytes, void** ptr);              /* zeroed fine-grained (uncached) device memory              */

@@ -92,7 +92,7 @@ static int fail(int code, const char* msg) {
 #define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
 int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
-static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 4: the same, two waves per tile, 5: hash encoding + 1x32 MLP on the bf16 split
+static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_no_fused_comp = 0;       // ngm_debug_disable_fused_comp
 static int g_last_comp_fused = 0;     // the last training backward did the compositing backward inside k_field_bwd_b3 (no k_stash_bwd launch)
 // true when launch_bwd_any's first candidate is k_field_bwd_b3 (no experiment switch in the way)
@@ -100,6 +100,24 @@ static bool bwd_b3_is_default() {
   static const bool off = getenv("NGM_BWD32") != nullptr || getenv("NGM_NO_BWD_B3") != nullptr;
   return !off;
 }
+// Which targets the LAST forward on a workspace wrote its per-ray loss seeds for (host-side bookkeeping by pointer identity:
+// the fused compositing backward trusts off_rayseed only when the forward that filled this workspace ran with the same
+// targets; a forward without targets, or with other targets, leaves the backward on k_stash_bwd, which derives the seeds
+// from targets + prediction itself).
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_seed_mu;
+static std::unordered_map<const void*, const void*> g_seed_targets;       // workspace -> targets.rgbds of the forward that wrote the seeds
+static void note_forward_seeds(const void* ws, const void* rgbds) {
+  std::lock_guard<std::mutex> lk(g_seed_mu);
+  if (rgbds) g_seed_targets[ws] = rgbds; else g_seed_targets.erase(ws);
+}
+static bool forward_wrote_seeds_for(const void* ws, const void* rgbds) {
+  std::lock_guard<std::mutex> lk(g_seed_mu);
+  auto it = g_seed_targets.find(ws);
+  return it != g_seed_targets.end() && it->second == rgbds;
+}
+
 static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool force32 = getenv("NGM_BWD32") != nullptr;
   static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
@@ -668,6 +686,7 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
   }
   e = ngm_launch_render_fwd(a, p.blocks_fwd, (hipStream_t)stream);
   if (e) return fail(e, "render_fwd: no kernel for this (D,H,L)");
+  if (save) note_forward_seeds(workspace, a.rayseed ? targets->rgbds : nullptr);
   e = check_launch("ngm_render_fwd");
   if (e) return e;
   if (has_tg && loss_sums) {      // loss_sums == NULL: deferred -- ngm_render_bwd* (loss_sums == NULL) reduces the partials itself
@@ -716,9 +735,10 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
   const bool no_fuse = no_fuse_env || g_no_fused_comp;
   const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
-  const bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && bwd_b3_is_default() && a.P < (1 << 24) &&
-                    (ngm_field_bwd_b3_applies(a) || ngm_hash_mlp_bwd_applies(a));
+  bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && bwd_b3_is_default() && a.P < (1 << 24) &&
+              forward_wrote_seeds_for(workspace, sb.tg.rgbds) && (ngm_field_bwd_b3_applies(a) || ngm_hash_mlp_bwd_applies(a));
   int e = 0;
+  const FieldBwdArgs a_plain = a;            // for the fall-back below: the launch records before the fused fields are set
   if (fuse) {
     a.fused_comp = 1; a.rc = *rcfg;
     a.rayseed = reinterpret_cast<const float*>(ws + p.off_rayseed);
@@ -739,6 +759,20 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
   if (e) return e;
   e = launch_bwd_any(a, a.blocks_per_field * a.F, st);
+  if (e == NGM_E_UNSUPPORTED && fuse) {
+    // the fused kernel declined after all (its own LDS / shape checks): composite in k_stash_bwd, then any MLP backward
+    fuse = false;
+    a = a_plain;
+    sb.xyz_out = a.hash_xyz;
+    a.hash_xyz_ready = a.hash_xyz != nullptr;
+    e = ngm_launch_stash_bwd(sb, st);
+    if (e) return fail(e, "render_bwd: unsupported geometry mode");
+    e = check_launch("ngm_stash_bwd");
+    if (e) return e;
+    e = prep_lattice_grad(fcfg, grads, rays->F, a, st);
+    if (e) return e;
+    e = launch_bwd_any(a, a.blocks_per_field * a.F, st);
+  }
   if (e) return fail(e, "render_bwd: no kernel for this (D,H,L)");
   e = check_launch("ngm_field_bwd");
   if (e) return e;

@@ -547,46 +547,61 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
   __shared__ float part[4][64];
   const int f = blockIdx.y, q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 64 + l;
+  // The kernel is a latency chain (a few KB per workgroup): everything that does not depend on the sums is issued FIRST --
+  // the parameter / moment loads of the quarter that will apply the update, the bias corrections (two fp64 pow) -- and the
+  // partial sums keep up to eight loads in flight per thread (they used to go four at a time, the Adam loads behind them).
+  int seg = -1;
+  int64_t so = 0;
+  float pv = 0.f, m0 = 0.f, v0 = 0.f, lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
+  if (q == 0 && p < a.ptot) {
+    for (int k = 0; k < a.nseg; ++k)
+      if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) { seg = k; break; }
+    if (seg >= 0 && a.seg[seg].param) {
+      const int64_t row = a.field_index ? a.field_index[f] : f;
+      so = row * a.seg[seg].pstride + (p - a.seg[seg].off);
+      pv = a.seg[seg].param[so]; m0 = a.seg[seg].m[so]; v0 = a.seg[seg].v[so];
+      const double step = (double)(a.step_dev ? *a.step_dev : a.step);
+      lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+    }
+  }
   float s = 0.f;
   if (p < a.ptot) {
-    // workgroup b of the backward kernel handled field b % F
+    // workgroup b of the backward kernel handled field b % F; quarter q sums blocks q, q + 4, ... in that order
     const float* src = a.partials + (int64_t)f * a.p_pad + p;
     const int64_t cs = (int64_t)a.F * a.p_pad;
     int c = q;
 #pragma unroll 1
+    for (; c + 28 < a.blocks_per_field; c += 32) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(c + 4 * j) * cs];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+#pragma unroll 1
     for (; c + 12 < a.blocks_per_field; c += 16) {
-      const float v0 = src[c * cs], v1 = src[(c + 4) * cs], v2 = src[(c + 8) * cs], v3 = src[(c + 12) * cs];
-      s += v0; s += v1; s += v2; s += v3;
+      const float v0_ = src[c * cs], v1 = src[(c + 4) * cs], v2 = src[(c + 8) * cs], v3 = src[(c + 12) * cs];
+      s += v0_; s += v1; s += v2; s += v3;
     }
     for (; c < a.blocks_per_field; c += 4) s += src[c * cs];
   }
   part[q][l] = s;
   __syncthreads();
-  if (q != 0 || p >= a.ptot) return;
+  if (q != 0 || p >= a.ptot || seg < 0) return;
   s = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
-  for (int k = 0; k < a.nseg; ++k) {
-    if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) {
-      const int64_t i = p - a.seg[k].off;
-      if (a.seg[k].dst) a.seg[k].dst[(int64_t)f * a.seg[k].stride + i] = s;
-      if (a.seg[k].param) {
-        // the update of rm.py:1183-1221 on row field_index[f], straight from the reduced gradient (no second
-        // launch, no gradient round trip); same arithmetic as k_adam_multi
-        const double step = (double)(a.step_dev ? *a.step_dev : a.step);
-        const float lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
-        const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
-        const int64_t row = a.field_index ? a.field_index[f] : f;
-        const int64_t o = row * a.seg[k].pstride + i;
-        const float pv = a.seg[k].param[o];
-        const float g = s + a.wd * pv;
-        const float mn = a.beta1 * a.seg[k].m[o] + (1.0f - a.beta1) * g;
-        const float vn = a.beta2 * a.seg[k].v[o] + (1.0f - a.beta2) * g * g;
-        a.seg[k].m[o] = mn; a.seg[k].v[o] = vn;
-        const float pn = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
-        a.seg[k].param[o] = pn;
-        if (a.seg[k].lp) ngm_stp(a.seg[k].lp, o, pn, a.seg[k].lp_dt);      // the reduced-precision copy the kernels read
-      }
-      break;
-    }
+  const int64_t i = p - a.seg[seg].off;
+  if (a.seg[seg].dst) a.seg[seg].dst[(int64_t)f * a.seg[seg].stride + i] = s;
+  if (a.seg[seg].param) {
+    // the update of rm.py:1183-1221 on row field_index[f], straight from the reduced gradient (no second launch, no
+    // gradient round trip); same arithmetic as k_adam_multi
+    const float g = s + a.wd * pv;
+    const float mn = a.beta1 * m0 + (1.0f - a.beta1) * g;
+    const float vn = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
+    a.seg[seg].m[so] = mn; a.seg[seg].v[so] = vn;
+    const float pn = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+    a.seg[seg].param[so] = pn;
+    if (a.seg[seg].lp) ngm_stp(a.seg[seg].lp, so, pn, a.seg[seg].lp_dt);      // the reduced-precision copy the kernels read
   }
 }
 

@@ -2,8 +2,11 @@
 //
 // The reference finds the K nearest field centres of every query point, evaluates each touched field
 // in a Python loop over boolean masks and blends with softmax(-distance_factor * dist).  Here:
-//   k_knn_assign  : exact K-nearest (K <= 4, all centres in LDS, per-wave candidate list), radius test, softmax weights;
-//                   per-workgroup LDS histogram -> one global atomic per field per workgroup
+//   k_knn_grid    : field centres binned into a uniform grid on the device (cell = the cover-grid spacing 2 r / sqrt 3 of
+//                   rm.py:299, never smaller than the mask radius; one workgroup: bounding box, counts, scan, fill)
+//   k_knn_assign  : exact K-nearest (K <= 4) per point from the 27 cells around it, the block of cells growing ring by ring
+//                   until the K-th neighbour found is provably the K-th nearest; radius test, softmax weights; per-workgroup
+//                   LDS histogram -> one global atomic per field per workgroup.  No limit on the number of fields.
 //   k_knn_offsets : exclusive scans over fields (segment offsets, tile offsets)
 //   k_knn_scatter : (point,k) pairs bucketed by field (counting sort)
 //   k_knn_eval    : one workgroup per 4096-pair tile of ONE field: that field's weights resident in
@@ -41,7 +44,16 @@ struct KnnArgs {
   int* tile_off;        // (NF+1)
   int* sorted;          // (P*K)  pair ids grouped by field
   float4* pair_out;     // (P*K)
+  // uniform grid over the field centres (built per call by k_knn_grid)
+  struct KnnGridHdr* grid;   // origin, cell size, dimensions (device)
+  int* cell_start;      // (max_cells + 1) exclusive prefix of the per-cell counts
+  int* cell_fill;       // (max_cells) fill cursors
+  float4* cell_c;       // (NF) centres grouped by cell: (x, y, z, field index as int bits)
+  int max_cells;
+  float cell_size;      // requested cell edge (>= mask radius); the kernel may coarsen it to fit max_cells
+  int hist_in_lds;      // per-workgroup field histograms fit the LDS (else: global atomics per pair)
 };
+struct KnnGridHdr { float x0, y0, z0, c, inv_c; int nx, ny, nz, ncells, pad; };
 
 // wave-wide min / max (uniform result): DPP row scans + row broadcasts, lane 63 read back (no LDS-pipe shuffles)
 template <int CTRL, int ROW_MASK>
@@ -57,116 +69,268 @@ __device__ __forceinline__ float wave_min_f(float v) {
 }
 __device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
 
-// K nearest centres, exact, with a per-wave candidate list.  The 64 points of a wave are consecutive samples of a
-// ray (or neighbours of a dense grid): they sit in a ball (c0, rho).  If D bounds the K-th nearest distance of c0
-// from above, the K nearest centres of EVERY point of the wave lie within D + 2 rho of c0 (triangle inequality), so
-// only those centres -- typically a handful of a few hundred -- are compared per point.  D = the K-th smallest of the
-// 64 lanes' minima over disjoint subsets of the centres (K distinct centres, hence an upper bound).  The list keeps
-// the field order, so distances, tie-breaking and results are bit-identical to the brute-force loop; incoherent
-// points only make the list long.
-__global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smf[];
-  float4* cpos = reinterpret_cast<float4*>(smf);       // NF centres, one 16-byte broadcast read each
-  int* hist = reinterpret_cast<int*>(smf + 4 * a.NF);  // NF
-  int* cand_all = hist + a.NF;                         // 4 waves x NF candidate indices
-  for (int i = threadIdx.x; i < a.NF; i += blockDim.x) cpos[i] = make_float4(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2], 0.f);
-  for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
-  __syncthreads();
-  const int K = a.K;
-  const int lane = threadIdx.x & 63;
-  int* cand = cand_all + (threadIdx.x >> 6) * a.NF;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < a.P; p0 += stride) {   // uniform trip count per wave
-    const int64_t p = p0 + threadIdx.x;
-    const bool live = p < a.P;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (live) { x = a.points[3 * p]; y = a.points[3 * p + 1]; z = a.points[3 * p + 2]; }
-    // ---- bounding ball of the wave's points
-    const float big = 3.0e38f;
-    const float lx = wave_min_f(live ? x : big), hx = wave_max_f(live ? x : -big);
-    const float ly = wave_min_f(live ? y : big), hy = wave_max_f(live ? y : -big);
-    const float lz = wave_min_f(live ? z : big), hz = wave_max_f(live ? z : -big);
-    int ncand = 0;
-    if (lx <= hx) {                                            // at least one live lane (wave-uniform)
-      const float cx = 0.5f * (lx + hx), cy = 0.5f * (ly + hy), cz = 0.5f * (lz + hz);
-      const float ex = x - cx, ey = y - cy, ez = z - cz;
-      const float rho = sqrtf(wave_max_f(live ? ex * ex + ey * ey + ez * ez : 0.f)) * 1.0001f + 1e-12f;
-      // ---- upper bound D of the K-th nearest distance of c0
-      float dmin = INFINITY;
-      for (int f = lane; f < a.NF; f += 64) {
-        const float4 c = cpos[f];
-        const float dx = cx - c.x, dy = cy - c.y, dz = cz - c.z;
-        dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
-      }
-      float D2 = INFINITY;
-      for (int k = 0; k < K; ++k) {
-        D2 = wave_min_f(dmin);
-        const unsigned long long who = __ballot(dmin == D2);
-        if (who && lane == __ffsll((long long)who) - 1) dmin = INFINITY;   // pop one lane's minimum per round
-      }
-      // fewer than K centres: D2 is inf and every centre stays a candidate.  Slack: the bound is compared in squared
-      // distances computed in fp32 -> widen by a relative 1e-4 (costs nothing, keeps the list a superset).
-      const float reach = (sqrtf(D2) + 2.0f * rho) * 1.0001f;
-      const float reach2 = reach * reach;
-      // ---- candidate list in field order
-      for (int f0 = 0; f0 < a.NF; f0 += 64) {
-        const int f = f0 + lane;
-        bool keep = false;
-        if (f < a.NF) {
-          const float4 c = cpos[f];
-          const float dx = cx - c.x, dy = cy - c.y, dz = cz - c.z;
-          keep = !(dx * dx + dy * dy + dz * dz > reach2);      // NaN-safe: keeps the centre
-        }
-        const unsigned long long m = __ballot(keep);
-        if (keep) cand[ncand + __popcll(m & ((1ull << lane) - 1ull))] = f;
-        ncand += __popcll(m);
-      }
-    }
-    WAVE_SYNC();
-    if (live) {
-    float bd[KNN_MAXK]; int bi[KNN_MAXK];
+// ---- uniform grid over the field centres -------------------------------------------------------------------------------
+// One workgroup of 1024 threads (the map is a few hundred to a few ten thousand centres): bounding box -> cell size / grid
+// dimensions (coarsened until the grid fits max_cells) -> per-cell counts -> exclusive scan -> centres grouped by cell.
+// The order of the centres inside a cell is whatever the atomics give: k_knn_assign breaks distance ties by field index,
+// so its result does not depend on it.
+__global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
+  __shared__ float red[6][16];
+  __shared__ int sscan[1024];
+  __shared__ KnnGridHdr h;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int f = t; f < a.NF; f += 1024)
 #pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
-    float worst = INFINITY;                                   // bd[K-1]: most centres are farther and skip the insertion
-    for (int ci = 0; ci < ncand; ++ci) {
-      const int f = cand[ci];
-      const float4 c = cpos[f];
-      const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
-      float d = dx * dx + dy * dy + dz * dz;
-      if (d < worst) {
-        int id = f;
-        // sorted insertion (stable: equal distances keep the lower field index first)
+    for (int d = 0; d < 3; ++d) { const float v = a.pos[3 * f + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
 #pragma unroll
-        for (int k = 0; k < KNN_MAXK; ++k) {
-          if (k < K && d < bd[k]) { const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti; }
-        }
-        worst = (K == 1) ? bd[0] : (K == 2) ? bd[1] : (K == 3) ? bd[2] : bd[3];
-      }
-    }
-    float dist[KNN_MAXK];
-#pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) dist[k] = sqrtf(bd[k]);
-    const bool inside = dist[0] < a.radius;                      // models.py:369
-    // softmax(-distance_factor * dist) over the K neighbours (models.py:384)
-    float mx = -INFINITY, e[KNN_MAXK], sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) if (k < K) mx = fmaxf(mx, -a.distance_factor * dist[k]);
-#pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) { e[k] = (k < K) ? expf(-a.distance_factor * dist[k] - mx) : 0.f; sum += e[k]; }
-#pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) {
-      if (k < K) {
-        a.pair_field[p * K + k] = inside ? bi[k] : -1;
-        a.pair_w[p * K + k] = e[k] / sum;
-        if (inside) atomicAdd(&hist[bi[k]], 1);
-      }
-    }
-    }
-    WAVE_SYNC();     // the next round overwrites the candidate list
+  for (int d = 0; d < 3; ++d) {
+    const float l = wave_min_f(lo[d]), u = wave_max_f(hi[d]);
+    if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = u; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.NF; i += blockDim.x)
-    if (hist[i]) atomicAdd(&a.counts[i], hist[i]);
+  if (t == 0) {
+    float L[3], U[3];
+    for (int d = 0; d < 3; ++d) {
+      L[d] = red[d][0]; U[d] = red[3 + d][0];
+      for (int w = 1; w < 16; ++w) { L[d] = fminf(L[d], red[d][w]); U[d] = fmaxf(U[d], red[3 + d][w]); }
+      if (!(L[d] <= U[d])) { L[d] = 0.f; U[d] = 0.f; }                // no (finite) centre
+    }
+    float c = a.cell_size;
+    int n[3];
+    for (int it = 0; it < 200; ++it) {
+      double cells = 1.0;
+      for (int d = 0; d < 3; ++d) {
+        const float e = (U[d] - L[d]) / c;
+        n[d] = (e < 1.0e6f) ? (int)e + 1 : 1000001;
+        cells *= (double)n[d];
+      }
+      if (cells <= (double)a.max_cells) break;
+      c *= 1.26f;                                                      // cells / 2 per step
+    }
+    h.x0 = L[0]; h.y0 = L[1]; h.z0 = L[2]; h.c = c; h.inv_c = 1.0f / c;
+    h.nx = n[0]; h.ny = n[1]; h.nz = n[2]; h.ncells = n[0] * n[1] * n[2]; h.pad = 0;
+    *a.grid = h;
+  }
+  __syncthreads();
+  const int nc = h.ncells;
+  for (int i = t; i <= nc; i += 1024) a.cell_start[i] = 0;
+  for (int i = t; i < nc; i += 1024) a.cell_fill[i] = 0;
+  __threadfence_block();
+  __syncthreads();
+  auto cell_of = [&](int f) {
+    const int ix = min(max((int)((a.pos[3 * f] - h.x0) * h.inv_c), 0), h.nx - 1);
+    const int iy = min(max((int)((a.pos[3 * f + 1] - h.y0) * h.inv_c), 0), h.ny - 1);
+    const int iz = min(max((int)((a.pos[3 * f + 2] - h.z0) * h.inv_c), 0), h.nz - 1);
+    return (iz * h.ny + iy) * h.nx + ix;
+  };
+  for (int f = t; f < a.NF; f += 1024) atomicAdd(&a.cell_start[cell_of(f)], 1);
+  __threadfence_block();
+  __syncthreads();
+  // exclusive scan of cell_start[0 .. nc): contiguous segments per thread, block scan of the segment sums
+  const int per = (nc + 1023) / 1024, b0 = min(nc, t * per), b1 = min(nc, b0 + per);
+  int sum = 0;
+  for (int i = b0; i < b1; ++i) sum += a.cell_start[i];
+  sscan[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (t >= d) ? sscan[t - d] : 0;
+    __syncthreads();
+    sscan[t] += v;
+    __syncthreads();
+  }
+  int run = sscan[t] - sum;
+  for (int i = b0; i < b1; ++i) { const int cnt = a.cell_start[i]; a.cell_start[i] = run; run += cnt; }
+  if (t == 1023) a.cell_start[nc] = sscan[1023];
+  __threadfence_block();
+  __syncthreads();
+  for (int f = t; f < a.NF; f += 1024) {
+    const int cidx = cell_of(f);
+    const int slot = a.cell_start[cidx] + atomicAdd(&a.cell_fill[cidx], 1);
+    a.cell_c[slot] = make_float4(a.pos[3 * f], a.pos[3 * f + 1], a.pos[3 * f + 2], __int_as_float(f));
+  }
+}
+
+// K nearest centres of every point, exact.  The (2 R + 1)^3 block of cells around the point's cell holds every centre
+// within R cell edges c of it.  Phase A decides the inside test of models.py:369 (c >= mask radius: R = 1 suffices) and
+// looks only at cells that can hold a centre within the mask radius -- four out of five samples of an image lie outside
+// every field and stop here.  Phase B (inside points) finds the K nearest: cells whose nearest face is already farther
+// than the current K-th best are skipped, rows are narrowed in x the same way, and the block grows ring by ring until the
+// K-th neighbour found lies within R c (R = 1 wherever the map is as dense as its cover grid).  Ties in distance go to the
+// lower field index, as in a loop over the fields in order: the brute-force result bit for bit.
+// GL: the grid (cell offsets + centres) staged in LDS -- maps up to a few thousand fields; larger ones read it through L1 / L2.
+// KK: the number of neighbours as a compile-time constant (the list insertion is the hot code: a wave executes it for the
+// union of its lanes' candidates)
+template <bool GL, int KK>
+__global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int knn_lds[];
+  const KnnGridHdr h = *a.grid;
+  int* hist = knn_lds;                                  // NF (hist_in_lds)
+  const int hist_n = a.hist_in_lds ? a.NF : 0;
+  const int* cs = a.cell_start;
+  const float4* cc = a.cell_c;
+  if (a.hist_in_lds)
+    for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
+  if constexpr (GL) {
+    float4* lcc = reinterpret_cast<float4*>(knn_lds + ((hist_n + 3) & ~3));
+    int* lcs = reinterpret_cast<int*>(lcc + a.NF);
+    for (int i = threadIdx.x; i < a.NF; i += blockDim.x) lcc[i] = a.cell_c[i];
+    for (int i = threadIdx.x; i <= h.ncells; i += blockDim.x) lcs[i] = a.cell_start[i];
+    cs = lcs; cc = lcc;
+  }
+  __syncthreads();
+  constexpr int K = KK;
+  const int maxR = max(h.nx, max(h.ny, h.nz));
+  const float c2 = h.c * h.c;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += stride) {
+    const float x = a.points[3 * p], y = a.points[3 * p + 1], z = a.points[3 * p + 2];
+    const float gx = (x - h.x0) * h.inv_c, gy = (y - h.y0) * h.inv_c, gz = (z - h.z0) * h.inv_c;
+    // cell of the point; far outside the grid (or NaN) it is clamped to two rings beyond: nothing is within c then
+    const float fx = fminf(fmaxf(floorf(gx), -2.0f), (float)h.nx + 1.0f), fy = fminf(fmaxf(floorf(gy), -2.0f), (float)h.ny + 1.0f),
+                fz = fminf(fmaxf(floorf(gz), -2.0f), (float)h.nz + 1.0f);
+    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float bd[KK]; int bi[KK];
+    float worst; int worst_i;
+    // scan the block of radius R; cells / row ends whose nearest face is not closer than `lim2` (world units squared; a
+    // fixed limit, or the running K-th best when `dynamic`) are skipped -- they cannot change the result
+    auto scan = [&](int R, float lim2, bool dynamic) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < KK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+      worst = INFINITY; worst_i = -1;
+      const int xs0 = max(ix - R, 0), xe0 = min(ix + R, h.nx - 1);
+      if (xs0 > xe0) return;
+      for (int oz = 0; oz <= 2 * R; ++oz) {
+        // own plane first, then alternating outwards: the running bound shrinks early
+        const int cz = iz + ((oz & 1) ? (oz + 1) / 2 : -(oz / 2));
+        if (cz < 0 || cz >= h.nz) continue;
+        const float lz = fmaxf(fmaxf((float)cz - gz, gz - (float)(cz + 1)), 0.f);
+        for (int oy = 0; oy <= 2 * R; ++oy) {
+          const int cy = iy + ((oy & 1) ? (oy + 1) / 2 : -(oy / 2));
+          if (cy < 0 || cy >= h.ny) continue;
+          const float ly = fmaxf(fmaxf((float)cy - gy, gy - (float)(cy + 1)), 0.f);
+          const float lat2 = (ly * ly + lz * lz) * c2 * 0.9999f;
+          const float lim = dynamic ? fminf(worst, lim2) : lim2;
+          if (!(lat2 < lim)) continue;
+          // cells of this row that can hold a centre closer than lim: |x - centre.x| < sqrt(lim - lat2)
+          int xs = xs0, xe = xe0;
+          if (lim < INFINITY) {
+            const float rem = __builtin_amdgcn_sqrtf(lim - lat2) * h.inv_c * 1.001f + 1e-4f;     // (1-ulp hardware root: the margin covers it)
+            xs = max(xs, (int)floorf(gx - rem)); xe = min(xe, (int)floorf(gx + rem));
+            if (xs > xe) continue;
+          }
+          const int rowb = (cz * h.ny + cy) * h.nx;
+          const int je = cs[rowb + xe + 1];
+          for (int j = cs[rowb + xs]; j < je; ++j) {
+            const float4 c = cc[j];
+            const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+            float d = dx * dx + dy * dy + dz * dz;
+            int id = __float_as_int(c.w);
+            if (d < worst || (d == worst && id < worst_i)) {
+              // sorted insertion; equal distances keep the lower field index first
+#pragma unroll
+              for (int k = 0; k < KK; ++k) {
+                if (k < K && (d < bd[k] || (d == bd[k] && id < bi[k]))) {
+                  const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
+                }
+              }
+              worst = bd[KK - 1];
+              worst_i = bi[KK - 1];
+            }
+          }
+        }
+      }
+    };
+    // ---- phase A: is any centre within the mask radius?  (a centre at distance < radius <= c sits in the 27 cells, and in a
+    // cell whose nearest face is closer than the radius)
+    // (only the nearest distance matters here: a plain minimum, no neighbour list -- the list costs ~25 instructions per
+    // candidate, and a wave executes the union of its lanes' candidates)
+    const float rad2 = a.radius * a.radius * 1.0002f;
+    float dmin = INFINITY;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+    worst = INFINITY; worst_i = -1;
+    {
+      float lyv[3], lzv[3];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        const int cy = iy + o - 1, cz = iz + o - 1;
+        lyv[o] = (cy < 0 || cy >= h.ny) ? INFINITY : fmaxf(fmaxf((float)cy - gy, gy - (float)(cy + 1)), 0.f);
+        lzv[o] = (cz < 0 || cz >= h.nz) ? INFINITY : fmaxf(fmaxf((float)cz - gz, gz - (float)(cz + 1)), 0.f);
+      }
+      const int xs0 = max(ix - 1, 0), xe0 = min(ix + 1, h.nx - 1);
+      const int row0 = ((iz - 1) * h.ny + (iy - 1)) * h.nx;
+      const float c2r = c2 * 0.9999f / rad2;               // lat2 in units of the (slightly enlarged) squared radius
+      for (int oz = 0; oz < 3; ++oz)
+        for (int oy = 0; oy < 3; ++oy) {
+          // a row (3 cells along x) is scanned whole when its nearest edge is within the radius: narrowing it in x as phase B
+          // does costs more instructions (root, two floors, clamps) than the one or two centres it spares
+          const float lat2 = (lyv[oy] * lyv[oy] + lzv[oz] * lzv[oz]) * c2r;
+          if (!(lat2 < 1.0f) || xs0 > xe0) continue;
+          const int rowb = row0 + (oz * h.ny + oy) * h.nx;
+          const int je = cs[rowb + xe0 + 1];
+          for (int j = cs[rowb + xs0]; j < je; ++j) {
+            const float4 c = cc[j];
+            const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+            float d = dx * dx + dy * dy + dz * dz;
+            dmin = fminf(dmin, d);
+            // the centres within the radius also start the neighbour list: where the map is as dense as its cover grid the K
+            // nearest are among them and phase B is not needed at all
+            if (d < rad2 && (d < worst || (d == worst && __float_as_int(c.w) < worst_i))) {
+              int id = __float_as_int(c.w);
+#pragma unroll
+              for (int k = 0; k < KK; ++k) {
+                if (k < K && (d < bd[k] || (d == bd[k] && id < bi[k]))) {
+                  const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
+                }
+              }
+              worst = bd[KK - 1];
+              worst_i = bi[KK - 1];
+            }
+          }
+        }
+    }
+    bool inside = sqrtf(dmin) < a.radius;                        // models.py:369 (the same squared distance as the list's bd[0])
+    // every centre closer than the radius has been seen: a K-th neighbour inside the radius is the K-th nearest
+    if (inside && !(worst < a.radius * a.radius)) {
+      // ---- phase B: the K nearest of an inside point with fewer than K centres within the radius
+      for (int R = 1;; ++R) {
+        scan(R, INFINITY, true);
+        // exact when the K-th found is within the block's guaranteed reach R c (a little less: fp32 cell arithmetic) or the
+        // block has swallowed the grid
+        const float reach = (float)R * h.c * 0.9999f;
+        if (worst <= reach * reach || R > maxR + 2) break;
+      }
+    }
+    if (inside) inside = sqrtf(bd[0]) < a.radius;                 // models.py:369 on the distance the blend uses
+    if (!inside) {                                                // outside every field: the blend writes outside_value
+#pragma unroll
+      for (int k = 0; k < KK; ++k)
+        if (k < K) a.pair_field[p * K + k] = -1;     // (k_knn_blend reads the weights of inside points only)
+      continue;
+    }
+    // softmax(-distance_factor * dist) over the K neighbours (models.py:384); dist[0] is the distance phase A tested
+    float dist[KK], mx = -INFINITY, e[KK], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+      if (k < K) { dist[k] = sqrtf(bd[k]); mx = fmaxf(mx, -a.distance_factor * dist[k]); }
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+      if (k < K) { e[k] = expf(-a.distance_factor * dist[k] - mx); sum += e[k]; }
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      if (k < K) {
+        a.pair_field[p * K + k] = bi[k];
+        a.pair_w[p * K + k] = e[k] / sum;
+        if (bi[k] >= 0) { if (a.hist_in_lds) atomicAdd(&hist[bi[k]], 1); else atomicAdd(&a.counts[bi[k]], 1); }
+      }
+    }
+  }
+  if (a.hist_in_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.NF; i += blockDim.x)
+      if (hist[i]) atomicAdd(&a.counts[i], hist[i]);
+  }
 }
 
 // exclusive scans over the fields (segment offsets, tile offsets): one wave, 64 fields per round
@@ -197,9 +361,18 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
   extern __shared__ int sc_lds[];
   int* hist = sc_lds;            // NF: pairs of this workgroup per field, then the reserved global base
   const int64_t n = a.P * a.K;
+  const int64_t base = (int64_t)blockIdx.x * (SC_ITEMS * 256);
+  if (!a.hist_in_lds) {          // maps too large for an LDS histogram (> ~38 000 fields): one global atomic per pair
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      const int fl = (i < n) ? a.pair_field[i] : -1;
+      if (fl >= 0) a.sorted[a.seg_off[fl] + atomicAdd(&a.cursor[fl], 1)] = (int)i;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < a.NF; i += blockDim.x) hist[i] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * (SC_ITEMS * 256);
   int fld[SC_ITEMS], rnk[SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; ++k) {
@@ -280,9 +453,14 @@ __global__ __launch_bounds__(256) void k_knn_blend(KnnArgs a) {
   }
 }
 
+// cells of the uniform grid over the centres: ~8 per field (the cover grid of rm.py:299 puts about one centre per cell; rooms
+// are not cubes), bounded so that the build stays a one-workgroup job
+static int knn_max_cells(int num_fields) { return (int)std::min<int64_t>(std::max<int64_t>(8 * (int64_t)num_fields, 512), 1 << 18); }
 int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
   const int64_t n = P * K;
-  return 256 * 8 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16);
+  const int64_t mc = knn_max_cells(num_fields);
+  return 256 * 12 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16) +
+         256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16);
 }
 
 template <int MI, int MH, int L>
@@ -325,8 +503,7 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
                    float* out, void* workspace, int64_t workspace_bytes, hipStream_t st) {
   if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
-  // k_knn_assign keeps centres + histogram + 4 candidate lists of every field in LDS: 36 B per field of the 160 KiB
-  if (num_fields > 4096 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
+  if (num_fields < 1 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
   KnnArgs a;
   a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.P = P; a.points = points; a.pos = pos; a.quat = quat;
   a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = mask_radius; a.out = out;
@@ -341,22 +518,49 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   a.tile_off = reinterpret_cast<int*>(carve(4 * (num_fields + 1)));
   a.sorted = reinterpret_cast<int*>(carve(4 * n));
   a.pair_out = reinterpret_cast<float4*>(carve(16 * n));
+  a.max_cells = knn_max_cells(num_fields);
+  a.grid = reinterpret_cast<KnnGridHdr*>(carve(256));
+  a.cell_start = reinterpret_cast<int*>(carve(4 * ((int64_t)a.max_cells + 1)));
+  a.cell_fill = reinterpret_cast<int*>(carve(4 * (int64_t)a.max_cells));
+  a.cell_c = reinterpret_cast<float4*>(carve(16 * (int64_t)num_fields));
+  // cell edge: the spacing of the reference's cover grid (2 r / sqrt 3, rm.py:299), never below the mask radius (the inside
+  // test is decided in the first ring); a non-positive radius (no field contains anything) still needs a positive edge
+  a.cell_size = std::max(std::max(1.1547005f * fc->field_radius, mask_radius), 1e-6f);
   (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
   const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
-  const size_t lds_a = (size_t)num_fields * (20 + 4 * 4);    // centres, histogram, 4 waves of candidate lists
-  if (lds_a > 48 * 1024) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_assign),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36);
-    if (attr != hipSuccess) return NGM_E_HIP;
-  }
+  // per-workgroup field histograms (assignment, scatter) in LDS while they fit (150 KB = 38 400 fields); beyond: global atomics
+  const size_t lds_h = (size_t)num_fields * 4;
+  a.hist_in_lds = lds_h <= 150 * 1024 ? 1 : 0;
+  static const hipError_t attr_a = [] {
+    hipError_t e = hipSuccess;
+#define NGM_KA(G, KK_, B) do { const hipError_t x = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_assign<G, KK_>), hipFuncAttributeMaxDynamicSharedMemorySize, B); if (x != hipSuccess) e = x; } while (0)
+    NGM_KA(false, 1, 150 * 1024); NGM_KA(false, 2, 150 * 1024); NGM_KA(false, 3, 150 * 1024); NGM_KA(false, 4, 150 * 1024);
+    NGM_KA(true, 1, 64 * 1024); NGM_KA(true, 2, 64 * 1024); NGM_KA(true, 3, 64 * 1024); NGM_KA(true, 4, 64 * 1024);
+#undef NGM_KA
+    return e;
+  }();
+  const hipError_t attr_g = attr_a;
+  // grid in LDS while histogram + centres + cell offsets stay within 64 KB (two workgroups per CU keep their latency hiding)
+  const size_t lds_grid = (((size_t)num_fields + 3) & ~(size_t)3) * 4 + (size_t)num_fields * 16 + ((size_t)a.max_cells + 1) * 4;
+  const bool grid_in_lds = a.hist_in_lds && attr_g == hipSuccess && lds_grid <= 64 * 1024;
+  static const hipError_t attr_s = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_scatter),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (attr_a != hipSuccess || attr_s != hipSuccess) return NGM_E_HIP;
   {
     NgmProfScope prof_(NGM_K_KNN_ASSIGN, st);
-    hipLaunchKernelGGL(k_knn_assign, dim3(std::max(pb, 1)), dim3(256), lds_a, st, a);
+    hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
+#define NGM_KL(KK_)                                                                                                    \
+    do {                                                                                                               \
+      if (grid_in_lds) hipLaunchKernelGGL((k_knn_assign<true, KK_>), dim3(std::max(pb, 1)), dim3(256), lds_grid, st, a);  \
+      else hipLaunchKernelGGL((k_knn_assign<false, KK_>), dim3(std::max(pb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a); \
+    } while (0)
+    if (K == 1) NGM_KL(1); else if (K == 2) NGM_KL(2); else if (K == 3) NGM_KL(3); else if (K == 4) NGM_KL(4); else return NGM_E_UNSUPPORTED;
+#undef NGM_KL
   }
   if (hipGetLastError() != hipSuccess) return NGM_E_HIP;      // an over-sized LDS request fails here, not four launches later
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
-  hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), (size_t)num_fields * 4, st, a);
+  hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a);
   const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
   const FieldShape s = field_shape(fc);
   int le = NGM_E_UNSUPPORTED;

@@ -90,10 +90,11 @@ struct FieldBwdArgs {
   int64_t act_layer_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
   GradAdam lattice_adam;              // optional (tensors != NULL, num == 1): k_hash_reduce applies Adam to the hash tables
-  // Fused compositing backward (k_field_bwd_b3 only, pointwise geometry modes, loss seeds): d_out then holds the forward's
-  // (colour, geometry) stash untouched, and the kernel does what k_stash_bwd does -- per-ray reverse scan, loss derivatives,
-  // the loss bookkeeping of its block 0 -- on the tile it is about to back-propagate.  Every wave walks a contiguous,
-  // ray-aligned range of tiles back to front (per_block is a multiple of 4 lcm(32, S)).
+  // Fused compositing backward (k_field_bwd_b3<FC> and k_hash_mlp_bwd<FC>, pointwise geometry modes, loss seeds written by the
+  // forward): d_out then holds the forward's (colour, geometry) stash untouched, and the kernel does what k_stash_bwd does --
+  // per-ray reverse scan, loss derivatives, the loss bookkeeping of its block 0 -- on the tile it is about to back-propagate.
+  // Every wave walks a contiguous range of tiles back to front; per_block is a plain multiple of 128 (k_hash_mlp_bwd: 256),
+  // the ray a range cuts is handled by comp_suffix_beyond (ngm_bwd16.h).
   int fused_comp;
   ngm_render_cfg rc;
   const float* rayseed;               // (F*R, 8) from the forward

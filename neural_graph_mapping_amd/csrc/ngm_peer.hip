@@ -11,7 +11,12 @@
 // Two parities: a rank can be at most one exchange ahead of the slowest (it cannot finish exchange k + 1 before every
 // rank has written k + 1, i.e. read all of k), so exchange k + 2 never overwrites unread data of exchange k.
 // The sequence number lives on the device and advances with every launch: graph replays need no host update.
-// The poll is bounded (~2 s); on expiry the kernel raises a sticky status word and returns what it has.
+// The poll is bounded (~2 s per peer: an unbounded spin of a kernel whose peer died would wedge the GPU); on expiry the
+// kernel raises bit 0 of a STICKY status word and returns what it has -- the sums are then partial, and the host treats a
+// non-zero status as fatal for the run (PeerExchange.check, called by the renderer every few iterations and before it
+// hands out losses): the collective this replaces would simply have waited.  A slot that already carries a LATER sequence
+// number (possible only after such a time-out: the fast rank went on) is accepted and raises bit 1, so that a late rank
+// falls back into step instead of timing out on every following exchange.
 #include "ngm_launch.h"
 
 __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, float* sums) {
@@ -29,19 +34,22 @@ __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, flo
   if (t < 16) {
     const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(px.mailbox[px.rank]) + (size_t)par * NGM_MAX_PEERS * 16;
     float total = 0.f;
-    bool late = false;
+    bool late = false, skew = false;
     for (int p = 0; p < W; ++p) {
       unsigned long long w = 0;
       int spins = 0;
       for (;;) {
         w = __hip_atomic_load(mine + p * 16 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((uint32_t)(w >> 32) == seq) break;
+        const int32_t ahead = (int32_t)((uint32_t)(w >> 32) - seq);
+        if (ahead == 0) break;
+        if (ahead > 0 && ahead < (1 << 30)) { skew = true; break; }   // the writer is past this exchange: resynchronise, flag it
         if (++spins > (1 << 21)) { late = true; break; }     // x ~1 us of s_sleep: about two seconds
         __builtin_amdgcn_s_sleep(32);
       }
       total += __uint_as_float((uint32_t)w);
     }
-    if (late) atomicExch(px.status, 1);
+    if (late) atomicOr(px.status, 1);
+    if (skew) atomicOr(px.status, 2);
     sums[t] = total;
   }
   if (t == 0) *px.seq = (unsigned long long)seq;

@@ -105,63 +105,87 @@ class PeerExchange:
     Every rank must call `allreduce` the same number of times (idle ranks with zeros)."""
 
     def __init__(self, group=None, device=None):
+        """Collective with a FIXED number of collectives on every rank whatever fails where: (1) handle gather, (2) "opened
+        every peer" gather, (3) self-test verdict gather.  A rank that fails locally carries ok = False into the next
+        gather instead of leaving the protocol, so no rank is ever left waiting in a gather nobody pairs with."""
         import ctypes as C
         from . import _capi as K
         self._K, self._C = K, C
         L = K.lib()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        if self.world > 8:
-            raise NotImplementedError("PeerExchange: one node, at most 8 ranks")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._opened = []
-        with torch.cuda.device(self.device):
-            own = C.c_void_p()
-            K.check(L.ngm_peer_alloc(L.ngm_peer_mailbox_bytes(), C.byref(own)), "ngm_peer_alloc")
-            self._own = own
-            state = C.c_void_p()
-            K.check(L.ngm_peer_alloc(64, C.byref(state)), "ngm_peer_alloc")      # seq (8 bytes) + status (4 bytes)
-            self._state = state
-            handle = C.create_string_buffer(64)
-            K.check(L.ngm_ipc_export(own, handle), "ngm_ipc_export")
-            handles = [None] * self.world
-            dist.all_gather_object(handles, (self.rank, handle.raw), group=group)
-            px = K.PeerExchange()
-            px.world, px.rank = self.world, self.rank
-            for r, raw in handles:
-                if r == self.rank:
-                    px.mailbox[r] = own.value
-                else:
-                    ptr = C.c_void_p()
-                    K.check(L.ngm_ipc_open(raw, C.byref(ptr)), f"ngm_ipc_open(rank {r})")
-                    self._opened.append(ptr)
-                    px.mailbox[r] = ptr.value
-            px.seq = state.value
-            px.status = state.value + 16
-            self._px = px
-            # self-test: every rank contributes rank + 1 in slot 0 -> world (world + 1) / 2 everywhere
-            probe = torch.zeros(16, device=self.device)
-            probe[0] = self.rank + 1.0
-            self.allreduce(probe)
-            torch.cuda.synchronize(self.device)
-            ok = self.status() == 0 and float(probe[0]) == self.world * (self.world + 1) / 2
+        self._opened, self._own, self._state, self._px = [], None, None, None
+        err, raw = None, None
+        # ---- local set-up; nothing collective in here
+        try:
+            if self.world > 8:
+                raise NotImplementedError("PeerExchange: one node, at most 8 ranks")
+            with torch.cuda.device(self.device):
+                own = C.c_void_p()
+                K.check(L.ngm_peer_alloc(L.ngm_peer_mailbox_bytes(), C.byref(own)), "ngm_peer_alloc")
+                self._own = own
+                state = C.c_void_p()
+                K.check(L.ngm_peer_alloc(64, C.byref(state)), "ngm_peer_alloc")      # seq (8 bytes) + status (4 bytes)
+                self._state = state
+                handle = C.create_string_buffer(64)
+                K.check(L.ngm_ipc_export(own, handle), "ngm_ipc_export")
+                raw = handle.raw
+        except Exception as e:                                   # noqa: BLE001
+            err = e
+        # ---- (1) handles; a rank whose allocation / export failed sends None
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (self.rank, raw), group=group)
+        ok = err is None and all(h is not None and h[1] is not None for h in handles)
+        if ok:
+            try:
+                with torch.cuda.device(self.device):
+                    px = K.PeerExchange()
+                    px.world, px.rank = self.world, self.rank
+                    for r, hraw in handles:
+                        if r == self.rank:
+                            px.mailbox[r] = self._own.value
+                        else:
+                            ptr = C.c_void_p()
+                            K.check(L.ngm_ipc_open(hraw, C.byref(ptr)), f"ngm_ipc_open(rank {r})")
+                            self._opened.append(ptr)
+                            px.mailbox[r] = ptr.value
+                    px.seq = self._state.value
+                    px.status = self._state.value + 16
+                    self._px = px
+            except Exception as e:                               # noqa: BLE001
+                err, ok = e, False
+        # ---- (2) did every rank map every peer?  only then is the self-test exchange safe to enter (it polls for all ranks)
+        opened = [None] * self.world
+        dist.all_gather_object(opened, bool(ok), group=group)
+        ok = all(opened)
+        if ok:
+            try:
+                with torch.cuda.device(self.device):
+                    # self-test: every rank contributes rank + 1 in slot 0 -> world (world + 1) / 2 everywhere
+                    probe = torch.zeros(16, device=self.device)
+                    probe[0] = self.rank + 1.0
+                    self.allreduce(probe)
+                    torch.cuda.synchronize(self.device)
+                    ok = self.status() == 0 and float(probe[0]) == self.world * (self.world + 1) / 2
+            except Exception as e:                               # noqa: BLE001
+                err, ok = e, False
+        # ---- (3) verdict
         verdict = [None] * self.world
         dist.all_gather_object(verdict, bool(ok), group=group)
         if not all(verdict):
             self.close()
-            raise RuntimeError(f"PeerExchange self-test failed (per rank: {verdict})")
+            raise RuntimeError(f"PeerExchange set-up failed (handles {[h is not None and h[1] is not None for h in handles]}, "
+                               f"opened {opened}, self-test {verdict}; this rank: {err})")
+        self._calls = 0
 
     @classmethod
     def try_create(cls, group=None, device=None):
-        """-> PeerExchange or None (the caller keeps torch.distributed.all_reduce).  Collective: the set-up either
-        succeeds on every rank or fails on every rank, except when the handle exchange itself breaks."""
+        """-> PeerExchange or None (the caller keeps torch.distributed.all_reduce).  Collective: the constructor runs the
+        same three gathers on every rank whatever fails, so this either succeeds on every rank or returns None on every
+        rank; nothing collective happens in the failure path."""
         try:
             return cls(group, device)
         except Exception as e:                                   # noqa: BLE001 - any failure means "use RCCL"
-            ok = [None] * dist.get_world_size(group)
-            try:
-                dist.all_gather_object(ok, False, group=group)   # pairs with the verdict gather of the ranks that got that far
-            except Exception:                                    # noqa: BLE001
-                pass
             import warnings
             warnings.warn(f"PeerExchange unavailable, using the process group's all_reduce: {e}")
             return None
@@ -174,9 +198,20 @@ class PeerExchange:
         K.check(K.lib().ngm_loss_exchange(C.byref(self._px), loss_sums.data_ptr(), st), "ngm_loss_exchange")
         return loss_sums
 
+    def check(self):
+        """Raise if any exchange so far timed out (its sums were PARTIAL: the loss normalisers of that iteration were wrong on
+        this rank) or found the ranks out of step.  Synchronises with the device; the renderer calls it every
+        `peer_check_interval` iterations and whenever it is asked for the exchange's health -- a time-out is fatal for the
+        run, exactly as a hung all-reduce would have been, only later."""
+        st = self.status()
+        if st:
+            raise RuntimeError(f"PeerExchange: loss exchange failed (status {st}: bit 0 = a peer did not deliver within ~2 s and "
+                               "the sums of that iteration were partial, bit 1 = ranks out of step); the parameters trained "
+                               "since are not those of the global loss -- restart from a checkpoint or use the process group")
+
     def status(self) -> int:
-        """0 = every exchange so far completed; 1 = some exchange waited ~2 s for a peer and gave up (sticky).
-        Synchronises with the device."""
+        """0 = every exchange so far completed; bit 0 = some exchange waited ~2 s for a peer and gave up, bit 1 = a slot carried a
+        later sequence number (ranks out of step after a time-out); sticky.  Synchronises with the device."""
         from . import hiprt as H
         torch.cuda.synchronize(self.device)
         out = self._C.c_int32(-1)
@@ -191,7 +226,7 @@ class PeerExchange:
         self._opened = []
         for name in ("_own", "_state"):
             p = getattr(self, name, None)
-            if p is not None:
+            if p is not None and p.value:
                 L.ngm_peer_free(p)
                 setattr(self, name, None)
 

@@ -126,6 +126,9 @@ class NeuralGraphRenderer:
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
         self.peer_exchange = None          # distributed.PeerExchange: the same sum as one kernel inside the captured iteration
+        self.peer_check_interval = 256     # iterations between PeerExchange.check() calls (a device synchronisation each)
+        self._peer_calls = 0
+        self.field_draw_generator = None   # torch.Generator of sample_target_mv(field_draw="balanced_by_owner"), see there
 
     def last_matmul(self, kernel: str = "forward") -> Optional[str]:
         """The arithmetic the library resolved `mlp_matmul` to in the LAST launch of the fused forward ("forward"), the
@@ -347,7 +350,17 @@ class NeuralGraphRenderer:
         cur = current_field_ids.to(dev)
         if field_draw == "balanced_by_owner" and world_size > 1 and not draws:
             from . import distributed as D
-            field_ids = D.draw_fields_balanced(cur, num_fields, num_train_fields, world_size)
+            # every rank must draw the SAME set: a dedicated generator, seeded identically everywhere and consumed by nothing
+            # else (the process-global CUDA stream also feeds the per-rank ray draws below, whose consumption may differ
+            # between ranks -- sharded / early-exit sampling -- and would silently desynchronise the active sets)
+            if self.field_draw_generator is None:
+                self.field_draw_generator = torch.Generator(device="cpu").manual_seed(0x5EED0F1E1D5)
+            field_ids = D.draw_fields_balanced(cur.cpu(), num_fields, num_train_fields, world_size,
+                                               generator=self.field_draw_generator).to(dev)
+            if getattr(self, "debug_check_field_draw", False) and self.process_group is not None:
+                ref = field_ids.clone()
+                torch.distributed.broadcast(ref, 0, group=self.process_group)
+                assert torch.equal(ref, field_ids), "balanced_by_owner: ranks drew different active sets"
         else:                                                      # rm.py:1280-1319
             n_obs = min(num_train_fields // 2, len(cur))
             sub_obs = d["subset_observed"].to(dev) if draws else torch.multinomial(torch.ones(len(cur), device=dev), n_obs)
@@ -517,9 +530,24 @@ class NeuralGraphRenderer:
             self._exchange(ctx["w"]["sums"])
         return self._iteration_backward(ctx, update)
 
+    def check_exchange(self):
+        """Raise if the in-graph loss exchange ever timed out or lost step (its sums were partial then, i.e. the update of
+        that iteration used wrong loss normalisers).  Synchronises; called automatically every `peer_check_interval`
+        iterations, call it yourself before trusting losses / checkpoints of a multi-GPU run.  No-op without PeerExchange."""
+        if self.peer_exchange is not None:
+            self.peer_exchange.check()
+
+    def _count_exchange(self):
+        """host-side bookkeeping of one (launched or replayed) exchange; the periodic health check"""
+        self._peer_calls += 1
+        if self.peer_exchange is not None and self.peer_check_interval and self._peer_calls % self.peer_check_interval == 0:
+            if not torch.cuda.is_current_stream_capturing():
+                self.peer_exchange.check()
+
     def _exchange(self, sums: torch.Tensor):
         if self.peer_exchange is not None:
             self.peer_exchange.allreduce(sums)       # one kernel on the current stream: xGMI peer writes, capturable
+            self._count_exchange()
         else:
             torch.distributed.all_reduce(sums, group=self.process_group)
 
@@ -670,6 +698,8 @@ class NeuralGraphRenderer:
             def replay():
                 graph.replay()
                 self._step += 1
+                if self.peer_exchange is not None:
+                    self._count_exchange()                    # the exchange is a kernel of this graph: periodic health check
                 return out
             replay.graph = graph
             return replay

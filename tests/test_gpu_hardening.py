@@ -17,6 +17,7 @@ from gpu_common import (DEV, NRGBD, close, grad_close, host_philox_draws, make_r
                         ragged_case, synth_target)
 from neural_graph_mapping_amd import _capi as K  # noqa: E402
 from neural_graph_mapping_amd import ops  # noqa: E402
+from oracle import ngm_oracle as O  # noqa: E402
 from test_gpu_configs import FOURIER, HASH, _perturb, _properties  # noqa: E402
 from test_gpu_parity import _permuto_train_case  # noqa: E402
 
@@ -125,3 +126,37 @@ def test_in_kernel_philox_equals_host_philox(n_c, n_g):
     _, t1, _ = ops.sample_rays(rc, t["ijs"].to(DEV), near, far, gt, seed=seed)
     _, t2, _ = ops.sample_rays(rc, t["ijs"].to(DEV), near, far, gt, u_c.to(DEV), u_g.to(DEV))
     assert torch.equal(t1, t2)
+
+
+# ------------------------------------------------------------------------------------------------ kNN evaluation, large maps
+@pytest.mark.parametrize("NF,K_,P,layout", [(10000, 2, 6000, "cover_grid"), (10000, 4, 4000, "random"), (5000, 2, 6000, "two_rooms"),
+                                            (40000, 2, 3000, "cover_grid")])
+def test_knn_assignment_large_maps_vs_oracle(NF, K_, P, layout):
+    """The nearest-field assignment bins the centres into a uniform grid on the device and grows the block of cells around a
+    point until the K-th neighbour is provably exact -- no limit on the number of fields (round 3: 4096).  10 000 fields on
+    the reference's cover grid (rm.py:299: spacing 2 r / sqrt 3), random centres (sparse regions: several rings), two distant
+    clusters (coarsened grid), and 40 000 fields (per-workgroup histograms no longer fit the LDS: global-atomic path)."""
+    torch.manual_seed(NF + K_)
+    fs = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)
+    fc = K.field_cfg(encoding="fourier", dim_enc=32, num_layers=1)
+    params = O.init_params(fs, NF, seed=NF % 1000, sigma=3.0)
+    r = 1.0
+    if layout == "cover_grid":
+        n = int(round(NF ** (1 / 3))) + 1
+        g = torch.arange(n) * (2 * r / 3 ** 0.5)
+        pos = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)[torch.randperm(n ** 3)[:NF]]
+        pos = pos + 1e-3 * torch.randn(NF, 3)                       # no exact distance ties (unpinned in the reference)
+        ext = float(g[-1])
+        pts = torch.rand(P, 3) * (ext + 4) - 2                      # inside the map, at its border and outside
+    elif layout == "random":
+        pos = torch.rand(NF, 3) * 60                                 # ~0.05 centres per r^3: most points see few neighbours nearby
+        pts = pos[torch.randint(0, NF, (P,))] + 0.7 * torch.randn(P, 3)
+    else:
+        pos = torch.cat([torch.rand(NF // 2, 3) * 8, torch.rand(NF - NF // 2, 3) * 8 + 500.0])
+        pts = torch.cat([torch.rand(P // 2, 3) * 10 - 1, torch.rand(P - P // 2, 3) * 10 + 499.0])
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
+    ref = O.field_set_forward_knn(pts, pos, quat, params, fs, num_knn=K_, distance_factor=10.0, outside_value=1.0)
+    out = ops.field_eval_knn(fc, {k: v.to(DEV) for k, v in params.items()}, pts.to(DEV), pos.to(DEV), quat.to(DEV), K_, 10.0, 1.0)
+    n_in = int((ref != 1.0).any(-1).sum())
+    assert n_in > P // 10, n_in                                      # the case does exercise fields
+    close(out, ref, rtol=3e-4, atol=3e-5)

@@ -74,9 +74,14 @@ int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, fl
 // ================================================================================================
 #define CQ_BR 32
 #define CQ_MAXS 1024
+// KEEP: colours and depths of the batch stay in LDS planes for the variance pass (batches of 256 samples, so that the planes
+// cost no occupancy: 6.5 KB per wave); !KEEP: rays longer than 256 samples re-read them from memory in batches of 1024.
+template <bool KEEP>
 struct CompWaveLds {
+  static constexpr int MAXS = KEEP ? 256 : CQ_MAXS;
   float ra[CQ_BR][12];
-  float wbuf[CQ_MAXS];
+  float wbuf[MAXS];
+  float cbuf[KEEP ? 4 : 1][KEEP ? MAXS : 1];       // colour (3), depth
 };
 
 struct Rgb3 { float x, y, z; };   // 12-byte element: one global_load_dwordx3 per lane instead of three strided dword loads
@@ -120,17 +125,18 @@ __device__ __forceinline__ void neus_partials(const CompositeArgs& a, int64_t ra
   *d_isd = P * gam * g0 * s0 + M * gam * g1 * s1;
 }
 
+template <bool KEEP>
 __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, int rays_per_wave) {
-  __shared__ CompWaveLds lds[NGM_WAVES_PER_BLOCK];
+  __shared__ CompWaveLds<KEEP> lds[NGM_WAVES_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  CompWaveLds& wl = lds[wave];
+  CompWaveLds<KEEP>& wl = lds[wave];
   const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
   const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
   const int S = a.S;
   const int mode = a.rc.geometry_mode;
   const int S_eff = (mode == NGM_GEO_DENSITY || mode == NGM_GEO_NEUS) ? S - 1 : S;
   const float inv_s = 1.0f / (float)S;
-  const int BR = max(1, min(CQ_BR, CQ_MAXS / S));
+  const int BR = max(1, min(CQ_BR, CompWaveLds<KEEP>::MAXS / S));
   for (int64_t rb = r_beg; rb < r_end; rb += BR) {
     const int nb = (int)min<int64_t>(BR, r_end - rb);
     const int nsamp = nb * S;
@@ -161,7 +167,10 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
           c0 = a.rc.color_factor * o.x; c1 = a.rc.color_factor * o.y; c2 = a.rc.color_factor * o.z; dp = -a.pcam[3 * g + 2];
         } else { const Rgb3 c = load_rgb(a.colors, g); c0 = c.x; c1 = c.y; c2 = c.z; dp = a.depths[g]; }
       }
-      if (valid) wl.wbuf[idx] = w;
+      if (valid) {
+        wl.wbuf[idx] = w;
+        if constexpr (KEEP) { wl.cbuf[0][idx] = c0; wl.cbuf[1][idx] = c1; wl.cbuf[2][idx] = c2; wl.cbuf[3][idx] = dp; }
+      }
       if (act && a.weights) a.weights[(rb + rl) * S_eff + k] = w;
       const float s0 = seg_scan_add(w * c0, k, lane), s1 = seg_scan_add(w * c1, k, lane),
                   s2 = seg_scan_add(w * c2, k, lane), s3 = seg_scan_add(w * dp, k, lane),
@@ -180,7 +189,10 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const float* ra = wl.ra[rl];
       const float w = valid ? wl.wbuf[idx] : 0.f;
       float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-      if (act) {
+      if constexpr (KEEP) {
+        // the variance pass around the finished means (rm.py:781-790) from the LDS planes: no second read of colours / depths
+        if (act) { e0 = ra[0] - wl.cbuf[0][idx]; e1 = ra[1] - wl.cbuf[1][idx]; e2 = ra[2] - wl.cbuf[2][idx]; e3 = ra[3] - wl.cbuf[3][idx]; }
+      } else if (act) {
         if (a.out4) {
           const float4 o = a.out4[g];
           e0 = ra[0] - a.rc.color_factor * o.x; e1 = ra[1] - a.rc.color_factor * o.y; e2 = ra[2] - a.rc.color_factor * o.z;
@@ -224,7 +236,8 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
-  hipLaunchKernelGGL(k_composite_fwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  if (a.S <= CompWaveLds<true>::MAXS) hipLaunchKernelGGL(k_composite_fwd<true>, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  else hipLaunchKernelGGL(k_composite_fwd<false>, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
   return 0;
 }
 

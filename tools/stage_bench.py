@@ -105,6 +105,27 @@ def main():
         torch.autograd.grad(out, list(params.values()), go, retain_graph=True)
     add("field_eval_bwd", timeit(fbwd, iters=10), flops=nsamp * 33792, bytes_=nsamp * 28,
         note="point-mode backward (k_field_bwd16, recomputes the forward), 33 792 algorithmic flop/sample")
+    del out, go, params, pts
+    # ---- hash encode stage (SURVEY 8d "Hash encode gathers": 16 levels x 4 vertices x 2 features x 4 B = 512 B of table
+    # gathers per sample): the reference's default field (hash 16 x 2 + 1 x 32 MLP, config/neural_graph_map.yaml:6-20) evaluated on
+    # flat points; the MLP adds 2 304 flop per sample (1.4 % of the kernel's instructions), so this IS the encode stage's time
+    fch = K.field_cfg(encoding="permuto", num_layers=1, nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4)
+    Fh, Ph = 8, N * S // 8 // 8
+    ph = {}
+    for n, shp in K.param_shapes(fch).items():
+        ph[n] = 0.3 * torch.randn(Fh, *shp, device=dev)
+    ptsh = torch.rand(Fh, Ph, 3, device=dev) * 1.6 - 0.8
+    posh = torch.zeros(Fh, 3, device=dev)
+    quath = torch.zeros(Fh, 4, device=dev)
+    quath[:, 0] = 1
+    with torch.no_grad():
+        add("hash_encode_fwd", timeit(lambda: ops.field_eval(fch, ph, ptsh, posh, quath)), bytes_=Fh * Ph * 512,
+            note="k_field_points_fwd<hash>: permutohedral simplex search + 64 gathers of 8 B per sample (8 fields x 512 KB tables: "
+                 "L2-resident) + 1x32 MLP; algorithmic gather bytes against the HBM peak as SURVEY 8d prices them")
+    res["stages"]["hash_encode_fwd"]["samples"] = Fh * Ph
+    res["stages"]["hash_encode_fwd"]["gather_GBps_vs_L2_gather_microbench_2200"] = round(
+        res["stages"]["hash_encode_fwd"]["GBps"] / 2200.0, 3)
+    del ph, ptsh
     # ---- M2: render only, no_grad, 4096 rays x 128 samples, eval-style single stratum (ngm_render_fwd
     # without targets / stash), through the reference-shaped render_ijs
     from neural_graph_mapping_amd import models as M

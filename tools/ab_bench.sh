@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B of variant libraries: tools/r4_ab.sh name1 name2 ... (lib/libngm_<name>.so; "hip" = the product library)
+# same-box A/B of variant libraries on the GPU box: gpurun -- 'bash tools/ab_bench.sh hip NAME ...'  (lib/libngm_<name>.so;
+# "hip" = the product library; variants from tools/variant_lib.sh).  Two runs each, interleaved.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 for rep in 1 2; do

@@ -21,6 +21,9 @@ NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h1 SQ_INSTS_VALU SQ_I
 NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h2 FETCH_SIZE
 NGM_MATMUL=auto NGM_CHECK=time_hash bash tools/pmc_pass.sh h3 WRITE_SIZE
 python tools/pmc_summary.py $(find gpurun_out/pmc_h1 gpurun_out/pmc_h2 gpurun_out/pmc_h3 -name "*counter_collection.csv") > $O/sq_counters_hash.txt 2>&1
+# HBM bytes + L2 hit rate of the hash variant's kernels (M1 batch) -> what bench.py puts into the hash rooflines' `traffic`
+bash tools/profile_hash.sh > $O/pmc_hash.log 2>&1; cp gpurun_out/pmc_hash.json $O/pmc_hash.json
+python tools/stage_bench.py --out $O/stage_bench.json > /dev/null 2>> $O/bench.err
 python bench.py --variant hash --no-cpu-baseline > $O/bench_line_hash.json 2>> $O/bench.err
 python bench.py --matmul f32 --no-cpu-baseline --no-aux-hash > $O/bench_line_f32.json 2>> $O/bench.err
 python bench.py --scene-sim > $O/scene_sim.json 2>> $O/bench.err

@@ -209,7 +209,7 @@ def hash_rooflines(kern, n_local, scale_note="", pmc_scale=1.0):
                                timing="HIP events on the launch stream, instrumented pass of the same steps",
                                note="priced against the HBM scatter it replaces (512 B/sample, SURVEY 8d); the kernel itself "
                                     "accumulates in LDS (its real HBM traffic is `traffic`: positions + dL/dE in, partial tables "
-                                    "out) and is VALU (simplex search) + LDS-atomic bound, see DESIGN 4")
+                                    "out) and is VALU (simplex search) + LDS-atomic bound, see DESIGN.md §4")
     if ff:
         ach = algo / (ff["avg_us"] * 1e-6) / 1e9
         pv = pmc_of("k_render_fwd")

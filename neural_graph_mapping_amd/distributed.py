@@ -69,7 +69,7 @@ def draw_fields_balanced(current_field_ids: torch.Tensor, num_fields: int, num_t
     made once PER OWNER RANK with a quota of num_train_fields / world (the first `num_train_fields % world` owners get one
     more), over that owner's fields only -- half of the quota among its currently observed fields, the rest uniformly
     among its other fields.  Every rank then trains the same number of fields in every iteration (as far as it owns
-    that many), where the reference's global draw puts 7 of 32 on the worst of 8 ranks against a mean of 4 (DESIGN 5).
+    that many), where the reference's global draw puts 7 of 32 on the worst of 8 ranks against a mean of 4 (DESIGN.md §7).
     Same generator state on every rank -> same set everywhere.  With world_size 1 this is the reference's draw."""
     if world_size <= 1:
         return draw_fields_reference(current_field_ids, num_fields, num_train_fields, generator)[0]

@@ -339,7 +339,7 @@ class NeuralGraphRenderer:
         replays recorded ones.  The geometry between the draws runs in two HIP kernels.
         field_draw="balanced_by_owner" (opt-in, with world_size) replaces the choice of fields by
         distributed.draw_fields_balanced: the same draw per owner rank with a quota of num_train_fields / world -- every
-        rank trains equally many fields per iteration; not the reference's distribution, see DESIGN 5."""
+        rank trains equally many fields per iteration; not the reference's distribution, see DESIGN.md §7."""
         if field_draw not in ("reference", "balanced_by_owner"):
             raise NotImplementedError(f"field_draw={field_draw!r}: 'reference' or 'balanced_by_owner'")
         cam = camera or self._camera

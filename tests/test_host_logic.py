@@ -185,7 +185,7 @@ def _cpu_renderer_cfg(cfg):
 
 
 def test_balanced_by_owner_field_draw():
-    """Opt-in sampler policy of DESIGN 5: every owner rank gets num_train_fields / world fields per iteration, half of them
+    """Opt-in sampler policy of DESIGN.md §7: every owner rank gets num_train_fields / world fields per iteration, half of them
     among its observed fields; same generator state -> same set on every rank; world 1 = the reference's draw."""
     from neural_graph_mapping_amd import distributed as D
     NF, FA, W = 200, 32, 8

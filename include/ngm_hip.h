@@ -238,6 +238,12 @@ int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float
 int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
                        const float* points, const float* field_pos, const float* field_quat,
                        float* out, void* stream);
+/* The positional encoding of the same points ALONE (standalone stage entry point for roofline accounting;
+ * positional_encodings.py:19-66 permutohedral hash, :164-276 Fourier / NeRF octaves): out (F,P,dim_enc).  The fused kernels
+ * never materialise this tensor.  Triplane: NGM_E_UNSUPPORTED. */
+int ngm_encode_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
+                   const float* points, const float* field_pos, const float* field_quat,
+                   float* out, void* stream);
 /* Backward of the above w.r.t. every parameter: d_out (F,P,4) -> grads.  workspace: see
  * ngm_field_eval_bwd_workspace(). */
 int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,

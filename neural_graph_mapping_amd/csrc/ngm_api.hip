@@ -369,6 +369,20 @@ int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   return check_launch("ngm_field_eval_fwd");
 }
 
+int ngm_encode_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                   const float* field_pos, const float* field_quat, float* out, void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !out || F < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_encode_fwd: bad argument");
+  if ((field_pos == nullptr) != (field_quat == nullptr)) return fail(NGM_E_INVALID, "pos/quat must both be given");
+  if (P == 0) return NGM_OK;
+  rc = ngm_launch_encode_points(*fcfg, *params, F, P, points, field_pos, field_quat, out, (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_encode_fwd: encoding not available as a standalone stage (triplane)");
+  return check_launch("ngm_encode_fwd");
+}
+
 // unit: samples a workgroup's range is a multiple of -- whole 32-sample tiles for each of its waves (4 waves: 128; the
 // hash network's 8-wave backward: 256)
 static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int64_t unit = 32 * NGM_WAVES_PER_BLOCK) {

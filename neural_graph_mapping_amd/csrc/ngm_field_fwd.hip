@@ -10,6 +10,8 @@
 #include "ngm_field.h"
 #include "ngm_launch.h"
 
+#include <algorithm>
+
 #define WAVE_SYNC()                                        \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -59,6 +61,88 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
     const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_encode_points: the positional encoding ALONE (standalone stage entry point for roofline accounting;
+// positional_encodings.py:19-66 hash / :164-276 Fourier, NeRF octaves): one lane per point, features to HBM as
+// (F, P, dim_enc).  The fused kernels never materialise this tensor (the features go straight into MFMA operand registers);
+// the arithmetic is theirs -- permuto_simplex + four 8-byte gathers per level, hardware sine of the argument in revolutions.
+// ------------------------------------------------------------------------------------------------
+struct EncodeArgs {
+  ngm_field_cfg fc; ngm_params pr; int F; int64_t P;
+  const float* points; const float* pos; const float* quat; float* out;
+};
+__global__ __launch_bounds__(256) void k_encode_points(EncodeArgs a) {
+  const int f = blockIdx.y;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  const int D = a.fc.dim_enc;
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const bool posed = a.pos != nullptr;
+  float px = 0, py = 0, pz = 0, qw = 1, qx = 0, qy = 0, qz = 0;
+  if (posed) {
+    px = a.pos[3 * f]; py = a.pos[3 * f + 1]; pz = a.pos[3 * f + 2];
+    qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
+  }
+  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float* pt = a.points + ((int64_t)f * a.P + p) * 3;
+    Vec3 v{pt[0], pt[1], pt[2]};
+    if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
+    const float x = v.x / div + off, y = v.y / div + off, z = v.z / div + off;
+    float* o = a.out + ((int64_t)f * a.P + p) * D;
+    if (a.fc.encoding == NGM_ENC_PERMUTO) {
+      for (int l0 = 0; l0 < a.fc.nr_levels; l0 += 2) {       // two levels = one 16-byte store
+        float ft[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int level = l0 + u;
+          if (level >= a.fc.nr_levels) break;
+          const float* hs = a.pr.shift + row * a.pr.shift_stride + 3 * level;
+          const float lp[8] = {a.fc.level_scale[3 * level], a.fc.level_scale[3 * level + 1], a.fc.level_scale[3 * level + 2], 0.f,
+                               hs[0], hs[1], hs[2], 0.f};
+          uint32_t idx[4]; float bw[4]; float2 tv[4];
+          permuto_simplex(x, y, z, lp, hc.mask, idx, bw);
+          ngm_ldp2x4(hc.tab, (size_t)level * hc.T, idx, hc.dt, tv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ft[2 * u] = fmaf(tv[r].x, bw[r], ft[2 * u]); ft[2 * u + 1] = fmaf(tv[r].y, bw[r], ft[2 * u + 1]); }
+        }
+        if (l0 + 1 < a.fc.nr_levels && (D & 3) == 0) *reinterpret_cast<float4*>(o + 2 * l0) = make_float4(ft[0], ft[1], ft[2], ft[3]);
+        else { o[2 * l0] = ft[0]; o[2 * l0 + 1] = ft[1]; if (l0 + 1 < a.fc.nr_levels) { o[2 * l0 + 2] = ft[2]; o[2 * l0 + 3] = ft[3]; } }
+      }
+    } else {
+      const float inv2pi = 0.15915494309189535f;
+      const int n_raw = (a.fc.encoding == NGM_ENC_FOURIER) ? (a.fc.raw_coords ? 3 : 0) : (a.fc.encoding == NGM_ENC_NERF ? 0 : 3);
+      for (int ft = 0; ft < D; ++ft) {
+        float val;
+        if (ft < n_raw) val = (ft == 0) ? x : (ft == 1) ? y : z;
+        else if (a.fc.encoding == NGM_ENC_FOURIER) {
+          const int64_t e0 = row * a.pr.enc_w_stride + (int64_t)(ft - n_raw) * 3;
+          const float arg = fmaf(ngm_ldp(a.pr.enc_w, e0 + 2, a.pr.dtype), z,
+                                 fmaf(ngm_ldp(a.pr.enc_w, e0 + 1, a.pr.dtype), y, ngm_ldp(a.pr.enc_w, e0, a.pr.dtype) * x));
+          val = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(arg * inv2pi));
+        } else if (a.fc.encoding == NGM_ENC_NERF) {
+          const int half = 3 * a.fc.num_octaves;
+          const int g = (ft < half) ? ft : ft - half;
+          const int d = g / a.fc.num_octaves, oc = g % a.fc.num_octaves;
+          const float m = exp2f((float)(a.fc.start_octave + oc)) * 3.14159265358979323846f;
+          const float rev = __builtin_amdgcn_fractf(m * ((d == 0) ? x : (d == 1) ? y : z) * inv2pi);
+          val = (ft < half) ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+        } else val = 0.f;
+        o[ft] = val;
+      }
+    }
+  }
+}
+int ngm_launch_encode_points(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points, const float* pos,
+                             const float* quat, float* out, hipStream_t st) {
+  if (fc.encoding == NGM_ENC_TRIPLANE) return NGM_E_UNSUPPORTED;
+  EncodeArgs a;
+  a.fc = fc; a.pr = pr; a.F = F; a.P = P; a.points = points; a.pos = pos; a.quat = quat; a.out = out;
+  const int bx = (int)std::min<int64_t>((P + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_encode_points, dim3(std::max(bx, 1), F), dim3(256), 0, st, a);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

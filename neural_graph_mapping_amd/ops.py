@@ -218,6 +218,21 @@ def field_eval(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None
     return torch.ops.ngm355.field_eval(cfg_blob(fc), _f32c(points, "points"), pos, quat, plist)
 
 
+def encode(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None, quat=None):
+    """The positional encoding alone (positional_encodings.py:19-66, 164-276): (F,P,3) points -> (F,P,dim_enc), no autograd.
+    Standalone stage entry point (ngm_encode_fwd) -- the fused kernels never materialise this tensor."""
+    names = K.param_names(fc)
+    plist = [params[n] for n in names]
+    _require_gpu(points, pos, quat, *plist)
+    pts = _f32c(points, "points")
+    F, P = pts.shape[0], pts.shape[1]
+    out = torch.empty(F, P, fc.dim_enc, device=pts.device, dtype=torch.float32)
+    ps = params_struct(fc, dict(zip(names, plist)))
+    K.check(K.lib().ngm_encode_fwd(C.byref(fc), C.byref(ps), F, P, _ptr(pts), _ptr(None if pos is None else _f32c(pos)),
+                                   _ptr(None if quat is None else _f32c(quat)), _ptr(out), _stream()), "ngm_encode_fwd")
+    return out
+
+
 @_op("field_eval_knn")
 def _field_eval_knn_op(fcfg: torch.Tensor, points: torch.Tensor, pos: torch.Tensor, quat: torch.Tensor,
                        params: List[torch.Tensor], num_knn: int, distance_factor: float, outside_value: float,

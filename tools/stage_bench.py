@@ -123,6 +123,10 @@ def main():
             note="k_field_points_fwd<hash>: permutohedral simplex search + 64 gathers of 8 B per sample (8 fields x 512 KB tables: "
                  "L2-resident) + 1x32 MLP; algorithmic gather bytes against the HBM peak as SURVEY 8d prices them")
     res["stages"]["hash_encode_fwd"]["samples"] = Fh * Ph
+    with torch.no_grad():
+        add("hash_encode_only", timeit(lambda: ops.encode(fch, ph, ptsh, posh, quath)), bytes_=Fh * Ph * 512,
+            note="ngm_encode_fwd (k_encode_points): the encoding alone, 32 features per sample written to HBM (128 B / sample on top "
+                 "of the gathers; real HBM traffic and L2 hit rate: a rocprofv3 --pmc pass over this script)")
     res["stages"]["hash_encode_fwd"]["gather_GBps_vs_L2_gather_microbench_2200"] = round(
         res["stages"]["hash_encode_fwd"]["GBps"] / 2200.0, 3)
     del ph, ptsh

@@ -66,7 +66,8 @@ enum ngm_loss_slot {
   NGM_LS_TSDF_SUM = 6,  /* sum (g*tau - (gt - t))^2 over truncation samples   */
   NGM_LS_TSDF_CNT = 7,
   NGM_LS_TERM_SUM = 8,  /* sum (term - term*)^2 over term_mask rays           */
-  NGM_LS_TERM_CNT = 9
+  NGM_LS_TERM_CNT = 9,
+  NGM_LS_PHOTO_L1_SUM = 10 /* photometric gaussian_nll only: sum |rgb - rgb*| for its L1 branch (losses.py:34-35) */
 };
 
 /* NeuralField architecture: models.py:69-128, positional_encodings.py:167-195,222-243 */
@@ -150,8 +151,13 @@ typedef struct ngm_grads {
 
 /* Loss modes of losses.py built into the fused kernels.  The variance-weighted modes (gaussian_nll / laplacian_nll,
  * losses.py:30-36, 64-75) need gradients through the rendered variances and are NOT built: the host layer raises. */
-typedef enum ngm_photometric_mode { NGM_PHOTO_L1 = 0, NGM_PHOTO_L2 = 1 } ngm_photometric_mode;
-typedef enum ngm_depth_mode { NGM_DEPTH_HUBER = 0 } ngm_depth_mode;
+/* losses.py:26-36.  GAUSSIAN_NLL: 0.5 e^2 / var + log sqrt(var) over the rendered colour variances (rm.py:781-785, no epsilon),
+ * replaced by the L1 loss whenever its global mean exceeds 2 (the reference's data-dependent switch). */
+typedef enum ngm_photometric_mode { NGM_PHOTO_L1 = 0, NGM_PHOTO_L2 = 1, NGM_PHOTO_GAUSSIAN_NLL = 2 } ngm_photometric_mode;
+/* losses.py:60-75.  GAUSSIAN_NLL: 0.5 e^2 / (var + 1e-15) + log sqrt(var + 1e-15); LAPLACIAN_NLL: |e| / sqrt(0.5 var + 1e-6)
+ * + 0.5 log(2 var + 1e-6), var = the rendered depth variance (rm.py:786-790).  The variance-weighted modes differentiate
+ * through the variances; they run the compositing backward as a launch of its own (k_stash_bwd). */
+typedef enum ngm_depth_mode { NGM_DEPTH_HUBER = 0, NGM_DEPTH_GAUSSIAN_NLL = 1, NGM_DEPTH_LAPLACIAN_NLL = 2 } ngm_depth_mode;
 
 /* Renderer + loss constants: rm.py:116-220, config/neural_graph_map.yaml */
 typedef struct ngm_render_cfg {
@@ -169,7 +175,7 @@ typedef struct ngm_render_cfg {
   float huber_delta;           /* 0.05, losses.py:63                          */
   float term_threshold;        /* 0.8, rm.py:1787                             */
   int32_t photometric_mode;    /* ngm_photometric_mode (config key photometric_loss, losses.py:26-29); ABI 3 */
-  int32_t depth_mode;          /* ngm_depth_mode (config key depth_loss, losses.py:60-63): huber only        */
+  int32_t depth_mode;          /* ngm_depth_mode (config key depth_loss, losses.py:60-75)                    */
 } ngm_render_cfg;
 
 /* One batch of rays: the reference's Target record (rm.py:43-58) in device memory. */

@@ -22,10 +22,10 @@ ENC = {"none": 0, "fourier": 1, "nerf": 2, "permuto": 3, "triplane": 4}
 TRI = {"sum": 0, "product": 1, "concat": 2}
 SCALE = {"no": 0, "unit_ball": 1, "unit_cube": 2}
 GEO = {"nrgbd": 0, "occupancy": 1, "density": 2, "neus": 3}
-PHOTO = {"l1": 0, "l2": 1}          # losses.py:26-29
-DEPTH = {"huber": 0}                # losses.py:60-63
+PHOTO = {"l1": 0, "l2": 1, "gaussian_nll": 2}                    # losses.py:26-36
+DEPTH = {"huber": 0, "gaussian_nll": 1, "laplacian_nll": 2}      # losses.py:60-75
 LS = dict(PHOTO_SUM=0, PHOTO_CNT=1, DEPTH_SUM=2, DEPTH_CNT=3, FS_SUM=4, FS_CNT=5, TSDF_SUM=6,
-          TSDF_CNT=7, TERM_SUM=8, TERM_CNT=9)
+          TSDF_CNT=7, TERM_SUM=8, TERM_CNT=9, PHOTO_L1_SUM=10)
 
 f32p = C.c_void_p
 LArr = C.c_void_p * (NGM_MAX_LAYERS + 1)
@@ -337,11 +337,9 @@ def render_cfg(geometry_mode="nrgbd", num_samples_coarse=8, num_samples_guided=1
                w_tsdf=50.0, huber_delta=0.05, term_threshold=0.8, overwrite_behind_camera=True,
                photometric_loss="l1", depth_loss="huber"):
     if photometric_loss not in PHOTO:
-        raise NotImplementedError(f"photometric_loss {photometric_loss!r}: the fused kernels build {sorted(PHOTO)} "
-                                  "(gaussian_nll needs gradients through the rendered variances, losses.py:30-36)")
+        raise NotImplementedError(f"photometric_loss {photometric_loss!r}: the kernels build {sorted(PHOTO)} (losses.py:26-36)")
     if depth_loss not in DEPTH:
-        raise NotImplementedError(f"depth_loss {depth_loss!r}: the fused kernels build {sorted(DEPTH)} "
-                                  "(gaussian_nll / laplacian_nll need gradients through the rendered variances, losses.py:64-75)")
+        raise NotImplementedError(f"depth_loss {depth_loss!r}: the kernels build {sorted(DEPTH)} (losses.py:60-75)")
     if range_depth_guided is None:
         range_depth_guided = truncation_distance
     return RenderCfg(GEO[geometry_mode], num_samples_coarse, num_samples_guided, int(bool(overwrite_behind_camera)),

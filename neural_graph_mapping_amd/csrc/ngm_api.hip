@@ -749,7 +749,11 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   static const bool no_fuse_env = getenv("NGM_NO_FUSED_COMP") != nullptr;
   const bool no_fuse = no_fuse_env || g_no_fused_comp;
   const bool pointwise = rcfg->geometry_mode != NGM_GEO_NEUS && rcfg->geometry_mode != NGM_GEO_DENSITY;
-  bool fuse = !no_fuse && sb.seed_mode == 0 && pointwise && bwd_b3_is_default() && a.P < (1 << 24) &&
+  // the variance-weighted loss modes (gradients through the rendered variances) are k_stash_bwd's
+  const bool nll_loss = rcfg->photometric_mode == NGM_PHOTO_GAUSSIAN_NLL || rcfg->depth_mode != NGM_DEPTH_HUBER;
+  if (nll_loss && sb.seed_mode == 0 && (!sb.pred.color_vars || !sb.pred.depth_vars))
+    return fail(NGM_E_INVALID, "render_bwd: the *_nll loss modes need pred.color_vars and pred.depth_vars");
+  bool fuse = !no_fuse && !nll_loss && sb.seed_mode == 0 && pointwise && bwd_b3_is_default() && a.P < (1 << 24) &&
               forward_wrote_seeds_for(workspace, sb.tg.rgbds) && (ngm_field_bwd_b3_applies(a) || ngm_hash_mlp_bwd_applies(a));
   int e = 0;
   const FieldBwdArgs a_plain = a;            // for the fall-back below: the launch records before the fused fields are set

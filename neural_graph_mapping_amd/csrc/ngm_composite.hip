@@ -386,11 +386,14 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   const int64_t nsamp_all = (r_end - r_beg) * S;
   const int64_t nsteps = (nsamp_all + 63) / 64;
   struct StepIn {
-    float4 sa, r0, r1, pr, tg; float2 sb; float term, tprob; unsigned char dm, tm;
+    float4 sa, r0, r1, pr, tg, vr; float2 sb; float term, tprob; unsigned char dm, tm;
   };
+  // variance-weighted loss modes (losses.py:30-36, 64-75): the loss reads the rendered variances (rm.py:781-790) and its
+  // gradient reaches the samples through them as well
+  const bool nll = a.seed_mode == 0 && (a.rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL || a.rc.depth_mode != NGM_DEPTH_HUBER);
   auto fetch = [&](int64_t st, StepIn& in) __attribute__((always_inline)) {
     const int64_t idx = st * 64 + lane;
-    in.sa = in.r0 = in.r1 = in.pr = in.tg = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.sa = in.r0 = in.r1 = in.pr = in.tg = in.vr = make_float4(0.f, 0.f, 0.f, 0.f);
     in.sb = make_float2(0.f, 0.f); in.term = in.tprob = 0.f; in.dm = in.tm = 0;
     if (st >= 0 && idx < nsamp_all) {
       const int64_t rl = idx / S;
@@ -403,6 +406,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
         in.pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
         in.tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
         in.term = a.pred.term_probs[ray];
+        if (nll) in.vr = make_float4(a.pred.color_vars[3 * ray], a.pred.color_vars[3 * ray + 1], a.pred.color_vars[3 * ray + 2],
+                                     a.pred.depth_vars[ray]);
         in.dm = a.tg.depth_mask[ray];
         if (a.tg.term_mask) { in.tm = a.tg.term_mask[ray]; in.tprob = a.tg.term_probs[ray]; }
       }
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     k_fs = n_fs > 0 ? a.rc.w_freespace * 2.0f / n_fs : 0.f;
     k_ts = n_ts > 0 ? a.rc.w_tsdf * 2.0f / n_ts : 0.f;
   }
+  const bool photo_l1 = a.seed_mode == 0 && (a.rc.photometric_mode == NGM_PHOTO_L1 || photo_nll_uses_l1(a.rc, sums));
   // the loss scalars ride along (one thread; saves a launch in the training step)
   if (a.loss_out && a.seed_mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) loss_values_from_sums(a.rc, sums, a.loss_out);
   float carryQ = 0.f;
@@ -455,6 +461,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     const int64_t ray = r_beg + rl, g = ray * S + k;
     float c0 = 0, c1 = 0, c2 = 0, geom = 0, t = 0, T = 0, dzc = 0, gt = 0;
     float dC0 = 0, dC1 = 0, dC2 = 0, dD = 0, dT = 0;
+    // d loss / d variance (colour x 3, depth) and the means the variances are taken around; zero outside the nll modes
+    float gV0 = 0, gV1 = 0, gV2 = 0, gVd = 0, mC0 = 0, mC1 = 0, mC2 = 0, mD = 0;
     const StepIn in = cur;
     fetch(st - 1, cur);                                  // no-op for st == 0
     if (valid) {
@@ -478,12 +486,35 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
           const float e0 = pr.x - tg.x, e1 = pr.y - tg.y, e2 = pr.z - tg.z;
           if (a.rc.photometric_mode == NGM_PHOTO_L2) {      // d mean(e^2) (losses.py:28-29)
             dC0 = 2.0f * k_photo * e0; dC1 = 2.0f * k_photo * e1; dC2 = 2.0f * k_photo * e2;
-          } else {                                           // d mean|e|  (losses.py:26-27)
+          } else if (photo_l1) {                             // d mean|e|  (losses.py:26-27; also gaussian_nll's L1 branch)
             dC0 = k_photo * ((e0 > 0.f) - (e0 < 0.f)); dC1 = k_photo * ((e1 > 0.f) - (e1 < 0.f));
             dC2 = k_photo * ((e2 > 0.f) - (e2 < 0.f));
+          } else {                                           // gaussian_nll (losses.py:30-33): 0.5 e^2 / v + 0.5 log v
+            const float4 v = in.vr;
+            dC0 = k_photo * e0 / v.x; dC1 = k_photo * e1 / v.y; dC2 = k_photo * e2 / v.z;
+            gV0 = k_photo * 0.5f * (1.0f / v.x - e0 * e0 / (v.x * v.x));
+            gV1 = k_photo * 0.5f * (1.0f / v.y - e1 * e1 / (v.y * v.y));
+            gV2 = k_photo * 0.5f * (1.0f / v.z - e2 * e2 / (v.z * v.z));
           }
           const float e = pr.w - tg.w, dl = a.rc.huber_delta;
-          dD = k_depth * ((fabsf(e) < dl) ? e : dl * ((e > 0.f) - (e < 0.f)));
+          if (a.rc.depth_mode == NGM_DEPTH_GAUSSIAN_NLL) {   // losses.py:64-69
+            const float v = in.vr.w + 1e-15f;
+            dD = k_depth * e / v;
+            gVd = k_depth * 0.5f * (1.0f / v - e * e / (v * v));
+          } else if (a.rc.depth_mode == NGM_DEPTH_LAPLACIAN_NLL) {   // losses.py:70-75: |e| / sqrt(0.5 v + 1e-6) + 0.5 log(2 v + 1e-6)
+            const float sv = 0.5f * in.vr.w + 1e-6f, rs = 1.0f / sqrtf(sv);
+            dD = k_depth * ((e > 0.f) - (e < 0.f)) * rs;
+            gVd = k_depth * (1.0f / (2.0f * in.vr.w + 1e-6f) - 0.25f * fabsf(e) * rs / sv);
+          } else
+            dD = k_depth * ((fabsf(e) < dl) ? e : dl * ((e > 0.f) - (e < 0.f)));
+          if (nll) {
+            // variances are taken around the finished means (rm.py:781-790): V = sum_k w_k (c_k - C)^2, so besides
+            // d V / d w_k = (c_k - C)^2 and d V / d c_k = 2 w_k (c_k - C) there is d V / d C = -2 C (1 - W), W = sum w = the
+            // termination probability (zero only where the weights sum to one); it joins the mean's own seed
+            mC0 = pr.x; mC1 = pr.y; mC2 = pr.z; mD = pr.w;
+            const float bg2 = 2.0f * (1.0f - term);
+            dC0 -= gV0 * bg2 * mC0; dC1 -= gV1 * bg2 * mC1; dC2 -= gV2 * bg2 * mC2; dD -= gVd * bg2 * mD;
+          }
         }
         if (a.tg.term_mask && in.tm) dT = k_term * (term - in.tprob);
       } else {
@@ -509,7 +540,14 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
         }
       } else occ = occ_pointwise(mode, gamma, geom, &dodg);
     }
-    const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * depth + dT;
+    // d loss / d w_k: through the means, the termination probability and (nll modes) the variances
+    auto a_of = [&](float q0, float q1, float q2, float qd) __attribute__((always_inline)) {
+      float v = dC0 * q0 + dC1 * q1 + dC2 * q2 + dD * qd + dT;
+      if (nll) v += gV0 * (q0 - mC0) * (q0 - mC0) + gV1 * (q1 - mC1) * (q1 - mC1) + gV2 * (q2 - mC2) * (q2 - mC2) +
+                    gVd * (qd - mD) * (qd - mD);
+      return v;
+    };
+    const float ak = a_of(c0, c1, c2, depth);
     float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
     seg_rscan_affine(A, B, kr, lane);
     const bool extends = valid && (kr > 63 - lane);
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
           const float2 pb = a.stashB[g - 1];
           const float tnp = ngm_sigmoid(isd * gamma * pa.w);
           if (tnp > tno) {                                          // occ_{k-1} > 0: the clamp is inactive
-            const float a_prev = dC0 * pa.x + dC1 * pa.y + dC2 * pa.z + dD * (-(dzc * pb.x)) + dT;
+            const float a_prev = a_of(pa.x, pa.y, pa.z, -(dzc * pb.x));
             const float Q_prev = fmaf(1.0f - occ, Qk, ak * occ);
             dtno -= pb.y * (a_prev - Q_prev) / (tnp + 1e-5f);
           }
@@ -553,7 +591,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
       if (a.rc.overwrite_behind_camera && dzc * t > 0.f) dg = 0.f;   // overwritten sample: no gradient reaches the MLP output
       {
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f dv = {cf * w * dC0, cf * w * dC1, cf * w * dC2, dg};
+        // d loss / d colour_k = w_k (d C + 2 d V (c_k - C)): the second term only in the nll modes (gV = 0 otherwise)
+        const v4f dv = {cf * w * (dC0 + 2.0f * gV0 * (c0 - mC0)), cf * w * (dC1 + 2.0f * gV1 * (c1 - mC1)),
+                        cf * w * (dC2 + 2.0f * gV2 * (c2 - mC2)), dg};
         // in place over the saved forward values, except in neus mode (neighbouring lanes / waves still read them)
         __builtin_nontemporal_store(dv, reinterpret_cast<v4f*>((a.d_out ? a.d_out : a.stashA) + g));   // read once, by the MLP backward
       }

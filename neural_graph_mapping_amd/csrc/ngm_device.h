@@ -534,11 +534,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination, photometric, depth, freespace,
 // tsdf.  Empty selections contribute 0 (the reference yields NaN).
+// photometric gaussian_nll: the reference returns the L1 loss instead whenever the mean NLL exceeds 2 (losses.py:34-35) -- a
+// decision on the GLOBAL mean, i.e. on the (all-reduced) sums; loss value and gradient seeds both follow it
+__device__ __forceinline__ bool photo_nll_uses_l1(const ngm_render_cfg& rc, const float* sums) {
+  const float n_m = sums[NGM_LS_PHOTO_CNT];
+  return rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL && n_m > 0 && sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) > 2.0f;
+}
 __device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out) {
   const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
               n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
   const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
-  const float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
+  float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
+  if (photo_nll_uses_l1(rc, sums)) lp = sums[NGM_LS_PHOTO_L1_SUM] / (3.0f * n_m);       // losses.py:34-35
   const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : 0.f;
   const float lf = n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : 0.f;
   const float ls = n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : 0.f;

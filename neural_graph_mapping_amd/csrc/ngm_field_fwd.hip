@@ -221,9 +221,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   // words (cnt_s: free-space | TSDF << 16, per sample; cnt_r: photometric | depth << 10 | termination << 20, per ray) --
   // three registers less in a kernel that sits at the 256-register limit, where a spilled accumulator is reloaded behind
   // the stash stores (one vmcnt for loads and stores: the reload waits for all of them)
-  float ls[10];
+  float ls[11];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) ls[i] = 0.f;
+  for (int i = 0; i < 11; ++i) ls[i] = 0.f;
   uint32_t cnt_s = 0, cnt_r = 0;
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
   const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
@@ -491,11 +491,23 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         const bool m = (ra[9] != 0.f) && (term > a.rc.term_threshold);  // rm.py:1787
         if (m) {
           const float p0 = tg.x - ra[0], p1 = tg.y - ra[1], p2 = tg.z - ra[2];
-          ls[NGM_LS_PHOTO_SUM] += (a.rc.photometric_mode == NGM_PHOTO_L2) ? fmaf(p2, p2, fmaf(p1, p1, p0 * p0))   // losses.py:28-29
-                                                                           : fabsf(p0) + fabsf(p1) + fabsf(p2);   // losses.py:26-27
+          const float l1 = fabsf(p0) + fabsf(p1) + fabsf(p2);
+          if (a.rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL) {        // losses.py:30-36: 0.5 e^2 / var + log sqrt(var), no epsilon
+            ls[NGM_LS_PHOTO_SUM] += (0.5f * p0 * p0 / ra[5] + logf(sqrtf(ra[5]))) + (0.5f * p1 * p1 / ra[6] + logf(sqrtf(ra[6]))) +
+                                    (0.5f * p2 * p2 / ra[7] + logf(sqrtf(ra[7])));
+            ls[NGM_LS_PHOTO_L1_SUM] += l1;                               // its L1 branch (mean NLL > 2), decided on the global sums
+          } else
+            ls[NGM_LS_PHOTO_SUM] += (a.rc.photometric_mode == NGM_PHOTO_L2) ? fmaf(p2, p2, fmaf(p1, p1, p0 * p0))   // losses.py:28-29
+                                                                             : l1;                                  // losses.py:26-27
           cnt_r += 1u;
           const float e = ra[3] - tg.w, ae = fabsf(e), dlt = a.rc.huber_delta;
-          ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);
+          if (a.rc.depth_mode == NGM_DEPTH_GAUSSIAN_NLL) {               // losses.py:64-69
+            const float dv = ra[8] + 1e-15f;
+            ls[NGM_LS_DEPTH_SUM] += 0.5f * e * e / dv + logf(sqrtf(dv));
+          } else if (a.rc.depth_mode == NGM_DEPTH_LAPLACIAN_NLL)         // losses.py:70-75
+            ls[NGM_LS_DEPTH_SUM] += ae / sqrtf(0.5f * ra[8] + 1e-6f) + 0.5f * logf(2.0f * ra[8] + 1e-6f);
+          else
+            ls[NGM_LS_DEPTH_SUM] += (ae < dlt) ? 0.5f * e * e : dlt * (ae - 0.5f * dlt);
           cnt_r += 1u << 10;
         }
         if (ra[10] != 0.f) {
@@ -531,14 +543,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     ls[NGM_LS_PHOTO_CNT] = (float)(cnt_r & 1023u); ls[NGM_LS_DEPTH_CNT] = (float)((cnt_r >> 10) & 1023u);
     ls[NGM_LS_TERM_CNT] = (float)(cnt_r >> 20);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 11; ++i) {
       const float v = wave_sum(ls[i]);
       if (lane == 0) red[wave * 16 + i] = v;
     }
     __syncthreads();
     if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
       float v = 0.f;
-      if (threadIdx.x < 10)
+      if (threadIdx.x < 11)
         for (int w = 0; w < nwaves; ++w) v += red[w * 16 + threadIdx.x];
       a.loss_partials[(int64_t)blockIdx.x * NGM_NUM_LOSS_SUMS + threadIdx.x] = v;
     }

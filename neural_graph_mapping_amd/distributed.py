@@ -238,7 +238,10 @@ def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsd
     def mean(num, den, scale=1.0):
         return torch.where(den > 0, num / (scale * den.clamp_min(1.0)), torch.zeros_like(num))
     pk, dk = "photometric_" + photometric_loss, "depth_" + depth_loss
-    out = {pk: mean(s[0], s[1], 3.0), dk: mean(s[2], s[3]), "freespace": mean(s[4], s[5]),
+    photo = mean(s[0], s[1], 3.0)
+    if photometric_loss == "gaussian_nll":                 # losses.py:34-35: the L1 loss whenever the mean NLL exceeds 2
+        photo = torch.where(photo > 2.0, mean(s[10], s[1], 3.0), photo)
+    out = {pk: photo, dk: mean(s[2], s[3]), "freespace": mean(s[4], s[5]),
            "tsdf": mean(s[6], s[7]), "termination": mean(s[8], s[9])}
     out["combined"] = (w_term * out["termination"] + w_photo * out[pk] + w_depth * out[dk]
                        + w_fs * out["freespace"] + w_tsdf * out["tsdf"])

@@ -71,11 +71,10 @@ def check_config(config: dict) -> None:
     if missing:
         raise KeyError(f"config lacks {missing}: NeuralGraphMap._read_config reads them unconditionally (rm.py:116-220)")
     if config["photometric_loss"] not in K.PHOTO:
-        raise NotImplementedError(f"photometric_loss {config['photometric_loss']!r} is not built (built: {sorted(K.PHOTO)}; "
-                                  "gaussian_nll, losses.py:30-36, needs gradients through the rendered colour variances)")
+        raise NotImplementedError(f"photometric_loss {config['photometric_loss']!r} is not built (built: {sorted(K.PHOTO)}, "
+                                  "losses.py:26-36)")
     if config["depth_loss"] not in K.DEPTH:
-        raise NotImplementedError(f"depth_loss {config['depth_loss']!r} is not built (built: {sorted(K.DEPTH)}; gaussian_nll / "
-                                  "laplacian_nll, losses.py:64-75, need gradients through the rendered depth variance)")
+        raise NotImplementedError(f"depth_loss {config['depth_loss']!r} is not built (built: {sorted(K.DEPTH)}, losses.py:60-75)")
     if config["geometry_mode"] not in K.GEO:
         raise ValueError(f"Unsupported geometry mode {config['geometry_mode']}")        # rm.py:760 wording
 
@@ -312,11 +311,16 @@ class NeuralGraphRenderer:
         tm = target.term_mask
         loss["termination"] = ((prediction.term_probs[tm] - target.term_probs[tm]) ** 2).mean()
         diff = target.rgbds[m][:, :3] - prediction.rgbds[m][:, :3]
+        dk = "depth_" + self._config["depth_loss"]
+        if rc.photometric_mode == K.PHOTO["gaussian_nll"] or rc.depth_mode != K.DEPTH["huber"]:
+            # the variance-weighted modes differentiate through the rendered variances, which this autograd path
+            # (render_ijs -> Prediction) does not propagate: they train through optimization_iteration (fused step)
+            raise NotImplementedError("compute_losses: the *_nll loss modes are built in the fused training step "
+                                      "(optimization_iteration / capture_iteration), not in the render_ijs autograd path")
         loss[pk] = diff.abs().mean() if rc.photometric_mode == K.PHOTO["l1"] else (diff ** 2).mean()   # losses.py:26-29
-        loss["depth_huber"] = torch.nn.functional.huber_loss(prediction.rgbds[m][:, 3], target.rgbds[m][:, 3],
-                                                             delta=rc.huber_delta)
+        loss[dk] = torch.nn.functional.huber_loss(prediction.rgbds[m][:, 3], target.rgbds[m][:, 3], delta=rc.huber_delta)
         total = (rc.w_termination * loss["termination"] + rc.w_photometric * loss[pk]
-                 + rc.w_depth * loss["depth_huber"])
+                 + rc.w_depth * loss[dk])
         if prediction.freespace_geometry is not None:
             loss["freespace"] = ((prediction.freespace_geometry - rc.truncation_distance) ** 2).mean()
             total = total + rc.w_freespace * loss["freespace"]

@@ -128,7 +128,8 @@ class RenderSpec:
     photometric_weight: float = 1.0
     depth_weight: float = 1.0
     huber_delta: float = 0.05                       # losses.py:63
-    photometric_loss: str = "l1"                    # losses.py:26-29 ("l1" | "l2"; gaussian_nll not restated)
+    photometric_loss: str = "l1"                    # losses.py:26-36: "l1" | "l2" | "gaussian_nll"
+    depth_loss: str = "huber"                       # losses.py:60-75: "huber" | "gaussian_nll" | "laplacian_nll"
 
     def __post_init__(self):
         if self.range_depth_guided is None:
@@ -628,24 +629,40 @@ def sample_target_sv(cam: CameraSpec, rgbd_image, c2w, positions, active_field_i
 
 
 def compute_losses(pred, target_rgbds, depth_mask, term_mask, term_target, rs: RenderSpec):
-    """Global masked means over all fields (rm.py:1787-1872); l1 / l2 photometric (losses.py:26-29) + huber depth
-    (losses.py:60-63); the loss dict key carries the mode like rm.py:1827."""
+    """Global masked means over all fields (rm.py:1787-1872); photometric l1 / l2 / gaussian_nll (losses.py:26-36), depth
+    huber / gaussian_nll / laplacian_nll (losses.py:60-75); the loss dict keys carry the mode like rm.py:1827, 1837.
+    The variance-weighted modes read the rendered variances (pred["color_vars"], pred["depth_vars"], rm.py:781-790) and
+    differentiate through them."""
     m = depth_mask & (pred["term_probs"] > 0.8)                     # rm.py:1787-1788
     loss = {}
     loss["termination"] = ((pred["term_probs"][term_mask] - term_target[term_mask]) ** 2).mean()
-    pk = "photometric_" + rs.photometric_loss
-    diff = target_rgbds[m][:, :3] - pred["rgbds"][m][:, :3]
+    pk, dk = "photometric_" + rs.photometric_loss, "depth_" + rs.depth_loss
+    # rm.py:1820-1825 hands the PREDICTION in as `measured_colors` and the target as `rendered_colors`
+    p_rgb, t_rgb = pred["rgbds"][m][:, :3], target_rgbds[m][:, :3]
     if rs.photometric_loss == "l1":
-        loss[pk] = diff.abs().mean()
+        loss[pk] = (p_rgb - t_rgb).abs().mean()
     elif rs.photometric_loss == "l2":
-        loss[pk] = (diff ** 2).mean()
+        loss[pk] = ((p_rgb - t_rgb) ** 2).mean()
+    elif rs.photometric_loss == "gaussian_nll":                     # losses.py:30-36 (no epsilon on the variance)
+        cv = pred["color_vars"][m]
+        nlls = 0.5 * (t_rgb - p_rgb) ** 2 / cv + torch.log(torch.sqrt(cv))
+        loss[pk] = (p_rgb - t_rgb).abs().mean() if nlls.mean() > 2 else nlls.mean()      # data-dependent switch to L1
     else:
         raise NotImplementedError(rs.photometric_loss)
-    loss["depth_huber"] = torch.nn.functional.huber_loss(
-        pred["rgbds"][m][:, 3], target_rgbds[m][:, 3], delta=rs.huber_delta)
+    p_d, t_d = pred["rgbds"][m][:, 3], target_rgbds[m][:, 3]
+    if rs.depth_loss == "huber":
+        loss[dk] = torch.nn.functional.huber_loss(p_d, t_d, delta=rs.huber_delta)
+    elif rs.depth_loss == "gaussian_nll":                           # losses.py:64-69
+        dv = pred["depth_vars"][m] + 1e-15
+        loss[dk] = (0.5 * (p_d - t_d) ** 2 / dv + torch.log(torch.sqrt(dv))).mean()
+    elif rs.depth_loss == "laplacian_nll":                          # losses.py:70-75
+        dv = pred["depth_vars"][m]
+        loss[dk] = ((t_d - p_d).abs() / torch.sqrt(0.5 * dv + 1e-6) + 0.5 * torch.log(2 * dv + 1e-6)).mean()
+    else:
+        raise NotImplementedError(rs.depth_loss)
     total = (rs.termination_weight * loss["termination"]
              + rs.photometric_weight * loss[pk]
-             + rs.depth_weight * loss["depth_huber"])
+             + rs.depth_weight * loss[dk])
     if pred["freespace_geometry"] is not None:
         loss["freespace"] = ((pred["freespace_geometry"] - rs.truncation_distance) ** 2).mean()
         total = total + rs.freespace_weight * loss["freespace"]

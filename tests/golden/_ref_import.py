@@ -129,7 +129,7 @@ def make_config(*, skip_mode="no", encoding="fourier", dim_enc=64, num_layers=2,
                 geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1,
                 field_radius=1.0, scale_mode="unit_cube", termination_weight=0.0,
                 freespace_weight=40.0, tsdf_weight=50.0, neus_initial_sd=1.0,
-                far_distance=8.0, eval_far_distance=8.0, eval_num_samples=None, photometric_loss="l1"):
+                far_distance=8.0, eval_far_distance=8.0, eval_num_samples=None, photometric_loss="l1", depth_loss="huber"):
     if encoding == "fourier":
         enc_type = "neural_graph_mapping.positional_encodings.PositionalEncodingFourier"
         enc_kwargs = dict(dim_in=3, dim_out=dim_enc, mu=fourier_mu, sigma=fourier_sigma,
@@ -156,7 +156,7 @@ def make_config(*, skip_mode="no", encoding="fourier", dim_enc=64, num_layers=2,
         ),
         device="cpu", learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5,
         freeze_model=False, termination_weight=termination_weight, photometric_weight=1.0,
-        photometric_loss=photometric_loss, depth_weight=1.0, depth_loss="huber",
+        photometric_loss=photometric_loss, depth_weight=1.0, depth_loss=depth_loss,
         freespace_weight=freespace_weight, tsdf_weight=tsdf_weight, field_radius=field_radius,
         block_size=3000000, pixel_block_size=8192, num_train_fields=32,
         num_rays_per_field=512, num_samples_depth_guided=num_samples_depth_guided,

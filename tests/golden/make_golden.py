@@ -196,14 +196,15 @@ def g5_quadrature():
 
 
 def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, dim_enc=64,
-                termination_weight=0.0, perturb=True, save_samples=False, inside=False, photometric_loss="l1"):
+                termination_weight=0.0, perturb=True, save_samples=False, inside=False, photometric_loss="l1",
+                depth_loss="huber", color_shift=0.0):
     cam = camera.Camera(**NRGBD_CAMERA)
     gen = torch.Generator().manual_seed(seed)
     pos = 0.5 * torch.randn(F, 3, generator=gen)
     quat = rand_quats(F, gen)
     cfg = make_config(encoding=encoding, dim_enc=dim_enc, num_layers=num_layers,
                       num_samples_coarse=n_c, num_samples_depth_guided=n_g,
-                      termination_weight=termination_weight, photometric_loss=photometric_loss)
+                      termination_weight=termination_weight, photometric_loss=photometric_loss, depth_loss=depth_loss)
     ngm = build_map(rm, cfg, F, pos, quat, seed=seed)
     ngm._camera = cam
     model = ngm._model
@@ -214,6 +215,8 @@ def _train_case(name, F, R, n_c, n_g, seed, encoding="fourier", num_layers=2, di
         # make geometry non-trivial: larger last-layer weights
         model.all_fields_params[f"_linears.{num_layers}.weight"].mul_(2.0)
     t = synth_target(F, R, cam, pos, gen, inside=inside)
+    if color_shift:                      # pushes the photometric gaussian_nll mean over 2: the L1 branch of losses.py:34-35
+        t["rgbds"][..., :3] += color_shift
     fids = torch.arange(F)
     target = make_target(t, fids)
     torch.manual_seed(seed + 1000)
@@ -742,10 +745,22 @@ def g17_extract_mesh():
          **{"p::" + k: v for k, v in model.all_fields_params.items()}, **out)
 
 
+def g20_train_nll():
+    """the variance-weighted loss modes (losses.py:30-36, 64-75): gradients flow through the rendered colour / depth variances
+    (rm.py:781-790).  Three configurations: gaussian_nll for both losses; l1 + laplacian_nll; and gaussian_nll photometric
+    with targets far off, where the reference's data-dependent switch (mean NLL > 2) returns the L1 loss instead."""
+    _train_case("g20_train_gnll_gnll", F=2, R=24, n_c=8, n_g=8, seed=200, termination_weight=0.5,
+                photometric_loss="gaussian_nll", depth_loss="gaussian_nll")
+    _train_case("g20_train_l1_lnll", F=2, R=24, n_c=8, n_g=8, seed=201, termination_weight=0.5,
+                photometric_loss="l1", depth_loss="laplacian_nll")
+    _train_case("g20_train_gnll_switch_l1", F=2, R=24, n_c=8, n_g=8, seed=202, termination_weight=0.5,
+                photometric_loss="gaussian_nll", depth_loss="huber", color_shift=40.0)
+
+
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings, g20_train_nll]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -53,6 +53,16 @@ CASES = {
     # photometric_loss: l2 (losses.py:28-29), fixture G18 from the real reference
     "g18_train_l2": (dict(encoding="fourier", dim_enc=64, num_layers=2),
                      dict(num_samples_coarse=8, num_samples_depth_guided=8, termination_weight=0.5, photometric_loss="l2")),
+    # the variance-weighted loss modes (losses.py:30-36, 64-75), fixtures G20 from the real reference; the third sits on the
+    # L1 branch of the photometric gaussian_nll's switch (mean NLL > 2)
+    "g20_train_gnll_gnll": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                            dict(num_samples_coarse=8, num_samples_depth_guided=8, termination_weight=0.5,
+                                 photometric_loss="gaussian_nll", depth_loss="gaussian_nll")),
+    "g20_train_l1_lnll": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                          dict(num_samples_coarse=8, num_samples_depth_guided=8, termination_weight=0.5, depth_loss="laplacian_nll")),
+    "g20_train_gnll_switch_l1": (dict(encoding="fourier", dim_enc=64, num_layers=2),
+                                 dict(num_samples_coarse=8, num_samples_depth_guided=8, termination_weight=0.5,
+                                      photometric_loss="gaussian_nll")),
     # cameras inside the field, near < 0: geometry of samples behind the camera overwritten (rm.py:614-622)
     "g10_train_behind_camera": (dict(encoding="fourier", dim_enc=64, num_layers=2),
                                 dict(num_samples_coarse=12, num_samples_depth_guided=8, termination_weight=0.5)),
@@ -180,7 +190,8 @@ def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0
     pos, quat, t = synth_target(F, R, seed=R)
     fs = O.FieldSpec(**fkw)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3,
-                      geometry_mode=geometry_mode, geometry_factor=geometry_factor)
+                      geometry_mode=geometry_mode, geometry_factor=geometry_factor,
+                      **{k: v for k, v in ckw_extra.items() if k in ("photometric_loss", "depth_loss")})
     params = O.init_params(fs, F, seed=R, sigma=3.0)
     params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)

@@ -196,3 +196,49 @@ def test_standalone_encode_stage_vs_oracle(enc):
         ok = (out.cpu() - ref).abs() <= 2e-4 + 2e-3 * ref.abs()
         assert float(ok.float().mean()) > 0.99
         assert float((out.cpu()[..., :16] - ref[..., :16]).abs().max()) < 2e-4      # the eight coarser levels: tight
+
+
+# ------------------------------------------------------------------------------------------------ variance-weighted losses
+@pytest.mark.parametrize("geom", ["nrgbd", "occupancy"])
+@pytest.mark.parametrize("photo,depth", [("gaussian_nll", "gaussian_nll"), ("l2", "laplacian_nll"), ("gaussian_nll", "huber")])
+@pytest.mark.parametrize("F,R,n_c,n_g", [(3, 37, 5, 2), (2, 130, 20, 4)])
+def test_nll_loss_modes_ragged_vs_oracle(F, R, n_c, n_g, photo, depth, geom):
+    """losses.py:30-36, 64-75 on ragged shapes (rays of 7 and 24 samples against 32-sample tiles): prediction, loss and every
+    gradient against the oracle, whose restatement of these modes is pinned by the G20 fixtures of the real reference.  The
+    gradient reaches the samples through the rendered variances as well (k_stash_bwd; the fused compositing backward is not
+    used for these modes).  Conditioning: the NLL divides by the rendered variance, which is a cancellation (sum w (c - C)^2)
+    and vanishes where one sample takes all the weight -- there e^2 / V^2 amplifies the fp32 rounding of V without bound in
+    ANY implementation; rays whose variances fall below 1e-4 are therefore taken out of the loss (depth mask off): 19-39 of
+    the masked rays stay in."""
+    from gpu_common import kink_free_draws
+    torch.manual_seed(F * 1000 + R)
+    fkw = dict(FOURIER)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geom,
+               geometry_factor=20.0, photometric_loss=photo, depth_loss=depth)
+    pos, quat, t = synth_target(F, R, seed=R)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geom,
+                      geometry_factor=20.0, photometric_loss=photo, depth_loss=depth)
+    params = O.init_params(fs, F, seed=R, sigma=3.0)
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    with torch.no_grad():
+        p0 = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, params, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    thin = (p0["color_vars"].min(-1).values < 1e-4) | (p0["depth_vars"] < 1e-4)
+    t["depth_mask"] = t["depth_mask"] & ~thin
+    assert int((t["depth_mask"] & (p0["term_probs"] > 0.8)).sum()) >= 5, "too few well-conditioned rays left"
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    loss["combined"].backward()
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    assert K.lib().ngm_debug_last_comp_fused() == 0 and K.lib().ngm_debug_last_bwd_variant() == 3
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    close(res["prediction"].color_vars, pred["color_vars"].detach(), rtol=1e-3, atol=1e-6)
+    close(res["prediction"].depth_vars, pred["depth_vars"].detach(), rtol=1e-3, atol=1e-6)
+    for k in ("photometric_" + photo, "depth_" + depth, "combined"):
+        close(res[k], loss[k].detach(), rtol=2e-3, atol=1e-5)
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 5e-3, k)

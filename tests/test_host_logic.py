@@ -164,11 +164,14 @@ def test_config_fails_loudly_like_the_reference():
             Rr.make_render_cfg(cam, bad)
     no_tsdf = {k: v for k, v in good.items() if k != "tsdf_weight"}
     assert Rr.make_render_cfg(cam, no_tsdf).w_tsdf == 0.0                 # config.get("tsdf_weight", 0.0), rm.py:135
-    with pytest.raises(NotImplementedError):
-        Rr.make_render_cfg(cam, {**good, "photometric_loss": "gaussian_nll"})
+    # every mode of losses.py is built (round 4: the variance-weighted ones too); an unknown mode still raises
+    assert Rr.make_render_cfg(cam, {**good, "photometric_loss": "gaussian_nll"}).photometric_mode == K.PHOTO["gaussian_nll"]
     for mode in ("gaussian_nll", "laplacian_nll"):
-        with pytest.raises(NotImplementedError):
-            Rr.make_render_cfg(cam, {**good, "depth_loss": mode})
+        assert Rr.make_render_cfg(cam, {**good, "depth_loss": mode}).depth_mode == K.DEPTH[mode]
+    with pytest.raises(NotImplementedError):
+        Rr.make_render_cfg(cam, {**good, "photometric_loss": "huber"})
+    with pytest.raises(NotImplementedError):
+        Rr.make_render_cfg(cam, {**good, "depth_loss": "l1"})
     with pytest.raises(ValueError):
         Rr.make_render_cfg(cam, {**good, "geometry_mode": "sdf"})
     with pytest.raises(KeyError):                                          # the renderer's constructor goes through the same check

@@ -314,6 +314,14 @@ int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
                           const float* d_term, const float* d_geom_samples,
                           const ngm_grads* grads, void* workspace, int64_t workspace_bytes,
                           void* stream);
+/* The same with seeds on the rendered variances as well (rm.py:781-790: V = sum_k w_k (c_k - C)^2): dL/d(color_vars) (F,R,3)
+ * and dL/d(depth_vars) (F,R), either may be NULL; `pred` = the forward's outputs (rgbds and term_probs are read: the means and
+ * the weight sum the variances are taken around).  What the reference's autograd does for losses.py's *_nll modes. */
+int ngm_render_bwd_seeded_vars(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
+                               const ngm_params* params, const ngm_rays* rays, const ngm_prediction* pred,
+                               const float* d_rgbds, const float* d_color_vars, const float* d_depth_vars,
+                               const float* d_term, const float* d_geom_samples, const ngm_grads* grads,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 /* read access to the per-sample values saved by ngm_render_fwd(train): copies geometry (F,R,S)
  * and sorted distances (F,R,S) out of the workspace (for Prediction.freespace_geometry /
  * tsdf_residuals, rm.py:624-639).  S = the samples per ray the forward ran with: S_c + S_g when

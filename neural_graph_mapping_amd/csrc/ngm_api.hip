@@ -871,6 +871,23 @@ int ngm_render_bwd_seeded(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg,
   return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int ngm_render_bwd_seeded_vars(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
+                               const ngm_rays* rays, const ngm_prediction* pred, const float* d_rgbds, const float* d_color_vars,
+                               const float* d_depth_vars, const float* d_term, const float* d_geom_samples,
+                               const ngm_grads* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+  int e = check_render(fcfg, rcfg, params, rays);
+  if (e) return e;
+  if (!d_rgbds || !grads) return fail(NGM_E_INVALID, "render_bwd_seeded_vars: NULL argument");
+  if ((d_color_vars || d_depth_vars) && (!pred || !pred->rgbds || !pred->term_probs))
+    return fail(NGM_E_INVALID, "render_bwd_seeded_vars: seeds on the variances need the forward's pred.rgbds and pred.term_probs");
+  StashBwdArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.seed_mode = 1; sb.d_rgbds = d_rgbds; sb.d_term = d_term; sb.d_geom_samples = d_geom_samples;
+  sb.d_cvars = d_color_vars; sb.d_dvars = d_depth_vars;
+  if (pred) sb.pred = *pred;
+  return render_bwd_common(fcfg, rcfg, params, rays, sb, grads, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int ngm_render_read_samples(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, int32_t F, int32_t R, int32_t S,
                             const void* workspace, float* geoms, float* dists, void* stream) {
   if (check_field_cfg(fcfg) || !rcfg || !workspace) return fail(NGM_E_INVALID, "render_read_samples: bad argument");

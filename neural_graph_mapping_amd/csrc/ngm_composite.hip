@@ -390,7 +390,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   };
   // variance-weighted loss modes (losses.py:30-36, 64-75): the loss reads the rendered variances (rm.py:781-790) and its
   // gradient reaches the samples through them as well
-  const bool nll = a.seed_mode == 0 && (a.rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL || a.rc.depth_mode != NGM_DEPTH_HUBER);
+  const bool nll = a.seed_mode == 0 ? (a.rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL || a.rc.depth_mode != NGM_DEPTH_HUBER)
+                                    : (a.d_cvars != nullptr || a.d_dvars != nullptr);     // explicit seeds on the variances
   auto fetch = [&](int64_t st, StepIn& in) __attribute__((always_inline)) {
     const int64_t idx = st * 64 + lane;
     in.sa = in.r0 = in.r1 = in.pr = in.tg = in.vr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -410,6 +411,11 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
                                      a.pred.depth_vars[ray]);
         in.dm = a.tg.depth_mask[ray];
         if (a.tg.term_mask) { in.tm = a.tg.term_mask[ray]; in.tprob = a.tg.term_probs[ray]; }
+      } else if (nll) {            // explicit seeds on the variances: the forward's means and weight sum, the seeds themselves
+        in.pr = reinterpret_cast<const float4*>(a.pred.rgbds)[ray];
+        in.term = a.pred.term_probs[ray];
+        in.vr = make_float4(a.d_cvars ? a.d_cvars[3 * ray] : 0.f, a.d_cvars ? a.d_cvars[3 * ray + 1] : 0.f,
+                            a.d_cvars ? a.d_cvars[3 * ray + 2] : 0.f, a.d_dvars ? a.d_dvars[ray] : 0.f);
       }
     }
   };
@@ -521,6 +527,12 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
         const float4 d = reinterpret_cast<const float4*>(a.d_rgbds)[ray];
         dC0 = d.x; dC1 = d.y; dC2 = d.z; dD = d.w;
         if (a.d_term) dT = a.d_term[ray];
+        if (nll) {                 // as above: d V / d C = -2 C (1 - W) joins the mean's seed
+          gV0 = in.vr.x; gV1 = in.vr.y; gV2 = in.vr.z; gVd = in.vr.w;
+          mC0 = in.pr.x; mC1 = in.pr.y; mC2 = in.pr.z; mD = in.pr.w;
+          const float bg2 = 2.0f * (1.0f - in.term);
+          dC0 -= gV0 * bg2 * mC0; dC1 -= gV1 * bg2 * mC1; dC2 -= gV2 * bg2 * mC2; dD -= gVd * bg2 * mD;
+        }
       }
     }
     const float depth = -(dzc * t);

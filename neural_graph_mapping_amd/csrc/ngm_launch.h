@@ -148,6 +148,8 @@ struct StashBwdArgs {
   const float* d_rgbds;       // (F,R,4)
   const float* d_term;        // (F,R)
   const float* d_geom_samples;// (F,R,S) or NULL
+  const float* d_cvars;       // seed mode 1, optional: dL/d(color_vars) (F,R,3) and dL/d(depth_vars) (F,R); `pred` then carries the
+  const float* d_dvars;       // forward's rgbds / term_probs (the means and the weight sum the variances are taken around)
   float* loss_out;            // (8) loss scalars from loss_sums (seed mode 0) or NULL
   // deferred loss reduction (single GPU: nothing happens between forward and backward): every workgroup sums the
   // forward's per-workgroup partials itself, in the fixed order of k_loss_reduce -> one launch less per step

@@ -453,14 +453,23 @@ def _render_ijs_bwd_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor
                        pos: torch.Tensor, quat: torch.Tensor, u_coarse: Optional[torch.Tensor],
                        u_guided: Optional[torch.Tensor], seed: int, near_const: float, far_const: float,
                        d_rgbds: torch.Tensor, d_term: torch.Tensor, d_geoms: Optional[torch.Tensor],
-                       workspace: torch.Tensor, params: List[torch.Tensor]) -> List[torch.Tensor]:
-    """gradients w.r.t. `params`; the backward kernels overwrite the saved forward values in `workspace` (single use)"""
+                       workspace: torch.Tensor, params: List[torch.Tensor], d_cvars: Optional[torch.Tensor] = None,
+                       d_dvars: Optional[torch.Tensor] = None, rgbds: Optional[torch.Tensor] = None,
+                       term: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """gradients w.r.t. `params`; the backward kernels overwrite the saved forward values in `workspace` (single use).
+    d_cvars / d_dvars: seeds on the rendered variances (losses.py's *_nll modes); then `rgbds` / `term` = the forward's outputs."""
     fc, rc = _field_cfg(fcfg), _render_cfg(rcfg)
     keep = []
     rays = _rays_from(rc, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, keep)
     names = K.param_names(fc)
     grads, gs = alloc_grads_separate(fc, rays.F, ijs.device)
     ps = params_struct(fc, dict(zip(names, params)))
+    if d_cvars is not None or d_dvars is not None:
+        pred = K.Prediction(_ptr(rgbds), None, None, _ptr(term))
+        K.check(K.lib().ngm_render_bwd_seeded_vars(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), C.byref(pred), _ptr(d_rgbds),
+                                                   _ptr(d_cvars), _ptr(d_dvars), _ptr(d_term), _ptr(d_geoms), C.byref(gs),
+                                                   workspace.data_ptr(), workspace.numel(), _stream()), "ngm_render_bwd_seeded_vars")
+        return [grads[n] for n in names]
     K.check(K.lib().ngm_render_bwd_seeded(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), _ptr(d_rgbds), _ptr(d_term),
                                           _ptr(d_geoms), C.byref(gs), workspace.data_ptr(), workspace.numel(), _stream()),
             "ngm_render_bwd_seeded")
@@ -469,7 +478,7 @@ def _render_ijs_bwd_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor
 
 @_render_ijs_bwd_op.register_fake
 def _(fcfg, rcfg, ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, seed, near_const, far_const, d_rgbds, d_term,
-      d_geoms, workspace, params):
+      d_geoms, workspace, params, d_cvars=None, d_dvars=None, rgbds=None, term=None):
     return [torch.empty_like(p, dtype=torch.float32) for p in params]      # gradients are fp32 whatever the storage dtype
 
 
@@ -482,8 +491,10 @@ def _render_ijs_setup(ctx, inputs, output):
     ctx.fcfg, ctx.rcfg, ctx.scalars, ctx.save = fcfg, rcfg, (seed, near_const, far_const), save
     ctx.present = [t is not None for t in ray_t]
     ctx.consumed = False
-    ctx.save_for_backward(*[t for t in ray_t if t is not None], output[6], *params)
+    # (rgbds and term_probs ride along for seeds on the variances: the means and the weight sum they are taken around)
+    ctx.save_for_backward(*[t for t in ray_t if t is not None], output[0], output[3], output[6], *params)
     ctx.n_params = len(params)
+    ctx.set_materialize_grads(False)       # an output the loss does not touch arrives as None (color_vars / depth_vars mostly)
 
 
 def _render_ijs_backward(ctx, grads):
@@ -495,13 +506,21 @@ def _render_ijs_backward(ctx, grads):
     ctx.consumed = True
     saved = list(ctx.saved_tensors)
     params = saved[len(saved) - ctx.n_params:]
-    ws = saved[len(saved) - ctx.n_params - 1]
+    rgbds, term, ws = saved[len(saved) - ctx.n_params - 3:len(saved) - ctx.n_params]
     it = iter(saved)
     ray_t = [next(it) if p else None for p in ctx.present]
-    d_rgbds, _, _, d_term, d_geoms, _, _ = grads
+    d_rgbds, d_cvars, d_dvars, d_term, d_geoms, _, _ = grads
     seed, near_const, far_const = ctx.scalars
-    g = torch.ops.ngm355.render_ijs_bwd(ctx.fcfg, ctx.rcfg, *ray_t, seed, near_const, far_const, d_rgbds.contiguous(),
-                                        d_term.contiguous(), d_geoms.contiguous() if d_geoms.numel() else None, ws, params)
+    d_rgbds = torch.zeros_like(rgbds) if d_rgbds is None else d_rgbds.contiguous()
+    d_term = torch.zeros_like(term) if d_term is None else d_term.contiguous()
+    d_geoms = None if (d_geoms is None or not d_geoms.numel()) else d_geoms.contiguous()
+    if d_cvars is not None or d_dvars is not None:      # the loss reads the rendered variances (losses.py's *_nll modes)
+        g = torch.ops.ngm355.render_ijs_bwd(ctx.fcfg, ctx.rcfg, *ray_t, seed, near_const, far_const, d_rgbds, d_term, d_geoms, ws,
+                                            params, None if d_cvars is None else d_cvars.contiguous(),
+                                            None if d_dvars is None else d_dvars.contiguous(), rgbds, term)
+    else:
+        g = torch.ops.ngm355.render_ijs_bwd(ctx.fcfg, ctx.rcfg, *ray_t, seed, near_const, far_const, d_rgbds, d_term, d_geoms, ws,
+                                            params)
     return (None,) * 17 + (g,)
 
 
@@ -511,7 +530,7 @@ _render_ijs_op.register_autograd(_render_ijs_backward, setup_context=_render_ijs
 def render_ijs_fused(fc: K.FieldCfg, rc: K.RenderCfg, params: Dict[str, torch.Tensor], ijs, c2ws, near, far, gt, pos, quat,
                      u_coarse=None, u_guided=None, seed=0, near_const=0.0, far_const=8.0):
     """-> (rgbds, color_vars, depth_vars, term_probs, geoms | None, dists | None); differentiable w.r.t. `params` through
-    rgbds / term_probs / geoms.  Dispatches through torch.ops.ngm355.render_ijs."""
+    rgbds / color_vars / depth_vars / term_probs / geoms.  Dispatches through torch.ops.ngm355.render_ijs."""
     plist = [params[n] for n in K.param_names(fc)]
     _require_gpu(ijs, c2ws, near, far, gt, pos, quat, u_coarse, u_guided, *plist)
     save = bool(gt is not None or (torch.is_grad_enabled() and any(t.requires_grad for t in plist)))
@@ -524,7 +543,9 @@ def render_ijs_fused(fc: K.FieldCfg, rc: K.RenderCfg, params: Dict[str, torch.Te
                                       int(K.lib().ngm_render_workspace(C.byref(fc), C.byref(rc), ijs.shape[0], ijs.shape[1], 1)) if save else 0,
                                       plist)
     rgbds, cvars, dvars, term, geoms, dists, _ = out
-    return (rgbds, cvars.detach(), dvars.detach(), term, geoms if save else None, dists.detach() if save else None)
+    # color_vars / depth_vars stay in the graph: a loss that reads them (losses.py's *_nll modes) seeds them, and the backward
+    # then runs ngm_render_bwd_seeded_vars; a loss that does not leaves their gradients None (set_materialize_grads(False))
+    return (rgbds, cvars, dvars, term, geoms if save else None, dists.detach() if save else None)
 
 
 # ------------------------------------------------------------------------------------------------

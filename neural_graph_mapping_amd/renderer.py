@@ -312,13 +312,21 @@ class NeuralGraphRenderer:
         loss["termination"] = ((prediction.term_probs[tm] - target.term_probs[tm]) ** 2).mean()
         diff = target.rgbds[m][:, :3] - prediction.rgbds[m][:, :3]
         dk = "depth_" + self._config["depth_loss"]
-        if rc.photometric_mode == K.PHOTO["gaussian_nll"] or rc.depth_mode != K.DEPTH["huber"]:
-            # the variance-weighted modes differentiate through the rendered variances, which this autograd path
-            # (render_ijs -> Prediction) does not propagate: they train through optimization_iteration (fused step)
-            raise NotImplementedError("compute_losses: the *_nll loss modes are built in the fused training step "
-                                      "(optimization_iteration / capture_iteration), not in the render_ijs autograd path")
-        loss[pk] = diff.abs().mean() if rc.photometric_mode == K.PHOTO["l1"] else (diff ** 2).mean()   # losses.py:26-29
-        loss[dk] = torch.nn.functional.huber_loss(prediction.rgbds[m][:, 3], target.rgbds[m][:, 3], delta=rc.huber_delta)
+        p_d, t_d = prediction.rgbds[m][:, 3], target.rgbds[m][:, 3]
+        if rc.photometric_mode == K.PHOTO["gaussian_nll"]:                   # losses.py:30-36 (the autograd path propagates
+            cv = prediction.color_vars[m]                                     # through the variances: render_ijs_bwd with seeds on them)
+            nlls = 0.5 * diff ** 2 / cv + torch.log(torch.sqrt(cv))
+            loss[pk] = diff.abs().mean() if nlls.mean() > 2 else nlls.mean()
+        else:
+            loss[pk] = diff.abs().mean() if rc.photometric_mode == K.PHOTO["l1"] else (diff ** 2).mean()   # losses.py:26-29
+        if rc.depth_mode == K.DEPTH["gaussian_nll"]:                         # losses.py:64-69
+            dv = prediction.depth_vars[m] + 1e-15
+            loss[dk] = (0.5 * (p_d - t_d) ** 2 / dv + torch.log(torch.sqrt(dv))).mean()
+        elif rc.depth_mode == K.DEPTH["laplacian_nll"]:                      # losses.py:70-75
+            dv = prediction.depth_vars[m]
+            loss[dk] = ((t_d - p_d).abs() / torch.sqrt(0.5 * dv + 1e-6) + 0.5 * torch.log(2 * dv + 1e-6)).mean()
+        else:
+            loss[dk] = torch.nn.functional.huber_loss(p_d, t_d, delta=rc.huber_delta)
         total = (rc.w_termination * loss["termination"] + rc.w_photometric * loss[pk]
                  + rc.w_depth * loss[dk])
         if prediction.freespace_geometry is not None:

@@ -589,9 +589,11 @@ def test_fused_train_step_golden(name):
         grad_close(res["grads"][k], v, 1e-2 if nerf else 2e-3, k)
 
 
-@pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field", "g18_train_l2"])
+@pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field", "g18_train_l2", "g20_train_gnll_gnll", "g20_train_l1_lnll",
+                                  "g20_train_gnll_switch_l1"])
 def test_render_ijs_autograd_path_golden(name):
-    """reference-style call sequence: render_ijs -> compute_losses -> backward (rm.py:1164-1186)."""
+    """reference-style call sequence: render_ijs -> compute_losses -> backward (rm.py:1164-1186).  G20: the *_nll loss modes,
+    whose autograd reaches the parameters through Prediction.color_vars / depth_vars as well (ngm_render_bwd_seeded_vars)."""
     g = load_golden(name)
     fkw, ckw = CASES[name]
     F = g["pos"].shape[0]

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, flo
         const int32_t ahead = (int32_t)((uint32_t)(w >> 32) - seq);
         if (ahead == 0) break;
         if (ahead > 0 && ahead < (1 << 30)) { skew = true; break; }   // the writer is past this exchange: resynchronise, flag it
-        if (++spins > (1 << 21)) { late = true; break; }     // x ~1 us of s_sleep: about two seconds
+        if (++spins > (1 << 21)) { late = true; w = 0; break; }   // x ~1 us of s_sleep: about two seconds; the slot still holds
+                                                                  // the word of two exchanges ago: contribute nothing, not that
         __builtin_amdgcn_s_sleep(32);
       }
       total += __uint_as_float((uint32_t)w);

@@ -291,3 +291,77 @@ def test_two_ranks_peer_exchange_inside_one_graph(tmp_path):
         close(res["last_loss"], last["combined"], rtol=1e-4, atol=1e-6)
         for k, v in res["params"].items():
             close(v, params1[k][res["ids"]], rtol=1e-4, atol=1e-6)
+
+
+def _peer_fail_worker(rank, world, port, out, where):
+    """one rank's set-up breaks at `where`; every rank must come back with None, nobody may hang in a collective"""
+    _init(rank, world, port)
+    from neural_graph_mapping_amd import _capi as K
+    L = K.lib()
+    if rank == 1:                    # sabotage THIS rank only: the failure is asymmetric
+        if where == "alloc":
+            real = L.ngm_peer_alloc
+            L.__dict__["ngm_peer_alloc"] = lambda *a: -4
+        elif where == "open":
+            real = L.ngm_ipc_open
+            L.__dict__["ngm_ipc_open"] = lambda *a: -4
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        px = D.PeerExchange.try_create(dist.group.WORLD, torch.device(DEV))
+    # the process group is still in step afterwards: a collective issued by everyone pairs up
+    x = torch.ones(1)
+    dist.all_reduce(x)
+    torch.save(dict(px_is_none=px is None, seen=float(x)), os.path.join(out, f"fail_{where}{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["alloc", "open"])
+def test_peer_exchange_setup_survives_an_asymmetric_failure(tmp_path, where):
+    """ADVICE (round 3): a set-up that fails on a subset of ranks used to leave the ranks with unequal collective counts
+    (gathers issued from the exception path) and could hang the fall-back to RCCL.  The set-up now runs the same three
+    gathers on every rank whatever fails where: `try_create` returns None on BOTH ranks and the next collective pairs."""
+    world = 2
+    mp.spawn(_peer_fail_worker, args=(world, _free_port(), str(tmp_path), where), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"fail_{where}{r}.pt"))
+        assert res["px_is_none"] and res["seen"] == world
+
+
+def _peer_timeout_worker(rank, world, port, out):
+    _init(rank, world, port)
+    px = D.PeerExchange(dist.group.WORLD)
+    x = torch.full((16,), float(rank + 1), device=DEV)
+    px.allreduce(x)                                       # a healthy exchange
+    torch.cuda.synchronize()
+    healthy = (px.status(), float(x[0]))
+    raised = None
+    if rank == 0:
+        # rank 1 does NOT enter the next exchange: rank 0 waits ~2 s for it, gives up, and must say so
+        y = torch.ones(16, device=DEV)
+        px.allreduce(y)
+        torch.cuda.synchronize()
+        try:
+            px.check()
+        except RuntimeError as e:
+            raised = str(e)
+        partial = float(y[0])
+    else:
+        partial = None
+    dist.barrier()
+    torch.save(dict(healthy=healthy, raised=raised, status=px.status(), partial=partial), os.path.join(out, f"timeout{rank}.pt"))
+    px.close()
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_timeout_is_reported_not_swallowed(tmp_path):
+    """ADVICE (round 3): a peer that does not arrive leaves PARTIAL sums; nothing ever read the sticky status word.  It is
+    fatal now: `PeerExchange.check()` (called by the renderer every `peer_check_interval` iterations and by
+    `check_exchange()`) raises on the rank that timed out."""
+    world = 2
+    mp.spawn(_peer_timeout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"timeout{r}.pt")) for r in range(world))
+    assert r0["healthy"] == (0, 3.0) and r1["healthy"] == (0, 3.0)
+    assert r0["status"] & 1 and r0["raised"] and "loss exchange failed" in r0["raised"]
+    assert r0["partial"] == 1.0                          # only its own contribution arrived
+    assert r1["status"] == 0

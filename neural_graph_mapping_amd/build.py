@@ -75,6 +75,12 @@ def build(fast=False, force=False, verbose=True, out=None):
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         with open(stamp, "w") as fh:
             fh.write(key)
+    if not out and not os.environ.get("NGM_HIPCC_EXTRA"):
+        # objects of earlier source states are dead weight (they travel to the GPU box with every snapshot): keep the current set
+        keep = {os.path.basename(o) for o in objs}
+        for f in os.listdir(OBJ):
+            if f.endswith(".o") and f.startswith("ngm_") and f not in keep:
+                os.remove(os.path.join(OBJ, f))
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB

@@ -821,9 +821,54 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
     }
   }
   __syncthreads();
-  float* dst = a.part + (((int64_t)f * a.fc.nr_levels + level) * a.chunks + chunk) * 2 * T;
   // LDS holds one plane per feature (8-byte stride: the 64 lanes of an atomic spread over 32 bank pairs; interleaved, 16-byte
-  // entries reach only 16); the partial table is written in the parameter layout [entry][feature]
+  // entries reach only 16); tables are written in the parameter layout [entry][feature]
+  if (a.chunks == 1) {
+    // This workgroup saw EVERY sample of its (field, level): its LDS table is the gradient.  It is written where
+    // k_hash_reduce would have put it, and the sparse Adam of that table follows right here -- no partial table through HBM
+    // (2 x 32 KB per level and field), no k_hash_reduce launch.  (The reference's default iteration: 32 fields x 16 levels =
+    // 512 workgroups = two per CU; the M1 batch has 4 chunks per level and keeps the reduction kernel.)
+    float* gdst = a.gtab + (int64_t)f * a.gstride + (int64_t)level * T * 2;
+    float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
+    int64_t prow = 0;
+    if (a.ad_param) {
+      const double step = (double)(a.ad_step_dev ? *a.ad_step_dev : a.ad_step);
+      lr_bc1 = (float)((double)a.ad_lr / (1.0 - pow((double)a.ad_beta1, step)));
+      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.ad_beta2, step)));
+      prow = (a.ad_field_index ? a.ad_field_index[f] : f) * a.ad_stride + (int64_t)level * T * 2;
+    }
+    for (int i4 = threadIdx.x; i4 < T / 2; i4 += blockDim.x) {            // float4 = two entries x two features
+      const int e0 = 2 * i4;
+      float4 s4;
+      s4.x = (float)((double)(long long)tab[e0] * (1.0 / 1099511627776.0));
+      s4.y = (float)((double)(long long)tab[T + e0] * (1.0 / 1099511627776.0));
+      s4.z = (float)((double)(long long)tab[e0 + 1] * (1.0 / 1099511627776.0));
+      s4.w = (float)((double)(long long)tab[T + e0 + 1] * (1.0 / 1099511627776.0));
+      reinterpret_cast<float4*>(gdst)[i4] = s4;
+      if (a.ad_param) {                                                     // same arithmetic as k_hash_reduce / k_adam_multi
+        const int64_t o4 = prow / 4 + i4;                                   // tables are 16-byte aligned rows (checked by the launcher)
+        float4 p = reinterpret_cast<float4*>(a.ad_param)[o4], m = reinterpret_cast<float4*>(a.ad_m)[o4],
+               v = reinterpret_cast<float4*>(a.ad_v)[o4];
+        float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &s4.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float g = pg[c] + a.ad_wd * pp[c];
+          const float mn = a.ad_beta1 * pm[c] + (1.0f - a.ad_beta1) * g;
+          const float vn = a.ad_beta2 * pv[c] + (1.0f - a.ad_beta2) * g * g;
+          pm[c] = mn; pv[c] = vn;
+          pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.ad_eps));
+        }
+        reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
+        reinterpret_cast<float4*>(a.ad_param)[o4] = p;
+        if (a.ad_lp) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ngm_stp(a.ad_lp, 4 * o4 + c, pp[c], a.ad_lp_dt);
+        }
+      }
+    }
+    return;
+  }
+  float* dst = a.part + (((int64_t)f * a.fc.nr_levels + level) * a.chunks + chunk) * 2 * T;
   for (int i = threadIdx.x; i < 2 * T; i += blockDim.x)
     dst[i] = (float)((double)(long long)tab[(i & 1) * T + (i >> 1)] * (1.0 / 1099511627776.0));
 }
@@ -914,7 +959,7 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
     NgmProfScope prof_(NGM_K_HASH_GRAD, st);
     hipLaunchKernelGGL(k_hash_grad, dim3(chunks * fb.fc.nr_levels * fb.F), dim3(512), lds, st, a);
   }
-  {
+  if (chunks > 1) {        // one chunk: k_hash_grad wrote the gradient table and applied the update itself
     NgmProfScope prof_(NGM_K_HASH_REDUCE, st);
     hipLaunchKernelGGL(k_hash_reduce, dim3((T / 2 + 255) / 256, fb.fc.nr_levels, fb.F), dim3(256), 0, st, a);
   }

@@ -1,8 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-( time python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/driver_like.json 2> gpurun_out/driver_like.err ) 2>&1 | tail -3
-python -c "
-import json; d=json.loads(open('gpurun_out/driver_like.json').read().strip().split('\n')[-1])
-print({k:(v if not isinstance(v,(dict,list)) else '...') for k,v in d.items()})
-print(d['ms_per_step_windows']); print(d['roofline']['frac'], d['roofline']['traffic']); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline']['sample'][:80])
-print(d['aux_default']['roofline_fwd']['l2_hit_rate'], d['aux_default']['roofline_fwd']['traffic'])"
+timeout 1200 python -m pytest tests -m gpu -x -q -k "permuto or hash or cfg2 or cfg3 or reduced_precision" 2>&1 | tail -4
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['aux_hash']['ms_per_step'], d['aux_hash']['kernels_us']); print('aux_default', d['aux_default']['ms_per_step'], d['aux_default']['kernels_us'])"

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   const int nc = h.ncells;
   for (int i = t; i <= nc; i += 1024) a.cell_start[i] = 0;
   for (int i = t; i < nc; i += 1024) a.cell_fill[i] = 0;
-  __threadfence_block();
+  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
   __syncthreads();
   auto cell_of = [&](int f) {
     const int ix = min(max((int)((a.pos[3 * f] - h.x0) * h.inv_c), 0), h.nx - 1);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
     return (iz * h.ny + iy) * h.nx + ix;
   };
   for (int f = t; f < a.NF; f += 1024) atomicAdd(&a.cell_start[cell_of(f)], 1);
-  __threadfence_block();
+  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
   __syncthreads();
   // exclusive scan of cell_start[0 .. nc): contiguous segments per thread, block scan of the segment sums
   const int per = (nc + 1023) / 1024, b0 = min(nc, t * per), b1 = min(nc, b0 + per);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   int run = sscan[t] - sum;
   for (int i = b0; i < b1; ++i) { const int cnt = a.cell_start[i]; a.cell_start[i] = run; run += cnt; }
   if (t == 1023) a.cell_start[nc] = sscan[1023];
-  __threadfence_block();
+  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
   __syncthreads();
   for (int f = t; f < a.NF; f += 1024) {
     const int cidx = cell_of(f);

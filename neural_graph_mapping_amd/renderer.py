@@ -8,6 +8,7 @@ the fused fast path ``optimization_iteration`` that the mapping loop calls once 
 """
 import ctypes as C
 from collections import namedtuple
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -723,14 +724,18 @@ class NeuralGraphRenderer:
                 ctx = self._iteration_forward(target, u_coarse, u_guided, seed, advance=True)
             with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 out = self._iteration_backward(ctx, True)
-        except RuntimeError:
-            # capture refused (runtime / collective library combination): plain launches still work
+        except RuntimeError as err:
+            # capture refused (runtime / collective library combination): plain launches still work, but the caller
+            # is told -- an iteration of ~10 launches is launch-bound without the graph (`replay.graph is None`)
             self._step = step0
             torch.cuda.synchronize()
+            warnings.warn(f"capture_iteration: graph capture refused ({err}); falling back to plain launches",
+                          RuntimeWarning, stacklevel=2)
 
             def eager():
                 return self.optimization_iteration(target, u_coarse, u_guided, seed=seed)
             eager.graph = None
+            eager.capture_error = str(err)
             return eager
         self._step -= 1
         sums, group = ctx["w"]["sums"], self.process_group

@@ -23,7 +23,7 @@ def main():
     quat = torch.zeros(NF, 4)
     quat[:, 0] = 1
     out = {}
-    for S in (128, 640):
+    for S in tuple(int(v) for v in os.environ.get("NGM_EVAL_S", "128,640").split(",")):
         model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
             encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
             encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 5 /* 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 6 /* 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -385,6 +385,21 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
                        const float* field_quat, int32_t num_knn, float distance_factor,
                        float outside_value, float mask_radius, float* out, void* workspace, int64_t workspace_bytes,
                        void* stream);
+
+/* ---- eval path, whole: render_image's loop over pixel blocks (rm.py:402-437) -------------------------------------------
+ * = per block of `ray_block` rays: Camera.sample_ijs_uniform + transform_points (rm.py:513-547, eval-style: one stratum of
+ * rcfg->num_samples_coarse samples, no depth guidance -- rays->gt / u_guided are ignored), NeuralFieldSet.forward(
+ * use_vmap=False) (models.py:347-405) and _quadrature (rm.py:709-799) on the blended outputs.  The same arithmetic as
+ * ngm_sample_rays_world -> ngm_field_eval_knn -> ngm_composite_fwd_packed per block, without their intermediates in memory:
+ * the samples are drawn inside the neighbour assignment, the blend happens inside the quadrature, the grid over the field
+ * centres is built once per call.  rays: rays->F * rays->R rays in all (field_pos / field_quat / pose_index unused); block b
+ * draws its jitter from u_coarse, or from the Philox stream (philox_seed + b * ray_block, ray index within the block).
+ * pred: (F*R, .) outputs, any may be NULL.  K, mask_radius as in ngm_field_eval_knn; S <= 1024. */
+int64_t ngm_render_eval_knn_workspace(const ngm_render_cfg* rcfg, int32_t num_fields, int32_t ray_block, int32_t num_knn);
+int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
+                        int32_t num_fields, const float* field_pos, const float* field_quat, const ngm_rays* rays,
+                        int32_t num_knn, float distance_factor, float outside_value, float mask_radius, int32_t ray_block,
+                        const ngm_prediction* pred, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- training-target sampler -------------------------------------------------------
  * Device part of NeuralGraphMap._sample_target_mv (rm.py:1259-1459).  The random draws stay with the caller

@@ -32,6 +32,11 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
                    const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
                    float* out, void* workspace, int64_t workspace_bytes, hipStream_t st);
 int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K);
+int64_t ngm_knn_render_workspace_bytes(int num_fields, int ray_block, int S, int K);
+int ngm_launch_render_eval_knn(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const ngm_params* pr, int num_fields,
+                               const float* pos, const float* quat, const ngm_rays* rays, int K, float distance_factor,
+                               float outside_value, float mask_radius, int ray_block, const ngm_prediction* pred,
+                               void* workspace, int64_t workspace_bytes, hipStream_t st);
 
 #include <mutex>
 #include <vector>
@@ -954,6 +959,34 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   if (e == NGM_E_WORKSPACE) return fail(e, "ngm_field_eval_knn: workspace too small");
   if (e) return fail(e, "ngm_field_eval_knn: not available for this configuration");
   return check_launch("ngm_field_eval_knn");
+}
+
+int64_t ngm_render_eval_knn_workspace(const ngm_render_cfg* rcfg, int32_t num_fields, int32_t ray_block, int32_t num_knn) {
+  const int K = num_knn < num_fields ? num_knn : num_fields;
+  if (!rcfg || num_fields < 1 || ray_block < 1 || K < 1 || rcfg->num_samples_coarse < 1) return NGM_E_INVALID;
+  return ngm_knn_render_workspace_bytes(num_fields, ray_block, rcfg->num_samples_coarse, K);
+}
+
+int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params, int32_t num_fields,
+                        const float* field_pos, const float* field_quat, const ngm_rays* rays, int32_t num_knn,
+                        float distance_factor, float outside_value, float mask_radius, int32_t ray_block,
+                        const ngm_prediction* pred, void* workspace, int64_t workspace_bytes, void* stream) {
+  int e = check_field_cfg(fcfg);
+  if (e) return e;
+  e = check_params(fcfg, params);
+  if (e) return e;
+  if (!rcfg || !rays || !pred || !field_pos || !field_quat || num_fields < 1 || ray_block < 1 || !rays->ijs || !rays->c2ws ||
+      rays->F < 0 || rays->R < 0)
+    return fail(NGM_E_INVALID, "ngm_render_eval_knn: bad argument");
+  if ((int64_t)rays->F * rays->R == 0) return NGM_OK;
+  const int K = num_knn < num_fields ? num_knn : num_fields;
+  if (K < 1 || K > 4) return fail(NGM_E_UNSUPPORTED, "ngm_render_eval_knn: K must be in [1,4]");
+  e = ngm_launch_render_eval_knn(fcfg, rcfg, params, num_fields, field_pos, field_quat, rays, K, distance_factor, outside_value,
+                                 mask_radius > 0.f ? mask_radius : fcfg->field_radius, ray_block, pred, workspace,
+                                 workspace_bytes, (hipStream_t)stream);
+  if (e == NGM_E_WORKSPACE) return fail(e, "ngm_render_eval_knn: workspace too small");
+  if (e) return fail(e, "ngm_render_eval_knn: not available for this configuration (samples per ray <= 1024, ray_block * samples * K < 2^31)");
+  return check_launch("ngm_render_eval_knn");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,11 +47,9 @@ __global__ void k_sample_rays(SamplerArgs a) {
       a.points_cam[3 * o + 2] = rg.dz * t;
     }
     if (a.points_world) {
-      const float* T = a.rays.c2w_per_ray ? a.rays.c2ws + ray * 16 : a.rays.c2ws;
-      const float cx = rg.dx * t, cy = rg.dy * t, cz = rg.dz * t;
-      a.points_world[3 * o] = (T[0] * cx + T[1] * cy + T[2] * cz) + T[3];
-      a.points_world[3 * o + 1] = (T[4] * cx + T[5] * cy + T[6] * cz) + T[7];
-      a.points_world[3 * o + 2] = (T[8] * cx + T[9] * cy + T[10] * cz) + T[11];
+      float wx, wy, wz;
+      sample_world_point(a.rays, rg, ray, t, &wx, &wy, &wz);
+      a.points_world[3 * o] = wx; a.points_world[3 * o + 1] = wy; a.points_world[3 * o + 2] = wz;
     }
     if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
   }
@@ -87,22 +85,52 @@ struct CompWaveLds {
 struct Rgb3 { float x, y, z; };   // 12-byte element: one global_load_dwordx3 per lane instead of three strided dword loads
 __device__ __forceinline__ Rgb3 load_rgb(const float* colors, int64_t g) { return *reinterpret_cast<const Rgb3*>(colors + 3 * g); }
 
-__device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t g) {
-  if (!a.out4) return a.geoms[g];
-  // packed eval path = _render_ijs(use_vmap=False): samples behind the camera get a constant (rm.py:614-622)
-  if (a.rc.overwrite_behind_camera && a.pcam[3 * g + 2] > 0.f) return behind_camera_geometry(a.rc.geometry_mode);
-  return a.out4[g].w;
+// packed sources (eval path = _render_ijs(use_vmap=False)): the (N,S,4) field outputs, or -- fused with the kNN blend
+// (k_knn_blend, models.py:384-401) -- the (point, neighbour) pair records it would have been formed from
+__device__ __forceinline__ bool comp_packed(const CompositeArgs& a) { return a.out4 || a.pair_field; }
+__device__ __forceinline__ float4 packed_out4(const CompositeArgs& a, int64_t g) {
+  if (!a.pair_field) return a.out4[g];
+  const int K = a.pair_K;
+  float4 o = make_float4(a.outside_value, a.outside_value, a.outside_value, a.outside_value);   // models.py:401
+  if (a.pair_field[g * K] >= 0) {
+    o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const float w = a.pair_w[g * K + k];
+      const float4 v = a.pair_out[g * K + k];
+      o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+    }
+  }
+  return o;
 }
-__device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int k, int S, float* docc = nullptr) {
+// camera-frame z of sample g of `ray`: stored, or direction.z * distance as the sampler forms it
+__device__ __forceinline__ float packed_pz(const CompositeArgs& a, int64_t ray, int64_t g) {
+#pragma clang fp contract(off)
+  if (a.pcam) return a.pcam[3 * g + 2];
+  return a.ray_dir[3 * ray + 2] * a.dists[g];
+}
+// samples behind the camera get a constant (rm.py:614-622)
+__device__ __forceinline__ float packed_geom(const CompositeArgs& a, const float4& o, float pz) {
+  if (a.rc.overwrite_behind_camera && pz > 0.f) return behind_camera_geometry(a.rc.geometry_mode);
+  return o.w;
+}
+__device__ __forceinline__ float geom_at(const CompositeArgs& a, int64_t ray, int64_t g) {
+  if (!comp_packed(a)) return a.geoms[g];
+  const float pz = (a.rc.overwrite_behind_camera) ? packed_pz(a, ray, g) : 0.f;
+  if (a.rc.overwrite_behind_camera && pz > 0.f) return behind_camera_geometry(a.rc.geometry_mode);
+  return a.pair_field ? packed_out4(a, g).w : a.out4[g].w;
+}
+// gself (optional): the geometry value of sample k itself, already formed by the caller
+__device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int k, int S, float* docc = nullptr,
+                                        const float* gself = nullptr) {
   const int mode = a.rc.geometry_mode;
   const int64_t g = ray * S + k;
-  const float gm = geom_at(a, g);
+  const float gm = gself ? *gself : geom_at(a, ray, g);
   if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY) return occ_pointwise(mode, a.rc.geometry_factor, gm, docc);
   if (k >= S - 1) return 0.f;   // density / neus drop the last sample (rm.py:749,758)
   if (mode == NGM_GEO_DENSITY) return occ_density(gm, a.dists[g + 1] - a.dists[g], docc);
   const float isd = a.isds ? a.isds[ray] : 1.0f;
   const float t0 = ngm_sigmoid(isd * a.rc.geometry_factor * gm);
-  const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * geom_at(a, g + 1));
+  const float t1 = ngm_sigmoid(isd * a.rc.geometry_factor * geom_at(a, ray, g + 1));
   return fmaxf((t0 - t1) / (t0 + 1e-5f), 0.f);
 }
 
@@ -114,7 +142,7 @@ __device__ __forceinline__ void neus_partials(const CompositeArgs& a, int64_t ra
   if (k >= S - 1) return;
   const int64_t g = ray * S + k;
   const float isd = a.isds ? a.isds[ray] : 1.0f, gam = a.rc.geometry_factor;
-  const float g0 = geom_at(a, g), g1 = geom_at(a, g + 1);
+  const float g0 = geom_at(a, ray, g), g1 = geom_at(a, ray, g + 1);
   const float u0 = ngm_sigmoid(isd * gam * g0), u1 = ngm_sigmoid(isd * gam * g1);
   const float den = u0 + 1e-5f;
   if ((u0 - u1) / den <= 0.f) return;                     // clamp_min(…, 0): zero gradient (torch: grad 0 at the kink too)
@@ -125,7 +153,56 @@ __device__ __forceinline__ void neus_partials(const CompositeArgs& a, int64_t ra
   *d_isd = P * gam * g0 * s0 + M * gam * g1 * s1;
 }
 
-template <bool KEEP>
+// Pair-record source (PK = neighbours per point): the blended outputs and camera-frame z of CH consecutive wave steps,
+// gathered together.  A step's loads form a dependent chain (pair_field -> weights and outputs of the inside points) and
+// the steps of a ray form another (the transmittance carry), so a wave that loads step by step sits out two memory
+// latencies per 64 samples; here the CH first-level loads are issued at once, then all second-level ones (outside points
+// read a dummy line: no branch between the loads), then the steps run from registers.
+template <int PK, int CH>
+__device__ __forceinline__ void pairs_gather(const CompositeArgs& a, int64_t rb, int S, float inv_s, int nsamp, int base0,
+                                             int lane, float4 (&o4)[CH], float (&pz)[CH]) {
+#pragma clang fp contract(off)
+  constexpr int PKn = PK > 0 ? PK : 1;
+  int pf[CH];
+  float tt[CH], dz[CH];
+  int64_t gg[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int idx = base0 + 64 * c + lane;
+    const bool valid = idx < nsamp;
+    const int idc = valid ? idx : 0;
+    const int rl = fdiv_idx2(idc, inv_s, S);
+    gg[c] = rb * S + idc;
+    const int f = a.pair_field[gg[c] * PKn];
+    pf[c] = valid ? f : -1;
+    tt[c] = a.dists[gg[c]];
+    dz[c] = a.ray_dir[3 * (rb + rl) + 2];
+  }
+  float w[CH][PKn];
+  float4 v[CH][PKn];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int k = 0; k < PKn; ++k) {
+      const int64_t j = pf[c] >= 0 ? gg[c] * PKn + k : 0;
+      w[c][k] = a.pair_w[j];
+      v[c][k] = a.pair_out[j];
+    }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < PKn; ++k) {      // the blend of k_knn_blend / packed_out4, same order
+      o.x = fmaf(w[c][k], v[c][k].x, o.x); o.y = fmaf(w[c][k], v[c][k].y, o.y);
+      o.z = fmaf(w[c][k], v[c][k].z, o.z); o.w = fmaf(w[c][k], v[c][k].w, o.w);
+    }
+    o4[c] = pf[c] >= 0 ? o : make_float4(a.outside_value, a.outside_value, a.outside_value, a.outside_value);   // models.py:401
+    pz[c] = dz[c] * tt[c];
+  }
+}
+
+// PK > 0: the packed source is the pair records of the kNN evaluation with PK neighbours per point (ngm_render_eval_knn)
+template <bool KEEP, int PK>
 __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, int rays_per_wave) {
   __shared__ CompWaveLds<KEEP> lds[NGM_WAVES_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,6 +213,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
   const int mode = a.rc.geometry_mode;
   const int S_eff = (mode == NGM_GEO_DENSITY || mode == NGM_GEO_NEUS) ? S - 1 : S;
   const float inv_s = 1.0f / (float)S;
+  const bool packed = comp_packed(a);
+  constexpr int CH = PK > 0 ? 4 : 1;                 // wave steps gathered together (pair-record source)
   const int BR = max(1, min(CQ_BR, CompWaveLds<KEEP>::MAXS / S));
   for (int64_t rb = r_beg; rb < r_end; rb += BR) {
     const int nb = (int)min<int64_t>(BR, r_end - rb);
@@ -146,14 +225,21 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
     }
     WAVE_SYNC();
     float carry = 1.0f;
-    for (int base = 0; base < nsamp; base += 64) {
+    // ---- pass 1: weights, means
+    auto step1 = [&](int base, const float4& o4g, float pzg) __attribute__((always_inline)) {
       const int idx = base + lane;
       const bool valid = idx < nsamp;
       const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
       const int k = valid ? idx - rl * S : 0;
       const int64_t g = (rb + rl) * S + k;
       const bool act = valid && k < S_eff;
-      const float occ = act ? occ_at(a, rb + rl, k, S) : 0.f;
+      float4 o4 = o4g;
+      float pz = pzg, gself = 0.f;
+      if constexpr (PK == 0) {
+        if (act && packed) { o4 = packed_out4(a, g); pz = packed_pz(a, rb + rl, g); }
+      }
+      if (act && packed) gself = packed_geom(a, o4, pz);
+      const float occ = act ? occ_at(a, rb + rl, k, S, nullptr, packed ? &gself : nullptr) : 0.f;
       float q = seg_scan_mul(1.0f - occ, k, lane);
       if (k > lane) q *= carry;
       const float up = lane_prev(q, carry);
@@ -162,10 +248,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const float w = act ? occ * T_excl : 0.f;
       float c0 = 0, c1 = 0, c2 = 0, dp = 0;
       if (act) {
-        if (a.out4) {
-          const float4 o = a.out4[g];
-          c0 = a.rc.color_factor * o.x; c1 = a.rc.color_factor * o.y; c2 = a.rc.color_factor * o.z; dp = -a.pcam[3 * g + 2];
-        } else { const Rgb3 c = load_rgb(a.colors, g); c0 = c.x; c1 = c.y; c2 = c.z; dp = a.depths[g]; }
+        if (packed) { c0 = a.rc.color_factor * o4.x; c1 = a.rc.color_factor * o4.y; c2 = a.rc.color_factor * o4.z; dp = -pz; }
+        else { const Rgb3 c = load_rgb(a.colors, g); c0 = c.x; c1 = c.y; c2 = c.z; dp = a.depths[g]; }
       }
       if (valid) {
         wl.wbuf[idx] = w;
@@ -178,8 +262,18 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const bool tail = valid && (k == S - 1 || lane == 63 || idx == nsamp - 1);
       if (tail) { float* ra = wl.ra[rl]; ra[0] += s0; ra[1] += s1; ra[2] += s2; ra[3] += s3; ra[4] += s4; }
       WAVE_SYNC();
+    };
+    for (int base0 = 0; base0 < nsamp; base0 += 64 * CH) {
+      float4 o4c[CH];
+      float pzc[CH];
+      if constexpr (PK > 0) pairs_gather<PK, CH>(a, rb, S, inv_s, nsamp, base0, lane, o4c, pzc);
+      else { o4c[0] = make_float4(0.f, 0.f, 0.f, 0.f); pzc[0] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base0 + 64 * c < nsamp) step1(base0 + 64 * c, o4c[c], pzc[c]);
     }
-    for (int base = 0; base < nsamp; base += 64) {
+    // ---- pass 2: the variances around the finished means (rm.py:781-790)
+    auto step2 = [&](int base, const float4& o4g, float pzg) __attribute__((always_inline)) {
       const int idx = base + lane;
       const bool valid = idx < nsamp;
       const int rl = valid ? fdiv_idx2(idx, inv_s, S) : 0;
@@ -190,13 +284,15 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       const float w = valid ? wl.wbuf[idx] : 0.f;
       float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
       if constexpr (KEEP) {
-        // the variance pass around the finished means (rm.py:781-790) from the LDS planes: no second read of colours / depths
+        // from the LDS planes: no second read of colours / depths
         if (act) { e0 = ra[0] - wl.cbuf[0][idx]; e1 = ra[1] - wl.cbuf[1][idx]; e2 = ra[2] - wl.cbuf[2][idx]; e3 = ra[3] - wl.cbuf[3][idx]; }
       } else if (act) {
-        if (a.out4) {
-          const float4 o = a.out4[g];
+        if (packed) {
+          float4 o = o4g;
+          float pz = pzg;
+          if constexpr (PK == 0) { o = packed_out4(a, g); pz = packed_pz(a, rb + rl, g); }
           e0 = ra[0] - a.rc.color_factor * o.x; e1 = ra[1] - a.rc.color_factor * o.y; e2 = ra[2] - a.rc.color_factor * o.z;
-          e3 = ra[3] + a.pcam[3 * g + 2];
+          e3 = ra[3] + pz;
         } else { const Rgb3 c = load_rgb(a.colors, g); e0 = ra[0] - c.x; e1 = ra[1] - c.y; e2 = ra[2] - c.z; e3 = ra[3] - a.depths[g]; }
       }
       const float v0 = seg_scan_add(w * (e0 * e0), k, lane), v1 = seg_scan_add(w * (e1 * e1), k, lane),
@@ -205,6 +301,18 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       WAVE_SYNC();
       if (tail) { float* rw = wl.ra[rl]; rw[5] += v0; rw[6] += v1; rw[7] += v2; rw[8] += v3; }
       WAVE_SYNC();
+    };
+    for (int base0 = 0; base0 < nsamp; base0 += 64 * CH) {
+      float4 o4c[CH];
+      float pzc[CH];
+      if constexpr (PK > 0 && !KEEP) pairs_gather<PK, CH>(a, rb, S, inv_s, nsamp, base0, lane, o4c, pzc);
+      else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { o4c[c] = make_float4(0.f, 0.f, 0.f, 0.f); pzc[c] = 0.f; }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base0 + 64 * c < nsamp) step2(base0 + 64 * c, o4c[c], pzc[c]);
     }
     if (lane < nb) {
       const int64_t ray = rb + lane;
@@ -215,6 +323,122 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
       if (a.Cv) { a.Cv[3 * ray] = ra[5]; a.Cv[3 * ray + 1] = ra[6]; a.Cv[3 * ray + 2] = ra[7]; }
       if (a.Dv) a.Dv[ray] = ra[8];
       if (a.term) a.term[ray] = 1.0f - (1.0f - ra[4]);
+    }
+    WAVE_SYNC();
+  }
+}
+
+// ---- whole-ray variant: S a multiple of 64, pointwise geometry modes (nrgbd, occupancy) ------------------------------------
+// Every wave step then lies inside one ray (k % 64 == lane), so the segment conditions of the scans above are what the DPP
+// bounds already enforce: the scans are the same lane exchanges without the compare / select per step (bit for bit the
+// same sums), the per-ray sums stay in registers, the planes of the ray (weights, colours, depth) stay in LDS for the
+// variance pass, and the loads of CH steps are issued together.  A fifth of the generic kernel's instructions per sample.
+__device__ __forceinline__ float wave_scan_add(float v) {
+  v += dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(0.f, v); v += dpp_take<NGM_DPP_ROW_SHR(2), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_SHR(4), 0xf>(0.f, v); v += dpp_take<NGM_DPP_ROW_SHR(8), 0xf>(0.f, v);
+  v += dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(0.f, v); v += dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+  v *= dpp_take<NGM_DPP_ROW_SHR(1), 0xf>(1.f, v); v *= dpp_take<NGM_DPP_ROW_SHR(2), 0xf>(1.f, v);
+  v *= dpp_take<NGM_DPP_ROW_SHR(4), 0xf>(1.f, v); v *= dpp_take<NGM_DPP_ROW_SHR(8), 0xf>(1.f, v);
+  v *= dpp_take<NGM_DPP_ROW_BCAST15, 0xa>(1.f, v); v *= dpp_take<NGM_DPP_ROW_BCAST31, 0xc>(1.f, v);
+  return v;
+}
+
+// N sum scans at once, value-minor inside a step: a register's DPP read then sits N - 1 instructions behind its write and
+// needs no wait states
+template <int N>
+__device__ __forceinline__ void wave_scan_add_n(float (&v)[N]) {
+#define NGM_WSA_STEP(CTRL, MASK) _Pragma("unroll") for (int i_ = 0; i_ < N; ++i_) v[i_] += dpp_take<CTRL, MASK>(0.f, v[i_]);
+  NGM_WSA_STEP(NGM_DPP_ROW_SHR(1), 0xf) NGM_WSA_STEP(NGM_DPP_ROW_SHR(2), 0xf) NGM_WSA_STEP(NGM_DPP_ROW_SHR(4), 0xf)
+  NGM_WSA_STEP(NGM_DPP_ROW_SHR(8), 0xf) NGM_WSA_STEP(NGM_DPP_ROW_BCAST15, 0xa) NGM_WSA_STEP(NGM_DPP_ROW_BCAST31, 0xc)
+#undef NGM_WSA_STEP
+}
+
+struct StepIn { float c0, c1, c2, dp, gm; };
+// SRC 0: separate tensors; 1..4: pair records with SRC neighbours per point; 5: packed (N,S,4) outputs + camera-frame points
+template <int SRC, int CH>
+__device__ __forceinline__ void whole_gather(const CompositeArgs& a, int64_t ray, int S, int base0, int lane, StepIn (&in)[CH]) {
+  if constexpr (SRC >= 1 && SRC <= 4) {
+    float4 o4[CH];
+    float pz[CH];
+    pairs_gather<SRC, CH>(a, ray, S, 1.0f / (float)S, S, base0, lane, o4, pz);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      in[c] = StepIn{a.rc.color_factor * o4[c].x, a.rc.color_factor * o4[c].y, a.rc.color_factor * o4[c].z, -pz[c],
+                     packed_geom(a, o4[c], pz[c])};
+  } else {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = min(base0 + 64 * c + lane, S - 1);        // steps past the ray's end re-read its last sample (unused)
+      const int64_t g = ray * S + k;
+      if constexpr (SRC == 5) {
+        const float4 o = a.out4[g];
+        const float pz = a.pcam[3 * g + 2];
+        in[c] = StepIn{a.rc.color_factor * o.x, a.rc.color_factor * o.y, a.rc.color_factor * o.z, -pz, packed_geom(a, o, pz)};
+      } else {
+        const Rgb3 col = load_rgb(a.colors, g);
+        in[c] = StepIn{col.x, col.y, col.z, a.depths[g], a.geoms[g]};
+      }
+    }
+  }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs a, int rays_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) float cw_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S;
+  float* const pw = cw_lds + (size_t)wave * 5 * S;      // planes: weight, colour (3), depth
+  float* const p0 = pw + S; float* const p1 = p0 + S; float* const p2 = p1 + S; float* const p3 = p2 + S;
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
+  const int mode = a.rc.geometry_mode;
+  constexpr int CH = (SRC >= 1 && SRC <= 4) ? 5 : 4;
+  for (int64_t ray = r_beg; ray < r_end; ++ray) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;       // running sums (wave-uniform)
+    float carry = 1.0f;
+    for (int base0 = 0; base0 < S; base0 += 64 * CH) {
+      StepIn in[CH];
+      whole_gather<SRC, CH>(a, ray, S, base0, lane, in);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = base0 + 64 * c + lane;
+        if (base0 + 64 * c < S) {
+          const float occ = occ_pointwise(mode, a.rc.geometry_factor, in[c].gm, nullptr);
+          float q = wave_scan_mul(1.0f - occ);
+          q *= carry;                                              // (carry = 1 in the ray's first step)
+          const float up = lane_prev(q, carry);
+          const float T_excl = (k == 0) ? 1.0f : (lane == 0 ? carry : up);
+          carry = lane_value(q, 63);
+          const float w = occ * T_excl;
+          pw[k] = w; p0[k] = in[c].c0; p1[k] = in[c].c1; p2[k] = in[c].c2; p3[k] = in[c].dp;
+          if (a.weights) a.weights[ray * S + k] = w;
+          float sv[5] = {w * in[c].c0, w * in[c].c1, w * in[c].c2, w * in[c].dp, w};
+          wave_scan_add_n<5>(sv);
+          m0 += lane_value(sv[0], 63); m1 += lane_value(sv[1], 63); m2 += lane_value(sv[2], 63); m3 += lane_value(sv[3], 63);
+          m4 += lane_value(sv[4], 63);
+        }
+      }
+    }
+    WAVE_SYNC();
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                  // variances around the finished means (rm.py:781-790)
+    for (int base = 0; base < S; base += 64) {
+      const int k = base + lane;
+      const float w = pw[k];
+      const float e0 = m0 - p0[k], e1 = m1 - p1[k], e2 = m2 - p2[k], e3 = m3 - p3[k];
+      float sv[4] = {w * (e0 * e0), w * (e1 * e1), w * (e2 * e2), w * (e3 * e3)};
+      wave_scan_add_n<4>(sv);
+      v0 += lane_value(sv[0], 63); v1 += lane_value(sv[1], 63); v2 += lane_value(sv[2], 63); v3 += lane_value(sv[3], 63);
+    }
+    if (lane == 0) {
+      if (a.rgbd) reinterpret_cast<float4*>(a.rgbd)[ray] = make_float4(m0, m1, m2, m3);
+      if (a.C) { a.C[3 * ray] = m0; a.C[3 * ray + 1] = m1; a.C[3 * ray + 2] = m2; }
+      if (a.D) a.D[ray] = m3;
+      if (a.Cv) { a.Cv[3 * ray] = v0; a.Cv[3 * ray + 1] = v1; a.Cv[3 * ray + 2] = v2; }
+      if (a.Dv) a.Dv[ray] = v3;
+      if (a.term) a.term[ray] = 1.0f - (1.0f - m4);
     }
     WAVE_SYNC();
   }
@@ -236,8 +460,35 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
-  if (a.S <= CompWaveLds<true>::MAXS) hipLaunchKernelGGL(k_composite_fwd<true>, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
-  else hipLaunchKernelGGL(k_composite_fwd<false>, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+  const bool keep = a.S <= CompWaveLds<true>::MAXS;
+  const int pk = a.pair_field ? a.pair_K : 0;
+  if (pk && (pk > 4 || !a.pair_w || !a.pair_out || !a.ray_dir || !a.dists || a.pcam || a.out4)) return NGM_E_INVALID;
+  const int gm = a.rc.geometry_mode;
+  if (a.S % 64 == 0 && (gm == NGM_GEO_NRGBD || gm == NGM_GEO_OCCUPANCY)) {
+    // whole-ray steps: the specialised kernel (same sums, a fifth of the instructions)
+    const size_t lds = (size_t)NGM_WAVES_PER_BLOCK * 5 * a.S * sizeof(float);
+    const int src = pk ? pk : (a.out4 ? 5 : 0);
+    static const hipError_t attr = [] {
+      hipError_t e = hipSuccess;
+#define NGM_CWA(SRC_) do { const hipError_t x = hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_fwd_whole<SRC_>), hipFuncAttributeMaxDynamicSharedMemorySize, NGM_WAVES_PER_BLOCK * 5 * CQ_MAXS * 4); if (x != hipSuccess) e = x; } while (0)
+      NGM_CWA(0); NGM_CWA(1); NGM_CWA(2); NGM_CWA(3); NGM_CWA(4); NGM_CWA(5);
+#undef NGM_CWA
+      return e;
+    }();
+    if (attr != hipSuccess) return NGM_E_HIP;
+#define NGM_CW(SRC_) hipLaunchKernelGGL((k_composite_fwd_whole<SRC_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw)
+    switch (src) { case 0: NGM_CW(0); break; case 1: NGM_CW(1); break; case 2: NGM_CW(2); break; case 3: NGM_CW(3); break;
+                   case 4: NGM_CW(4); break; default: NGM_CW(5); break; }
+#undef NGM_CW
+    return 0;
+  }
+#define NGM_CF(PK_)                                                                                                     \
+  do {                                                                                                                  \
+    if (keep) hipLaunchKernelGGL((k_composite_fwd<true, PK_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);  \
+    else hipLaunchKernelGGL((k_composite_fwd<false, PK_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);      \
+  } while (0)
+  if (pk == 0) NGM_CF(0); else if (pk == 1) NGM_CF(1); else if (pk == 2) NGM_CF(2); else if (pk == 3) NGM_CF(3); else NGM_CF(4);
+#undef NGM_CF
   return 0;
 }
 

@@ -218,8 +218,11 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: the integer multiplies
+    // are quarter-rate and all there is to a round
+    const uint64_t pr0 = (uint64_t)0xD2511F53u * c0, pr1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(pr0 >> 32), lo0 = (uint32_t)pr0;
+    const uint32_t hi1 = (uint32_t)(pr1 >> 32), lo1 = (uint32_t)pr1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -311,7 +314,18 @@ __device__ __forceinline__ RayGeom ray_geom(const ngm_render_cfg& cfg, const ngm
   return g;
 }
 
-// jitter draw for source element (stratum `which`, index i) of global ray `ray`
+// utils.transform_points (utils.py:276-286 via rm.py:547) of the camera-frame sample d t of `ray`: p_w = R p_c + t, the
+// products summed left to right, every operation rounded separately
+__device__ __forceinline__ void sample_world_point(const ngm_rays& rays, const RayGeom& rg, int64_t ray, float t, float* wx,
+                                                   float* wy, float* wz) {
+#pragma clang fp contract(off)
+  const float* T = rays.c2w_per_ray ? rays.c2ws + ray * 16 : rays.c2ws;
+  const float cx = rg.dx * t, cy = rg.dy * t, cz = rg.dz * t;
+  *wx = (T[0] * cx + T[1] * cy + T[2] * cz) + T[3];
+  *wy = (T[4] * cx + T[5] * cy + T[6] * cz) + T[7];
+  *wz = (T[8] * cx + T[9] * cy + T[10] * cz) + T[11];
+}
+
 // Philox stream offset of this launch: read ONCE per kernel (the device-side part is what a hipGraph replay advances);
 // re-reading it per draw put a global-load latency in front of every sample of the sampler.
 __device__ __forceinline__ uint64_t philox_launch_offset(const ngm_rays& rays) {

@@ -16,6 +16,7 @@
 #include "ngm_launch.h"
 
 #include <algorithm>
+#include <cstring>
 
 #define WAVE_SYNC()                                        \
   do {                                                     \
@@ -26,6 +27,7 @@
 
 #define KNN_TILE 4096
 #define KNN_MAXK 4
+#define CQ_MAXS_EVAL 1024      // samples per ray the quadrature kernel takes (CQ_MAXS of ngm_composite.hip)
 
 struct KnnArgs {
   ngm_field_cfg fc;
@@ -49,9 +51,23 @@ struct KnnArgs {
   int* cell_start;      // (max_cells + 1) exclusive prefix of the per-cell counts
   int* cell_fill;       // (max_cells) fill cursors
   float4* cell_c;       // (NF) centres grouped by cell: (x, y, z, field index as int bits)
+  // per cell of the grid extended by one ring: the centres a point of that cell can be within the mask radius of (box
+  // distance < radius; at most 27 cells per centre) -- the inside test and, where the map is dense, the whole search
+  int* near_start;      // (4 * max_cells + 1) exclusive prefix over the extended cells
+  float4* near_c;       // (27 * NF)
   int max_cells;
   float cell_size;      // requested cell edge (>= mask radius); the kernel may coarsen it to fit max_cells
   int hist_in_lds;      // per-workgroup field histograms fit the LDS (else: global atomics per pair)
+  // point source: `points` (P,3), or -- gen != 0, ngm_render_eval_knn -- point p is sample p % S of ray p / S of one block of
+  // eval-style rays (single stratum): k_knn_raytab leaves the ray-level quantities in `ray_dir` / `ray_tab`, the assignment draws
+  // the sample's distance and forms the point exactly as k_sample_rays would, leaves the distance in `dist`; the evaluation
+  // re-forms the point from those
+  int gen, S;
+  ngm_render_cfg rc;
+  ngm_rays rays;
+  float* dist;          // (P)
+  float* ray_dir;       // (P / S, 3)
+  float4* ray_tab;      // (P / S) near, far - near, (far - near) / S of the ray's stratum
 };
 struct KnnGridHdr { float x0, y0, z0, c, inv_c; int nx, ny, nz, ncells, pad; };
 
@@ -99,13 +115,13 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
     float c = a.cell_size;
     int n[3];
     for (int it = 0; it < 200; ++it) {
-      double cells = 1.0;
+      double cells = 1.0, ext = 1.0;
       for (int d = 0; d < 3; ++d) {
         const float e = (U[d] - L[d]) / c;
         n[d] = (e < 1.0e6f) ? (int)e + 1 : 1000001;
-        cells *= (double)n[d];
+        cells *= (double)n[d]; ext *= (double)(n[d] + 2);
       }
-      if (cells <= (double)a.max_cells) break;
+      if (cells <= (double)a.max_cells && ext <= 4.0 * (double)a.max_cells) break;
       c *= 1.26f;                                                      // cells / 2 per step
     }
     h.x0 = L[0]; h.y0 = L[1]; h.z0 = L[2]; h.c = c; h.inv_c = 1.0f / c;
@@ -127,28 +143,103 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   for (int f = t; f < a.NF; f += 1024) atomicAdd(&a.cell_start[cell_of(f)], 1);
   __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
   __syncthreads();
-  // exclusive scan of cell_start[0 .. nc): contiguous segments per thread, block scan of the segment sums
-  const int per = (nc + 1023) / 1024, b0 = min(nc, t * per), b1 = min(nc, b0 + per);
-  int sum = 0;
-  for (int i = b0; i < b1; ++i) sum += a.cell_start[i];
-  sscan[t] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = (t >= d) ? sscan[t - d] : 0;
+  // exclusive scan of arr[0 .. n) in place, arr[n] = total: contiguous segments per thread, block scan of the segment sums
+  auto exclusive_scan = [&](int* arr, int n) {
+    const int per = (n + 1023) / 1024, b0 = min(n, t * per), b1 = min(n, b0 + per);
+    int sum = 0;
+    for (int i = b0; i < b1; ++i) sum += arr[i];
+    sscan[t] = sum;
     __syncthreads();
-    sscan[t] += v;
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = (t >= d) ? sscan[t - d] : 0;
+      __syncthreads();
+      sscan[t] += v;
+      __syncthreads();
+    }
+    int run = sscan[t] - sum;
+    for (int i = b0; i < b1; ++i) { const int cnt = arr[i]; arr[i] = run; run += cnt; }
+    if (t == 1023) arr[n] = sscan[1023];
+    __threadfence();
     __syncthreads();
-  }
-  int run = sscan[t] - sum;
-  for (int i = b0; i < b1; ++i) { const int cnt = a.cell_start[i]; a.cell_start[i] = run; run += cnt; }
-  if (t == 1023) a.cell_start[nc] = sscan[1023];
-  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
-  __syncthreads();
+  };
+  exclusive_scan(a.cell_start, nc);
   for (int f = t; f < a.NF; f += 1024) {
     const int cidx = cell_of(f);
     const int slot = a.cell_start[cidx] + atomicAdd(&a.cell_fill[cidx], 1);
     a.cell_c[slot] = make_float4(a.pos[3 * f], a.pos[3 * f + 1], a.pos[3 * f + 2], __int_as_float(f));
   }
+  __threadfence();
+  __syncthreads();
+  // Per cell of the grid extended by one ring: the centres closer to the cell's box than the mask radius (a little more:
+  // the points are binned in fp32).  Four out of five samples of an image are nowhere near a field and fall on an empty
+  // list; for the others the list replaces the walk over the 27 cells.  Count, scan, fill.
+  const int ex = h.nx + 2, ey = h.ny + 2, ez = h.nz + 2, ne = ex * ey * ez;
+  const float reach = a.radius * 1.001f + 1e-3f * h.c, reach2 = reach * reach;
+  auto visit = [&](int e, bool fill) {
+    const int cx = e % ex - 1, cy = (e / ex) % ey - 1, cz = e / (ex * ey) - 1;
+    const float bx0 = h.x0 + (float)cx * h.c, by0 = h.y0 + (float)cy * h.c, bz0 = h.z0 + (float)cz * h.c;
+    int cnt = 0;
+    const int base = fill ? a.near_start[e] : 0;
+    for (int nz = max(cz - 1, 0); nz <= min(cz + 1, h.nz - 1); ++nz)
+      for (int ny = max(cy - 1, 0); ny <= min(cy + 1, h.ny - 1); ++ny) {
+        const int xs = max(cx - 1, 0), xe = min(cx + 1, h.nx - 1);
+        if (xs > xe) continue;
+        const int rowb = (nz * h.ny + ny) * h.nx;
+        for (int j = a.cell_start[rowb + xs]; j < a.cell_start[rowb + xe + 1]; ++j) {
+          const float4 c = a.cell_c[j];
+          const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - (bx0 + h.c)), 0.f), dy = fmaxf(fmaxf(by0 - c.y, c.y - (by0 + h.c)), 0.f),
+                      dz = fmaxf(fmaxf(bz0 - c.z, c.z - (bz0 + h.c)), 0.f);
+          if (dx * dx + dy * dy + dz * dz < reach2) { if (fill) a.near_c[base + cnt] = c; ++cnt; }
+        }
+      }
+    return cnt;
+  };
+  __threadfence();
+  __syncthreads();
+  for (int e = t; e < ne; e += 1024) a.near_start[e] = visit(e, false);
+  __threadfence();
+  __syncthreads();
+  exclusive_scan(a.near_start, ne);
+  for (int e = t; e < ne; e += 1024) (void)visit(e, true);
+}
+
+// ---- point source -------------------------------------------------------------------------------------------------------
+// generated points (a.gen): the sampler's arithmetic (ray_geom, strat_t, sample_world_point of ngm_device.h), so that the fused
+// image path gives the points -- bit for bit -- that k_sample_rays would have written
+// per ray of the block, once: direction (camera frame) and the stratum's (near, span, span / S) -- the ray-level part of
+// ray_geom / strat_t, which every one of the ray's S samples would otherwise repeat (three IEEE divisions, a root, two
+// int64 conversions)
+__global__ __launch_bounds__(256) void k_knn_raytab(KnnArgs a) {
+#pragma clang fp contract(off)
+  const int64_t nr = a.P / a.S;
+  for (int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ray < nr; ray += (int64_t)gridDim.x * blockDim.x) {
+    const RayGeom rg = ray_geom(a.rc, a.rays, ray, false);
+    a.ray_dir[3 * ray] = rg.dx; a.ray_dir[3 * ray + 1] = rg.dy; a.ray_dir[3 * ray + 2] = rg.dz;
+    const float span = rg.far - rg.near;
+    a.ray_tab[ray] = make_float4(rg.near, span, span / (float)a.S, 0.f);
+  }
+}
+__device__ __forceinline__ void knn_point_draw(const KnnArgs& a, uint64_t poff, int64_t p, float* x, float* y, float* z) {
+#pragma clang fp contract(off)
+  const uint32_t ray = (uint32_t)p / (uint32_t)a.S;
+  const int e = (int)((uint32_t)p - ray * (uint32_t)a.S);
+  RayGeom rg;
+  rg.dx = a.ray_dir[3 * ray]; rg.dy = a.ray_dir[3 * ray + 1]; rg.dz = a.ray_dir[3 * ray + 2];
+  const float4 st = a.ray_tab[ray];                      // near, span, delta
+  // strat_t (ngm_device.h) on the ray's precomputed span and delta: t = (delta u + lin_e span) + near
+  const float u = jitter(a.rays, poff, 0, ray, a.S, e);
+  const float b = strat_lin(a.rays.lin_coarse, a.S, e) * st.y;
+  const float du = st.z * u;
+  const float sm = du + b;
+  const float t = sm + st.x;
+  a.dist[p] = t;
+  sample_world_point(a.rays, rg, ray, t, x, y, z);
+}
+__device__ __forceinline__ void knn_point_again(const KnnArgs& a, int64_t p, float* x, float* y, float* z) {
+  const uint32_t ray = (uint32_t)p / (uint32_t)a.S;
+  RayGeom rg;
+  rg.dx = a.ray_dir[3 * ray]; rg.dy = a.ray_dir[3 * ray + 1]; rg.dz = a.ray_dir[3 * ray + 2];
+  sample_world_point(a.rays, rg, ray, a.dist[p], x, y, z);
 }
 
 // K nearest centres of every point, exact.  The (2 R + 1)^3 block of cells around the point's cell holds every centre
@@ -183,13 +274,27 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
   const int maxR = max(h.nx, max(h.ny, h.nz));
   const float c2 = h.c * h.c;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t poff = a.gen ? philox_launch_offset(a.rays) : 0ull;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += stride) {
-    const float x = a.points[3 * p], y = a.points[3 * p + 1], z = a.points[3 * p + 2];
+    float x, y, z;
+    if (a.gen) knn_point_draw(a, poff, p, &x, &y, &z);
+    else { x = a.points[3 * p]; y = a.points[3 * p + 1]; z = a.points[3 * p + 2]; }
     const float gx = (x - h.x0) * h.inv_c, gy = (y - h.y0) * h.inv_c, gz = (z - h.z0) * h.inv_c;
     // cell of the point; far outside the grid (or NaN) it is clamped to two rings beyond: nothing is within c then
     const float fx = fminf(fmaxf(floorf(gx), -2.0f), (float)h.nx + 1.0f), fy = fminf(fmaxf(floorf(gy), -2.0f), (float)h.ny + 1.0f),
                 fz = fminf(fmaxf(floorf(gz), -2.0f), (float)h.nz + 1.0f);
     const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    // the centres this point can be within the mask radius of: the list of its cell (none two rings outside the grid)
+    int nj0 = 0, nj1 = 0;
+    if (!(ix < -1 || ix > h.nx || iy < -1 || iy > h.ny || iz < -1 || iz > h.nz)) {
+      const int e = ((iz + 1) * (h.ny + 2) + (iy + 1)) * (h.nx + 2) + (ix + 1);
+      nj0 = a.near_start[e]; nj1 = a.near_start[e + 1];
+    }
+    if (nj0 == nj1) {                                            // nowhere near a field: outside, no search
+#pragma unroll
+      for (int k = 0; k < KK; ++k) a.pair_field[p * KK + k] = -1;
+      continue;
+    }
     float bd[KK]; int bi[KK];
     float worst; int worst_i;
     // scan the block of radius R; cells / row ends whose nearest face is not closer than `lim2` (world units squared; a
@@ -241,54 +346,30 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
         }
       }
     };
-    // ---- phase A: is any centre within the mask radius?  (a centre at distance < radius <= c sits in the 27 cells, and in a
-    // cell whose nearest face is closer than the radius)
-    // (only the nearest distance matters here: a plain minimum, no neighbour list -- the list costs ~25 instructions per
-    // candidate, and a wave executes the union of its lanes' candidates)
+    // ---- phase A: is any centre within the mask radius?  Every such centre is in the cell's list; the ones within the
+    // radius also start the neighbour list -- where the map is as dense as its cover grid the K nearest are among them and
+    // phase B is not needed at all
     const float rad2 = a.radius * a.radius * 1.0002f;
     float dmin = INFINITY;
 #pragma unroll
     for (int k = 0; k < KK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
     worst = INFINITY; worst_i = -1;
-    {
-      float lyv[3], lzv[3];
+    for (int j = nj0; j < nj1; ++j) {
+      const float4 c = a.near_c[j];
+      const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+      float d = dx * dx + dy * dy + dz * dz;
+      dmin = fminf(dmin, d);
+      if (d < rad2 && (d < worst || (d == worst && __float_as_int(c.w) < worst_i))) {
+        int id = __float_as_int(c.w);
 #pragma unroll
-      for (int o = 0; o < 3; ++o) {
-        const int cy = iy + o - 1, cz = iz + o - 1;
-        lyv[o] = (cy < 0 || cy >= h.ny) ? INFINITY : fmaxf(fmaxf((float)cy - gy, gy - (float)(cy + 1)), 0.f);
-        lzv[o] = (cz < 0 || cz >= h.nz) ? INFINITY : fmaxf(fmaxf((float)cz - gz, gz - (float)(cz + 1)), 0.f);
-      }
-      const int xs0 = max(ix - 1, 0), xe0 = min(ix + 1, h.nx - 1);
-      const int row0 = ((iz - 1) * h.ny + (iy - 1)) * h.nx;
-      const float c2r = c2 * 0.9999f / rad2;               // lat2 in units of the (slightly enlarged) squared radius
-      for (int oz = 0; oz < 3; ++oz)
-        for (int oy = 0; oy < 3; ++oy) {
-          // a row (3 cells along x) is scanned whole when its nearest edge is within the radius: narrowing it in x as phase B
-          // does costs more instructions (root, two floors, clamps) than the one or two centres it spares
-          const float lat2 = (lyv[oy] * lyv[oy] + lzv[oz] * lzv[oz]) * c2r;
-          if (!(lat2 < 1.0f) || xs0 > xe0) continue;
-          const int rowb = row0 + (oz * h.ny + oy) * h.nx;
-          const int je = cs[rowb + xe0 + 1];
-          for (int j = cs[rowb + xs0]; j < je; ++j) {
-            const float4 c = cc[j];
-            const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
-            float d = dx * dx + dy * dy + dz * dz;
-            dmin = fminf(dmin, d);
-            // the centres within the radius also start the neighbour list: where the map is as dense as its cover grid the K
-            // nearest are among them and phase B is not needed at all
-            if (d < rad2 && (d < worst || (d == worst && __float_as_int(c.w) < worst_i))) {
-              int id = __float_as_int(c.w);
-#pragma unroll
-              for (int k = 0; k < KK; ++k) {
-                if (k < K && (d < bd[k] || (d == bd[k] && id < bi[k]))) {
-                  const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
-                }
-              }
-              worst = bd[KK - 1];
-              worst_i = bi[KK - 1];
-            }
+        for (int k = 0; k < KK; ++k) {
+          if (k < K && (d < bd[k] || (d == bd[k] && id < bi[k]))) {
+            const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
           }
         }
+        worst = bd[KK - 1];
+        worst_i = bi[KK - 1];
+      }
     }
     bool inside = sqrtf(dmin) < a.radius;                        // models.py:369 (the same squared distance as the list's bd[0])
     // every centre closer than the radius has been seen: a K-th neighbour inside the radius is the K-th nearest
@@ -429,7 +510,10 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
     if (valid) {
       pair = a.sorted[idx];
       const int64_t p = pair / a.K;
-      Vec3 v{a.points[3 * p] - px, a.points[3 * p + 1] - py, a.points[3 * p + 2] - pz};   // models.py:377-381
+      float wx, wy, wz;
+      if (a.gen) knn_point_again(a, p, &wx, &wy, &wz);
+      else { wx = a.points[3 * p]; wy = a.points[3 * p + 1]; wz = a.points[3 * p + 2]; }
+      Vec3 v{wx - px, wy - py, wz - pz};                                                   // models.py:377-381
       v = quat_rotate_inv(qw, qx, qy, qz, v);
       x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
     }
@@ -460,7 +544,12 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
   const int64_t n = P * K;
   const int64_t mc = knn_max_cells(num_fields);
   return 256 * 12 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16) +
-         256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16);
+         256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16) + 16 * mc + 16 * 27 * (int64_t)num_fields + 1024;
+}
+// + the distances of the generated samples and the ray directions of one block of rays (ngm_render_eval_knn)
+int64_t ngm_knn_render_workspace_bytes(int num_fields, int ray_block, int S, int K) {
+  const int64_t P = (int64_t)ray_block * S;
+  return ngm_knn_workspace_bytes(num_fields, P, K) + 4 * (P + 64) + 28 * ((int64_t)ray_block + 64) + 1024;
 }
 
 template <int MI, int MH, int L>
@@ -499,37 +588,36 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
-int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
-                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
-                   float* out, void* workspace, int64_t workspace_bytes, hipStream_t st) {
-  if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
-  if (num_fields < 1 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
-  KnnArgs a;
-  a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.P = P; a.points = points; a.pos = pos; a.quat = quat;
-  a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = mask_radius; a.out = out;
-  const int64_t n = P * K;
+// workspace carving shared by the two entry points; `a.NF`, `a.K`, `a.P` (the largest P of the call) are set
+static void knn_carve(KnnArgs& a, void* workspace, char** end) {
+  const int64_t n = a.P * a.K;
   char* w = reinterpret_cast<char*>(((int64_t)workspace + 255) / 256 * 256);
   auto carve = [&](int64_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
   a.pair_field = reinterpret_cast<int*>(carve(4 * n));
   a.pair_w = reinterpret_cast<float*>(carve(4 * n));
-  a.counts = reinterpret_cast<int*>(carve(4 * num_fields));
-  a.cursor = reinterpret_cast<int*>(carve(4 * num_fields));
-  a.seg_off = reinterpret_cast<int*>(carve(4 * (num_fields + 1)));
-  a.tile_off = reinterpret_cast<int*>(carve(4 * (num_fields + 1)));
+  a.counts = reinterpret_cast<int*>(carve(4 * a.NF));
+  a.cursor = reinterpret_cast<int*>(carve(4 * a.NF));
+  a.seg_off = reinterpret_cast<int*>(carve(4 * (a.NF + 1)));
+  a.tile_off = reinterpret_cast<int*>(carve(4 * (a.NF + 1)));
   a.sorted = reinterpret_cast<int*>(carve(4 * n));
   a.pair_out = reinterpret_cast<float4*>(carve(16 * n));
-  a.max_cells = knn_max_cells(num_fields);
+  a.max_cells = knn_max_cells(a.NF);
   a.grid = reinterpret_cast<KnnGridHdr*>(carve(256));
   a.cell_start = reinterpret_cast<int*>(carve(4 * ((int64_t)a.max_cells + 1)));
   a.cell_fill = reinterpret_cast<int*>(carve(4 * (int64_t)a.max_cells));
-  a.cell_c = reinterpret_cast<float4*>(carve(16 * (int64_t)num_fields));
-  // cell edge: the spacing of the reference's cover grid (2 r / sqrt 3, rm.py:299), never below the mask radius (the inside
-  // test is decided in the first ring); a non-positive radius (no field contains anything) still needs a positive edge
-  a.cell_size = std::max(std::max(1.1547005f * fc->field_radius, mask_radius), 1e-6f);
-  (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)num_fields, st);
-  const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
+  a.cell_c = reinterpret_cast<float4*>(carve(16 * (int64_t)a.NF));
+  a.near_start = reinterpret_cast<int*>(carve(4 * (4 * (int64_t)a.max_cells + 1)));
+  a.near_c = reinterpret_cast<float4*>(carve(16 * 27 * (int64_t)a.NF));
+  *end = w;
+}
+
+// grid build (optional) -> assignment -> offsets -> scatter -> per-field evaluation of the pairs; the blend is the caller's
+static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
+  const int64_t n = a.P * a.K;
+  (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)a.NF, st);
+  const int pb = (int)std::min<int64_t>((a.P + 255) / 256, 4096);
   // per-workgroup field histograms (assignment, scatter) in LDS while they fit (150 KB = 38 400 fields); beyond: global atomics
-  const size_t lds_h = (size_t)num_fields * 4;
+  const size_t lds_h = (size_t)a.NF * 4;
   a.hist_in_lds = lds_h <= 150 * 1024 ? 1 : 0;
   static const hipError_t attr_a = [] {
     hipError_t e = hipSuccess;
@@ -539,16 +627,16 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
 #undef NGM_KA
     return e;
   }();
-  const hipError_t attr_g = attr_a;
   // grid in LDS while histogram + centres + cell offsets stay within 64 KB (two workgroups per CU keep their latency hiding)
-  const size_t lds_grid = (((size_t)num_fields + 3) & ~(size_t)3) * 4 + (size_t)num_fields * 16 + ((size_t)a.max_cells + 1) * 4;
-  const bool grid_in_lds = a.hist_in_lds && attr_g == hipSuccess && lds_grid <= 64 * 1024;
+  const size_t lds_grid = (((size_t)a.NF + 3) & ~(size_t)3) * 4 + (size_t)a.NF * 16 + ((size_t)a.max_cells + 1) * 4;
+  const bool grid_in_lds = a.hist_in_lds && lds_grid <= 64 * 1024;
   static const hipError_t attr_s = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_scatter),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (attr_a != hipSuccess || attr_s != hipSuccess) return NGM_E_HIP;
+  const int K = a.K;
   {
     NgmProfScope prof_(NGM_K_KNN_ASSIGN, st);
-    hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
+    if (build_grid) hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
 #define NGM_KL(KK_)                                                                                                    \
     do {                                                                                                               \
       if (grid_in_lds) hipLaunchKernelGGL((k_knn_assign<true, KK_>), dim3(std::max(pb, 1)), dim3(256), lds_grid, st, a);  \
@@ -561,8 +649,8 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
   hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a);
-  const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + num_fields;
-  const FieldShape s = field_shape(fc);
+  const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + a.NF;
+  const FieldShape s = field_shape(&a.fc);
   int le = NGM_E_UNSUPPORTED;
   {
     NgmProfScope prof_eval_(NGM_K_KNN_EVAL, st);
@@ -574,7 +662,83 @@ int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields
     else if (s.MI == 2 && s.MH == 2 && s.L == 3) le = launch_eval<2, 2, 3>(a, max_tiles, st);
 #endif
   }
+  return le;
+}
+
+static void knn_common(KnnArgs& a, const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, const float* pos,
+                       const float* quat, int K, float distance_factor, float outside_value, float mask_radius) {
+  memset(&a, 0, sizeof(a));
+  a.fc = *fc; a.pr = *pr; a.NF = num_fields; a.K = K; a.pos = pos; a.quat = quat;
+  a.distance_factor = distance_factor; a.outside_value = outside_value; a.radius = mask_radius;
+  // cell edge: the spacing of the reference's cover grid (2 r / sqrt 3, rm.py:299), never below the mask radius (the inside
+  // test is decided in the first ring); a non-positive radius (no field contains anything) still needs a positive edge
+  a.cell_size = std::max(std::max(1.1547005f * fc->field_radius, mask_radius), 1e-6f);
+}
+
+int ngm_launch_knn(const ngm_field_cfg* fc, const ngm_params* pr, int num_fields, int64_t P, const float* points,
+                   const float* pos, const float* quat, int K, float distance_factor, float outside_value, float mask_radius,
+                   float* out, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (workspace_bytes < ngm_knn_workspace_bytes(num_fields, P, K) || !workspace) return NGM_E_WORKSPACE;
+  if (num_fields < 1 || P * K > 0x7fffffff) return NGM_E_UNSUPPORTED;
+  KnnArgs a;
+  knn_common(a, fc, pr, num_fields, pos, quat, K, distance_factor, outside_value, mask_radius);
+  a.P = P; a.points = points; a.out = out;
+  char* end;
+  knn_carve(a, workspace, &end);
+  const int le = knn_stages(a, true, st);
   if (le) return le;
+  const int pb = (int)std::min<int64_t>((P + 255) / 256, 4096);
   hipLaunchKernelGGL(k_knn_blend, dim3(std::max(pb, 1)), dim3(256), 0, st, a);
+  return 0;
+}
+
+// render_image's block loop (rm.py:402-437) as one call: per block of `ray_block` rays the samples are drawn inside the
+// assignment, evaluated per field and blended inside the quadrature -- between the stages only the pair records, the sample
+// distances and the ray directions touch memory; the grid over the centres is built once.  Block b draws from the Philox
+// stream (seed + b * ray_block, ray index within the block), as a caller looping over the blocks with the staged entry
+// points (ngm_sample_rays_world -> ngm_field_eval_knn -> ngm_composite_fwd_packed) would.
+int ngm_launch_render_eval_knn(const ngm_field_cfg* fc, const ngm_render_cfg* rc, const ngm_params* pr, int num_fields,
+                               const float* pos, const float* quat, const ngm_rays* rays, int K, float distance_factor,
+                               float outside_value, float mask_radius, int ray_block, const ngm_prediction* pred,
+                               void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  const int S = rc->num_samples_coarse;
+  const int64_t total = (int64_t)rays->F * rays->R;
+  if (ray_block < 1 || S < 1 || S > CQ_MAXS_EVAL || (int64_t)ray_block * S * K > 0x7fffffff || num_fields < 1) return NGM_E_UNSUPPORTED;
+  if (workspace_bytes < ngm_knn_render_workspace_bytes(num_fields, ray_block, S, K) || !workspace) return NGM_E_WORKSPACE;
+  KnnArgs a;
+  knn_common(a, fc, pr, num_fields, pos, quat, K, distance_factor, outside_value, mask_radius);
+  a.P = (int64_t)ray_block * S;
+  char* w;
+  knn_carve(a, workspace, &w);
+  a.dist = reinterpret_cast<float*>(w); w += (4 * a.P + 255) / 256 * 256;
+  a.ray_dir = reinterpret_cast<float*>(w); w += (12 * (int64_t)ray_block + 255) / 256 * 256;
+  a.ray_tab = reinterpret_cast<float4*>(w);
+  a.gen = 1; a.S = S; a.rc = *rc;
+  for (int64_t r0 = 0; r0 < total; r0 += ray_block) {
+    const int nr = (int)std::min<int64_t>(ray_block, total - r0);
+    ngm_rays rb = *rays;
+    rb.F = 1; rb.R = nr; rb.gt = nullptr; rb.u_guided = nullptr;
+    rb.ijs = rays->ijs + 2 * r0;
+    if (rays->c2w_per_ray) rb.c2ws = rays->c2ws + 16 * r0;
+    if (rays->near) rb.near = rays->near + r0;
+    if (rays->far) rb.far = rays->far + r0;
+    if (rays->u_coarse) rb.u_coarse = rays->u_coarse + r0 * S;
+    rb.philox_seed = rays->philox_seed + (uint64_t)r0;
+    a.rays = rb;
+    a.P = (int64_t)nr * S;
+    hipLaunchKernelGGL(k_knn_raytab, dim3((nr + 255) / 256), dim3(256), 0, st, a);
+    const int le = knn_stages(a, r0 == 0, st);
+    if (le) return le;
+    CompositeArgs c;
+    memset(&c, 0, sizeof(c));
+    c.rc = *rc; c.N = nr; c.S = S; c.dists = a.dist; c.ray_dir = a.ray_dir;
+    c.pair_field = a.pair_field; c.pair_w = a.pair_w; c.pair_out = a.pair_out; c.pair_K = K; c.outside_value = outside_value;
+    c.rgbd = pred->rgbds ? pred->rgbds + 4 * r0 : nullptr;
+    c.Cv = pred->color_vars ? pred->color_vars + 3 * r0 : nullptr;
+    c.Dv = pred->depth_vars ? pred->depth_vars + r0 : nullptr;
+    c.term = pred->term_probs ? pred->term_probs + r0 : nullptr;
+    const int ce = ngm_launch_composite_fwd(c, st);
+    if (ce) return ce;
+  }
   return 0;
 }

@@ -125,6 +125,9 @@ struct CompositeArgs {
   const float* colors; const float* geoms; const float* dists; const float* depths; const float* isds;
   // packed source (eval path): (N,S,4) field outputs + camera-frame points; rgbd output (N,4)
   const float4* out4; const float* pcam; float* rgbd;
+  // packed source fused with the kNN blend (ngm_render_eval_knn): the pair records instead of out4, the rays' camera-frame
+  // directions (N,3) instead of pcam (depth = -direction.z * distance)
+  const int* pair_field; const float* pair_w; const float4* pair_out; int pair_K; float outside_value; const float* ray_dir;
   // outputs fwd
   float* C; float* D; float* Cv; float* Dv; float* term; float* weights;
   // bwd seeds / outputs

@@ -394,6 +394,63 @@ def composite_packed(rc: K.RenderCfg, field_out4, dists, points_cam):
                                                    _f32c(points_cam).reshape(N, S, 3)))
 
 
+@_op("render_eval_knn")
+def _render_eval_knn_op(fcfg: torch.Tensor, rcfg: torch.Tensor, ijs: torch.Tensor, c2ws: torch.Tensor,
+                        near: Optional[torch.Tensor], far: Optional[torch.Tensor], u: Optional[torch.Tensor], seed: int,
+                        near_const: float, far_const: float, pos: torch.Tensor, quat: torch.Tensor, params: List[torch.Tensor],
+                        num_knn: int, distance_factor: float, outside_value: float, field_index: Optional[torch.Tensor],
+                        mask_radius: float, ray_block: int) -> List[torch.Tensor]:
+    fc, rc = _field_cfg(fcfg), _render_cfg(rcfg)
+    N, NF = ijs.shape[0], pos.shape[0]
+    dev = ijs.device
+    rgbd, cv, dv, term = (torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
+                          torch.empty(N, device=dev))
+    if N == 0:
+        return [rgbd, cv, dv, term]
+    ps = params_struct(fc, dict(zip(K.param_names(fc), params)), field_index)
+    keep = []
+    rays = make_rays(rc, ijs[None], c2ws, None if near is None else near[None], None if far is None else far[None], None,
+                     pos[:1], quat[:1], None if u is None else u[None], None, seed, near_const=near_const, far_const=far_const,
+                     keep=keep)
+    pred = K.Prediction(_ptr(rgbd), _ptr(cv), _ptr(dv), _ptr(term))
+    L = K.lib()
+    ray_block = max(1, min(int(ray_block), N))
+    wsb = L.ngm_render_eval_knn_workspace(C.byref(rc), NF, ray_block, num_knn)
+    if wsb < 0:
+        raise K.NgmError("ngm_render_eval_knn_workspace: bad argument")
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    K.check(L.ngm_render_eval_knn(C.byref(fc), C.byref(rc), C.byref(ps), NF, _ptr(_f32c(pos)), _ptr(_f32c(quat)), C.byref(rays),
+                                  num_knn, distance_factor, outside_value, mask_radius, ray_block, C.byref(pred), _ptr(ws), wsb,
+                                  _stream()), "ngm_render_eval_knn")
+    return [rgbd, cv, dv, term]
+
+
+@_render_eval_knn_op.register_fake
+def _(fcfg, rcfg, ijs, c2ws, near, far, u, seed, near_const, far_const, pos, quat, params, num_knn, distance_factor,
+      outside_value, field_index, mask_radius, ray_block):
+    N = ijs.shape[0]
+    f = lambda *shape: torch.empty(*shape, device=ijs.device, dtype=torch.float32)
+    return [f(N, 4), f(N, 3), f(N), f(N)]
+
+
+def render_eval_knn(fc, rc: K.RenderCfg, params, ijs, c2ws, pos, quat, num_knn=2, distance_factor=10.0, outside_value=1.0,
+                    near=None, far=None, u=None, seed=0, near_const=0.0, far_const=8.0, field_index=None, mask_radius=None,
+                    ray_block=8192):
+    """render_image's block loop (rm.py:402-437) in one call: eval-style samples of the rays `ijs` (N,2) -> kNN-blended
+    fields -> quadrature; -> (rgbd (N,4), color_vars (N,3), depth_vars (N,), term (N,)).  The results equal
+    sample_rays_world -> field_eval_knn -> composite_packed per block of `ray_block` rays (block b drawing with seed +
+    b * ray_block); the samples, the blended outputs and the camera-frame points never reach memory.
+    Dispatches through torch.ops.ngm355.render_eval_knn."""
+    plist = [params[n] for n in K.param_names(fc)]
+    _require_gpu(ijs, c2ws, pos, quat, near, far, u, *plist)
+    if ijs.dtype != torch.int64 or ijs.dim() != 2:
+        raise TypeError("ijs must be int64 (N,2) [row, col]")
+    return tuple(torch.ops.ngm355.render_eval_knn(cfg_blob(fc), cfg_blob(rc), ijs.contiguous(), c2ws, near, far, u, int(seed),
+                                                  float(near_const), float(far_const), pos, quat, plist, int(num_knn),
+                                                  float(distance_factor), float(outside_value), field_index,
+                                                  float(mask_radius) if mask_radius else 0.0, int(ray_block)))
+
+
 # ------------------------------------------------------------------------------------------------
 # fused render (NeuralGraphMap._render_ijs(use_vmap=True), rm.py:439-666) with autograd
 # ------------------------------------------------------------------------------------------------

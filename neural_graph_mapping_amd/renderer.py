@@ -125,6 +125,7 @@ class NeuralGraphRenderer:
         self._step_dev = None
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
+        self.eval_fused = True             # render_pixels: one ngm_render_eval_knn call (False: the staged per-block entry points)
         self.peer_exchange = None          # distributed.PeerExchange: the same sum as one kernel inside the captured iteration
         self.peer_check_interval = 256     # iterations between PeerExchange.check() calls (a device synchronisation each)
         self._peer_calls = 0
@@ -479,6 +480,14 @@ class NeuralGraphRenderer:
         params = {k: v for k, v in params.items() if k != "_neus_sd"}
         m = self._model
         block = int(cfg.get("pixel_block_size", 8192))
+        if self.eval_fused:
+            # the whole loop below as one call (ngm_render_eval_knn): same blocks, same draws, same arithmetic; the samples,
+            # the blended field outputs and the camera-frame points stay out of memory
+            rgbd, _, dv, _ = ops.render_eval_knn(
+                self._fc, rc, params, ijs, c2w, pos, quat, m._num_knn, m._distance_factor, m._outside_value,
+                u=None if u is None else u[begin:end], seed=seed + begin, near_const=cfg.get("eval_near_distance", 0.0),
+                far_const=cfg.get("eval_far_distance", 8.0), ray_block=block)
+            return rgbd, dv
         rgbds, dvars = [], []
         for s0 in range(0, ijs.shape[0], block):
             ij = ijs[s0:s0 + block]

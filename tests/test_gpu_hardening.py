@@ -242,3 +242,39 @@ def test_nll_loss_modes_ragged_vs_oracle(F, R, n_c, n_g, photo, depth, geom):
         close(res[k], loss[k].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         grad_close(res["grads"][k], po[k].grad, 5e-3, k)
+
+
+# ------------------------------------------------------------------------------------------------ fused image path
+@pytest.mark.parametrize("geo,S,K_,block,explicit_u", [("nrgbd", 24, 2, 1000, True), ("nrgbd", 640, 2, 700, False),
+                                                       ("density", 96, 3, 4096, False), ("occupancy", 64, 1, 333, True),
+                                                       ("neus", 40, 2, 512, False)])
+def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, explicit_u):
+    """render_pixels as ONE call (ngm_render_eval_knn: samples drawn inside the neighbour assignment, blend inside the
+    quadrature, grid over the centres built once) against the staged per-block entry points (ngm_sample_rays_world ->
+    ngm_field_eval_knn -> ngm_composite_fwd_packed): the same blocks, draws and arithmetic, so the images are EQUAL bit for
+    bit -- explicit jitter or in-kernel Philox, ragged last block, every geometry mode, K = 1..3, rays that leave every field
+    and (camera inside the map, far plane behind it) samples on both sides of the fields."""
+    torch.manual_seed(S)
+    g = torch.arange(-1.0, 1.01, 0.5)
+    pos = torch.stack(torch.meshgrid(g, g, torch.tensor([-2.0, -1.5]), indexing="ij"), -1).reshape(-1, 3)
+    pos = pos + 1e-3 * torch.randn_like(pos)
+    NF = pos.shape[0]
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
+    r = make_renderer(FOURIER, dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_mode=geo,
+                                    eval_near_distance=0.0, eval_far_distance=4.0, eval_num_samples=S,
+                                    pixel_block_size=block), NF)
+    r._model._num_knn = K_
+    _perturb(r)
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.1, -0.2, 0.3])
+    begin, end = 640 * 200 + 17, 640 * 200 + 17 + 2500                      # not aligned to anything
+    u = torch.rand(640 * 480, S, device=DEV) if explicit_u else None
+    outs = []
+    for fused in (True, False):
+        r.eval_fused = fused
+        outs.append(r.render_pixels(c2w.to(DEV), begin, end, u=u, seed=11))
+    assert outs[0][0].shape == (end - begin, 4) and torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if geo == "nrgbd":
+        assert bool((outs[0][0][:, :3] != outs[0][0][:1, :3]).any())        # the image is not one constant colour

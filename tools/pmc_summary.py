@@ -11,7 +11,7 @@ for path in sys.argv[1:]:
             k = row["Kernel_Name"].split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
-    if not any(s in k for s in ("k_field_bwd", "k_render_fwd", "k_stash_bwd", "k_grad_reduce", "k_composite", "k_field_points", "k_hash")):
+    if not any(s in k for s in ("k_field_bwd", "k_render_fwd", "k_stash_bwd", "k_grad_reduce", "k_composite", "k_field_points", "k_hash", "k_knn")):
         continue
     print(k)
     for c, v in sorted(cs.items()):

@@ -245,6 +245,23 @@ __device__ __forceinline__ Vec3 quat_rotate_inv(float w, float ux, float uy, flo
   const Vec3 c = cross3(u, t);
   return Vec3{v.x + w * t.x + c.x, v.y + w * t.y + c.y, v.z + w * t.z + c.z};
 }
+// world point -> field-local -> scaled coordinates (models.py:329-339, 278-285) for the STANDALONE evaluation kernels (vmap-style
+// k_field_points_fwd and the kNN path's k_knn_eval), every operation rounded separately: the two then give the same bits for
+// the same point whatever the optimiser fuses around them (an ulp of difference here is 2^7 pi ulps in a NeRF octave argument)
+__device__ __forceinline__ Vec3 scaled_local_point(Vec3 p, bool posed, float px, float py, float pz, float qw, float qx, float qy,
+                                                   float qz, float div, float off) {
+#pragma clang fp contract(off)
+  Vec3 v = p;
+  if (posed) {
+    v = Vec3{p.x - px, p.y - py, p.z - pz};
+    const Vec3 u{-qx, -qy, -qz};
+    Vec3 t{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    t.x *= 2.0f; t.y *= 2.0f; t.z *= 2.0f;
+    const Vec3 c{u.y * t.z - u.z * t.y, u.z * t.x - u.x * t.z, u.x * t.y - u.y * t.x};
+    v = Vec3{v.x + qw * t.x + c.x, v.y + qw * t.y + c.y, v.z + qw * t.z + c.z};
+  }
+  return Vec3{v.x / div + off, v.y / div + off, v.z / div + off};
+}
 __device__ __forceinline__ void scale_consts(int scale_mode, float radius, float* div, float* off) {
   if (scale_mode == NGM_SCALE_UNIT_CUBE) { *div = 2.0f * radius; *off = 0.5f; }
   else if (scale_mode == NGM_SCALE_UNIT_BALL) { *div = radius; *off = 0.0f; }

@@ -20,8 +20,9 @@
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
-template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false>
-__global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a) {
+// NT: threads per workgroup; the bf16-split variant (83 KB of weights: one workgroup per CU) runs eight waves on them
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false, int NT = NGM_BLOCK>
+__global__ __launch_bounds__(NT) void k_field_points_fwd(PointsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
@@ -48,15 +49,14 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_field_points_fwd(PointsFwdArgs a)
   const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
   const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
   const int64_t beg = (int64_t)chunk * a.per_block, end = min(a.P, beg + a.per_block);
-  for (int64_t base = beg + wave * 64; base < end; base += NGM_BLOCK) {
+  for (int64_t base = beg + wave * 64; base < end; base += NT) {
     const int64_t idx = base + lane;
     const bool valid = idx < end;
     float x = 0, y = 0, z = 0;
     if (valid) {
       const float* p = a.points + ((int64_t)f * a.P + idx) * 3;
-      Vec3 v{p[0], p[1], p[2]};
-      if (posed) { v = Vec3{v.x - px, v.y - py, v.z - pz}; v = quat_rotate_inv(qw, qx, qy, qz, v); }
-      x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
+      const Vec3 v = scaled_local_point(Vec3{p[0], p[1], p[2]}, posed, px, py, pz, qw, qx, qy, qz, div, off);
+      x = v.x; y = v.y; z = v.z;
     }
     const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
@@ -599,9 +599,9 @@ static int launch_points(const PointsFwdArgs& a, int blocks, hipStream_t st) {
     if (b3_wanted(a.fc)) {       // standalone evaluation: the mode is a preference here (fp32 MFMA where not compiled)
       g_ngm_last_matmul[1] = NGM_MATMUL_BF16X3;
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
-      (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, 0, 0, true>,
+      (void)hipFuncSetAttribute((const void*)k_field_points_fwd<MI, MH, L, false, 0, 0, true, 512>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false, 0, 0, true>), dim3(blocks), blk, lds, st, a);
+      hipLaunchKernelGGL((k_field_points_fwd<MI, MH, L, false, 0, 0, true, 512>), dim3(blocks), dim3(512), lds, st, a);
       return 0;
     }
   }

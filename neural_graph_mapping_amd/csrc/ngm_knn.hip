@@ -3,15 +3,21 @@
 // The reference finds the K nearest field centres of every query point, evaluates each touched field
 // in a Python loop over boolean masks and blends with softmax(-distance_factor * dist).  Here:
 //   k_knn_grid    : field centres binned into a uniform grid on the device (cell = the cover-grid spacing 2 r / sqrt 3 of
-//                   rm.py:299, never smaller than the mask radius; one workgroup: bounding box, counts, scan, fill)
-//   k_knn_assign  : exact K-nearest (K <= 4) per point from the 27 cells around it, the block of cells growing ring by ring
-//                   until the K-th neighbour found is provably the K-th nearest; radius test, softmax weights; per-workgroup
-//                   LDS histogram -> one global atomic per field per workgroup.  No limit on the number of fields.
+//                   rm.py:299, never smaller than the mask radius; one workgroup: bounding box, counts, scan, fill), then per
+//                   cell of the grid extended by one ring the list of centres a point of that cell can be inside of
+//   k_knn_assign  : exact K-nearest (K <= 4) per point: the cell's list decides the inside test (most samples of an image
+//                   fall on an empty list and stop there) and seeds the neighbour list; where fewer than K centres are within
+//                   the radius the block of cells around the point grows ring by ring until the K-th neighbour found is
+//                   provably the K-th nearest; softmax weights; per-workgroup LDS histogram -> one global atomic per field
+//                   per workgroup.  No limit on the number of fields.
 //   k_knn_offsets : exclusive scans over fields (segment offsets, tile offsets)
 //   k_knn_scatter : (point,k) pairs bucketed by field (counting sort)
-//   k_knn_eval    : one workgroup per 4096-pair tile of ONE field: that field's weights resident in
+//   k_knn_eval    : one workgroup per 2048-pair tile of ONE field: that field's weights resident in
 //                   LDS, MLP on the matrix cores (same eval_64 as the train kernels)
 //   k_knn_blend   : out[p] = sum_k w_k out_{p,k}, or outside_value on all channels
+// ngm_render_eval_knn (render_image's block loop, rm.py:402-437) runs the same stages per block of rays with the points
+// GENERATED inside the assignment (k_knn_raytab + the sampler's arithmetic; only the sample distances are kept) and the blend
+// done inside the quadrature (k_composite_fwd* on the pair records): no point, blended output or camera-frame point in memory.
 #include "ngm_field.h"
 #include "ngm_launch.h"
 
@@ -25,8 +31,13 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-#define KNN_TILE 4096
+#ifndef KNN_TILE
+#define KNN_TILE 512
+#endif
 #define KNN_MAXK 4
+#ifndef KNN_EVAL_B3_THREADS
+#define KNN_EVAL_B3_THREADS 512
+#endif
 #define CQ_MAXS_EVAL 1024      // samples per ray the quadrature kernel takes (CQ_MAXS of ngm_composite.hip)
 
 struct KnnArgs {
@@ -437,7 +448,7 @@ __global__ void k_knn_offsets(KnnArgs a) {
 // Counting-sort scatter in two levels: every workgroup ranks its SC_ITEMS * 256 pairs per field with LDS atomics,
 // reserves one contiguous range per field with ONE global atomic, then writes.  (One global atomic per pair on the
 // per-field cursor serialised badly -- neighbouring pixels hit the same field -- and took 80 % of render_image.)
-#define SC_ITEMS 8
+#define SC_ITEMS 32
 __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
   extern __shared__ int sc_lds[];
   int* hist = sc_lds;            // NF: pairs of this workgroup per field, then the reserved global base
@@ -472,53 +483,68 @@ __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
     if (fld[k] >= 0) a.sorted[hist[fld[k]] + rnk[k]] = (int)(base + k * 256 + threadIdx.x);
 }
 
-template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false>
-__global__ __launch_bounds__(NGM_BLOCK) void k_knn_eval(KnnArgs a) {
+// Persistent workgroups: workgroup b owns a contiguous run of the (field-ordered) KNN_TILE-pair tiles, so it stages a
+// field's weights once per field it meets (one or two per run), not once per tile, and the runs are equal to within one
+// small tile.  NT: threads per workgroup -- the bf16-split variant keeps 83 KB of weights per workgroup, so one workgroup
+// per CU: eight waves (two per SIMD, as in the training forward) instead of four share them.
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false, int NT = NGM_BLOCK>
+__global__ __launch_bounds__(NT) void k_knn_eval(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int total_tiles = a.tile_off[a.NF];
-  if ((int)blockIdx.x >= total_tiles) return;
-  // field of this tile: last f with tile_off[f] <= blockIdx.x
+  const int per = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(total_tiles, t0 + per);
+  if (t0 >= t1) return;
+  // field of the first tile: last f with tile_off[f] <= t0
   int lo = 0, hi = a.NF - 1;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
-  const int f = lo;
-  const int tile = blockIdx.x - a.tile_off[f];
-  const int beg = a.seg_off[f] + tile * KNN_TILE, end = min(a.seg_off[f + 1], beg + KNN_TILE);
-  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  {
-    FieldStage<MI, MH, L, SKIP == 2> fstage;       // every parameter load in flight at once, then the permuting LDS writes
-    fstage.issue(a.fc, a.pr, row);
-    fstage.commit(sm, a.fc);
-  }
-  __syncthreads();
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= t0) lo = mid; else hi = mid - 1; }
+  int f = lo, cur = -1;
   ngm_u32x4* const b3w = reinterpret_cast<ngm_u32x4*>(sm + FieldLds<MI, MH, L, SKIP == 2>::TOTAL);
-  if constexpr (B3) {          // ngm_matmul_mode BF16X3: bf16 weight planes behind the fp32 fragments (ngm_field.h)
-    b3_build_planes<MI, MH, L>(sm, b3w);
-    __syncthreads();
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float div, off;
   scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
-  const float px = a.pos[3 * f], py = a.pos[3 * f + 1], pz = a.pos[3 * f + 2];
-  const float qw = a.quat[4 * f], qx = a.quat[4 * f + 1], qy = a.quat[4 * f + 2], qz = a.quat[4 * f + 3];
-  const HashCtx hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
-  const TriCtx tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
-  for (int base = beg + wave * 64; base < end; base += NGM_BLOCK) {
-    const int idx = base + lane;
-    const bool valid = idx < end;
-    float x = 0, y = 0, z = 0;
-    int pair = 0;
-    if (valid) {
-      pair = a.sorted[idx];
-      const int64_t p = pair / a.K;
-      float wx, wy, wz;
-      if (a.gen) knn_point_again(a, p, &wx, &wy, &wz);
-      else { wx = a.points[3 * p]; wy = a.points[3 * p + 1]; wz = a.points[3 * p + 2]; }
-      Vec3 v{wx - px, wy - py, wz - pz};                                                   // models.py:377-381
-      v = quat_rotate_inv(qw, qx, qy, qz, v);
-      x = v.x / div + off; y = v.y / div + off; z = v.z / div + off;
+  float px = 0, py = 0, pz = 0, qw = 1, qx = 0, qy = 0, qz = 0;
+  HashCtx hc = make_hash_ctx(a.fc, a.pr, 0, nullptr);
+  TriCtx tc = make_tri_ctx(a.fc, a.pr, 0, nullptr);
+  for (int t = t0; t < t1; ++t) {
+    while (a.tile_off[f + 1] <= t) ++f;                          // (fields without pairs own no tile)
+    if (f != cur) {
+      if (cur >= 0) __syncthreads();                             // every wave is done with the previous field's weights
+      const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+      {
+        FieldStage<MI, MH, L, SKIP == 2> fstage;     // every parameter load in flight at once, then the permuting LDS writes
+        fstage.issue(a.fc, a.pr, row);
+        fstage.commit(sm, a.fc);
+      }
+      __syncthreads();
+      if constexpr (B3) {        // ngm_matmul_mode BF16X3: bf16 weight planes behind the fp32 fragments (ngm_field.h)
+        b3_build_planes<MI, MH, L>(sm, b3w);
+        __syncthreads();
+      }
+      px = a.pos[3 * f]; py = a.pos[3 * f + 1]; pz = a.pos[3 * f + 2];
+      qw = a.quat[4 * f]; qx = a.quat[4 * f + 1]; qy = a.quat[4 * f + 2]; qz = a.quat[4 * f + 3];
+      hc = make_hash_ctx(a.fc, a.pr, row, nullptr);
+      tc = make_tri_ctx(a.fc, a.pr, row, nullptr);
+      cur = f;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
-    if (valid) a.pair_out[pair] = o;
+    const int tile = t - a.tile_off[f];
+    const int beg = a.seg_off[f] + tile * KNN_TILE, end = min(a.seg_off[f + 1], beg + KNN_TILE);
+    for (int base = beg + wave * 64; base < end; base += NT) {
+      const int idx = base + lane;
+      const bool valid = idx < end;
+      float x = 0, y = 0, z = 0;
+      int pair = 0;
+      if (valid) {
+        pair = a.sorted[idx];
+        const int64_t p = pair / a.K;
+        float wx, wy, wz;
+        if (a.gen) knn_point_again(a, p, &wx, &wy, &wz);
+        else { wx = a.points[3 * p]; wy = a.points[3 * p + 1]; wz = a.points[3 * p + 2]; }
+        const Vec3 v = scaled_local_point(Vec3{wx, wy, wz}, true, px, py, pz, qw, qx, qy, qz, div, off);   // models.py:377-381
+        x = v.x; y = v.y; z = v.z;
+      }
+      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
+      if (valid) a.pair_out[pair] = o;
+    }
   }
 }
 
@@ -552,8 +578,23 @@ int64_t ngm_knn_render_workspace_bytes(int num_fields, int ray_block, int S, int
   return ngm_knn_workspace_bytes(num_fields, P, K) + 4 * (P + 64) + 28 * ((int64_t)ray_block + 64) + 1024;
 }
 
+// compute units of the device: the persistent evaluation kernel runs one workgroup per CU in its 83 KB bf16-split variant
+// (eight waves), four per CU in the fp32 variants (<= 35 KB, four waves each)
+static int knn_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount : 256;
+    (void)hipGetLastError();
+  }
+  return n;
+}
+
 template <int MI, int MH, int L>
-static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
+static int launch_eval(const KnnArgs& a, int max_tiles, hipStream_t st) {
+  const int grid = std::max(1, std::min(max_tiles, 4 * knn_num_cus())), grid_b3 = std::max(1, std::min(max_tiles, knn_num_cus()));
 #define NGM_KE(NC, HS, SK)                                                                                             \
   do {                                                                                                                 \
     const size_t lds = FieldLds<MI, MH, L, (SK) == 2>::TOTAL * sizeof(float);                                          \
@@ -568,9 +609,9 @@ static int launch_eval(const KnnArgs& a, int grid, hipStream_t st) {
         (a.fc.encoding == NGM_ENC_FOURIER || a.fc.encoding == NGM_ENC_NONE)) {
       g_ngm_last_matmul[2] = NGM_MATMUL_BF16X3;
       const size_t lds = FieldLds<MI, MH, L>::TOTAL * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
-      (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, 0, 0, true>,
+      (void)hipFuncSetAttribute((const void*)k_knn_eval<MI, MH, L, false, 0, 0, true, KNN_EVAL_B3_THREADS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false, 0, 0, true>), dim3(grid), dim3(NGM_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((k_knn_eval<MI, MH, L, false, 0, 0, true, KNN_EVAL_B3_THREADS>), dim3(grid_b3), dim3(KNN_EVAL_B3_THREADS), lds, st, a);
       return 0;
     }
   }
@@ -649,7 +690,7 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
   hipLaunchKernelGGL(k_knn_offsets, dim3(1), dim3(64), 0, st, a);
   const int nb = (int)((n + SC_ITEMS * 256 - 1) / (SC_ITEMS * 256));
   hipLaunchKernelGGL(k_knn_scatter, dim3(std::max(nb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a);
-  const int max_tiles = (int)((n + KNN_TILE - 1) / KNN_TILE) + a.NF;
+  const int max_tiles = (int)std::min<int64_t>((n + KNN_TILE - 1) / KNN_TILE + a.NF, 0x7fffffff);
   const FieldShape s = field_shape(&a.fc);
   int le = NGM_E_UNSUPPORTED;
   {

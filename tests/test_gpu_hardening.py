@@ -278,3 +278,14 @@ def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, expl
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     if geo == "nrgbd":
         assert bool((outs[0][0][:, :3] != outs[0][0][:1, :3]).any())        # the image is not one constant colour
+
+
+def test_knn_path_does_not_depend_on_stale_workspace_contents():
+    """tools/knn_stress.py: the caching allocator's free blocks (which the workspace is carved from) are filled with random bits
+    before every call; maps of 3 .. 40 000 fields, K = 1 .. 4; every blended output against a brute-force fp64 neighbour
+    search (constant-output fields, so the output identifies the neighbours and their weights)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import knn_stress
+    assert knn_stress.main(10) == 0

@@ -28,6 +28,9 @@ python bench.py --variant hash --no-cpu-baseline > $O/bench_line_hash.json 2>> $
 python bench.py --matmul f32 --no-cpu-baseline --no-aux-hash > $O/bench_line_f32.json 2>> $O/bench.err
 python bench.py --scene-sim > $O/scene_sim.json 2>> $O/bench.err
 python tools/eval_bench.py > $O/eval_bench.json 2>> $O/bench.err
+# per-kernel times of the image path (render_image 640 x 480 x 640): rocprofv3 kernel stats of five renders
+( cd /tmp && export TMPDIR=/tmp && NGM_EVAL_S=640 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/evalprof -o ev -- python $GRAFT_REPO_ROOT/tools/eval_bench.py > $O/evalprof.log 2>&1 )
+python tools/knn_stress.py 100 > $O/knn_stress.txt 2>&1
 timeout 120 tools/micro/gather_rate > $O/gather_rate.txt 2>&1
 timeout 120 tools/micro/dot2c_split > $O/dot2c_split.txt 2>&1
 head -30 $O/sq_counters.txt

@@ -359,29 +359,33 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
     };
     // ---- phase A: is any centre within the mask radius?  Every such centre is in the cell's list; the ones within the
     // radius also start the neighbour list -- where the map is as dense as its cover grid the K nearest are among them and
-    // phase B is not needed at all
+    // phase B is not needed at all.  A wave walks the union of its lanes' lists and nearly every candidate is within the
+    // radius of SOME lane, so the insertion is branch-free: (distance bits, field index) as one 64-bit key -- distances are
+    // non-negative, so the integer order of the keys is the order (distance, then lower field index) of the list -- and a
+    // chain of K min / max pairs; candidates beyond the radius carry the all-ones key of an empty slot.
     const float rad2 = a.radius * a.radius * 1.0002f;
-    float dmin = INFINITY;
+    unsigned long long key[KK];
 #pragma unroll
-    for (int k = 0; k < KK; ++k) { bd[k] = INFINITY; bi[k] = -1; }
-    worst = INFINITY; worst_i = -1;
+    for (int k = 0; k < KK; ++k) key[k] = ~0ull;
     for (int j = nj0; j < nj1; ++j) {
       const float4 c = a.near_c[j];
       const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
-      float d = dx * dx + dy * dy + dz * dz;
-      dmin = fminf(dmin, d);
-      if (d < rad2 && (d < worst || (d == worst && __float_as_int(c.w) < worst_i))) {
-        int id = __float_as_int(c.w);
+      const float d = dx * dx + dy * dy + dz * dz;
+      unsigned long long kv = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
+      kv = (d < rad2) ? kv : ~0ull;
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-          if (k < K && (d < bd[k] || (d == bd[k] && id < bi[k]))) {
-            const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
-          }
-        }
-        worst = bd[KK - 1];
-        worst_i = bi[KK - 1];
+      for (int k = 0; k < KK; ++k) {
+        const unsigned long long lo = kv < key[k] ? kv : key[k], hi = kv < key[k] ? key[k] : kv;
+        key[k] = lo; kv = hi;
       }
     }
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      bi[k] = (int)(unsigned)(key[k] & 0xffffffffull);
+      bd[k] = (key[k] == ~0ull) ? INFINITY : __uint_as_float((unsigned)(key[k] >> 32));
+    }
+    worst = bd[KK - 1]; worst_i = bi[KK - 1];
+    const float dmin = bd[0];                                    // (no centre within the radius: infinity, outside)
     bool inside = sqrtf(dmin) < a.radius;                        // models.py:369 (the same squared distance as the list's bd[0])
     // every centre closer than the radius has been seen: a K-th neighbour inside the radius is the K-th nearest
     if (inside && !(worst < a.radius * a.radius)) {

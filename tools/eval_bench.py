@@ -78,7 +78,28 @@ def main():
                                         unit="TFLOP/s", frac=flop / t / 1e12 / 157.3, knn_assign_ms=round(kern["knn_assign"]["total_ms"], 3),
                                         note="jitter differs between the counted pass and the timed pass (Philox offsets): the pair "
                                              "count is exact to ~1e-3")
-    print(json.dumps(dict(workload="render_image 640x480, Fourier(64)+2x64 fields, kNN blend K=2", **out)))
+    if os.environ.get("NGM_EVAL_HASH", "1") != "0":
+        # the reference's default network (permutohedral hash 16 x 2 + 1 x 32, neural_graph_map.yaml:6-20) on the same image
+        model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+            encoding_type="neural_graph_mapping.positional_encodings.PermutohedralEncoding",
+            encoding_kwargs=dict(pos_dim=3, log2_hashmap_size=12, nr_levels=16, nr_feat_per_level=2, coarsest_scale=1.0,
+                                 finest_scale=1e-4, init_scale=1e-5), num_layers=1, dim_out=4),
+            num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=0.5, scale_mode="unit_cube").to(dev)
+        cfg = Rr.shipped_config(field_radius=0.5, eval_near_distance=0.0, eval_far_distance=8.0, eval_num_samples=640)
+        r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
+        r.add_fields(NF)
+        r.set_field_poses(pos.to(dev), quat.to(dev))
+        c2w = torch.eye(4, device=dev)
+        r.render_image(c2w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r.render_image(c2w)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["S640_hash"] = dict(ms_per_image=round(dt * 1e3, 2), ray_samples_per_s=640 * 480 * 640 / dt, fields=NF,
+                                network="hash 16x2 (T=4096) + 1x32", knn_matmul=r.last_matmul("knn"))
+    print(json.dumps(dict(workload="render_image 640x480, Fourier(64)+2x64 fields (and the default hash network), kNN blend K=2", **out)))
 
 
 if __name__ == "__main__":

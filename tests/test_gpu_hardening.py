@@ -289,3 +289,36 @@ def test_knn_path_does_not_depend_on_stale_workspace_contents():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import knn_stress
     assert knn_stress.main(10) == 0
+
+
+def test_fused_image_entry_with_per_ray_poses_and_bounds():
+    """ngm_render_eval_knn with everything per ray (c2ws (N,4,4), near (N,), far (N,)) and in-kernel Philox, against the three
+    staged operators called block by block with the seeds the entry documents (seed + block start): equal bit for bit."""
+    torch.manual_seed(5)
+    N, S, K_, block, seed = 3000, 64, 2, 1024, 77
+    g = torch.arange(-1.0, 1.01, 0.5)
+    pos = torch.stack(torch.meshgrid(g, g, torch.tensor([-2.0, -1.5]), indexing="ij"), -1).reshape(-1, 3)
+    pos = (pos + 1e-3 * torch.randn_like(pos)).to(DEV)
+    NF = pos.shape[0]
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1).to(DEV)
+    r = make_renderer(FOURIER, dict(num_samples_coarse=8, num_samples_depth_guided=16), NF)
+    _perturb(r)
+    params = {k: v for k, v in r._model.kernel_params().items() if k != "_neus_sd"}
+    fc = r._fc
+    rc = K.render_cfg(num_samples_coarse=S, num_samples_guided=0, fx=554.2562584220408, fy=554.2562584220408, cx=319.5, cy=239.5)
+    ijs = torch.stack((torch.randint(0, 480, (N,)), torch.randint(0, 640, (N,))), -1).to(DEV)
+    c2ws = torch.eye(4).repeat(N, 1, 1)
+    c2ws[:, :3, 3] = 0.2 * torch.randn(N, 3)
+    c2ws = c2ws.to(DEV)
+    near, far = (0.5 * torch.rand(N)).to(DEV), (3.0 + torch.rand(N)).to(DEV)
+    rgbd, cv, dv, term = ops.render_eval_knn(fc, rc, params, ijs, c2ws, pos, quat, K_, 10.0, 1.0, near=near, far=far, seed=seed,
+                                             ray_block=block)
+    outs = []
+    for s0 in range(0, N, block):
+        sl = slice(s0, s0 + block)
+        pc, pw, dist = ops.sample_rays_world(rc, ijs[sl][None], c2ws[sl][None], near[sl][None], far[sl][None], seed=seed + s0)
+        o4 = ops.field_eval_knn(fc, params, pw.view(-1, 3), pos, quat, K_, 10.0, 1.0)
+        outs.append(ops.composite_packed(rc, o4, dist.view(-1, S), pc.view(-1, S, 3)))
+    for i, t in enumerate((rgbd, cv, dv, term)):
+        assert torch.equal(t, torch.cat([o[i] for o in outs])), i
+    assert bool((term > 0.5).any()) and bool((rgbd[:, :3] != rgbd[:1, :3]).any())   # the rays do meet fields, and different ones

@@ -69,6 +69,7 @@ struct KnnArgs {
   int max_cells;
   float cell_size;      // requested cell edge (>= mask radius); the kernel may coarsen it to fit max_cells
   int hist_in_lds;      // per-workgroup field histograms fit the LDS (else: global atomics per pair)
+  int near_inline;      // k_knn_grid builds the candidate lists itself (small maps); else k_knn_near_* do
   // point source: `points` (P,3), or -- gen != 0, ngm_render_eval_knn -- point p is sample p % S of ray p / S of one block of
   // eval-style rays (single stratum): k_knn_raytab leaves the ray-level quantities in `ray_dir` / `ray_tab`, the assignment draws
   // the sample's distance and forms the point exactly as k_sample_rays would, leaves the distance in `dist`; the evaluation
@@ -101,6 +102,55 @@ __device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
 // dimensions (coarsened until the grid fits max_cells) -> per-cell counts -> exclusive scan -> centres grouped by cell.
 // The order of the centres inside a cell is whatever the atomics give: k_knn_assign breaks distance ties by field index,
 // so its result does not depend on it.
+// exclusive scan of arr[0 .. n) in place by one workgroup of 1024 threads, arr[n] = total: contiguous segments per thread,
+// block scan of the segment sums (sscan: 1024 ints of LDS)
+__device__ __forceinline__ void block_exclusive_scan_1024(int* arr, int n, int* sscan) {
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024, b0 = min(n, t * per), b1 = min(n, b0 + per);
+  int sum = 0;
+  for (int i = b0; i < b1; ++i) sum += arr[i];
+  sscan[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (t >= d) ? sscan[t - d] : 0;
+    __syncthreads();
+    sscan[t] += v;
+    __syncthreads();
+  }
+  int run = sscan[t] - sum;
+  for (int i = b0; i < b1; ++i) { const int cnt = arr[i]; arr[i] = run; run += cnt; }
+  if (t == 1023) arr[n] = sscan[1023];
+  __threadfence();
+  __syncthreads();
+}
+
+// Candidate list of extended cell e (the grid plus one ring): the centres closer to the cell's box than the mask radius (a
+// little more: the points are binned in fp32).  Four out of five samples of an image are nowhere near a field and fall
+// on an empty list; for the others the list replaces the walk over the 27 cells.  fill = false: count only.
+__device__ __forceinline__ int knn_near_visit(const KnnArgs& a, const KnnGridHdr& h, int e, bool fill) {
+  const int ex = h.nx + 2, ey = h.ny + 2;
+  const float reach = a.radius * 1.001f + 1e-3f * h.c, reach2 = reach * reach;
+  const int cx = e % ex - 1, cy = (e / ex) % ey - 1, cz = e / (ex * ey) - 1;
+  const float bx0 = h.x0 + (float)cx * h.c, by0 = h.y0 + (float)cy * h.c, bz0 = h.z0 + (float)cz * h.c;
+  int cnt = 0;
+  const int base = fill ? a.near_start[e] : 0;
+  for (int nz = max(cz - 1, 0); nz <= min(cz + 1, h.nz - 1); ++nz)
+    for (int ny = max(cy - 1, 0); ny <= min(cy + 1, h.ny - 1); ++ny) {
+      const int xs = max(cx - 1, 0), xe = min(cx + 1, h.nx - 1);
+      if (xs > xe) continue;
+      const int rowb = (nz * h.ny + ny) * h.nx;
+      for (int j = a.cell_start[rowb + xs]; j < a.cell_start[rowb + xe + 1]; ++j) {
+        const float4 c = a.cell_c[j];
+        const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - (bx0 + h.c)), 0.f), dy = fmaxf(fmaxf(by0 - c.y, c.y - (by0 + h.c)), 0.f),
+                    dz = fmaxf(fmaxf(bz0 - c.z, c.z - (bz0 + h.c)), 0.f);
+        if (dx * dx + dy * dy + dz * dz < reach2) { if (fill) a.near_c[base + cnt] = c; ++cnt; }
+      }
+    }
+  return cnt;
+}
+
+// a.near_inline: the candidate lists are built by this workgroup as well (small maps: one launch); otherwise by the three
+// kernels below on the whole device (a map of 40 000 centres: 2 ms -> a fraction of that)
 __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   __shared__ float red[6][16];
   __shared__ int sscan[1024];
@@ -143,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   const int nc = h.ncells;
   for (int i = t; i <= nc; i += 1024) a.cell_start[i] = 0;
   for (int i = t; i < nc; i += 1024) a.cell_fill[i] = 0;
-  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
+  __threadfence();            // the counts are changed by L2 atomics below: no stale L1 line may serve the reads after them
   __syncthreads();
   auto cell_of = [&](int f) {
     const int ix = min(max((int)((a.pos[3 * f] - h.x0) * h.inv_c), 0), h.nx - 1);
@@ -152,66 +202,39 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
     return (iz * h.ny + iy) * h.nx + ix;
   };
   for (int f = t; f < a.NF; f += 1024) atomicAdd(&a.cell_start[cell_of(f)], 1);
-  __threadfence();            // the counts were changed by L2 atomics: no stale L1 line may serve the reads below
+  __threadfence();
   __syncthreads();
-  // exclusive scan of arr[0 .. n) in place, arr[n] = total: contiguous segments per thread, block scan of the segment sums
-  auto exclusive_scan = [&](int* arr, int n) {
-    const int per = (n + 1023) / 1024, b0 = min(n, t * per), b1 = min(n, b0 + per);
-    int sum = 0;
-    for (int i = b0; i < b1; ++i) sum += arr[i];
-    sscan[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const int v = (t >= d) ? sscan[t - d] : 0;
-      __syncthreads();
-      sscan[t] += v;
-      __syncthreads();
-    }
-    int run = sscan[t] - sum;
-    for (int i = b0; i < b1; ++i) { const int cnt = arr[i]; arr[i] = run; run += cnt; }
-    if (t == 1023) arr[n] = sscan[1023];
-    __threadfence();
-    __syncthreads();
-  };
-  exclusive_scan(a.cell_start, nc);
+  block_exclusive_scan_1024(a.cell_start, nc, sscan);
   for (int f = t; f < a.NF; f += 1024) {
     const int cidx = cell_of(f);
     const int slot = a.cell_start[cidx] + atomicAdd(&a.cell_fill[cidx], 1);
     a.cell_c[slot] = make_float4(a.pos[3 * f], a.pos[3 * f + 1], a.pos[3 * f + 2], __int_as_float(f));
   }
+  if (!a.near_inline) return;
   __threadfence();
   __syncthreads();
-  // Per cell of the grid extended by one ring: the centres closer to the cell's box than the mask radius (a little more:
-  // the points are binned in fp32).  Four out of five samples of an image are nowhere near a field and fall on an empty
-  // list; for the others the list replaces the walk over the 27 cells.  Count, scan, fill.
-  const int ex = h.nx + 2, ey = h.ny + 2, ez = h.nz + 2, ne = ex * ey * ez;
-  const float reach = a.radius * 1.001f + 1e-3f * h.c, reach2 = reach * reach;
-  auto visit = [&](int e, bool fill) {
-    const int cx = e % ex - 1, cy = (e / ex) % ey - 1, cz = e / (ex * ey) - 1;
-    const float bx0 = h.x0 + (float)cx * h.c, by0 = h.y0 + (float)cy * h.c, bz0 = h.z0 + (float)cz * h.c;
-    int cnt = 0;
-    const int base = fill ? a.near_start[e] : 0;
-    for (int nz = max(cz - 1, 0); nz <= min(cz + 1, h.nz - 1); ++nz)
-      for (int ny = max(cy - 1, 0); ny <= min(cy + 1, h.ny - 1); ++ny) {
-        const int xs = max(cx - 1, 0), xe = min(cx + 1, h.nx - 1);
-        if (xs > xe) continue;
-        const int rowb = (nz * h.ny + ny) * h.nx;
-        for (int j = a.cell_start[rowb + xs]; j < a.cell_start[rowb + xe + 1]; ++j) {
-          const float4 c = a.cell_c[j];
-          const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - (bx0 + h.c)), 0.f), dy = fmaxf(fmaxf(by0 - c.y, c.y - (by0 + h.c)), 0.f),
-                      dz = fmaxf(fmaxf(bz0 - c.z, c.z - (bz0 + h.c)), 0.f);
-          if (dx * dx + dy * dy + dz * dz < reach2) { if (fill) a.near_c[base + cnt] = c; ++cnt; }
-        }
-      }
-    return cnt;
-  };
+  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  for (int e = t; e < ne; e += 1024) a.near_start[e] = knn_near_visit(a, h, e, false);
   __threadfence();
   __syncthreads();
-  for (int e = t; e < ne; e += 1024) a.near_start[e] = visit(e, false);
-  __threadfence();
-  __syncthreads();
-  exclusive_scan(a.near_start, ne);
-  for (int e = t; e < ne; e += 1024) (void)visit(e, true);
+  block_exclusive_scan_1024(a.near_start, ne, sscan);
+  for (int e = t; e < ne; e += 1024) (void)knn_near_visit(a, h, e, true);
+}
+// the candidate lists of a large map, on the whole device: count -> scan (one workgroup) -> fill
+__global__ __launch_bounds__(256) void k_knn_near_count(KnnArgs a) {
+  const KnnGridHdr h = *a.grid;
+  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) a.near_start[e] = knn_near_visit(a, h, e, false);
+}
+__global__ __launch_bounds__(1024) void k_knn_near_scan(KnnArgs a) {
+  __shared__ int sscan[1024];
+  const KnnGridHdr h = *a.grid;
+  block_exclusive_scan_1024(a.near_start, (h.nx + 2) * (h.ny + 2) * (h.nz + 2), sscan);
+}
+__global__ __launch_bounds__(256) void k_knn_near_fill(KnnArgs a) {
+  const KnnGridHdr h = *a.grid;
+  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) (void)knn_near_visit(a, h, e, true);
 }
 
 // ---- point source -------------------------------------------------------------------------------------------------------
@@ -681,7 +704,16 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
   const int K = a.K;
   {
     NgmProfScope prof_(NGM_K_KNN_ASSIGN, st);
-    if (build_grid) hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
+    if (build_grid) {
+      a.near_inline = a.NF <= 2048 ? 1 : 0;
+      hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
+      if (!a.near_inline) {
+        const int nb = (int)std::min<int64_t>((4 * (int64_t)a.max_cells + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_knn_near_count, dim3(nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_knn_near_scan, dim3(1), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(k_knn_near_fill, dim3(nb), dim3(256), 0, st, a);
+      }
+    }
 #define NGM_KL(KK_)                                                                                                    \
     do {                                                                                                               \
       if (grid_in_lds) hipLaunchKernelGGL((k_knn_assign<true, KK_>), dim3(std::max(pb, 1)), dim3(256), lds_grid, st, a);  \

@@ -245,24 +245,28 @@ def test_nll_loss_modes_ragged_vs_oracle(F, R, n_c, n_g, photo, depth, geom):
 
 
 # ------------------------------------------------------------------------------------------------ fused image path
-@pytest.mark.parametrize("geo,S,K_,block,explicit_u", [("nrgbd", 24, 2, 1000, True), ("nrgbd", 640, 2, 700, False),
-                                                       ("density", 96, 3, 4096, False), ("occupancy", 64, 1, 333, True),
-                                                       ("neus", 40, 2, 512, False)])
-def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, explicit_u):
+@pytest.mark.parametrize("geo,S,K_,block,explicit_u,net", [("nrgbd", 24, 2, 1000, True, "fourier"), ("nrgbd", 640, 2, 700, False, "fourier"),
+                                                           ("density", 96, 3, 4096, False, "fourier"), ("occupancy", 64, 1, 333, True, "fourier"),
+                                                           ("neus", 40, 2, 512, False, "fourier"), ("nrgbd", 128, 4, 600, False, "hash"),
+                                                           ("nrgbd", 64, 2, 2048, True, "fourier_f32")])
+def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, explicit_u, net):
     """render_pixels as ONE call (ngm_render_eval_knn: samples drawn inside the neighbour assignment, blend inside the
     quadrature, grid over the centres built once) against the staged per-block entry points (ngm_sample_rays_world ->
     ngm_field_eval_knn -> ngm_composite_fwd_packed): the same blocks, draws and arithmetic, so the images are EQUAL bit for
     bit -- explicit jitter or in-kernel Philox, ragged last block, every geometry mode, K = 1..3, rays that leave every field
-    and (camera inside the map, far plane behind it) samples on both sides of the fields."""
+    and (camera inside the map, far plane behind it) samples on both sides of the fields; the default hash network and the
+    exact-fp32 evaluation kernel as well."""
     torch.manual_seed(S)
     g = torch.arange(-1.0, 1.01, 0.5)
     pos = torch.stack(torch.meshgrid(g, g, torch.tensor([-2.0, -1.5]), indexing="ij"), -1).reshape(-1, 3)
     pos = pos + 1e-3 * torch.randn_like(pos)
     NF = pos.shape[0]
     quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
-    r = make_renderer(FOURIER, dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_mode=geo,
-                                    eval_near_distance=0.0, eval_far_distance=4.0, eval_num_samples=S,
-                                    pixel_block_size=block), NF)
+    ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_mode=geo, eval_near_distance=0.0,
+               eval_far_distance=4.0, eval_num_samples=S, pixel_block_size=block)
+    if net == "fourier_f32":
+        ckw["mlp_matmul"] = "f32"                                          # the exact-fp32 MFMA evaluation kernel (four waves)
+    r = make_renderer(HASH if net == "hash" else FOURIER, ckw, NF)
     r._model._num_knn = K_
     _perturb(r)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))

@@ -29,7 +29,9 @@ struct SamplerArgs {
   float* points_cam; float* distances; float* dirs; float* points_world;
 };
 
-__global__ void k_sample_rays(SamplerArgs a) {
+// one thread per source element (rays longer than SR_MAXS samples): every element draws its own jitter and, for its rank,
+// up to three draws of the other stratum again
+__global__ void k_sample_rays_elem(SamplerArgs a) {
 #pragma clang fp contract(off)
   const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
   const int S_c = a.rc.num_samples_coarse, S_g = a.S - S_c;
@@ -55,12 +57,73 @@ __global__ void k_sample_rays(SamplerArgs a) {
   }
 }
 
+// A wave per batch of whole rays (as the fused forward does it): the ray-level quantities once per ray, ONE draw per element
+// into an LDS plane, then the closed-form ranks read their neighbours' draws from there -- the per-element kernel above
+// spends four Philox blocks and a ray set-up (three IEEE divisions, a root) on every sample.  Same arithmetic, same bits.
+#define SR_MAXS 1024
+struct SampWaveLds { float u[SR_MAXS]; float rt[32][8]; };
+__global__ __launch_bounds__(NGM_BLOCK) void k_sample_rays(SamplerArgs a, int rays_per_wave) {
+#pragma clang fp contract(off)
+  __shared__ SampWaveLds lds[NGM_WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SampWaveLds& wl = lds[wave];
+  const int64_t N = (int64_t)a.rays.F * a.rays.R;
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(N, gw * rays_per_wave), r_end = min(N, r_beg + rays_per_wave);
+  const int S = a.S, S_c = a.rc.num_samples_coarse, S_g = S - S_c;
+  const float inv_s = 1.0f / (float)S;
+  const uint64_t poff = philox_launch_offset(a.rays);
+  const int BR = max(1, min(32, SR_MAXS / S));
+  for (int64_t rb = r_beg; rb < r_end; rb += BR) {
+    const int nb = (int)min<int64_t>(BR, r_end - rb);
+    const int nsamp = nb * S;
+    if (lane < nb) {
+      const int64_t ray = rb + lane;
+      const RayGeom rg = ray_geom(a.rc, a.rays, ray, S_g > 0);
+      float* rt = wl.rt[lane];
+      rt[0] = rg.dx; rt[1] = rg.dy; rt[2] = rg.dz; rt[3] = rg.near; rt[4] = rg.far; rt[5] = rg.gnear; rt[6] = rg.gfar; rt[7] = rg.gt;
+      if (a.dirs) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
+    }
+    for (int idx = lane; idx < nsamp; idx += 64) {
+      const int rl = fdiv_idx2(idx, inv_s, S), e = idx - rl * S;
+      wl.u[idx] = (e < S_c) ? jitter(a.rays, poff, 0, rb + rl, S_c, e) : jitter(a.rays, poff, 1, rb + rl, S_g, e - S_c);
+    }
+    WAVE_SYNC();
+    for (int idx = lane; idx < nsamp; idx += 64) {
+      const int rl = fdiv_idx2(idx, inv_s, S), e = idx - rl * S;
+      const int64_t ray = rb + rl;
+      const float* rt = wl.rt[rl];
+      RayGeom rg;
+      rg.dx = rt[0]; rg.dy = rt[1]; rg.dz = rt[2]; rg.near = rt[3]; rg.far = rt[4]; rg.gnear = rt[5]; rg.gfar = rt[6]; rg.gt = rt[7];
+      float t; int rank;
+      sample_rank(a.rc, a.rays, poff, rg, ray, e, S_c, S_g, &t, &rank, wl.u + rl * S);
+      const int64_t o = ray * S + rank;
+      if (a.distances) a.distances[o] = t;
+      if (a.points_cam) { a.points_cam[3 * o] = rg.dx * t; a.points_cam[3 * o + 1] = rg.dy * t; a.points_cam[3 * o + 2] = rg.dz * t; }
+      if (a.points_world) {
+        float wx, wy, wz;
+        sample_world_point(a.rays, rg, ray, t, &wx, &wy, &wz);
+        a.points_world[3 * o] = wx; a.points_world[3 * o + 1] = wy; a.points_world[3 * o + 2] = wz;
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+
+static int comp_grid(int64_t N, int S, int* rays_per_wave);
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
                        float* dirs, float* points_world, hipStream_t st) {
   SamplerArgs a{*rc, *rays, S, points_cam, distances, dirs, points_world};
-  const int64_t total = (int64_t)rays->F * rays->R * S;
+  const int64_t N = (int64_t)rays->F * rays->R;
+  if (S <= SR_MAXS) {
+    int rpw;
+    const int blocks = comp_grid(N, S, &rpw);
+    hipLaunchKernelGGL(k_sample_rays, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);
+    return 0;
+  }
+  const int64_t total = N * S;
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_sample_rays, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_sample_rays_elem, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
   return 0;
 }
 
@@ -566,7 +629,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
       }
       const float ak = dC0 * c0 + dC1 * c1 + dC2 * c2 + dD * dp + dT;
       float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
-      seg_rscan_affine(A, B, kr, lane);
+      seg_rscan_affine64(A, B, kr, lane);
       const bool extends = valid && (kr > 63 - lane);
       const float Qend = extends ? carryQ : 0.f;
       const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);
@@ -812,7 +875,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
     };
     const float ak = a_of(c0, c1, c2, depth);
     float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
-    seg_rscan_affine(A, B, kr, lane);
+    seg_rscan_affine64(A, B, kr, lane);
     const bool extends = valid && (kr > 63 - lane);
     const float Qend = extends ? carryQ : 0.f;
     const float nA = __shfl_down(A, 1, 64), nB = __shfl_down(B, 1, 64);

@@ -277,9 +277,10 @@ __device__ __forceinline__ void knn_point_again(const KnnArgs& a, int64_t p, flo
 }
 
 // K nearest centres of every point, exact.  The (2 R + 1)^3 block of cells around the point's cell holds every centre
-// within R cell edges c of it.  Phase A decides the inside test of models.py:369 (c >= mask radius: R = 1 suffices) and
-// looks only at cells that can hold a centre within the mask radius -- four out of five samples of an image lie outside
-// every field and stop here.  Phase B (inside points) finds the K nearest: cells whose nearest face is already farther
+// within R cell edges c of it.  Phase A decides the inside test of models.py:369 from the candidate list of the point's cell
+// (k_knn_grid: every centre a point of that cell can be within the mask radius of) -- four out of five samples of an image
+// fall on an empty list and stop here -- and seeds the neighbour list with the centres within the radius.  Phase B (inside
+// points with fewer than K centres within the radius) finds the K nearest: cells whose nearest face is already farther
 // than the current K-th best are skipped, rows are narrowed in x the same way, and the block grows ring by ring until the
 // K-th neighbour found lies within R c (R = 1 wherever the map is as dense as its cover grid).  Ties in distance go to the
 // lower field index, as in a loop over the fields in order: the brute-force result bit for bit.

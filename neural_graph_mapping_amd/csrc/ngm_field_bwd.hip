@@ -553,24 +553,40 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
   int seg = -1;
   int64_t so = 0;
   float pv = 0.f, m0 = 0.f, v0 = 0.f, lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
-  if (q == 0 && p < a.ptot) {
+  const bool adam = q == 0 && p < a.ptot;
+  if (adam) {
     for (int k = 0; k < a.nseg; ++k)
       if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) { seg = k; break; }
     if (seg >= 0 && a.seg[seg].param) {
       const int64_t row = a.field_index ? a.field_index[f] : f;
       so = row * a.seg[seg].pstride + (p - a.seg[seg].off);
       pv = a.seg[seg].param[so]; m0 = a.seg[seg].m[so]; v0 = a.seg[seg].v[so];
-      const double step = (double)(a.step_dev ? *a.step_dev : a.step);
-      lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
-      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
     }
   }
+  // workgroup b of the backward kernel handled field b % F; quarter q sums blocks q, q + 4, ... in that order
+  const float* src = a.partials + (int64_t)f * a.p_pad + p;
+  const int64_t cs = (int64_t)a.F * a.p_pad;
+  int c = q;
+  // the first eight partials travel while the bias corrections are computed: a wave issues in order, and the two fp64 pow
+  // (~2 us of instructions) in front of these loads used to be a second latency in the chain
+  float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool pre = p < a.ptot && c + 28 < a.blocks_per_field;
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = src[(c + 4 * j) * cs];
+  }
+  if (adam && seg >= 0 && a.seg[seg].param) {
+    const double step = (double)(a.step_dev ? *a.step_dev : a.step);
+    lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+  }
   float s = 0.f;
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v8[j];
+    c += 32;
+  }
   if (p < a.ptot) {
-    // workgroup b of the backward kernel handled field b % F; quarter q sums blocks q, q + 4, ... in that order
-    const float* src = a.partials + (int64_t)f * a.p_pad + p;
-    const int64_t cs = (int64_t)a.F * a.p_pad;
-    int c = q;
 #pragma unroll 1
     for (; c + 28 < a.blocks_per_field; c += 32) {
       float v[8];
@@ -749,6 +765,14 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
   const int T = 1 << a.fc.log2_hashmap_size;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) tab[i] = 0ull;
+  // Adam's bias corrections (two double-precision pow) once per workgroup, up front, by one thread -- not by all 512 in the
+  // epilogue; read back after the barrier that ends the sample loop
+  __shared__ float adam_c[2];
+  if (a.chunks == 1 && a.ad_param && threadIdx.x == 0) {
+    const double step = (double)(a.ad_step_dev ? *a.ad_step_dev : a.ad_step);
+    adam_c[0] = (float)((double)a.ad_lr / (1.0 - pow((double)a.ad_beta1, step)));
+    adam_c[1] = (float)(1.0 / sqrt(1.0 - pow((double)a.ad_beta2, step)));
+  }
   float lp[8];
   {
     const float* hs = a.pr.shift + row * a.pr.shift_stride + 3 * level;
@@ -832,9 +856,7 @@ __global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
     float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
     int64_t prow = 0;
     if (a.ad_param) {
-      const double step = (double)(a.ad_step_dev ? *a.ad_step_dev : a.ad_step);
-      lr_bc1 = (float)((double)a.ad_lr / (1.0 - pow((double)a.ad_beta1, step)));
-      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.ad_beta2, step)));
+      lr_bc1 = adam_c[0]; inv_sqrt_bc2 = adam_c[1];
       prow = (a.ad_field_index ? a.ad_field_index[f] : f) * a.ad_stride + (int64_t)level * T * 2;
     }
     for (int i4 = threadIdx.x; i4 < T / 2; i4 += blockDim.x) {            // float4 = two entries x two features

@@ -35,6 +35,11 @@
 #define KNN_TILE 512
 #endif
 #define KNN_MAXK 4
+// the candidate lists are kept per SUB-cell (edge c / KNN_SUB) of the grid extended by one ring: a list holds the centres within
+// the mask radius of its box, and a box of half the edge sees half as many (13 instead of 26 on a cover-grid map) -- the
+// assignment walks its list for every point near a field
+#define KNN_SUB 2
+#define KNN_NEAR_PER_FIELD (27 * KNN_SUB * KNN_SUB * KNN_SUB)   // a centre is listed by sub-cells of its own and the 26 adjacent cells only
 #ifndef KNN_EVAL_B3_THREADS
 #define KNN_EVAL_B3_THREADS 512
 #endif
@@ -64,8 +69,8 @@ struct KnnArgs {
   float4* cell_c;       // (NF) centres grouped by cell: (x, y, z, field index as int bits)
   // per cell of the grid extended by one ring: the centres a point of that cell can be within the mask radius of (box
   // distance < radius; at most 27 cells per centre) -- the inside test and, where the map is dense, the whole search
-  int* near_start;      // (4 * max_cells + 1) exclusive prefix over the extended cells
-  float4* near_c;       // (27 * NF)
+  int* near_start;      // (KNN_SUB^3 * 4 * max_cells + 1) exclusive prefix over the sub-cells of the extended grid
+  float4* near_c;       // (KNN_NEAR_PER_FIELD * NF)
   int max_cells;
   float cell_size;      // requested cell edge (>= mask radius); the kernel may coarsen it to fit max_cells
   int hist_in_lds;      // per-workgroup field histograms fit the LDS (else: global atomics per pair)
@@ -124,14 +129,18 @@ __device__ __forceinline__ void block_exclusive_scan_1024(int* arr, int n, int* 
   __syncthreads();
 }
 
-// Candidate list of extended cell e (the grid plus one ring): the centres closer to the cell's box than the mask radius (a
+// Candidate list of sub-cell e of the extended grid (the grid plus one ring): the centres closer to its box than the mask radius (a
 // little more: the points are binned in fp32).  Four out of five samples of an image are nowhere near a field and fall
 // on an empty list; for the others the list replaces the walk over the 27 cells.  fill = false: count only.
+__device__ __forceinline__ int knn_near_cells(const KnnGridHdr& h) { return (h.nx + 2) * (h.ny + 2) * (h.nz + 2) * KNN_SUB * KNN_SUB * KNN_SUB; }
 __device__ __forceinline__ int knn_near_visit(const KnnArgs& a, const KnnGridHdr& h, int e, bool fill) {
-  const int ex = h.nx + 2, ey = h.ny + 2;
+  const int ex = (h.nx + 2) * KNN_SUB, ey = (h.ny + 2) * KNN_SUB;
   const float reach = a.radius * 1.001f + 1e-3f * h.c, reach2 = reach * reach;
-  const int cx = e % ex - 1, cy = (e / ex) % ey - 1, cz = e / (ex * ey) - 1;
-  const float bx0 = h.x0 + (float)cx * h.c, by0 = h.y0 + (float)cy * h.c, bz0 = h.z0 + (float)cz * h.c;
+  // sub-cell (sx, sy, sz) in units of c / KNN_SUB from the grid origin, -KNN_SUB .. (n + 1) KNN_SUB - 1; its coarse cell
+  const int sx = e % ex - KNN_SUB, sy = (e / ex) % ey - KNN_SUB, sz = e / (ex * ey) - KNN_SUB;
+  const int cx = (sx + KNN_SUB) / KNN_SUB - 1, cy = (sy + KNN_SUB) / KNN_SUB - 1, cz = (sz + KNN_SUB) / KNN_SUB - 1;
+  const float w = h.c * (1.0f / KNN_SUB);
+  const float bx0 = h.x0 + (float)sx * w, by0 = h.y0 + (float)sy * w, bz0 = h.z0 + (float)sz * w;
   int cnt = 0;
   const int base = fill ? a.near_start[e] : 0;
   for (int nz = max(cz - 1, 0); nz <= min(cz + 1, h.nz - 1); ++nz)
@@ -141,8 +150,8 @@ __device__ __forceinline__ int knn_near_visit(const KnnArgs& a, const KnnGridHdr
       const int rowb = (nz * h.ny + ny) * h.nx;
       for (int j = a.cell_start[rowb + xs]; j < a.cell_start[rowb + xe + 1]; ++j) {
         const float4 c = a.cell_c[j];
-        const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - (bx0 + h.c)), 0.f), dy = fmaxf(fmaxf(by0 - c.y, c.y - (by0 + h.c)), 0.f),
-                    dz = fmaxf(fmaxf(bz0 - c.z, c.z - (bz0 + h.c)), 0.f);
+        const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - (bx0 + w)), 0.f), dy = fmaxf(fmaxf(by0 - c.y, c.y - (by0 + w)), 0.f),
+                    dz = fmaxf(fmaxf(bz0 - c.z, c.z - (bz0 + w)), 0.f);
         if (dx * dx + dy * dy + dz * dz < reach2) { if (fill) a.near_c[base + cnt] = c; ++cnt; }
       }
     }
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   if (!a.near_inline) return;
   __threadfence();
   __syncthreads();
-  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  const int ne = knn_near_cells(h);
   for (int e = t; e < ne; e += 1024) a.near_start[e] = knn_near_visit(a, h, e, false);
   __threadfence();
   __syncthreads();
@@ -223,17 +232,17 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
 // the candidate lists of a large map, on the whole device: count -> scan (one workgroup) -> fill
 __global__ __launch_bounds__(256) void k_knn_near_count(KnnArgs a) {
   const KnnGridHdr h = *a.grid;
-  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  const int ne = knn_near_cells(h);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) a.near_start[e] = knn_near_visit(a, h, e, false);
 }
 __global__ __launch_bounds__(1024) void k_knn_near_scan(KnnArgs a) {
   __shared__ int sscan[1024];
   const KnnGridHdr h = *a.grid;
-  block_exclusive_scan_1024(a.near_start, (h.nx + 2) * (h.ny + 2) * (h.nz + 2), sscan);
+  block_exclusive_scan_1024(a.near_start, knn_near_cells(h), sscan);
 }
 __global__ __launch_bounds__(256) void k_knn_near_fill(KnnArgs a) {
   const KnnGridHdr h = *a.grid;
-  const int ne = (h.nx + 2) * (h.ny + 2) * (h.nz + 2);
+  const int ne = knn_near_cells(h);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) (void)knn_near_visit(a, h, e, true);
 }
 
@@ -322,7 +331,12 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
     // the centres this point can be within the mask radius of: the list of its cell (none two rings outside the grid)
     int nj0 = 0, nj1 = 0;
     if (!(ix < -1 || ix > h.nx || iy < -1 || iy > h.ny || iz < -1 || iz > h.nz)) {
-      const int e = ((iz + 1) * (h.ny + 2) + (iy + 1)) * (h.nx + 2) + (ix + 1);
+      // sub-cell of the point inside its (extended) cell; a point that fp32 puts just across a sub-cell face is covered by
+      // the margin of the lists' reach
+      const int ux = min(max((int)floorf(gx * KNN_SUB), ix * KNN_SUB), ix * KNN_SUB + KNN_SUB - 1),
+                uy = min(max((int)floorf(gy * KNN_SUB), iy * KNN_SUB), iy * KNN_SUB + KNN_SUB - 1),
+                uz = min(max((int)floorf(gz * KNN_SUB), iz * KNN_SUB), iz * KNN_SUB + KNN_SUB - 1);
+      const int e = ((uz + KNN_SUB) * ((h.ny + 2) * KNN_SUB) + (uy + KNN_SUB)) * ((h.nx + 2) * KNN_SUB) + (ux + KNN_SUB);
       nj0 = a.near_start[e]; nj1 = a.near_start[e + 1];
     }
     if (nj0 == nj1) {                                            // nowhere near a field: outside, no search
@@ -598,7 +612,7 @@ int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
   const int64_t n = P * K;
   const int64_t mc = knn_max_cells(num_fields);
   return 256 * 12 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16) +
-         256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16) + 16 * mc + 16 * 27 * (int64_t)num_fields + 1024;
+         256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16) + 16 * KNN_SUB * KNN_SUB * KNN_SUB * mc + 16 * KNN_NEAR_PER_FIELD * (int64_t)num_fields + 1024;
 }
 // + the distances of the generated samples and the ray directions of one block of rays (ngm_render_eval_knn)
 int64_t ngm_knn_render_workspace_bytes(int num_fields, int ray_block, int S, int K) {
@@ -675,8 +689,8 @@ static void knn_carve(KnnArgs& a, void* workspace, char** end) {
   a.cell_start = reinterpret_cast<int*>(carve(4 * ((int64_t)a.max_cells + 1)));
   a.cell_fill = reinterpret_cast<int*>(carve(4 * (int64_t)a.max_cells));
   a.cell_c = reinterpret_cast<float4*>(carve(16 * (int64_t)a.NF));
-  a.near_start = reinterpret_cast<int*>(carve(4 * (4 * (int64_t)a.max_cells + 1)));
-  a.near_c = reinterpret_cast<float4*>(carve(16 * 27 * (int64_t)a.NF));
+  a.near_start = reinterpret_cast<int*>(carve(4 * (KNN_SUB * KNN_SUB * KNN_SUB * 4 * (int64_t)a.max_cells + 1)));
+  a.near_c = reinterpret_cast<float4*>(carve(16 * KNN_NEAR_PER_FIELD * (int64_t)a.NF));
   *end = w;
 }
 
@@ -709,7 +723,7 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
       a.near_inline = a.NF <= 2048 ? 1 : 0;
       hipLaunchKernelGGL(k_knn_grid, dim3(1), dim3(1024), 0, st, a);
       if (!a.near_inline) {
-        const int nb = (int)std::min<int64_t>((4 * (int64_t)a.max_cells + 255) / 256, 2048);
+        const int nb = (int)std::min<int64_t>((KNN_SUB * KNN_SUB * KNN_SUB * 4 * (int64_t)a.max_cells + 255) / 256, 2048);
         hipLaunchKernelGGL(k_knn_near_count, dim3(nb), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_knn_near_scan, dim3(1), dim3(1024), 0, st, a);
         hipLaunchKernelGGL(k_knn_near_fill, dim3(nb), dim3(256), 0, st, a);

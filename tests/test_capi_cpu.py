@@ -103,7 +103,7 @@ def test_ops_are_registered_with_the_dispatcher(capi):
     from torch._subclasses.fake_tensor import FakeTensorMode
     from neural_graph_mapping_amd import mesh, ops  # noqa: F401
     names = {"sample_rays", "field_eval", "field_eval_bwd", "field_eval_knn", "quadrature", "quadrature_bwd",
-             "composite_packed", "render_ijs", "render_ijs_bwd", "adam_sparse_", "marching_cubes"}
+             "composite_packed", "render_ijs", "render_ijs_bwd", "adam_sparse_", "marching_cubes", "render_eval_knn"}
     for n in names:
         assert hasattr(torch.ops.ngm355, n), n
     assert "Tensor(a0!) param" in str(torch.ops.ngm355.adam_sparse_.default._schema)        # declared as mutating
@@ -123,6 +123,12 @@ def test_ops_are_registered_with_the_dispatcher(capi):
         o = torch.ops.ngm355.field_eval(ops.cfg_blob(fc), torch.empty(1, 8, 3, device="cuda"), None, None,
                                         [torch.empty(p.shape, device="cuda") for p in params])
         assert tuple(o.shape) == (1, 8, 4)
+        ij1 = torch.empty(7, 2, dtype=torch.int64, device="cuda")
+        e4 = torch.empty(4, 4, device="cuda")
+        out = torch.ops.ngm355.render_eval_knn(ops.cfg_blob(fc), ops.cfg_blob(rc), ij1, e4, None, None, None, 0, 0.0, 8.0,
+                                               torch.empty(3, 3, device="cuda"), torch.empty(3, 4, device="cuda"),
+                                               [torch.empty(p.shape, device="cuda") for p in params], 2, 10.0, 1.0, None, 0.0, 8192)
+        assert [tuple(o.shape) for o in out] == [(7, 4), (7, 3), (7,), (7,)]
 
 
 def test_graft_entry_build_passes():

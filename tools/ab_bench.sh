@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 for rep in 1 2; do
 for n in "$@"; do
-  NGM_LIB_PATH=$PWD/neural_graph_mapping_amd/lib/libngm_$n.so timeout 300 python bench.py --no-cpu-baseline --no-aux-hash > gpurun_out/ab_${n}_$rep.json 2> gpurun_out/ab_${n}_$rep.err || tail -3 gpurun_out/ab_${n}_$rep.err
+  NGM_LIB_PATH=$PWD/neural_graph_mapping_amd/lib/libngm_$n.so timeout 300 python bench.py --no-cpu-baseline --no-aux-hash --no-aux-default > gpurun_out/ab_${n}_$rep.json 2> gpurun_out/ab_${n}_$rep.err || tail -3 gpurun_out/ab_${n}_$rep.err
 done; done
 python - "$@" <<'PY'
 import json,sys

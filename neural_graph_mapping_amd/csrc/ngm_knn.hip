@@ -202,6 +202,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   const int nc = h.ncells;
   for (int i = t; i <= nc; i += 1024) a.cell_start[i] = 0;
   for (int i = t; i < nc; i += 1024) a.cell_fill[i] = 0;
+  for (int i = t; i < a.NF; i += 1024) a.counts[i] = 0;     // pairs per field: zero for the first assignment (k_knn_offsets re-zeroes)
   __threadfence();            // the counts are changed by L2 atomics below: no stale L1 line may serve the reads after them
   __syncthreads();
   auto cell_of = [&](int f) {
@@ -481,7 +482,7 @@ __global__ void k_knn_offsets(KnnArgs a) {
       const int oc = __shfl_up(sc, d, 64), ot = __shfl_up(st, d, 64);
       if (lane >= d) { sc += oc; st += ot; }
     }
-    if (f < a.NF) { a.seg_off[f] = so + sc - c; a.tile_off[f] = to + st - t; a.cursor[f] = 0; }
+    if (f < a.NF) { a.seg_off[f] = so + sc - c; a.tile_off[f] = to + st - t; a.cursor[f] = 0; a.counts[f] = 0; }   // counts: ready for the next block's assignment
     so += __shfl(sc, 63, 64); to += __shfl(st, 63, 64);
   }
   if (lane == 0) { a.seg_off[a.NF] = so; a.tile_off[a.NF] = to; }
@@ -697,7 +698,7 @@ static void knn_carve(KnnArgs& a, void* workspace, char** end) {
 // grid build (optional) -> assignment -> offsets -> scatter -> per-field evaluation of the pairs; the blend is the caller's
 static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
   const int64_t n = a.P * a.K;
-  (void)hipMemsetAsync(a.counts, 0, 4 * (size_t)a.NF, st);
+  // (the pair counts are zero here: k_knn_grid zeroes them, k_knn_offsets re-zeroes them after use)
   const int pb = (int)std::min<int64_t>((a.P + 255) / 256, 4096);
   // per-workgroup field histograms (assignment, scatter) in LDS while they fit (150 KB = 38 400 fields); beyond: global atomics
   const size_t lds_h = (size_t)a.NF * 4;

@@ -263,7 +263,7 @@ def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, expl
     NF = pos.shape[0]
     quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
     ckw = dict(num_samples_coarse=8, num_samples_depth_guided=16, geometry_mode=geo, eval_near_distance=0.0,
-               eval_far_distance=4.0, eval_num_samples=S, pixel_block_size=block)
+               eval_far_distance=4.0, eval_num_samples=S, pixel_block_size=block, eval_ray_block=block)
     if net == "fourier_f32":
         ckw["mlp_matmul"] = "f32"                                          # the exact-fp32 MFMA evaluation kernel (four waves)
     r = make_renderer(HASH if net == "hash" else FOURIER, ckw, NF)

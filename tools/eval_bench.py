@@ -29,6 +29,8 @@ def main():
             encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4),
             num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=0.5, scale_mode="unit_cube").to(dev)
         cfg = Rr.shipped_config(field_radius=0.5, eval_near_distance=0.0, eval_far_distance=8.0, eval_num_samples=S)
+        if os.environ.get("NGM_EVAL_RAY_BLOCK"):
+            cfg["eval_ray_block"] = int(os.environ["NGM_EVAL_RAY_BLOCK"])
         r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
         r.add_fields(NF)
         r.set_field_poses(pos.to(dev), quat.to(dev))

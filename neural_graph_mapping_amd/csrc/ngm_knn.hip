@@ -35,6 +35,9 @@
 #define KNN_TILE 512
 #endif
 #define KNN_MAXK 4
+#ifndef KNN_ASSIGN_MAX_WG
+#define KNN_ASSIGN_MAX_WG 4096
+#endif
 // the candidate lists are kept per SUB-cell (edge c / KNN_SUB) of the grid extended by one ring: a list holds the centres within
 // the mask radius of its box, and a box of half the edge sees half as many (13 instead of 26 on a cover-grid map) -- the
 // assignment walks its list for every point near a field
@@ -699,7 +702,7 @@ static void knn_carve(KnnArgs& a, void* workspace, char** end) {
 static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
   const int64_t n = a.P * a.K;
   // (the pair counts are zero here: k_knn_grid zeroes them, k_knn_offsets re-zeroes them after use)
-  const int pb = (int)std::min<int64_t>((a.P + 255) / 256, 4096);
+  const int pb = (int)std::min<int64_t>((a.P + 255) / 256, KNN_ASSIGN_MAX_WG);
   // per-workgroup field histograms (assignment, scatter) in LDS while they fit (150 KB = 38 400 fields); beyond: global atomics
   const size_t lds_h = (size_t)a.NF * 4;
   a.hist_in_lds = lds_h <= 150 * 1024 ? 1 : 0;

@@ -35,6 +35,11 @@
 #define KNN_TILE 512
 #endif
 #define KNN_MAXK 4
+// copies of the per-field pair counters: 4096 workgroups flushing their histograms into ~100 addresses serialise on the
+// device-scope atomics; sixteen copies, summed by k_knn_offsets
+#ifndef KNN_COUNT_REPL
+#define KNN_COUNT_REPL 16
+#endif
 #ifndef KNN_ASSIGN_MAX_WG
 #define KNN_ASSIGN_MAX_WG 4096
 #endif
@@ -59,7 +64,7 @@ struct KnnArgs {
   // workspace
   int* pair_field;      // (P*K)  field of the pair, -1 if the point is outside every field
   float* pair_w;        // (P*K)
-  int* counts;          // (NF)   pairs per field
+  int* counts;          // (KNN_COUNT_REPL, NF) pairs per field, replicated: workgroup b adds into copy b % KNN_COUNT_REPL
   int* cursor;          // (NF)
   int* seg_off;         // (NF+1)
   int* tile_off;        // (NF+1)
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_knn_grid(KnnArgs a) {
   const int nc = h.ncells;
   for (int i = t; i <= nc; i += 1024) a.cell_start[i] = 0;
   for (int i = t; i < nc; i += 1024) a.cell_fill[i] = 0;
-  for (int i = t; i < a.NF; i += 1024) a.counts[i] = 0;     // pairs per field: zero for the first assignment (k_knn_offsets re-zeroes)
+  for (int i = t; i < KNN_COUNT_REPL * a.NF; i += 1024) a.counts[i] = 0;     // pairs per field: zero for the first assignment (k_knn_offsets re-zeroes)
   __threadfence();            // the counts are changed by L2 atomics below: no stale L1 line may serve the reads after them
   __syncthreads();
   auto cell_of = [&](int f) {
@@ -460,14 +465,14 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
       if (k < K) {
         a.pair_field[p * K + k] = bi[k];
         a.pair_w[p * K + k] = e[k] / sum;
-        if (bi[k] >= 0) { if (a.hist_in_lds) atomicAdd(&hist[bi[k]], 1); else atomicAdd(&a.counts[bi[k]], 1); }
+        if (bi[k] >= 0) { if (a.hist_in_lds) atomicAdd(&hist[bi[k]], 1); else atomicAdd(&a.counts[(int64_t)(blockIdx.x % KNN_COUNT_REPL) * a.NF + bi[k]], 1); }
       }
     }
   }
   if (a.hist_in_lds) {
     __syncthreads();
     for (int i = threadIdx.x; i < a.NF; i += blockDim.x)
-      if (hist[i]) atomicAdd(&a.counts[i], hist[i]);
+      if (hist[i]) atomicAdd(&a.counts[(int64_t)(blockIdx.x % KNN_COUNT_REPL) * a.NF + i], hist[i]);
   }
 }
 
@@ -477,7 +482,11 @@ __global__ void k_knn_offsets(KnnArgs a) {
   int so = 0, to = 0;
   for (int f0 = 0; f0 < a.NF; f0 += 64) {
     const int f = f0 + lane;
-    const int c = (f < a.NF) ? a.counts[f] : 0;
+    int c = 0;
+    if (f < a.NF) {
+#pragma unroll
+      for (int r = 0; r < KNN_COUNT_REPL; ++r) { c += a.counts[(int64_t)r * a.NF + f]; a.counts[(int64_t)r * a.NF + f] = 0; }   // summed, and ready for the next block
+    }
     const int t = (c + KNN_TILE - 1) / KNN_TILE;
     int sc = c, st = t;                  // inclusive wave scans
 #pragma unroll
@@ -485,7 +494,7 @@ __global__ void k_knn_offsets(KnnArgs a) {
       const int oc = __shfl_up(sc, d, 64), ot = __shfl_up(st, d, 64);
       if (lane >= d) { sc += oc; st += ot; }
     }
-    if (f < a.NF) { a.seg_off[f] = so + sc - c; a.tile_off[f] = to + st - t; a.cursor[f] = 0; a.counts[f] = 0; }   // counts: ready for the next block's assignment
+    if (f < a.NF) { a.seg_off[f] = so + sc - c; a.tile_off[f] = to + st - t; a.cursor[f] = 0; }
     so += __shfl(sc, 63, 64); to += __shfl(st, 63, 64);
   }
   if (lane == 0) { a.seg_off[a.NF] = so; a.tile_off[a.NF] = to; }
@@ -615,7 +624,7 @@ static int knn_max_cells(int num_fields) { return (int)std::min<int64_t>(std::ma
 int64_t ngm_knn_workspace_bytes(int num_fields, int64_t P, int K) {
   const int64_t n = P * K;
   const int64_t mc = knn_max_cells(num_fields);
-  return 256 * 12 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)(4 * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16) +
+  return 256 * 12 + 4 * (n + 255) + 4 * (n + 255) + 4 * (int64_t)((3 + KNN_COUNT_REPL) * num_fields + 64) + 4 * (n + 255) + 16 * (n + 16) +
          256 + 4 * (2 * mc + 2) + 16 * ((int64_t)num_fields + 16) + 16 * KNN_SUB * KNN_SUB * KNN_SUB * mc + 16 * KNN_NEAR_PER_FIELD * (int64_t)num_fields + 1024;
 }
 // + the distances of the generated samples and the ray directions of one block of rays (ngm_render_eval_knn)
@@ -682,7 +691,7 @@ static void knn_carve(KnnArgs& a, void* workspace, char** end) {
   auto carve = [&](int64_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
   a.pair_field = reinterpret_cast<int*>(carve(4 * n));
   a.pair_w = reinterpret_cast<float*>(carve(4 * n));
-  a.counts = reinterpret_cast<int*>(carve(4 * a.NF));
+  a.counts = reinterpret_cast<int*>(carve(4 * (int64_t)KNN_COUNT_REPL * a.NF));
   a.cursor = reinterpret_cast<int*>(carve(4 * a.NF));
   a.seg_off = reinterpret_cast<int*>(carve(4 * (a.NF + 1)));
   a.tile_off = reinterpret_cast<int*>(carve(4 * (a.NF + 1)));

@@ -503,7 +503,9 @@ __global__ void k_knn_offsets(KnnArgs a) {
 // Counting-sort scatter in two levels: every workgroup ranks its SC_ITEMS * 256 pairs per field with LDS atomics,
 // reserves one contiguous range per field with ONE global atomic, then writes.  (One global atomic per pair on the
 // per-field cursor serialised badly -- neighbouring pixels hit the same field -- and took 80 % of render_image.)
+#ifndef SC_ITEMS
 #define SC_ITEMS 32
+#endif
 __global__ __launch_bounds__(256) void k_knn_scatter(KnnArgs a) {
   extern __shared__ int sc_lds[];
   int* hist = sc_lds;            // NF: pairs of this workgroup per field, then the reserved global base

@@ -282,6 +282,43 @@ def aux_default_line(dev, args, use_graph):
                 launch="hipGraph replay" if use_graph else "eager", kernels_us={k: round(v["avg_us"], 2) for k, v in kh.items()}, **roof)
 
 
+def aux_render_image_line(dev):
+    """The evaluation path: `render_image` 640 x 480 pixels x 640 eval samples, kNN-blended (K = 2) over a
+    map of 126 Fourier(64) + 2x64 fields on a 9 x 7 x 2 grid in front of the camera -- ONE C call (ngm_render_eval_knn).
+    Median of five renders after one warm-up; the same workload as tools/eval_bench.py."""
+    import time
+    from neural_graph_mapping_amd import models as M
+    from neural_graph_mapping_amd import renderer as Rr
+    torch.manual_seed(0)
+    g = torch.arange(-2.0, 2.01, 0.5)
+    pos = torch.stack(torch.meshgrid(g, g[:7], torch.tensor([-3.0, -2.5]), indexing="ij"), -1).reshape(-1, 3)
+    NF, S = pos.shape[0], 640
+    quat = torch.zeros(NF, 4)
+    quat[:, 0] = 1
+    model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=D_ENC, mu=0.0, sigma=4.0, raw_coords=True), num_layers=N_LAYERS, dim_out=4),
+        num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=0.5, scale_mode="unit_cube").to(dev)
+    cfg = Rr.shipped_config(field_radius=0.5, eval_near_distance=0.0, eval_far_distance=8.0, eval_num_samples=S)
+    cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
+    r.add_fields(NF)
+    r.set_field_poses(pos.to(dev), quat.to(dev))
+    c2w = torch.eye(4, device=dev)
+    r.render_image(c2w)
+    times = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.render_image(c2w)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[2]
+    return dict(workload=f"render_image 640 x 480 x {S} eval samples, kNN blend (K = 2) over {NF} Fourier({D_ENC}) + {N_LAYERS}x64 fields, "
+                         "in-kernel Philox jitter, one ngm_render_eval_knn call (internal blocks of 32768 rays)",
+                ms_per_image=1e3 * dt, value=640 * 480 * S / dt, unit="ray-samples/s (render only)", knn_matmul=r.last_matmul("knn"))
+
+
 def launch_ranks(n):
     """Re-exec this script under torch.distributed.run with n ranks on this node; returns the exit code."""
     import socket
@@ -431,7 +468,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.0,
                     help="keep timing windows until this much timed GPU work has run (default 0: exactly --windows)")
     ap.add_argument("--no-aux-default", action="store_true",
-                    help="skip `aux_default`: the reference's default iteration (32 fields x 512 rays x (8 + 16) samples, "
+                    help="skip `aux_default` and `aux_render_image`: the reference's default iteration (32 fields x 512 rays x (8 + 16) samples, "
                          "hash 16 x 2 + 1 x 32 network: config/neural_graph_map.yaml)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
@@ -626,6 +663,9 @@ def main():
     aux_default = None
     if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_default:
         aux_default = aux_default_line(dev, args, use_graph)
+    aux_image = None
+    if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_default:
+        aux_image = aux_render_image_line(dev)
     if rank == 0:
         n_local = F_PER_GPU * R * (S_C + S_G)
         value = world * n_local * args.steps / dt
@@ -704,6 +744,8 @@ def main():
             res["aux_hash"] = aux_hash
         if aux_default:
             res["aux_default"] = aux_default
+        if aux_image:
+            res["aux_render_image"] = aux_image
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -459,6 +459,10 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
   const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
   const int mode = a.rc.geometry_mode;
   constexpr int CH = (SRC >= 1 && SRC <= 4) ? 5 : 4;
+  // most wave steps of an image lie outside every field: all 64 geometry values are the constant outside value, and so is
+  // their occupancy -- computed once here (two expf, two IEEE divisions otherwise, per sample)
+  const float gm_ref = a.outside_value;
+  const float occ_ref = occ_pointwise(mode, a.rc.geometry_factor, gm_ref, nullptr);
   for (int64_t ray = r_beg; ray < r_end; ++ray) {
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;       // running sums (wave-uniform)
     float carry = 1.0f;
@@ -469,7 +473,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
       for (int c = 0; c < CH; ++c) {
         const int k = base0 + 64 * c + lane;
         if (base0 + 64 * c < S) {
-          const float occ = occ_pointwise(mode, a.rc.geometry_factor, in[c].gm, nullptr);
+          const bool all_ref = __builtin_amdgcn_ballot_w64(in[c].gm != gm_ref) == 0ull;      // (wave-uniform; same function, same input)
+          const float occ = all_ref ? occ_ref : occ_pointwise(mode, a.rc.geometry_factor, in[c].gm, nullptr);
           float q = wave_scan_mul(1.0f - occ);
           q *= carry;                                              // (carry = 1 in the ray's first step)
           const float up = lane_prev(q, carry);

@@ -696,7 +696,6 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_stash_bwd(StashBwdArgs a, int ray
   const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
   const int64_t r_beg = min(N, gw * rays_per_wave), r_end = min(N, r_beg + rays_per_wave);
   const int S = a.S;
-  const float inv_s = 1.0f / (float)S;
   const float tau = a.rc.truncation_distance, gamma = a.rc.geometry_factor, cf = a.rc.color_factor;
   const int mode = a.rc.geometry_mode;
   // The streams of a step (stash, ray table, per-ray predictions / targets) are fetched ONE STEP AHEAD: the first step's

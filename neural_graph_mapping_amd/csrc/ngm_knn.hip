@@ -279,7 +279,8 @@ __device__ __forceinline__ void knn_point_draw(const KnnArgs& a, uint64_t poff, 
   rg.dx = a.ray_dir[3 * ray]; rg.dy = a.ray_dir[3 * ray + 1]; rg.dz = a.ray_dir[3 * ray + 2];
   const float4 st = a.ray_tab[ray];                      // near, span, delta
   // strat_t (ngm_device.h) on the ray's precomputed span and delta: t = (delta u + lin_e span) + near
-  const float u = jitter(a.rays, poff, 0, ray, a.S, e);
+  // jitter() of the sampler with its element index ray * S + e == p taken as is (no 64-bit multiply per sample)
+  const float u = a.rays.u_coarse ? a.rays.u_coarse[p] : philox_uniform(a.rays.philox_seed, poff, (uint64_t)p, 0u);
   const float b = strat_lin(a.rays.lin_coarse, a.S, e) * st.y;
   const float du = st.z * u;
   const float sm = du + b;

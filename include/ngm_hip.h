@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 6 /* 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 7 /* 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -250,6 +250,15 @@ int ngm_field_eval_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
 int ngm_encode_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
                    const float* points, const float* field_pos, const float* field_quat,
                    float* out, void* stream);
+/* Backward of the encoding alone: d_enc (F,P,dim_enc) -> the encoding's parameter gradients, fully overwritten.  Fourier
+ * (positional_encodings.py:197-212): grads->enc_w (F, dim_enc - 3, 3) = sum_p d_enc cos(W x) x; permutohedral hash
+ * (:19-66): grads->lattice (F, L, T, 2) through the table-gradient kernel of the training step.  NeRF octaves / no encoding
+ * have no parameters (returns NGM_OK, nothing written); the triplane encoding returns NGM_E_UNSUPPORTED (its gradient exists
+ * inside ngm_field_eval_bwd only).  Other members of `grads` are ignored. */
+int64_t ngm_encode_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64_t P);
+int ngm_encode_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                   const float* field_pos, const float* field_quat, const float* d_enc, const ngm_grads* grads,
+                   void* workspace, int64_t workspace_bytes, void* stream);
 /* Backward of the above w.r.t. every parameter: d_out (F,P,4) -> grads.  workspace: see
  * ngm_field_eval_bwd_workspace(). */
 int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,

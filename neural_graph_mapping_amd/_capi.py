@@ -135,6 +135,10 @@ def lib():
     L.ngm_field_eval_fwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, vp]
     L.ngm_encode_fwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, vp]
     L.ngm_encode_fwd.restype = C.c_int
+    L.ngm_encode_bwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp]
+    L.ngm_encode_bwd.restype = C.c_int
+    L.ngm_encode_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
+    L.ngm_encode_bwd_workspace.restype = i64
     L.ngm_field_eval_bwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp]
     L.ngm_field_eval_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
     L.ngm_field_eval_bwd_workspace.restype = i64
@@ -205,7 +209,7 @@ def lib():
 
 EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto_fill_scales", "ngm_sample_rays", "ngm_sample_rays_world",
             "ngm_composite_fwd_packed",
-            "ngm_field_eval_fwd", "ngm_encode_fwd", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
+            "ngm_field_eval_fwd", "ngm_encode_fwd", "ngm_encode_bwd", "ngm_encode_bwd_workspace", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_bwd_seeded_vars", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_render_eval_knn", "ngm_render_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",

@@ -388,6 +388,60 @@ int ngm_encode_fwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t 
   return check_launch("ngm_encode_fwd");
 }
 
+static int64_t hash_scratch_bytes(const ngm_field_cfg* fc, int F, int64_t P);
+static void carve_hash_scratch(const ngm_field_cfg* fc, int F, int64_t P, char* base, FieldBwdArgs& a);
+
+int64_t ngm_encode_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64_t P) {
+  if (!fcfg || F < 1 || P < 0) return NGM_E_INVALID;
+  if (fcfg->encoding == NGM_ENC_PERMUTO) return hash_scratch_bytes(fcfg, F, P) + 512;
+  if (fcfg->encoding == NGM_ENC_FOURIER) return ngm_encode_bwd_fourier_scratch(F, P) + 512;
+  return 256;
+}
+
+int ngm_encode_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                   const float* field_pos, const float* field_quat, const float* d_enc, const ngm_grads* grads, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !d_enc || !grads || F < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_encode_bwd: bad argument");
+  if ((field_pos == nullptr) != (field_quat == nullptr)) return fail(NGM_E_INVALID, "pos/quat must both be given");
+  if (fcfg->encoding == NGM_ENC_TRIPLANE)
+    return fail(NGM_E_UNSUPPORTED, "ngm_encode_bwd: the triplane encoding has no standalone backward stage (ngm_field_eval_bwd)");
+  if (fcfg->encoding != NGM_ENC_PERMUTO && fcfg->encoding != NGM_ENC_FOURIER) return NGM_OK;     // no parameters
+  if (!workspace || workspace_bytes < ngm_encode_bwd_workspace(fcfg, F, P)) return fail(NGM_E_WORKSPACE, "ngm_encode_bwd: workspace too small");
+  char* base = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (fcfg->encoding == NGM_ENC_FOURIER) {
+    if (!grads->enc_w) return fail(NGM_E_INVALID, "ngm_encode_bwd: grads->enc_w is NULL");
+    if (P == 0) {
+      const int64_t n = (int64_t)(fcfg->dim_enc - (fcfg->raw_coords ? 3 : 0)) * 3;
+      for (int f = 0; f < F; ++f) (void)hipMemsetAsync(grads->enc_w + f * grads->enc_w_stride, 0, 4 * (size_t)n, st);
+      return check_launch("ngm_encode_bwd");
+    }
+    rc = ngm_launch_encode_bwd_fourier(*fcfg, *params, F, P, points, field_pos, field_quat, d_enc, grads->enc_w, grads->enc_w_stride,
+                                       reinterpret_cast<float*>(base), st);
+    if (rc) return fail(rc, "ngm_encode_bwd: launch failed");
+    return check_launch("ngm_encode_bwd");
+  }
+  if (!grads->lattice) return fail(NGM_E_INVALID, "ngm_encode_bwd: grads->lattice is NULL");
+  FieldBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = F; a.P = P;
+  carve_hash_scratch(fcfg, F, P, base, a);
+  a.lattice_grad = grads->lattice; a.lattice_grad_stride = grads->lattice_stride;
+  if (P == 0) {
+    const int64_t n = (int64_t)fcfg->nr_levels * ((int64_t)1 << fcfg->log2_hashmap_size) * 2;
+    for (int f = 0; f < F; ++f) (void)hipMemsetAsync(grads->lattice + f * grads->lattice_stride, 0, 4 * (size_t)n, st);
+    return check_launch("ngm_encode_bwd");
+  }
+  rc = ngm_launch_encode_bwd_prep_hash(*fcfg, *params, F, P, points, field_pos, field_quat, d_enc, a.hash_dE, a.hash_xyz, st);
+  if (!rc) rc = ngm_launch_hash_grad(a, st);
+  if (rc) return fail(rc, "ngm_encode_bwd: table size not supported by the table-gradient kernel");
+  return check_launch("ngm_encode_bwd");
+}
+
 // unit: samples a workgroup's range is a multiple of -- whole 32-sample tiles for each of its waves (4 waves: 128; the
 // hash network's 8-wave backward: 256)
 static void plan_bwd(int F, int64_t P, int64_t* per_block, int* bpf, int64_t unit = 32 * NGM_WAVES_PER_BLOCK) {

@@ -11,6 +11,7 @@
 #include "ngm_launch.h"
 
 #include <algorithm>
+#include <cstring>
 
 #define WAVE_SYNC()                                        \
   do {                                                     \
@@ -142,6 +143,124 @@ int ngm_launch_encode_points(const ngm_field_cfg& fc, const ngm_params& pr, int 
   a.fc = fc; a.pr = pr; a.F = F; a.P = P; a.points = points; a.pos = pos; a.quat = quat; a.out = out;
   const int bx = (int)std::min<int64_t>((P + 255) / 256, 4096);
   hipLaunchKernelGGL(k_encode_points, dim3(std::max(bx, 1), F), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the encoding ALONE (ngm_encode_bwd): d_enc (F, P, dim_enc) -> the encoding's parameter
+// gradients.  Fourier: dW[j][c] = sum_p d_enc[p][n_raw + j] cos(W_j . x_p) x_p[c] (positional_encodings.py:197-212), a wave
+// per subset of the points with lane = feature, per-wave partials summed in a fixed order (deterministic).  Hash: the
+// gradients are transposed to the level-major stream k_hash_grad reads (what k_hash_mlp_bwd hands it in the training step)
+// together with the scaled local positions; the table gradient is that kernel's.  NeRF octaves / no encoding: no parameters.
+// ------------------------------------------------------------------------------------------------
+struct EncodeBwdArgs {
+  ngm_field_cfg fc; ngm_params pr; int F; int64_t P;
+  const float* points; const float* pos; const float* quat; const float* d_enc;
+  float2* dE; float4* xyz;                   // hash: outputs for k_hash_grad
+  float* part; int nblk; int64_t per_blk;    // fourier: [F][nblk][4][64][3] partial sums
+  float* grad; int64_t grad_stride;          // fourier: (F, dim_enc - n_raw, 3)
+};
+__device__ __forceinline__ Vec3 encode_local_point(const EncodeBwdArgs& a, int f, int64_t p, float div, float off) {
+  const float* pt = a.points + ((int64_t)f * a.P + p) * 3;
+  Vec3 v{pt[0], pt[1], pt[2]};
+  if (a.pos) {
+    const float px = a.pos[3 * f], py = a.pos[3 * f + 1], pz = a.pos[3 * f + 2];
+    v = Vec3{v.x - px, v.y - py, v.z - pz};
+    v = quat_rotate_inv(a.quat[4 * f], a.quat[4 * f + 1], a.quat[4 * f + 2], a.quat[4 * f + 3], v);
+  }
+  return Vec3{v.x / div + off, v.y / div + off, v.z / div + off};      // the arithmetic of k_encode_points
+}
+__global__ __launch_bounds__(256) void k_encode_bwd_prep_hash(EncodeBwdArgs a) {
+  const int f = blockIdx.y, D = a.fc.dim_enc, nlev = a.fc.nr_levels;
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const int64_t NP = (int64_t)a.F * a.P;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = (int64_t)f * a.P + p;
+    const Vec3 v = encode_local_point(a, f, p, div, off);
+    a.xyz[g] = make_float4(v.x, v.y, v.z, 0.f);
+    const float* d = a.d_enc + g * D;
+    if ((D & 3) == 0 && nlev * 2 == D) {          // 16-byte row reads (two levels each), 8-byte level-major writes
+      for (int l0 = 0; l0 < nlev; l0 += 2) {
+        const float4 q = *reinterpret_cast<const float4*>(d + 2 * l0);
+        a.dE[l0 * NP + g] = make_float2(q.x, q.y);
+        a.dE[(l0 + 1) * NP + g] = make_float2(q.z, q.w);
+      }
+    } else {
+      for (int level = 0; level < nlev; ++level) a.dE[level * NP + g] = make_float2(d[2 * level], d[2 * level + 1]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_encode_bwd_fourier(EncodeBwdArgs a) {
+  const int f = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
+  const int D = a.fc.dim_enc, n_raw = a.fc.raw_coords ? 3 : 0, nfeat = D - n_raw;
+  float div, off;
+  scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+  const bool act = lane < nfeat;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  if (act) {
+    const int64_t e0 = row * a.pr.enc_w_stride + (int64_t)lane * 3;
+    w0 = ngm_ldp(a.pr.enc_w, e0, a.pr.dtype); w1 = ngm_ldp(a.pr.enc_w, e0 + 1, a.pr.dtype); w2 = ngm_ldp(a.pr.enc_w, e0 + 2, a.pr.dtype);
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const int64_t beg = (int64_t)blk * a.per_blk, end = min(a.P, beg + a.per_blk);
+  // tiles of 256 points: every thread transforms ONE point into the field's scaled local frame (three IEEE divisions, the
+  // quaternion) and parks it in LDS; then each wave walks its quarter of the tile with lane = feature (the point is an LDS
+  // broadcast, the gradients one coalesced 244-byte row)
+  __shared__ float4 xl[256];
+  for (int64_t t0 = beg; t0 < end; t0 += 256) {
+    const int64_t pt = t0 + threadIdx.x;
+    if (pt < end) { const Vec3 v = encode_local_point(a, f, pt, div, off); xl[threadIdx.x] = make_float4(v.x, v.y, v.z, 0.f); }
+    __syncthreads();
+    const int n = (int)min<int64_t>(256, end - t0);
+#pragma unroll 4
+    for (int t = wave; t < n; t += 4) {
+      const float4 v = xl[t];
+      const float arg = fmaf(w2, v.z, fmaf(w1, v.y, w0 * v.x));                   // the argument k_encode_points forms
+      const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(arg * 0.15915494309189535f));
+      const float d = act ? a.d_enc[((int64_t)f * a.P + t0 + t) * D + n_raw + lane] : 0.f;
+      const float dc = d * c;
+      s0 = fmaf(dc, v.x, s0); s1 = fmaf(dc, v.y, s1); s2 = fmaf(dc, v.z, s2);
+    }
+    __syncthreads();
+  }
+  float* dst = a.part + ((((int64_t)f * a.nblk + blk) * 4 + wave) * 64 + lane) * 3;
+  dst[0] = s0; dst[1] = s1; dst[2] = s2;
+}
+__global__ __launch_bounds__(192) void k_encode_bwd_fourier_reduce(EncodeBwdArgs a) {
+  const int f = blockIdx.x, t = threadIdx.x, j = t / 3, c = t % 3;
+  const int nfeat = a.fc.dim_enc - (a.fc.raw_coords ? 3 : 0);
+  if (j >= nfeat) return;
+  float s = 0.f;
+  for (int q = 0; q < a.nblk * 4; ++q) s += a.part[(((int64_t)f * a.nblk * 4 + q) * 64 + j) * 3 + c];     // fixed order
+  a.grad[(int64_t)f * a.grad_stride + (int64_t)j * 3 + c] = s;
+}
+int64_t ngm_encode_bwd_fourier_scratch(int F, int64_t P) {
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((P + 1023) / 1024, 256));
+  return (int64_t)F * nblk * 4 * 64 * 3 * 4;
+}
+int ngm_launch_encode_bwd_fourier(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points,
+                                  const float* pos, const float* quat, const float* d_enc, float* grad, int64_t grad_stride,
+                                  float* scratch, hipStream_t st) {
+  EncodeBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = fc; a.pr = pr; a.F = F; a.P = P; a.points = points; a.pos = pos; a.quat = quat; a.d_enc = d_enc;
+  a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>((P + 1023) / 1024, 256));
+  a.per_blk = (P + a.nblk - 1) / a.nblk;
+  a.part = scratch; a.grad = grad; a.grad_stride = grad_stride;
+  hipLaunchKernelGGL(k_encode_bwd_fourier, dim3(a.nblk, F), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_encode_bwd_fourier_reduce, dim3(F), dim3(192), 0, st, a);
+  return 0;
+}
+int ngm_launch_encode_bwd_prep_hash(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points,
+                                    const float* pos, const float* quat, const float* d_enc, float2* dE, float4* xyz,
+                                    hipStream_t st) {
+  EncodeBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = fc; a.pr = pr; a.F = F; a.P = P; a.points = points; a.pos = pos; a.quat = quat; a.d_enc = d_enc; a.dE = dE; a.xyz = xyz;
+  const int bx = (int)std::min<int64_t>((P + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_encode_bwd_prep_hash, dim3(std::max(bx, 1), F), dim3(256), 0, st, a);
   return 0;
 }
 

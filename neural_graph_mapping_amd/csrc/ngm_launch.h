@@ -172,6 +172,13 @@ struct StashBwdArgs {
 // forward, 1 = the point evaluation, 2 = the kNN evaluation; values NGM_MATMUL_F32 / NGM_MATMUL_BF16X3, -1 = none yet
 extern int g_ngm_last_matmul[3];
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
+int64_t ngm_encode_bwd_fourier_scratch(int F, int64_t P);
+int ngm_launch_encode_bwd_fourier(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points,
+                                  const float* pos, const float* quat, const float* d_enc, float* grad, int64_t grad_stride,
+                                  float* scratch, hipStream_t st);
+int ngm_launch_encode_bwd_prep_hash(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points,
+                                    const float* pos, const float* quat, const float* d_enc, float2* dE, float4* xyz,
+                                    hipStream_t st);
 int ngm_launch_encode_points(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points, const float* pos,
                              const float* quat, float* out, hipStream_t st);   // the positional encoding alone -> (F, P, dim_enc)
 int ngm_launch_render_fwd(const RenderFwdArgs& a, int blocks, hipStream_t st);

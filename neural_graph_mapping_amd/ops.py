@@ -233,6 +233,34 @@ def encode(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None, qu
     return out
 
 
+def encode_bwd(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, d_enc, pos=None, quat=None) -> Dict[str, torch.Tensor]:
+    """Backward of `encode` w.r.t. the encoding's own parameters (ngm_encode_bwd): d_enc (F,P,dim_enc) ->
+    {"_encoding._linear.weight": (F, dim_enc - 3, 3)} (Fourier) or {"_encoding.lattice_values": (F, L, T, 2)} (hash);
+    {} for the parameter-free encodings."""
+    names = K.param_names(fc)
+    plist = [params[n] for n in names]
+    _require_gpu(points, d_enc, pos, quat, *plist)
+    pts, de = _f32c(points, "points"), _f32c(d_enc, "d_enc")
+    F, P = pts.shape[0], pts.shape[1]
+    if tuple(de.shape) != (F, P, fc.dim_enc):
+        raise ValueError(f"d_enc must be (F, P, dim_enc) = {(F, P, fc.dim_enc)}, got {tuple(de.shape)}")
+    ps = params_struct(fc, dict(zip(names, plist)))
+    out, g = {}, K.Grads()
+    if fc.encoding == K.ENC["fourier"]:
+        t = out["_encoding._linear.weight"] = torch.empty(F, *K.param_shapes(fc)["_encoding._linear.weight"], device=pts.device)
+        g.enc_w, g.enc_w_stride = t.data_ptr(), t.stride(0)
+    elif fc.encoding == K.ENC["permuto"]:
+        t = out["_encoding.lattice_values"] = torch.empty(F, *K.param_shapes(fc)["_encoding.lattice_values"], device=pts.device)
+        g.lattice, g.lattice_stride = t.data_ptr(), t.stride(0)
+    L = K.lib()
+    wsb = L.ngm_encode_bwd_workspace(C.byref(fc), F, P)
+    ws = torch.empty(max(int(wsb), 256), device=pts.device, dtype=torch.uint8)
+    K.check(L.ngm_encode_bwd(C.byref(fc), C.byref(ps), F, P, _ptr(pts), _ptr(None if pos is None else _f32c(pos)),
+                             _ptr(None if quat is None else _f32c(quat)), _ptr(de), C.byref(g), _ptr(ws), ws.numel(), _stream()),
+            "ngm_encode_bwd")
+    return out
+
+
 @_op("field_eval_knn")
 def _field_eval_knn_op(fcfg: torch.Tensor, points: torch.Tensor, pos: torch.Tensor, quat: torch.Tensor,
                        params: List[torch.Tensor], num_knn: int, distance_factor: float, outside_value: float,

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/ngm_hip.h but not exported"
     assert sorted(capi.EXPORTED) == names
-    assert L.ngm_abi_version() == 6
+    assert L.ngm_abi_version() == 7
 
 
 def test_struct_layouts_match_header(capi, tmp_path):

@@ -326,3 +326,41 @@ def test_fused_image_entry_with_per_ray_poses_and_bounds():
     for i, t in enumerate((rgbd, cv, dv, term)):
         assert torch.equal(t, torch.cat([o[i] for o in outs])), i
     assert bool((term > 0.5).any()) and bool((rgbd[:, :3] != rgbd[:1, :3]).any())   # the rays do meet fields, and different ones
+
+
+@pytest.mark.parametrize("enc,P", [("fourier", 1111), ("fourier", 70000), ("permuto", 1500), ("permuto", 40000), ("nerf", 300)])
+def test_standalone_encode_backward_stage_vs_oracle_autograd(enc, P):
+    """ngm_encode_bwd: d_enc (F,P,dim_enc) -> the encoding's own parameter gradients, against autograd
+    through the oracle's `encode` (Fourier: d sin(W x) / dW; hash: the table gradient, through the training step's
+    k_hash_grad -- one chunk and several chunks per level; NeRF octaves: no parameters, nothing returned)."""
+    torch.manual_seed(7)
+    F = 3
+    if enc == "permuto":
+        fs = O.FieldSpec(**HASH)
+        fc = K.field_cfg(encoding="permuto", num_layers=1, nr_levels=16, log2_hashmap_size=12, coarsest_scale=1.0, finest_scale=1e-4)
+        name = "_encoding.lattice_values"
+    elif enc == "fourier":
+        fs = O.FieldSpec(**FOURIER)
+        fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)
+        name = "_encoding._linear.weight"
+    else:
+        fs = O.FieldSpec(encoding="nerf", num_octaves=8, num_layers=1)
+        fc = K.field_cfg(encoding="nerf", num_octaves=8, num_layers=1)
+        name = None
+    params = O.init_params(fs, F, seed=2)
+    if enc == "permuto":
+        params[name] += 0.1 * torch.randn_like(params[name])
+    pos = 0.5 * torch.randn(F, 3)
+    quat = torch.nn.functional.normalize(torch.randn(F, 4), dim=-1)
+    pts = pos[:, None] + 0.6 * torch.randn(F, P, 3)
+    d_enc = torch.randn(F, P, fc.dim_enc)
+    got = ops.encode_bwd(fc, {k: v.to(DEV) for k, v in params.items()}, pts.to(DEV), d_enc.to(DEV), pos.to(DEV), quat.to(DEV))
+    if name is None:
+        assert got == {}
+        return
+    pr = {k: v.clone().requires_grad_(k == name) for k, v in params.items()}
+    (O.encode(O.world_to_field(pts, pos, quat, 1.0, "unit_cube"), pr, fs) * d_enc).sum().backward()
+    ref = pr[name].grad
+    assert got[name].shape == ref.shape
+    # sums of up to 70 000 terms of either sign: compared against the gradient's scale, as every other gradient test is
+    grad_close(got[name], ref, 2e-3 if enc == "fourier" else 1e-2, name)

@@ -129,7 +129,20 @@ def main():
                  "of the gathers; real HBM traffic and L2 hit rate: a rocprofv3 --pmc pass over this script)")
     res["stages"]["hash_encode_fwd"]["gather_GBps_vs_L2_gather_microbench_2200"] = round(
         res["stages"]["hash_encode_fwd"]["GBps"] / 2200.0, 3)
-    del ph, ptsh
+    deh = torch.randn(Fh, Ph, fch.dim_enc, device=dev)
+    with torch.no_grad():
+        add("hash_encode_bwd", timeit(lambda: ops.encode_bwd(fch, ph, ptsh, deh, posh, quath), iters=10), bytes_=Fh * Ph * 512,
+            note="ngm_encode_bwd: transposition of d_enc to the level-major stream + k_hash_grad (+ k_hash_reduce): 512 B of table "
+                 "scatter per sample as SURVEY 8d prices it (the kernel accumulates in LDS: Q23.40 integer atomics, deterministic)")
+    del ph, ptsh, deh
+    ptsf = torch.rand(8, N * S // 8 // 8, 3, device=dev) * 1.6 - 0.8
+    pf = {n: 0.3 * torch.randn(8, *shp, device=dev) for n, shp in K.param_shapes(fc).items()}
+    def_ = torch.randn(8, ptsf.shape[1], fc.dim_enc, device=dev)
+    with torch.no_grad():
+        add("fourier_encode_bwd", timeit(lambda: ops.encode_bwd(fc, pf, ptsf, def_, posh, quath), iters=10),
+            bytes_=8 * ptsf.shape[1] * (12 + 4 * (fc.dim_enc - 3)),
+            note="ngm_encode_bwd (Fourier): reads the points and d_enc once (12 + 244 B / sample), 61 cosines per sample")
+    del ptsf, pf, def_
     # ---- M2: render only, no_grad, 4096 rays x 128 samples, eval-style single stratum (ngm_render_fwd
     # without targets / stash), through the reference-shaped render_ijs
     from neural_graph_mapping_amd import models as M

@@ -149,9 +149,8 @@ typedef struct ngm_grads {
   int64_t planes_stride;
 } ngm_grads;
 
-/* Loss modes of losses.py built into the fused kernels.  The variance-weighted modes (gaussian_nll / laplacian_nll,
- * losses.py:30-36, 64-75) need gradients through the rendered variances and are NOT built: the host layer raises. */
-/* losses.py:26-36.  GAUSSIAN_NLL: 0.5 e^2 / var + log sqrt(var) over the rendered colour variances (rm.py:781-785, no epsilon),
+/* Loss modes of losses.py built into the fused kernels: all of them.
+ * losses.py:26-36.  GAUSSIAN_NLL: 0.5 e^2 / var + log sqrt(var) over the rendered colour variances (rm.py:781-785, no epsilon),
  * replaced by the L1 loss whenever its global mean exceeds 2 (the reference's data-dependent switch). */
 typedef enum ngm_photometric_mode { NGM_PHOTO_L1 = 0, NGM_PHOTO_L2 = 1, NGM_PHOTO_GAUSSIAN_NLL = 2 } ngm_photometric_mode;
 /* losses.py:60-75.  GAUSSIAN_NLL: 0.5 e^2 / (var + 1e-15) + log sqrt(var + 1e-15); LAPLACIAN_NLL: |e| / sqrt(0.5 var + 1e-6)

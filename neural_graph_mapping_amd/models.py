@@ -255,12 +255,24 @@ class NeuralFieldSet(torch.nn.Module):
     # -- evaluation ----------------------------------------------------------------------------
     def forward(self, query_points, field_positions=None, field_orientations=None, field_ids=None,
                 use_vmap: bool = True, field_radius: Optional[float] = None) -> torch.Tensor:
-        fc = self.field_cfg(field_radius)
+        """models.py:287-405.  The `field_radius` ARGUMENT only widens / narrows the inside test of the kNN branch
+        (`knn_dists[:, 0] < field_radius`, models.py:333-334, 368); the local coordinates are always scaled with the
+        radius the set was constructed with (`_scale_local_points`, models.py:278-285), and the vmap branch never reads
+        the argument at all (models.py:336-345).  Caller that relies on it: the colour pass of `_extract_mesh`,
+        run_mapping.py:2320-2332 (`field_radius=self._field_radius + 0.1`)."""
+        fc = self.field_cfg()                       # scaling: the set's own radius, whatever the argument says
         if use_vmap:
             params = {k: v for k, v in self.vmap_fields_params.items() if k != "_neus_sd"}
             return ops.field_eval(fc, params, query_points, field_positions, field_orientations)
+        if field_radius is None:
+            field_radius = self._field_radius
+        if field_radius is None:
+            # the reference compares `knn_dists[:, 0] < None` here (models.py:368) and raises a TypeError
+            raise TypeError("forward(use_vmap=False) needs a field radius (constructor or argument): the reference's "
+                            "inside test `knn_dists[:, 0] < field_radius` fails on None (models.py:368)")
         lead = query_points.shape[:-1]
         params = self.kernel_params()
         out = ops.field_eval_knn(fc, params, query_points.reshape(-1, 3), field_positions, field_orientations,
-                                 self._num_knn, self._distance_factor, self._outside_value, field_ids)
+                                 self._num_knn, self._distance_factor, self._outside_value, field_ids,
+                                 mask_radius=float(field_radius))
         return out.reshape(*lead, -1)

@@ -102,8 +102,12 @@ class NeuralGraphRenderer:
 
     def __init__(self, model: NeuralFieldSet, camera: Camera, config: dict, device="cuda"):
         self._model, self._camera, self._config, self._device = model, camera, dict(config), device
+        # two radii, as in the reference: NeuralGraphMap._field_radius (run_mapping.py:137: sampler margins, near / far, grid
+        # spacing, the mesh colour pass' `+ 0.1`) and the MODEL's own (models.py:278-285: the scaling of local coordinates and
+        # the default inside test of the kNN branch).  The shipped configs set both from one YAML anchor; the kernels' field
+        # configuration always carries the model's.
         self._field_radius = config.get("field_radius", model._field_radius)
-        self._fc = model.field_cfg(self._field_radius)
+        self._fc = model.field_cfg()
         # hidden layers of the forward kernels: "f32" = exact-fp32 MFMA; "bf16x3" = exact three-way bf16 split with fp32
         # accumulation (include/ngm_hip.h ngm_matmul_mode; fp32-level accuracy, same tolerances, bitwise deterministic,
         # 16x the matrix rate; fails loudly where not compiled); "auto" (default) = the split wherever it is compiled

@@ -757,10 +757,49 @@ def g20_train_nll():
                 photometric_loss="gaussian_nll", depth_loss="huber", color_shift=40.0)
 
 
+def g21_field_radius_override():
+    """`NeuralFieldSet.forward(..., field_radius=r + 0.1)` exactly as `_extract_mesh` calls it for the vertex colours
+    (run_mapping.py:2320-2332): the argument widens only the inside test (models.py:333-334, 368); the local coordinates
+    keep the set's own scaling (models.py:278-285).  Both branches, radius 0.8 (so that 1 / (2 r) is not a power of two),
+    a third of the points placed in the shell r <= |p - c| < r + 0.1 of their nearest centre, some beyond it."""
+    gen = torch.Generator().manual_seed(21)
+    NF, P, r = 4, 360, 0.8
+    pos = torch.tensor([[0.0, 0.0, 0.0], [0.9, 0.1, 0.0], [0.2, 1.0, -0.3], [3.0, 3.0, 3.0]])
+    quat = rand_quats(NF, gen)
+    cfg = make_config(field_radius=r)
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=210)
+    model = ngm._model
+    assert model._field_radius == r and model._scale_mode == "unit_cube"
+    for k, v in model.all_fields_params.items():
+        if v.dim() > 1:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    # points on shells around randomly chosen centres: inside, in the widened shell, outside both
+    c = torch.randint(0, NF, (P,), generator=gen)
+    d = torch.nn.functional.normalize(torch.randn(P, 3, generator=gen), dim=-1)
+    rad = torch.cat((r * torch.rand(P // 3, generator=gen), r + 0.1 * torch.rand(P // 3, generator=gen),
+                     r + 0.1 + 0.3 * torch.rand(P - 2 * (P // 3), generator=gen)))
+    pts = pos[c] + rad[:, None] * d
+    with torch.no_grad():
+        out_knn = model(pts, pos, quat, None, use_vmap=False, field_radius=r + 0.1)
+        out_knn_default = model(pts, pos, quat, None, use_vmap=False)
+        ids = torch.tensor([2, 0, 3])
+        model.set_vmap_fields(ids)
+        q = pos[ids][:, None, :] + 0.5 * torch.randn(3, 50, 3, generator=gen)
+        out_vmap = model(q, pos[ids], quat[ids], ids, use_vmap=True, field_radius=r + 0.1)
+        out_vmap_default = model(q, pos[ids], quat[ids], ids, use_vmap=True)
+    assert torch.equal(out_vmap, out_vmap_default)        # the vmap branch never reads the argument
+    n_shell = int(((out_knn != out_knn_default).any(-1)).sum())
+    assert n_shell > P // 6, n_shell                      # the shell points really differ between the two calls
+    arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+    save("g21_field_radius_override", points=pts, pos=pos, quat=quat, radius=np.float32(r), mask_radius=np.float32(r + 0.1),
+         out_knn=out_knn, out_knn_default=out_knn_default, vmap_ids=ids, query=q, out_vmap=out_vmap, **arrays)
+
+
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
-             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings, g20_train_nll]
+             g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings, g20_train_nll,
+             g21_field_radius_override]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -52,6 +52,37 @@ def test_struct_layouts_match_header(capi, tmp_path):
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
+def test_integration_md_level3_snippet_matches_the_library(capi, tmp_path):
+    """INTEGRATION.md's Level-3 ctypes stub is what a reference maintainer would paste: EXECUTE its fenced block (the real
+    library substituted for the bare file name) and compare the struct definitions printed there with the C structs --
+    sizeof from a C program compiled against include/ngm_hip.h, every field offset against the _capi mirrors.  (Round 4's
+    page had a FieldCfg 8 bytes short of ngm_field_cfg: the library would have read two ints past the caller's struct.)"""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    snippet = [b for b in blocks if "class FieldCfg(C.Structure)" in b]
+    assert len(snippet) == 1
+    code = snippet[0].replace('C.CDLL("libngm_hip.so")', f"C.CDLL({capi.LIB_PATH!r})")
+    assert code != snippet[0]
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:Level-3", "exec"), ns)          # defines lib, FieldCfg, Params, field_set_forward
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ngm_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+                   "sizeof(ngm_field_cfg),sizeof(ngm_params),offsetof(ngm_field_cfg,tri_mode),offsetof(ngm_params,neus_sd_stride));"
+                   "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sz_fc, sz_p, off_tri, off_neus = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert C.sizeof(ns["FieldCfg"]) == sz_fc == 268
+    assert C.sizeof(ns["Params"]) == sz_p
+    assert ns["FieldCfg"].tri_mode.offset == off_tri and ns["Params"].neus_sd_stride.offset == off_neus
+    for doc, mirror in ((ns["FieldCfg"], capi.FieldCfg), (ns["Params"], capi.Params)):
+        assert [(n, getattr(doc, n).offset, getattr(doc, n).size) for n, _ in doc._fields_] == \
+               [(n, getattr(mirror, n).offset, getattr(mirror, n).size) for n, _ in mirror._fields_]
+    assert callable(ns["field_set_forward"]) and ns["lib"].ngm_abi_version() == capi.lib().ngm_abi_version()
+    # no stale "not built" statements about the loss modes on the page or in the header
+    assert "and are not built" not in md and "are NOT built" not in open(HEADER).read()
+
+
 def test_workspace_sizing_and_validation_without_gpu(capi):
     L = capi.lib()
     fc = capi.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)

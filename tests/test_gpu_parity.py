@@ -238,6 +238,81 @@ def test_neural_field_set_module_matches_oracle():
     close(out, O.field_set_forward_vmap(q, pos, quat, pcpu, ospec))
 
 
+def _g21_module(g, **kw):
+    r = float(g["radius"])
+    fs = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=64, mu=0.0, sigma=4.0, raw_coords=True), num_layers=2, dim_out=4,
+        neus_initial_sd=1.0), num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=r, scale_mode="unit_cube",
+        **kw).to(DEV)
+    fs.add_fields(g["pos"].shape[0])
+    for k, v in split_prefix(g, "p::").items():
+        fs.all_fields_params[k].copy_(v.to(DEV))
+    fs.refresh_lp()
+    return fs
+
+
+def test_module_forward_field_radius_argument_golden():
+    """Boundary row (b): `NeuralFieldSet.forward(field_radius=...)` through the drop-in CLASS (not the op): fixture G21 from
+    the real reference, called as run_mapping.py:2320-2332 calls it.  The argument widens the inside test of the kNN branch
+    only (models.py:368); the scaling keeps the constructor's radius (models.py:278-285); the vmap branch ignores it."""
+    g = load_golden("g21_field_radius_override")
+    fs = _g21_module(g)
+    mr = float(g["mask_radius"])
+    pts, pos, quat = g["points"].to(DEV), g["pos"].to(DEV), g["quat"].to(DEV)
+    out = fs(pts, pos, quat, None, use_vmap=False, field_radius=mr)
+    close(out, g["out_knn"], rtol=2e-4, atol=3e-5)
+    out_d = fs(pts, pos, quat, None, use_vmap=False)
+    close(out_d, g["out_knn_default"], rtol=2e-4, atol=3e-5)
+    shell = (g["out_knn"] != g["out_knn_default"]).any(-1)
+    assert int(shell.sum()) > 60 and bool((out.cpu()[shell] != 1.0).any(-1).all())      # shell points ARE evaluated
+    assert torch.equal(out_d.cpu()[shell], torch.ones(int(shell.sum()), 4))             # ... and are not without it
+    # leading dims are restored, field_ids maps slots to parameter rows (models.py:347-349, 395)
+    perm = torch.tensor([2, 0, 3, 1])
+    fs2 = _g21_module(g)
+    for k in fs2.all_fields_params:
+        fs2.all_fields_params[k][perm] = fs.all_fields_params[k].clone()
+    out_p = fs2(pts.view(4, -1, 3), pos, quat, perm.to(DEV), use_vmap=False, field_radius=mr)
+    assert out_p.shape == (4, pts.shape[0] // 4, 4)
+    assert torch.equal(out_p.reshape(-1, 4), out)
+    ids = g["vmap_ids"].long().to(DEV)
+    fs.set_vmap_fields(ids)
+    q = g["query"].to(DEV)
+    out_v = fs(q, pos[ids], quat[ids], ids, use_vmap=True, field_radius=mr)
+    close(out_v, g["out_vmap"], rtol=2e-4, atol=2e-5)
+    assert torch.equal(out_v, fs(q, pos[ids], quat[ids], ids, use_vmap=True))           # bitwise: the argument is unread
+
+
+@pytest.mark.parametrize("scale_mode,r", [("unit_cube", 0.7), ("unit_ball", 1.3), ("no", 0.9)])
+def test_module_forward_field_radius_argument_vs_oracle(scale_mode, r):
+    """the same contract against the oracle with separate scale / mask radii, every scale mode, 30 fields, K = 2"""
+    torch.manual_seed(7)
+    NF, P = 30, 20000
+    fs = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
+        encoding_kwargs=dict(dim_in=3, dim_out=32, mu=0.0, sigma=3.0, raw_coords=True), num_layers=1, dim_out=4),
+        num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=r, scale_mode=scale_mode).to(DEV)
+    fs.add_fields(NF)
+    ospec = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)
+    params = O.init_params(ospec, NF, seed=3, sigma=3.0)
+    for k, v in params.items():
+        fs.all_fields_params[k].copy_(v.to(DEV))
+    pos = torch.rand(NF, 3) * 4
+    quat = torch.nn.functional.normalize(torch.randn(NF, 4), dim=-1)
+    pts = torch.rand(P, 3) * 5 - 0.5
+    for mr in (r + 0.1, 0.5 * r, None):
+        ref = O.field_set_forward_knn(pts, pos, quat, params, ospec, radius=r, scale_mode=scale_mode, mask_radius=mr)
+        out = fs(pts.to(DEV), pos.to(DEV), quat.to(DEV), None, use_vmap=False, field_radius=mr)
+        close(out, ref, rtol=3e-4, atol=3e-5)
+    ids = torch.tensor([5, 17, 2])
+    fs.set_vmap_fields(ids.to(DEV))
+    q = pos[ids][:, None] + 0.4 * r * torch.randn(3, 333, 3)
+    ref = O.field_set_forward_vmap(q, pos[ids], quat[ids], {k: v[ids] for k, v in params.items()}, ospec, radius=r,
+                                   scale_mode=scale_mode)
+    out = fs(q.to(DEV), pos[ids].to(DEV), quat[ids].to(DEV), ids.to(DEV), use_vmap=True, field_radius=r + 0.1)
+    close(out, ref, rtol=3e-4, atol=3e-5)
+
+
 # ------------------------------------------------------------------------------ quadrature (G5)
 @pytest.mark.parametrize("mode", ["nrgbd", "occupancy", "density", "neus"])
 @pytest.mark.parametrize("S", [2, 24, 128])

@@ -54,6 +54,36 @@ def test_unsupported_variants_raise():
         M.NeuralFieldSet(**{**SET_KW, "field_radius": None})
 
 
+def test_forward_field_radius_argument_reaches_the_kernel_as_mask_radius_only(monkeypatch):
+    """models.py:333-337, 367-378: the argument is the inside test's radius; scaling keeps the constructor's (host wiring only:
+    the ops are replaced by recorders, the arithmetic is tested on the GPU against fixture G21)"""
+    fs = M.NeuralFieldSet(**{**SET_KW, "field_radius": 0.8})
+    fs.add_fields(2)
+    fs.set_vmap_fields(None)
+    seen = {}
+
+    def knn(fc, params, pts, pos, quat, num_knn, dfac, outside, field_index=None, mask_radius=None):
+        seen["knn"] = (fc.field_radius, mask_radius, num_knn, dfac, outside, field_index)
+        return torch.zeros(pts.shape[0], 4)
+
+    def vmap(fc, params, q, pos=None, quat=None):
+        seen["vmap"] = fc.field_radius
+        return torch.zeros(*q.shape[:-1], 4)
+    monkeypatch.setattr(M.ops, "field_eval_knn", knn)
+    monkeypatch.setattr(M.ops, "field_eval", vmap)
+    pts, pos, quat = torch.zeros(2, 5, 3), torch.zeros(2, 3), torch.tensor([[1.0, 0, 0, 0]] * 2)
+    assert fs(pts, pos, quat, None, use_vmap=False, field_radius=0.9).shape == (2, 5, 4)
+    assert seen["knn"][:2] == (pytest.approx(0.8), pytest.approx(0.9)) and seen["knn"][2:5] == (2, 10.0, 1.0)
+    fs(pts, pos, quat, None, use_vmap=False)
+    assert seen["knn"][:2] == (pytest.approx(0.8), pytest.approx(0.8))
+    fs(pts, pos, quat, None, use_vmap=True, field_radius=0.9)
+    assert seen["vmap"] == pytest.approx(0.8)
+    free = M.NeuralFieldSet(**{**SET_KW, "field_radius": None, "scale_mode": "no"})
+    free.add_fields(2)
+    with pytest.raises(TypeError):              # the reference evaluates `dists < None` (models.py:368)
+        free(pts, pos, quat, None, use_vmap=False)
+
+
 def test_camera_effective_principal_point():
     cam = Rr.Camera(640, 480, 554.25, 554.25, 319.5, 239.5, pixel_center=0.0)
     fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)

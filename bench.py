@@ -319,6 +319,68 @@ def aux_render_image_line(dev):
                 ms_per_image=1e3 * dt, value=640 * 480 * S / dt, unit="ray-samples/s (render only)", knn_matmul=r.last_matmul("knn"))
 
 
+def aux_m2_line(dev, variant, matmul="auto", launches=200):
+    """M2 of SURVEY 8d: RENDER ONLY, no gradient, no stash -- F x R = 8 x 512 = 4096 rays, S = 128 samples uniform in
+    [near, far], no depth guidance (eval-style).  Timed AT THE C ABI: `launches` back-to-back ngm_render_fwd calls (inference
+    workspace = NULL, loss sums = NULL) on torch's current stream -- HIP events around every launch (the library's profile
+    hooks) give the kernel time, a synchronize-bracketed wall clock around the whole loop gives the end-to-end rate incl.
+    launch overhead (no Python layer between the launches beyond the ctypes call).  Fourier: MFMA roofline on the 16 896
+    algorithmic flop / sample; hash: HBM roofline on the 512 B of table gathers / sample (as SURVEY 8d prices them)."""
+    from neural_graph_mapping_amd import _capi as K
+    from neural_graph_mapping_amd import ops
+    L = K.lib()
+    S = S_C + S_G
+    r = build_renderer(dev, F_PER_GPU, variant, s_c=S, s_g=0, matmul=matmul)
+    pos, quat, t = synth_target(F_PER_GPU, R, seed=1000)
+    fc, rc = r._fc, r._rc_plain
+    keep = []
+    rays = ops.make_rays(rc, t.ijs.to(dev), t.c2ws.to(dev), t.near_distances.to(dev), t.far_distances.to(dev), None, pos.to(dev),
+                         quat.to(dev), seed=11, keep=keep)
+    ps = ops.params_struct(fc, r._model.kernel_params())
+    rgbds, cvars = torch.empty(F_PER_GPU, R, 4, device=dev), torch.empty(F_PER_GPU, R, 3, device=dev)
+    dvars, term = torch.empty(F_PER_GPU, R, device=dev), torch.empty(F_PER_GPU, R, device=dev)
+    pred = K.Prediction(rgbds.data_ptr(), cvars.data_ptr(), dvars.data_ptr(), term.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        K.check(L.ngm_render_fwd(C.byref(fc), C.byref(rc), C.byref(ps), C.byref(rays), None, C.byref(pred), None, None, 0, st),
+                "ngm_render_fwd (M2)")
+    for _ in range(50):
+        launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        launch()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / launches
+    L.ngm_profile_reset()
+    L.ngm_profile_enable(1)
+    for _ in range(launches):
+        launch()
+    torch.cuda.synchronize()
+    L.ngm_profile_enable(0)
+    ms, n = C.c_double(0), C.c_int64(0)
+    L.ngm_profile_read(K.KERNEL_IDS["render_fwd"], C.byref(ms), C.byref(n))
+    us = 1e3 * ms.value / max(n.value, 1)
+    n_samp = F_PER_GPU * R * S
+    if variant == "hash":
+        ach = 512 * n_samp / (us * 1e-6) / 1e9
+        roof = dict(bound="hbm", kernel="k_render_fwd<1,1,1,hash> (inference instance: no stash)", achieved=ach, peak=PEAK_HBM_GBS,
+                    unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, algorithmic_bytes_per_launch=512 * n_samp,
+                    note="512 B of table gathers per sample (SURVEY 8d) against the HBM peak; the tables are L2-resident, the honest "
+                         "ceiling is the L2 -> L1 gather rate (aux_hash.roofline_fwd.l2_gather_ceiling)")
+    else:
+        ach = FLOP_FWD * n_samp / (us * 1e-6) / 1e12
+        roof = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (inference instance: no stash)", achieved=ach, peak=PEAK_F32_MFMA_TF,
+                    unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TF, traffic=None, algorithmic_flop_per_launch=FLOP_FWD * n_samp)
+    roof.update(avg_launch_us=us, launches_timed=int(n.value), timing="HIP events on the launch stream around every launch")
+    return dict(workload=f"M2: render only (no gradient, no stash), {F_PER_GPU} fields x {R} rays x {S} samples uniform in [near, far], "
+                         + ("Fourier(64,raw)+2x64 MLP" if variant != "hash" else "permutohedral hash 16x2 + 1x32 MLP (parity unpinned)")
+                         + ", in-kernel Philox jitter, ngm_render_fwd called back to back at the C ABI",
+                value=n_samp / wall, unit="ray-samples/s (render only)", us_per_call_wall=1e6 * wall, kernel_us=us,
+                matmul=r.last_matmul("forward") or r.mlp_matmul, checksum=float(rgbds.double().sum()), roofline=roof)
+
+
 def launch_ranks(n):
     """Re-exec this script under torch.distributed.run with n ranks on this node; returns the exit code."""
     import socket
@@ -465,8 +527,10 @@ def main():
     ap.add_argument("--windows", type=int, default=11,
                     help="number of consecutive timed windows of --steps steps each (after ONE --warmup phase); the line's "
                          "ms_per_step / value are the median window, all windows are listed in ms_per_step_windows")
-    ap.add_argument("--min-seconds", type=float, default=0.0,
-                    help="keep timing windows until this much timed GPU work has run (default 0: exactly --windows)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="keep adding timed windows of --steps steps (same protocol, median headline) until this much timed GPU "
+                         "work has run, so that an external sampler (rocm-smi, the driver's gpu_busy) sees the load: 11 windows of "
+                         "20 steps are 55 ms.  0: exactly --windows windows")
     ap.add_argument("--no-aux-default", action="store_true",
                     help="skip `aux_default` and `aux_render_image`: the reference's default iteration (32 fields x 512 rays x (8 + 16) samples, "
                          "hash 16 x 2 + 1 x 32 network: config/neural_graph_map.yaml)")
@@ -663,9 +727,10 @@ def main():
     aux_default = None
     if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_default:
         aux_default = aux_default_line(dev, args, use_graph)
-    aux_image = None
+    aux_image = aux_m2 = None
     if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_default:
         aux_image = aux_render_image_line(dev)
+        aux_m2 = dict(fourier=aux_m2_line(dev, "fourier", args.matmul), hash=aux_m2_line(dev, "hash", args.matmul))
     if rank == 0:
         n_local = F_PER_GPU * R * (S_C + S_G)
         value = world * n_local * args.steps / dt
@@ -674,7 +739,9 @@ def main():
                    ms_per_step=1e3 * dt / args.steps,
                    ms_per_step_windows=dict(n=len(wins), steps_each=args.steps, median=1e3 * dt / args.steps,
                                             min=1e3 * min(wins) / args.steps, max=1e3 * max(wins) / args.steps,
-                                            first=1e3 * wins[0] / args.steps, all=[round(1e3 * w / args.steps, 5) for w in wins],
+                                            first=1e3 * wins[0] / args.steps, timed_seconds=round(sum(wins), 4),
+                                            all=[round(1e3 * w / args.steps, 5) for w in wins[:64]],
+                                            all_note="the first 64 windows" if len(wins) > 64 else "every window",
                                             headline="median window"),
                    sclk_mhz=sclk, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
                    dtype=DTYPE_LABEL[resolved], data="synthetic",
@@ -746,6 +813,8 @@ def main():
             res["aux_default"] = aux_default
         if aux_image:
             res["aux_render_image"] = aux_image
+        if aux_m2:
+            res["aux_m2"] = aux_m2
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

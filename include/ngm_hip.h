@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 7 /* 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 8 /* 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -539,9 +539,11 @@ int ngm_debug_disable_fused_comp(int on);
  *   handles by any means  ->  ngm_ipc_open(handle_of_rank_p, &px.mailbox[p]) for p != rank, px.mailbox[rank] = mailbox;
  *   px.seq / px.status: 8 + 4 bytes of zeroed device memory of this rank (ngm_peer_alloc works for them too).
  * Every rank must call ngm_loss_exchange the same number of times (idle ranks with zeros), like the collective it replaces.
- * A rank that waits ~2 s for a peer sets bit 0 of *status (sticky) and returns the PARTIAL sum; a slot that already carries a
- * later sequence number (ranks out of step after such a time-out) is accepted and sets bit 1.  A non-zero status is fatal for
- * the run (the sums of that iteration were wrong): check it after synchronising, as often as a wrong update may go unnoticed. */
+ * A rank that waits longer than the time-out for a peer (default 30 s, ngm_peer_set_timeout; the all-reduce this replaces
+ * would wait forever, a kernel must not: a dead peer would wedge the GPU) sets bit 0 of *status (sticky) and returns NaN in
+ * all 16 sums: the losses and the update of THAT iteration are NaN on this rank, so the failure is visible at once and no
+ * parameter is trained on partial normalisers.  A slot that already carries a later sequence number (ranks out of step
+ * after such a time-out) is accepted and sets bit 1.  A non-zero status is fatal for the run. */
 #define NGM_MAX_PEERS 8
 typedef struct ngm_peer_exchange {
   int32_t world, rank;
@@ -556,6 +558,9 @@ int ngm_ipc_export(void* ptr, unsigned char handle[64]);    /* hipIpcGetMemHandl
 int ngm_ipc_open(const unsigned char handle[64], void** ptr);   /* hipIpcOpenMemHandle (lazy peer access)               */
 int ngm_ipc_close(void* ptr);
 int ngm_loss_exchange(const ngm_peer_exchange* px, float* loss_sums /* (16) device, summed in place */, void* stream);
+/* How long an exchange waits for a peer before it gives up (process-wide, applies to launches and graph captures made
+ * afterwards; <= 0 keeps the current value).  Returns the previous value in seconds.  Default 30 s, or NGM_PEER_TIMEOUT_S. */
+double ngm_peer_set_timeout(double seconds);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """Build the gfx950 C-ABI library (libngm_hip.so) in-tree with hipcc.
 
-    python -m neural_graph_mapping_amd.build [--fast] [--force]
+    python -m neural_graph_mapping_amd.build [--fast] [--force] [--prune]
 
 hipcc cross-compiles for gfx950 without a GPU.  Objects are cached under csrc/_obj (keyed by a hash
 of the sources + flags); the shared library lands in neural_graph_mapping_amd/lib/ and travels to
@@ -52,13 +52,25 @@ def _compile(src, flags):
     return obj
 
 
-def build(fast=False, force=False, verbose=True, out=None):
+def build(fast=False, force=False, verbose=True, out=None, prune=False):
     """out: file name of a VARIANT library (developer experiments: `NGM_HIPCC_EXTRA="-DX" ... --out=libngm_x.so`,
     loaded by the tools through NGM_LIB_PATH); the product library is always lib/libngm_hip.so."""
     global LIB
     LIB = os.path.join(LIBDIR, out) if out else os.path.join(LIBDIR, "libngm_hip.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    import fcntl
+    lock = open(os.path.join(OBJ, ".lock"), "w")          # one build at a time per object directory (compile + link + prune)
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_locked(fast, force, verbose, out, prune)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(fast, force, verbose, out, prune):
+    global LIB
     flags = FLAGS + (["-DNGM_FAST_BUILD"] if fast else [])
     flags += os.environ.get("NGM_HIPCC_EXTRA", "").split()      # e.g. -DNGM_PHASE_TIMING (debug builds)
     if force:
@@ -75,12 +87,16 @@ def build(fast=False, force=False, verbose=True, out=None):
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         with open(stamp, "w") as fh:
             fh.write(key)
-    if not out and not os.environ.get("NGM_HIPCC_EXTRA"):
-        # objects of earlier source states are dead weight (they travel to the GPU box with every snapshot): keep the current set
+    if prune and not out and not os.environ.get("NGM_HIPCC_EXTRA"):
+        # `--prune` only (explicit): objects of earlier source states are dead weight on the way to the GPU box, but deleting them
+        # by default made alternating fast / full builds evict each other and could take objects away from a build running in
+        # another process between its compile and its link.  Objects younger than ten minutes are never touched.
+        import time
         keep = {os.path.basename(o) for o in objs}
         for f in os.listdir(OBJ):
-            if f.endswith(".o") and f.startswith("ngm_") and f not in keep:
-                os.remove(os.path.join(OBJ, f))
+            fp = os.path.join(OBJ, f)
+            if f.endswith(".o") and f.startswith("ngm_") and f not in keep and time.time() - os.path.getmtime(fp) > 600:
+                os.remove(fp)
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB
@@ -88,4 +104,4 @@ def build(fast=False, force=False, verbose=True, out=None):
 
 if __name__ == "__main__":
     outs = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--out=")]
-    build(fast="--fast" in sys.argv, force="--force" in sys.argv, out=outs[0] if outs else None)
+    build(fast="--fast" in sys.argv, force="--force" in sys.argv, out=outs[0] if outs else None, prune="--prune" in sys.argv)

@@ -115,7 +115,12 @@ static std::mutex g_seed_mu;
 static std::unordered_map<const void*, const void*> g_seed_targets;       // workspace -> targets.rgbds of the forward that wrote the seeds
 static void note_forward_seeds(const void* ws, const void* rgbds) {
   std::lock_guard<std::mutex> lk(g_seed_mu);
-  if (rgbds) g_seed_targets[ws] = rgbds; else g_seed_targets.erase(ws);
+  if (!rgbds) { g_seed_targets.erase(ws); return; }
+  // bounded: a caller that allocates a fresh workspace per forward (the autograd ops do) would otherwise grow the map by one
+  // entry per distinct address for the life of the process.  Dropping old entries is safe: a backward that finds none runs the
+  // separate k_stash_bwd instead of the fused seeds (same results, one launch more).
+  if (g_seed_targets.size() >= 4096) g_seed_targets.clear();
+  g_seed_targets[ws] = rgbds;
 }
 static bool forward_wrote_seeds_for(const void* ws, const void* rgbds) {
   std::lock_guard<std::mutex> lk(g_seed_mu);
@@ -1111,6 +1116,8 @@ int ngm_ipc_close(void* ptr) {
   const hipError_t e = hipIpcCloseMemHandle(ptr);
   return e == hipSuccess ? NGM_OK : hip_fail(e, "hipIpcCloseMemHandle");
 }
+double ngm_peer_set_timeout(double seconds) { return ngm_peer_set_timeout_impl(seconds); }
+
 int ngm_loss_exchange(const ngm_peer_exchange* px, float* loss_sums, void* stream) {
   if (!px || !loss_sums || !px->seq || !px->status) return fail(NGM_E_INVALID, "ngm_loss_exchange: NULL");
   if (px->world < 1 || px->world > NGM_MAX_PEERS || px->rank < 0 || px->rank >= px->world)

@@ -193,6 +193,7 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st);
 int ngm_launch_loss_exchange(const ngm_peer_exchange& px, float* sums, hipStream_t st);   // ngm_peer.hip
+double ngm_peer_set_timeout_impl(double seconds);
 int ngm_peer_alloc_impl(int64_t bytes, void** out);
 
 int ngm_launch_target_visibility(const ngm_keyframes& kf, int F, const float* field_pos, int num_offsets, const float* offsets,

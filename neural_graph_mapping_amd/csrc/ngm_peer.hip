@@ -11,15 +11,17 @@
 // Two parities: a rank can be at most one exchange ahead of the slowest (it cannot finish exchange k + 1 before every
 // rank has written k + 1, i.e. read all of k), so exchange k + 2 never overwrites unread data of exchange k.
 // The sequence number lives on the device and advances with every launch: graph replays need no host update.
-// The poll is bounded (~2 s per peer: an unbounded spin of a kernel whose peer died would wedge the GPU); on expiry the
-// kernel raises bit 0 of a STICKY status word and returns what it has -- the sums are then partial, and the host treats a
-// non-zero status as fatal for the run (PeerExchange.check, called by the renderer every few iterations and before it
-// hands out losses): the collective this replaces would simply have waited.  A slot that already carries a LATER sequence
+// The poll is bounded (an unbounded spin of a kernel whose peer died would wedge the GPU): `max_spins` x ~1 us, 30 s by default
+// (ngm_peer_set_timeout) -- long enough for a rank that writes a checkpoint, renders an evaluation image on rank 0 only or
+// sits in a garbage collection, which the all-reduce this replaces would simply have waited for.  On expiry the kernel raises
+// bit 0 of a STICKY status word and returns NaN in every sum: the losses of that iteration and the parameters its update
+// touches become NaN on this rank -- visible in the same iteration, never a silently wrong normaliser (PeerExchange.check
+// raises on the status; the renderer calls it before checkpoints and every few iterations).  A slot that already carries a LATER sequence
 // number (possible only after such a time-out: the fast rank went on) is accepted and raises bit 1, so that a late rank
 // falls back into step instead of timing out on every following exchange.
 #include "ngm_launch.h"
 
-__global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, float* sums) {
+__global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, float* sums, uint32_t max_spins) {
   const int t = threadIdx.x, slot = t & 15, peer = t >> 4;
   const uint32_t seq = (uint32_t)(*px.seq) + 1u;
   const int par = seq & 1u;
@@ -43,21 +45,31 @@ __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, flo
         const int32_t ahead = (int32_t)((uint32_t)(w >> 32) - seq);
         if (ahead == 0) break;
         if (ahead > 0 && ahead < (1 << 30)) { skew = true; break; }   // the writer is past this exchange: resynchronise, flag it
-        if (++spins > (1 << 21)) { late = true; w = 0; break; }   // x ~1 us of s_sleep: about two seconds; the slot still holds
-                                                                  // the word of two exchanges ago: contribute nothing, not that
+        if ((uint32_t)++spins > max_spins) { late = true; w = 0; break; }   // x ~1 us of s_sleep; the slot still holds the word of
+                                                                            // two exchanges ago: contribute nothing, not that
         __builtin_amdgcn_s_sleep(32);
       }
       total += __uint_as_float((uint32_t)w);
     }
     if (late) atomicOr(px.status, 1);
     if (skew) atomicOr(px.status, 2);
-    sums[t] = total;
+    sums[t] = late ? __uint_as_float(0x7fc00000u) : total;      // a time-out poisons the iteration instead of mis-normalising it
   }
   if (t == 0) *px.seq = (unsigned long long)seq;
 }
 
+static double g_peer_timeout_s = [] { const char* e = getenv("NGM_PEER_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 30.0; }();
+double ngm_peer_set_timeout_impl(double seconds) {
+  const double prev = g_peer_timeout_s;
+  if (seconds > 0.0) g_peer_timeout_s = seconds;
+  return prev;
+}
+
 int ngm_launch_loss_exchange(const ngm_peer_exchange& px, float* sums, hipStream_t st) {
-  hipLaunchKernelGGL(k_loss_exchange, dim3(1), dim3(128), 0, st, px, sums);
+  // one poll iteration = s_sleep(32) + a system-scope load: ~0.95 us measured ((1 << 21) spins = ~2 s in round 4's tests)
+  const double spins = g_peer_timeout_s * (double)(1 << 20);
+  const uint32_t max_spins = spins > 4.0e9 ? 4000000000u : (uint32_t)spins;
+  hipLaunchKernelGGL(k_loss_exchange, dim3(1), dim3(128), 0, st, px, sums, max_spins);
   return 0;
 }
 

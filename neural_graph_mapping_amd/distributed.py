@@ -104,14 +104,20 @@ class PeerExchange:
     with a self-test exchange; any failure raises, so that a caller can keep the RCCL path (`try_create`).
     Every rank must call `allreduce` the same number of times (idle ranks with zeros)."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, timeout_s: Optional[float] = None):
         """Collective with a FIXED number of collectives on every rank whatever fails where: (1) handle gather, (2) "opened
         every peer" gather, (3) self-test verdict gather.  A rank that fails locally carries ok = False into the next
-        gather instead of leaving the protocol, so no rank is ever left waiting in a gather nobody pairs with."""
+        gather instead of leaving the protocol, so no rank is ever left waiting in a gather nobody pairs with.
+        `timeout_s`: how long an exchange waits for a peer (process-wide, `ngm_peer_set_timeout`; default 30 s or
+        NGM_PEER_TIMEOUT_S) -- a rank that stalls longer (checkpoint I/O, a rank-0-only evaluation) poisons that iteration's
+        sums with NaN and raises the sticky status; size it for the longest stall the application has between iterations."""
         import ctypes as C
         from . import _capi as K
         self._K, self._C = K, C
         L = K.lib()
+        if timeout_s is not None:
+            L.ngm_peer_set_timeout(float(timeout_s))
+        self.timeout_s = float(L.ngm_peer_set_timeout(0.0))
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._opened, self._own, self._state, self._px = [], None, None, None
@@ -205,12 +211,13 @@ class PeerExchange:
         run, exactly as a hung all-reduce would have been, only later."""
         st = self.status()
         if st:
-            raise RuntimeError(f"PeerExchange: loss exchange failed (status {st}: bit 0 = a peer did not deliver within ~2 s and "
-                               "the sums of that iteration were partial, bit 1 = ranks out of step); the parameters trained "
-                               "since are not those of the global loss -- restart from a checkpoint or use the process group")
+            raise RuntimeError(f"PeerExchange: loss exchange failed (status {st}: bit 0 = a peer did not deliver within "
+                               f"{self.timeout_s:g} s and the sums of that iteration were poisoned with NaN, bit 1 = ranks out of "
+                               "step); the fields trained in that iteration hold NaN -- restart from a checkpoint, raise the "
+                               "time-out (PeerExchange(timeout_s=...)) or use the process group")
 
     def status(self) -> int:
-        """0 = every exchange so far completed; bit 0 = some exchange waited ~2 s for a peer and gave up, bit 1 = a slot carried a
+        """0 = every exchange so far completed; bit 0 = some exchange waited `timeout_s` for a peer and gave up, bit 1 = a slot carried a
         later sequence number (ranks out of step after a time-out); sticky.  Synchronises with the device."""
         from . import hiprt as H
         torch.cuda.synchronize(self.device)

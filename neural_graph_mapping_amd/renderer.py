@@ -130,6 +130,8 @@ class NeuralGraphRenderer:
         self._ws_cache = {}
         self.process_group = None          # torch.distributed group for the loss all-reduce (None: single GPU)
         self.eval_fused = True             # render_pixels: one ngm_render_eval_knn call (False: the staged per-block entry points)
+        self.eval_fallbacks = []           # why a fused evaluation call was retried with a smaller block / left to the staged loop
+        self.last_eval_path = None
         self.peer_exchange = None          # distributed.PeerExchange: the same sum as one kernel inside the captured iteration
         self.peer_check_interval = 256     # iterations between PeerExchange.check() calls (a device synchronisation each)
         self._peer_calls = 0
@@ -163,7 +165,9 @@ class NeuralGraphRenderer:
     # -- checkpoint interchange (rm.py:2147-2173) ------------------------------------------------
     def save_model(self, path: str) -> None:
         """torch.save of {map_dict, all_fields_params, state_dict}: the reference's checkpoint layout
-        (optimizer moments are not saved there either)."""
+        (optimizer moments are not saved there either).  With a peer exchange the health of every exchange so far is
+        checked first: parameters trained behind a timed-out exchange are not written."""
+        self.check_exchange()
         torch.save({"map_dict": self._global_map_dict, "all_fields_params": self._model.all_fields_params,
                     "state_dict": self._model.state_dict()}, path)
 
@@ -492,11 +496,30 @@ class NeuralGraphRenderer:
             # 14.3 -> 13.1 ms per 640-sample image, 5.8 -> 4.2 ms at 128 samples).  The in-kernel jitter stream is seeded
             # per block, so the block size decides WHICH draws a pixel gets (not their distribution; explicit `u` is
             # unaffected); with eval_ray_block = pixel_block_size the image equals the staged loop below bit for bit.
-            rgbd, _, dv, _ = ops.render_eval_knn(
-                self._fc, rc, params, ijs, c2w, pos, quat, m._num_knn, m._distance_factor, m._outside_value,
-                u=None if u is None else u[begin:end], seed=seed + begin, near_const=cfg.get("eval_near_distance", 0.0),
-                far_const=cfg.get("eval_far_distance", 8.0), ray_block=int(cfg.get("eval_ray_block") or max(block, 32768)))
-            return rgbd, dv
+            # Memory: the transient workspace grows with the block (about 1.2 GB at S = 640, K = 2; 3.7 GB at S = 1024, K = 4).  A
+            # block that does not fit (torch OOM, NGM_E_WORKSPACE) is halved down to the reference's pixel_block_size; if even
+            # that fails -- or the library reports a shape the fused call does not support -- the staged loop below runs, as
+            # it would have with eval_fused = False.  The fall-back is reported once (`eval_fallbacks`), never silent about
+            # WHICH path ran: `last_eval_path`.
+            rb = int(cfg.get("eval_ray_block") or max(block, 32768))
+            while True:
+                try:
+                    rgbd, _, dv, _ = ops.render_eval_knn(
+                        self._fc, rc, params, ijs, c2w, pos, quat, m._num_knn, m._distance_factor, m._outside_value,
+                        u=None if u is None else u[begin:end], seed=seed + begin, near_const=cfg.get("eval_near_distance", 0.0),
+                        far_const=cfg.get("eval_far_distance", 8.0), ray_block=rb)
+                    self.last_eval_path = f"fused, ray_block {rb}"
+                    return rgbd, dv
+                except (K.NgmError, torch.cuda.OutOfMemoryError) as e:
+                    self.eval_fallbacks.append(f"ray_block {rb}: {type(e).__name__}: {str(e)[:200]}")
+                    if isinstance(e, torch.cuda.OutOfMemoryError):
+                        torch.cuda.empty_cache()
+                    if rb <= block or (isinstance(e, K.NgmError) and "workspace" not in str(e).lower()):
+                        break                                   # staged loop
+                    rb = max(block, rb // 2)
+            self.last_eval_path = "staged (fused call failed, see eval_fallbacks)"
+        else:
+            self.last_eval_path = "staged"
         rgbds, dvars = [], []
         for s0 in range(0, ijs.shape[0], block):
             ij = ijs[s0:s0 + block]

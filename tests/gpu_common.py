@@ -19,9 +19,33 @@ def close(a, b, rtol=2e-4, atol=2e-5):
     torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol)
 
 
+# what the oracle comparisons actually measured, written by tests/conftest.py at the end of a -m gpu session to
+# gpurun_out/parity_margins.txt (committed per round as profiles/rNN_parity_margins.txt): every gradient comparison's worst
+# relative error next to its bar, and the share of rays kink_free_draws took out of a batch before the comparison
+MARGINS = []
+KINK = []
+
+
+def _test_id():
+    import os
+    return os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+
+
+def lattice_level_errors(a, b):
+    """hash table gradient (F, L, T, 2): worst |a - b| per level as a fraction of that LEVEL's max |grad| -> list of L floats"""
+    a, b = a.cpu(), b.cpu()
+    L = b.shape[1]
+    d = (a - b).abs().permute(1, 0, 2, 3).reshape(L, -1).max(-1).values
+    return (d / b.abs().permute(1, 0, 2, 3).reshape(L, -1).max(-1).values.clamp_min(1e-30)).tolist()
+
+
 def grad_close(a, b, tol=2e-3, name=""):
     scale = b.abs().max().clamp_min(1e-12)
     err = float((a.cpu() - b.cpu()).abs().max() / scale)
+    rec = dict(test=_test_id(), name=name, err=err, tol=tol)
+    if name == "_encoding.lattice_values" and b.dim() == 4:
+        rec["per_level"] = lattice_level_errors(a, b)
+    MARGINS.append(rec)
     assert err < tol, (name, err)
 
 
@@ -134,15 +158,17 @@ def synth_target(F, R, seed=0):
                            term_probs=(gt < far).float(), term_mask=(gt > near) & (gt != 0))
 
 
-def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=40, seed=4321):
+def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=40, seed=4321, max_neutralised=0.15):
     """Redraw the jitter of every SAMPLE whose fp64 hidden pre-activations come within `margin` of a ReLU kink.
     The loss gradient is discontinuous there, so two correct fp32 implementations (different summation order) may put
     the sample on different sides and differ by that sample's whole contribution; away from the kinks the strict
     gradient bar (2e-3 of max |grad|) applies.
-    A few samples cannot be moved out of the band (a hidden unit whose inputs are all dead there and whose bias is
-    ~0 is "at the kink" over a whole region): after a few rounds the rays that still hold such samples are taken out
-    of the loss (gt = 0, masks false: no term of rm.py:1769-1872 sees them), so a flip there cannot matter.
-    Returns (u_coarse, u_guided, t) with the offending elements redrawn (t: copy with those rays neutralised)."""
+    A few samples cannot be moved out of the band (a hidden unit whose pre-activation stays near zero across a whole
+    stratum): their rays first get a narrower band (down to margin / 8), and the rays that still hold such samples are taken
+    out of the loss (gt = 0, masks false: no term of rm.py:1769-1872 sees them), so a flip there cannot matter.
+    Returns (u_coarse, u_guided, t) with the offending elements redrawn (t: copy with those rays neutralised).  The share of
+    neutralised rays is recorded (KINK -> gpurun_out/parity_margins.txt) and bounded by `max_neutralised` (the metric-size
+    comparisons pass 0.02: "M1-size vs oracle" must mean at least 98 % of the batch)."""
     gen = torch.Generator().manual_seed(seed)
     u_c = u_c.clone()
     u_g = None if u_g is None else u_g.clone()
@@ -153,6 +179,7 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
     n_c = u_c.shape[-1]
     c2ws = t["c2ws"] if t["c2ws"].dim() == 4 else t["c2ws"][None, None]
     dead = torch.zeros(t["gt"].shape, dtype=torch.bool)
+    mar = torch.full(t["gt"].shape, margin, dtype=torch.float64)            # per-ray band, see below
     for it in range(tries):
         pts_cam, ts, _, order = O.sample_rays(t["ijs"], NRGBD, t["near"], t["far"], t["gt"] if u_g is not None else None,
                                               rs, u_c, u_g, return_order=True)
@@ -161,19 +188,30 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
         x = O.world_to_field(pts_w, pos.double(), quat.double(), rs.field_radius, rs.scale_mode)
         pres = []
         O.field_mlp(O.encode(x, p64, fs), p64, fs, pre_out=pres)
-        bad = torch.zeros(F, R * S, dtype=torch.bool)
+        near0 = torch.full((F, R * S), float("inf"), dtype=torch.float64)
         for pre in pres:
-            bad |= (pre.abs() < margin).any(-1)
-        bad = bad.view(F, R, S) & ~dead[..., None]
+            near0 = torch.minimum(near0, pre.abs().min(-1).values)
+        bad = (near0.view(F, R, S) < mar[..., None]) & ~dead[..., None]
         if not bad.any():
-            assert float(dead.float().mean()) < 0.15, "too many rays neutralised for a meaningful comparison"
+            frac = float(dead.float().mean())
+            KINK.append(dict(test=_test_id(), rays=int(dead.numel()), samples_per_ray=int(S), neutralised_rays=int(dead.sum()),
+                             neutralised_frac=frac, narrowed_rays=int(((mar < margin) & ~dead).sum()),
+                             min_margin=float(mar[~dead].min()) if (~dead).any() else margin, redraw_rounds=it))
+            assert frac <= max_neutralised, f"{frac:.4f} of the rays neutralised (> {max_neutralised}): not a meaningful comparison"
             return u_c, u_g, t
-        if it >= 12:
+        if it >= tries - 4:
             dead |= bad.any(-1)
             t["gt"][dead] = 0.0
             t["depth_mask"][dead] = False
             t["term_mask"][dead] = False
             continue
+        if it >= 8:
+            # dense strata (3 mm in the depth-guided interval) across a SLOWLY varying pre-activation: the band |pre| < margin is
+            # wider than a stratum there, some sample always sits in it and no redraw can leave.  Such rays get a narrower band,
+            # halved per round down to margin / 8 (6e-6: still several times the 1-2e-6 by which two fp32 evaluations of a
+            # pre-activation differ); only what is stuck even then is neutralised.  Both counts are reported.
+            stuck = bad.any(-1)
+            mar[stuck] = torch.clamp(mar[stuck] * 0.5, min=margin / 8)
         f, r, k = bad.nonzero(as_tuple=True)
         src = order[f, r, k]
         is_c = src < n_c
@@ -183,7 +221,7 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
     raise AssertionError("kink_free_draws did not converge")
 
 
-def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0, **ckw_extra):
+def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0, max_neutralised=0.15, **ckw_extra):
     torch.manual_seed(F * 1000 + R)
     ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geometry_mode,
                geometry_factor=geometry_factor, **ckw_extra)
@@ -195,7 +233,7 @@ def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0
     params = O.init_params(fs, F, seed=R, sigma=3.0)
     params[f"_linears.{fkw['num_layers']}.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), (torch.rand(F, R, n_g) if n_g else None)
-    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, max_neutralised=max_neutralised)
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
     r = make_renderer(fkw, ckw, F, params)

@@ -330,7 +330,8 @@ def test_peer_exchange_setup_survives_an_asymmetric_failure(tmp_path, where):
 
 def _peer_timeout_worker(rank, world, port, out):
     _init(rank, world, port)
-    px = D.PeerExchange(dist.group.WORLD)
+    px = D.PeerExchange(dist.group.WORLD, timeout_s=2.0)  # the default is 30 s (an all-reduce would wait for ever)
+    assert px.timeout_s == 2.0
     x = torch.full((16,), float(rank + 1), device=DEV)
     px.allreduce(x)                                       # a healthy exchange
     torch.cuda.synchronize()
@@ -345,7 +346,7 @@ def _peer_timeout_worker(rank, world, port, out):
             px.check()
         except RuntimeError as e:
             raised = str(e)
-        partial = float(y[0])
+        partial = bool(torch.isnan(y).all())
     else:
         partial = None
     dist.barrier()
@@ -355,13 +356,13 @@ def _peer_timeout_worker(rank, world, port, out):
 
 
 def test_peer_exchange_timeout_is_reported_not_swallowed(tmp_path):
-    """ADVICE (round 3): a peer that does not arrive leaves PARTIAL sums; nothing ever read the sticky status word.  It is
-    fatal now: `PeerExchange.check()` (called by the renderer every `peer_check_interval` iterations and by
+    """ADVICE (rounds 3, 4): a peer that does not arrive within the (configurable, default 30 s) time-out poisons the sums of
+    that exchange with NaN -- loss and update of the iteration are NaN at once, never silently mis-normalised -- and it is fatal: `PeerExchange.check()` (called by the renderer every `peer_check_interval` iterations and by
     `check_exchange()`) raises on the rank that timed out."""
     world = 2
     mp.spawn(_peer_timeout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"timeout{r}.pt")) for r in range(world))
     assert r0["healthy"] == (0, 3.0) and r1["healthy"] == (0, 3.0)
     assert r0["status"] & 1 and r0["raised"] and "loss exchange failed" in r0["raised"]
-    assert r0["partial"] == 1.0                          # only its own contribution arrived
+    assert r0["partial"] is True                         # the sums of a timed-out exchange are NaN: the iteration is visibly dead
     assert r1["status"] == 0

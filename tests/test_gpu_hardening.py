@@ -26,7 +26,7 @@ from test_gpu_parity import _permuto_train_case  # noqa: E402
 def test_m1_size_fourier_train_step_vs_oracle():
     """the bench line's batch shape through the bench line's kernels (fused forward, bf16-split backward with the fused
     compositing backward), against the CPU oracle on the same explicit jitter: 524 288 samples"""
-    ragged_case(8, 512, 64, 64, dict(FOURIER))
+    ragged_case(8, 512, 64, 64, dict(FOURIER), max_neutralised=0.02)     # >= 98 % of the batch is compared (measured: 99.9 %)
     L = K.lib()
     assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_comp_fused() == 1
     assert L.ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
@@ -34,7 +34,7 @@ def test_m1_size_fourier_train_step_vs_oracle():
 
 def test_m1_size_hash_train_step_vs_oracle():
     """the reference's default network on the same batch (tolerances of the hash tests: forward 2e-3 / 2e-4, gradients 1e-2)"""
-    _permuto_train_case(8, 512, 64, 64, "auto")
+    _permuto_train_case(8, 512, 64, 64, "auto", max_neutralised=0.02)
     assert K.lib().ngm_debug_last_comp_fused() == 1
 
 

@@ -1025,7 +1025,7 @@ def test_permuto_fused_train_step_vs_oracle(F, R, n_c, n_g, mm):
         K.lib().ngm_debug_disable_fused_comp(0)
 
 
-def _permuto_train_case(F, R, n_c, n_g, mm):
+def _permuto_train_case(F, R, n_c, n_g, mm, max_neutralised=0.15):
     torch.manual_seed(5)
     fs = O.FieldSpec(num_layers=1, **PERMUTO)
     rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g)
@@ -1033,7 +1033,7 @@ def _permuto_train_case(F, R, n_c, n_g, mm):
     params = O.init_params(fs, F, seed=9)
     params["_linears.1.weight"] *= 2.0
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
-    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, max_neutralised=max_neutralised)
     po = {k: v.clone().requires_grad_(k != "_encoding.random_shift_per_level") for k, v in params.items()}
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
     loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)

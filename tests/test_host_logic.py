@@ -84,6 +84,40 @@ def test_forward_field_radius_argument_reaches_the_kernel_as_mask_radius_only(mo
         free(pts, pos, quat, None, use_vmap=False)
 
 
+def test_fused_image_call_falls_back_instead_of_failing(monkeypatch):
+    """a fused evaluation block that does not fit (torch OOM / NGM_E_WORKSPACE) is halved down to pixel_block_size,
+    then the staged per-block loop runs; which path ran is readable (host wiring only: the ops are recorders)."""
+    model = M.NeuralFieldSet(**SET_KW)
+    cam = Rr.Camera(64, 48, 50.0, 50.0, 31.5, 23.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(eval_num_samples=16, pixel_block_size=1024), device="cpu")
+    r.add_fields(2)
+    r.set_field_poses(torch.zeros(2, 3), torch.tensor([[1.0, 0, 0, 0]] * 2))
+    calls = []
+
+    def fused(fc, rc, params, ijs, c2w, pos, quat, *a, ray_block=0, **kw):
+        calls.append(ray_block)
+        if ray_block > 8192:
+            raise torch.cuda.OutOfMemoryError("fake")
+        if ray_block > 1024:
+            raise K.NgmError("ngm_render_eval_knn failed with status -3: ngm_render_eval_knn: workspace too small")
+        n = ijs.shape[0]
+        return torch.zeros(n, 4), None, torch.zeros(n), None
+    monkeypatch.setattr(Rr.ops, "render_eval_knn", fused)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    rgbd, dv = r.render_image(torch.eye(4))
+    assert calls == [32768, 16384, 8192, 4096, 2048, 1024] and rgbd.shape == (48, 64, 4)
+    assert r.last_eval_path == "fused, ray_block 1024" and len(r.eval_fallbacks) == 5
+
+    staged = []
+    monkeypatch.setattr(Rr.ops, "render_eval_knn", lambda *a, **k: (_ for _ in ()).throw(K.NgmError("status -4: unsupported shape")))
+    monkeypatch.setattr(Rr.ops, "sample_rays_world", lambda rc, ij, *a, **k: (staged.append(ij.shape[0]),
+                        (torch.zeros(ij.shape[0], 16, 3), torch.zeros(ij.shape[0], 16, 3), torch.zeros(ij.shape[0], 16)))[1])
+    monkeypatch.setattr(Rr.ops, "field_eval_knn", lambda fc, p, pts, *a, **k: torch.zeros(pts.shape[0], 4))
+    monkeypatch.setattr(Rr.ops, "composite_packed", lambda rc, o, d, pc: (torch.zeros(d.shape[0], 4), None, torch.zeros(d.shape[0]), None))
+    rgbd, _ = r.render_image(torch.eye(4))
+    assert staged == [1024, 1024, 1024] and r.last_eval_path.startswith("staged") and rgbd.shape == (48, 64, 4)
+
+
 def test_camera_effective_principal_point():
     cam = Rr.Camera(640, 480, 554.25, 554.25, 319.5, 239.5, pixel_center=0.0)
     fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)

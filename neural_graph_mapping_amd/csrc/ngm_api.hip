@@ -99,6 +99,7 @@ static unsigned long long* g_debug_cycles = nullptr;
 int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_no_fused_comp = 0;       // ngm_debug_disable_fused_comp
+static int g_last_stash_mode = -1;    // FieldBwdArgs::act_half of the last MLP backward that read an activation stash
 static int g_last_comp_fused = 0;     // the last training backward did the compositing backward inside k_field_bwd_b3 (no k_stash_bwd launch)
 // true when launch_bwd_any's first candidate is k_field_bwd_b3 (no experiment switch in the way)
 static bool bwd_b3_is_default() {
@@ -113,6 +114,18 @@ static bool bwd_b3_is_default() {
 #include <unordered_map>
 static std::mutex g_seed_mu;
 static std::unordered_map<const void*, const void*> g_seed_targets;       // workspace -> targets.rgbds of the forward that wrote the seeds
+static std::unordered_map<const void*, int> g_ws_act_layers;              // workspace -> hidden layers the last training forward stashed (0: all)
+static void note_forward_stash(const void* ws, int act_layers) {
+  std::lock_guard<std::mutex> lk(g_seed_mu);
+  if (g_ws_act_layers.size() >= 4096) g_ws_act_layers.clear();
+  g_ws_act_layers[ws] = act_layers;
+}
+// -1: no record (another process wrote the workspace, or the record was dropped): trust the backward's own predicate
+static int forward_stash_layers(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_seed_mu);
+  auto it = g_ws_act_layers.find(ws);
+  return it == g_ws_act_layers.end() ? -1 : it->second;
+}
 static void note_forward_seeds(const void* ws, const void* rgbds) {
   std::lock_guard<std::mutex> lk(g_seed_mu);
   if (!rgbds) { g_seed_targets.erase(ws); return; }
@@ -140,7 +153,13 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   // 32-sample-tile recompute
   static const bool no_b3 = getenv("NGM_NO_BWD_B3") != nullptr;
   int e = NGM_E_UNSUPPORTED;
-  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
+  g_last_stash_mode = a.act ? a.act_half : -1;
+  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act && a.act_half == 2) { e = ngm_launch_field_bwd_b3p(a, blocks, st); g_last_bwd_variant = 3; }
+  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act && a.act_half != 2) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
+  if (a.act_half && e == NGM_E_UNSUPPORTED) {                   // no other kernel reads a half stash: never fall through
+    snprintf(g_err, sizeof(g_err), "render_bwd: the forward stashed one hidden layer (split path) but k_field_bwd_b3 does not take this problem");
+    return NGM_E_INVALID;
+  }
   if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_hash_mlp_bwd(a, blocks, st); g_last_bwd_variant = 5; }
   g_last_comp_fused = (a.fused_comp && e == 0) ? 1 : 0;
   if (a.fused_comp && e) return e;                              // no other kernel composites: never fall through
@@ -576,6 +595,8 @@ struct RenderPlan {
   int64_t p_pad;
   int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
+  int stash_mode;                  // 0: every hidden layer, fp32; 1: layer 0 only, fp32 (half stash); 2: layer 0 only, bf16 planes
+  int64_t planes_field_stride;     // stash_mode 2: bytes per field
   int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
 };
 // The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
@@ -592,6 +613,34 @@ static int act_stash_kind(const ngm_field_cfg* fc) {
   if (fc->encoding == NGM_ENC_TRIPLANE) return 0;      // 32-sample-tile backward (recompute: it needs the taps anyway)
   // with a skip connection the stashed activation no longer tells the ReLU mask
   return (fc->skip_mode == NGM_SKIP_NO && th == 4 && ti == 4 && fc->num_layers >= 1 && fc->num_layers <= 2) ? 1 : 0;
+}
+
+#ifndef NGM_STASH_DEFAULT
+#define NGM_STASH_DEFAULT 2
+#endif
+// Half stash (round 5): with two hidden layers on the split path the forward stashes layer 0's output only and
+// k_field_bwd_b3<.., HS> recomputes the output layer's input from it on the matrix pipe: 256 instead of 512 bytes of stash per
+// sample each way.  Decided from the field configuration and the samples per field alone, so that ngm_render_fwd and
+// ngm_render_bwd* (which see the same fcfg and rays) agree; the forward's choice is also recorded per workspace.
+// NGM_FULL_STASH=1: both layers, as before (A/B, and what every other backward kernel reads).
+// NGM_STASH=full | half | planes overrides the default (A/B on one box); NGM_FULL_STASH=1 = NGM_STASH=full.
+static int g_stash_override = -1;      // ngm_debug_stash_mode
+static int stash_pref() {
+  if (g_stash_override >= 0) return g_stash_override;
+  static const int pref = [] {
+    const char* e = getenv("NGM_STASH");
+    if (getenv("NGM_FULL_STASH")) return 0;
+    if (!e) return NGM_STASH_DEFAULT;
+    return !strcmp(e, "full") ? 0 : !strcmp(e, "half") ? 1 : !strcmp(e, "planes") ? 2 : NGM_STASH_DEFAULT;
+  }();
+  return pref;
+}
+static bool half_stash_applies(const ngm_field_cfg* fc, int64_t P) {
+  if (stash_pref() == 0 || !bwd_b3_is_default() || fc->num_layers != 2 || act_stash_kind(fc) != 1) return false;
+  FieldBwdArgs probe;
+  memset(&probe, 0, sizeof(probe));
+  probe.fc = *fc; probe.P = P; probe.act = reinterpret_cast<const float*>(1);
+  return ngm_field_bwd_b3_applies(probe);
 }
 
 static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc, int F, int R, bool guided, bool train) {
@@ -671,7 +720,16 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     const int kind = act_stash_kind(fc);
     if (kind == 1) {
       p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
-      p.off_act = o; o = align_up(o + fc->num_layers * p.act_layer_stride * 4 + 64, 256);
+      const bool half = half_stash_applies(fc, (int64_t)R * p.S);                              // half stash: layer 0's output only
+      // ... as bf16 planes when the forward runs the split arithmetic (it forms them anyway) and the planes backward is compiled
+      p.stash_mode = !half ? 0 : (stash_pref() == 2 && p.b3 && ngm_field_bwd_b3p_compiled(fc)) ? 2 : 1;
+      p.off_act = o;
+      if (p.stash_mode == 2) {
+        p.planes_field_stride = (((int64_t)R * p.S + 31) / 32) * 12288;
+        o = align_up(o + (int64_t)F * p.planes_field_stride + 64, 256);
+      } else {
+        o = align_up(o + (half ? 1 : fc->num_layers) * p.act_layer_stride * 4 + 64, 256);
+      }
     } else if (kind == 2) {
       p.act_layer_stride = align_up(NS, 32) * 32 + 1024;      // one "layer": the 32-feature encoding
       p.off_act = o; o = align_up(o + p.act_layer_stride * 4 + 64, 256);
@@ -756,6 +814,10 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
     a.stashB = reinterpret_cast<float2*>(ws + p.off_stashB);
     a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
     if (p.act_layer_stride) { a.act = reinterpret_cast<float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
+    a.act_layers = (a.act && p.stash_mode) ? 1 : 0;
+    a.act_planes = (a.act && p.stash_mode == 2) ? 1 : 0;
+    a.act_planes_field_stride = p.planes_field_stride;
+    note_forward_stash(workspace, p.stash_mode);
     static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
     if (timing) {
       if (!g_debug_cycles_fwd) { (void)hipMalloc(&g_debug_cycles_fwd, NGM_FWD_DEBUG_WORDS * 8); (void)hipMemset(g_debug_cycles_fwd, 0, NGM_FWD_DEBUG_WORDS * 8); }
@@ -807,6 +869,11 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   a.raytab = sb.raytab; a.stashB = sb.stashB; a.d_out = neus ? sb.d_out : sb.stashA;
   a.partials = reinterpret_cast<float*>(ws + p.off_gradpart); a.p_pad = p.p_pad;
   if (p.act_layer_stride) { a.act = reinterpret_cast<const float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
+  {
+    const int rec = forward_stash_layers(workspace);       // what the forward on THIS workspace wrote (-1: no record: the plan's mode)
+    a.act_half = a.act ? (rec < 0 ? p.stash_mode : rec) : 0;
+    a.act_planes_field_stride = p.planes_field_stride;
+  }
   // Compositing backward inside the MLP backward (k_field_bwd_b3<FC>, k_hash_mlp_bwd<FC>): loss seeds, pointwise geometry
   // modes, and a kernel that implements it about to be chosen.  Otherwise k_stash_bwd runs first and leaves
   // dL/d(raw outputs) in place of the forward's stash.  NGM_NO_FUSED_COMP=1: never.
@@ -1116,6 +1183,14 @@ int ngm_ipc_close(void* ptr) {
   const hipError_t e = hipIpcCloseMemHandle(ptr);
   return e == hipSuccess ? NGM_OK : hip_fail(e, "hipIpcCloseMemHandle");
 }
+int ngm_debug_last_stash_mode(void) { return g_last_stash_mode; }
+int ngm_debug_stash_mode(int mode) {
+  const int prev = stash_pref();
+  if (mode >= 0 && mode <= 2) g_stash_override = mode;
+  else if (mode == -2) g_stash_override = -1;
+  return prev;
+}
+
 double ngm_peer_set_timeout(double seconds) { return ngm_peer_set_timeout_impl(seconds); }
 
 int ngm_loss_exchange(const ngm_peer_exchange* px, float* loss_sums, void* stream) {

@@ -25,16 +25,22 @@
 #define HT 2048                 // floats of one 32 x 64 activation tile
 #define PLANE_G 512             // 16-byte granules of one weight plane: [nt 2][kb 4][kh 2][n 32]
 
-template <int L, bool EG>
+// HS ("half stash", L = 2 only): the forward stashed layer 0's output alone; the output layer's input H2 = relu(W1 H1 + b1) is
+// recomputed per tile on the matrix pipe (48 more MFMAs) from the H1 tile that is DMA'd anyway.  One more plane set (W1 in the
+// forward orientation), one tile buffer per wave instead of two (H1 is in registers -- rows for the recompute, columns for the
+// weight gradient -- before dY overwrites it), half the transfers and half the stash traffic.
+template <int L, bool EG, bool HS = false>
 struct LdsB3b {
-  static constexpr int NPL = (L - 1) + (EG ? 1 : 0);                 // layers whose data gradient is needed
+  static_assert(!HS || L == 2, "half stash: two hidden layers");
+  static constexpr int NPL = (L - 1) + (EG ? 1 : 0) + (HS ? 1 : 0);  // layers whose data gradient is needed (+ HS: layer 1 forward)
   static constexpr int plane_slot(int l) { return EG ? l : l - 1; }  // 16-byte units: slot * 3 * PLANE_G
-  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512;         // floats; + per-feature constants: float4 wout[64], enc[64]
+  static constexpr int fwd_slot() { return NPL - 1; }                // HS: W1 for the recompute, granule = W1[32 nt + n][16 kb + 8 kh + e]
+  static constexpr int PLANES = NPL * 3 * PLANE_G * 4 + 512 + 64;    // floats; + per-feature constants: float4 wout[64], enc[64], float b1[64]
   static constexpr int CONSTS = NPL * 3 * PLANE_G * 4;
   // per wave: the output layer's input tile, (L = 2) layer 1's input tile, the input landing buffer, points, d_out.
   // Single buffers: the next tile's transfers are issued when all of them are free (see the tile loop).
   static constexpr int HL = 0;
-  static constexpr int H1 = HT;
+  static constexpr int H1 = HS ? 0 : HT;                             // HS: the one tile buffer (H1 -> dY of layer 1 -> dY of layer 0)
   static constexpr int INB = H1 + ((L == 2) ? HT : 0);               // float4 [2 halves][4 pieces][16] + (fused compositing) [2 pieces][32]
   static constexpr int PB = INB + 768;                               // float4 [32]
   static constexpr int OB = PB + 128;                                // float4 [32]
@@ -43,7 +49,11 @@ struct LdsB3b {
   static constexpr int INB2 = OB + 128;
   static constexpr int PB2 = INB2 + 768;
   static constexpr int OB2 = PB2 + 128;
-  static constexpr int WAVE_TOTAL = OB2 + 128;
+  // HS: the per-feature sums (output-weight, bias, Fourier-matrix gradients: 18 floats per lane) live here between the phases
+  // that touch them -- as loop-long registers next to the recompute's operands they were spilled to scratch, and a scratch
+  // reload is a full exposed memory round trip on a one-wave SIMD.  float4 [5][64 lanes]
+  static constexpr int ACCL = OB2 + 128;
+  static constexpr int WAVE_TOTAL = ACCL + (HS ? 5 * 256 : 0);
   static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave
   static constexpr int EPI = B3B_WAVES * NT * 1024;
   static constexpr int BODY = PLANES + B3B_WAVES * WAVE_TOTAL;
@@ -254,6 +264,36 @@ __device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, cons
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int o = 16 * kb + 8 * kh + e;
+      x[e] = (o < H && c < Din) ? x[e] : 0.f;
+    }
+    ngm_bf16x8 h, m, lo;
+    b3_split8(x, h, m, lo);
+    P[g] = __builtin_bit_cast(ngm_u32x4, h);
+    P[PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, m);
+    P[2 * PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, lo);
+  }
+}
+
+// HS: weight planes of layer l in the FORWARD orientation, for Y^T[s][32 nt + n] = sum_i X[s][i] W[32 nt + n][i] with the rows
+// of the X tile as A operand (same lane / k order as the data gradient's): granule (plane, nt, kb, kh, n) = W[32 nt + n][16 kb + 8 kh + e]
+__device__ __forceinline__ void build_fwd_planes(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int l, ngm_u32x4* P) {
+  const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
+  const float* W = pr.w[l];
+  const int64_t w0 = row * pr.w_stride[l];
+  for (int g = threadIdx.x; g < PLANE_G; g += B3B_THREADS) {
+    const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
+    const int o = 32 * nt + n;
+    float x[8];
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 16 * kb + 8 * kh + e;
+      off[e] = (o < H && c < Din) ? o * Din + c : 0;
+    }
+    ngm_ldp_gather<8>(W, w0, off, pr.dtype, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 16 * kb + 8 * kh + e;
       x[e] = (o < H && c < Din) ? x[e] : 0.f;
     }
     ngm_bf16x8 h, m, lo;

@@ -29,13 +29,105 @@
 #include "ngm_bwd_b3.h"
 
 // ------------------------------------------------------------------------------------------------
+// HS: H2^T = H1 W1^T (48 MFMAs, the structure of a data gradient: A = rows of the H1 tile, B = W1's forward planes) with the
+// tile's ENCODING evaluated in the shadows of those MFMAs.  The two streams are independent (positions vs. H1 rows), and this
+// is the one kernel instance with the registers to keep the 32 sines (+ 32 cosines, Fourier) until layer 0 wants them.
+// Scheduling by construction, not by sched_group_barrier: every MFMA is followed by one slice of vector work -- one (sample,
+// feature-tile) pair of the encoding: ~9 instructions, or one pair of the next k-block's operand split: 11 -- and a full
+// scheduling fence; each slice's results are pinned to their slice by an empty volatile asm (their uses are a phase away, and
+// instruction selection otherwise sinks the pure sine / cosine down to them, out from under the MFMAs).
+template <bool NEED_COS, bool ENC_GRAD>
+__device__ __forceinline__ void recompute_with_encoding(const ngm_u32x4* __restrict__ P, const float* __restrict__ tile,
+                                                        const float* __restrict__ pb, const float4 (&encw)[2], int lane,
+                                                        f32x16 (&Hc)[2], float (&Eb)[2][2][8], float (&Cb)[2][2][8]) {
+  const int hi = lane >> 5;
+  const float inv2pi = 0.15915494309189535f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  RowRegs R;
+  PlaneRegs W[2];
+  float4 pq[2][4];                   // positions of the quarter in work / the next one
+  load_rows(tile, lane, R);
+  load_planes(P, 0, lane, W[0]);
+  auto ldq = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = q >> 1, e = 4 * (q & 1) + j;
+      pq[q & 1][j] = *reinterpret_cast<const float4*>(pb + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+    }
+  };
+  ldq(0);
+  __builtin_amdgcn_sched_barrier(0);
+  B3Op A = b3_rows(R.g[0][0], R.g[0][1]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const PlaneRegs& Wk = W[kb & 1];
+    if (kb < 3) { load_planes(P, kb + 1, lane, W[(kb + 1) & 1]); ldq(kb + 1); }
+    uint32_t nh[4], nm[4], nl[4];
+    auto enc = [&](int idx) __attribute__((always_inline)) {           // element idx of quarter kb: sample j, feature tile m
+      const int j = idx >> 1, m = idx & 1, b = kb >> 1, e = 4 * (kb & 1) + j;
+      float4 p = pq[kb & 1][j];
+      asm volatile("" : "+v"(p.x));                                       // ... and its input: not before this slice either
+      const float4 w = encw[m];
+      const float arg = fmaf(w.z, p.z, fmaf(w.y, p.y, w.x * p.x));
+      const float rev = __builtin_amdgcn_fractf(arg * inv2pi);
+      const float sn = __builtin_amdgcn_sinf(rev);
+      float v = sn;
+      if (NEED_COS) v = (w.w == NGM_FK_COS) ? __builtin_amdgcn_cosf(rev) : sn;
+      if (m == 0) v = (w.w == NGM_FK_RAW) ? arg : v;                    // raw coordinates are features 0..2
+      asm volatile("" : "+v"(v));
+      Eb[b][m][e] = v;
+      if (ENC_GRAD) {
+        float c = __builtin_amdgcn_cosf(rev);
+        asm volatile("" : "+v"(c));
+        Cb[b][m][e] = c;
+      }
+    };
+    auto spl = [&](int pr) __attribute__((always_inline)) {           // pair pr of the next k-block's eight row values
+      if (kb < 3) {
+        const float4 g = R.g[kb < 3 ? kb + 1 : 3][pr >> 1];
+        float x0 = (pr & 1) ? g.z : g.x, x1 = (pr & 1) ? g.w : g.y;
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        b3_split2(x0, x1, nh[pr], nm[pr], nl[pr]);
+        asm volatile("" : "+v"(nh[pr]), "+v"(nm[pr]), "+v"(nl[pr]));
+      }
+    };
+#define NGM_HS_STEP(PA, PW, NT_, Z, WORK)                                                                       \
+    asm volatile("" : "+v"(A.PA));            /* the MFMA not before its step (its operands are ready long before) */ \
+    Hc[NT_] = mfma_bf16(A.PA, __builtin_bit_cast(ngm_bf16x8, Wk.PW[NT_]), (Z) ? zero : Hc[NT_]);                \
+    WORK;                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+    NGM_HS_STEP(l, h, 0, kb == 0, enc(0))
+    NGM_HS_STEP(l, h, 1, kb == 0, spl(0))
+    NGM_HS_STEP(h, l, 0, false, enc(1))
+    NGM_HS_STEP(h, l, 1, false, enc(2))
+    NGM_HS_STEP(m, m, 0, false, spl(1))
+    NGM_HS_STEP(m, m, 1, false, enc(3))
+    NGM_HS_STEP(m, h, 0, false, enc(4))
+    NGM_HS_STEP(m, h, 1, false, spl(2))
+    NGM_HS_STEP(h, m, 0, false, enc(5))
+    NGM_HS_STEP(h, m, 1, false, enc(6))
+    NGM_HS_STEP(h, h, 0, false, spl(3))
+    NGM_HS_STEP(h, h, 1, false, enc(7))
+#undef NGM_HS_STEP
+    if (kb < 3) {
+      A.h = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{nh[0], nh[1], nh[2], nh[3]});
+      A.m = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{nm[0], nm[1], nm[2], nm[3]});
+      A.l = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{nl[0], nl[1], nl[2], nl[3]});
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FC: the compositing backward of k_stash_bwd fused into the input phase (FieldBwdArgs::fused_comp): the d_out stream then
 // carries the forward's (colour, geometry) stash, every wave walks a contiguous ray-aligned range of tiles BACK TO FRONT
 // and carries the suffix value Q of the per-ray recursion Q_{k-1} = a_k o_k + (1 - o_k) Q_k from tile to tile.
-template <int L, bool NEED_COS, bool ENC_GRAD, bool FC = false>
+// HS: half stash (FieldBwdArgs::act_half, L = 2): only layer 0's output was stashed; the output layer's input is recomputed
+// from it per tile (LdsB3b).
+template <int L, bool NEED_COS, bool ENC_GRAD, bool FC = false, bool HS = false>
 __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  using LY = LdsB3b<L, ENC_GRAD>;
+  using LY = LdsB3b<L, ENC_GRAD, HS>;
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,6 +141,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   float* pbuf2 = wl + LY::PB2;
   float* obuf2 = wl + LY::OB2;
   const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wl);
+  float4* accl = reinterpret_cast<float4*>(wl + LY::ACCL) + lane;      // HS: slot q of this lane at accl[64 q]
+  if constexpr (HS) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) accl[64 * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   f32x16 acc[L][2][2];
 #pragma unroll
@@ -120,7 +217,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
       issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
     }
-    issue_tile32(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::HL * 4);
+    if constexpr (!HS) issue_tile32(fs.act[L - 1], fs.gb, first, end, lane, wl_lds + LY::HL * 4);
     if (L == 2) issue_tile32(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::H1 * 4);
   }
   // per-feature constants (output-layer column, encoding row): LDS, re-read by the phase that needs them -- as
@@ -135,6 +232,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
                                        ngm_ldp(W, w0 + 2 * H + ft, a.pr.dtype), ngm_ldp(W, w0 + 3 * H + ft, a.pr.dtype))
                          : make_float4(0.f, 0.f, 0.f, 0.f);
     cenc[ft] = enc_row_of(a.fc, a.pr, row, ft);
+    if constexpr (HS) sm[LY::CONSTS + 512 + ft] = (ft < H) ? ngm_ldp(a.pr.b[1], row * a.pr.b_stride[1] + ft, a.pr.dtype) : 0.f;
   }
   // FC: the global loss normalisers, as in k_stash_bwd (from the all-reduced sums, or summed here by every workgroup from
   // the forward's per-workgroup partials in k_loss_reduce's fixed order: identical everywhere, deterministic)
@@ -150,6 +248,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   }
   if (ENC_GRAD) build_dgrad_planes(a.fc, a.pr, row, 0, planes + LY::plane_slot(0) * 3 * PLANE_G);
   if (L == 2) build_dgrad_planes(a.fc, a.pr, row, 1, planes + LY::plane_slot(1) * 3 * PLANE_G);
+  if constexpr (HS) build_fwd_planes(a.fc, a.pr, row, 1, planes + LY::fwd_slot() * 3 * PLANE_G);
   __syncthreads();
   __shared__ __attribute__((aligned(16))) float s_k[8];   // FC: the five normalisers, re-read per tile (loop-long registers would spill)
   if constexpr (FC) {
@@ -278,28 +377,83 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     // Every LDS read of a phase is issued at its top (sched_barrier keeps it there): one wave per SIMD, so the latency
     // is hidden by this wave's own arithmetic or not at all.
     f32x16 dY[2], Xc[2];
+    float Eb[2][2][8];               // the tile's encoding, weight-gradient operand layout (lane = feature, 8 samples per k-block)
+    float Cb[2][2][8];               // HS + Fourier: cos of the same arguments, for the Fourier-matrix gradient
     {
       f32x16 Hc[2];
       const float4 wout[2] = {cwout[i], cwout[32 + i]};
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Hc[m][r] = HLb[COL_OFF(m, r)];
-      if (L == 2) {                  // layer 1's input columns: in flight under the output layer's arithmetic (one wave per SIMD:
-                                     // a load issued where it is needed is a stall of a full LDS round trip)
+      float4 dOa[2][8];              // both halves' d_out rows up front, as for the positions below
+      if constexpr (HS) {
+        // recompute H2 = relu(W1 H1 + b1) transposed: A = the H1 tile's rows (lane = sample), B = W1's forward planes, C fragment =
+        // lane = output feature, registers = samples: the "lane = feature" layout the rest of this phase works in.  Same block
+        // structure as a data gradient (row splits of k-block k + 1 under the MFMAs of k-block k).
+        const ngm_u32x4* fwdP = planes + LY::fwd_slot() * 3 * PLANE_G;
+#ifndef NGM_HS_NO_EARLY_ENC
+        // ... with the ENCODING of this tile in the shadows of its 48 MFMAs: sine (and, Fourier, cosine) of the tile's 32 x 64
+        // (sample, feature) pairs need only the positions, the recompute only the H1 rows -- two independent streams, and this
+        // kernel instance has the registers to keep the 32 + 32 results until layer 0 wants them (the full-stash kernel does not:
+        // docs/DESIGN_NOTEBOOK.md 7.1).  A quarter of the pairs per k-block; the vector phase that is left behind layer 0's data
+        // gradient is the Fourier-matrix gradient alone.
+        {
+          const float4 encw[2] = {cenc[i], cenc[32 + i]};
+          recompute_with_encoding<NEED_COS, ENC_GRAD>(fwdP, H1b, pb_c, encw, lane, Hc, Eb, Cb);
+        }
+#else
+        {
+          RowRegs Rh;
+          PlaneRegs Wf;
+          load_rows(H1b, lane, Rh);
+          load_planes(fwdP, 0, lane, Wf);
+          __builtin_amdgcn_sched_barrier(0);
+          dgrad_b3(fwdP, Rh, Wf, lane, Hc);
+        }
+#endif
+        // layer 1's input columns (weight gradient operand, ReLU mask of layer 0) and the d_out rows: in flight under the bias / ReLU
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dOa[0][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * (e >> 2) + 4 * hi + (e & 3)));
+        const float b1v[2] = {sm[LY::CONSTS + 512 + i], sm[LY::CONSTS + 512 + 32 + i]};
+        {
+          const float4 a0 = accl[0], a1 = accl[64];
+          const float2 a2 = reinterpret_cast<const float2*>(accl + 128)[0];
+          dwo[0][0] = a0.x; dwo[0][1] = a0.y; dwo[0][2] = a0.z; dwo[0][3] = a0.w;
+          dwo[1][0] = a1.x; dwo[1][1] = a1.y; dwo[1][2] = a1.z; dwo[1][3] = a1.w;
+          dbh[L - 1][0] = a2.x; dbh[L - 1][1] = a2.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Hc[m][r] = fmaxf(Hc[m][r] + b1v[m], 0.f);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Hc[m][r] = HLb[COL_OFF(m, r)];
+        if (L == 2) {                  // layer 1's input columns: in flight under the output layer's arithmetic (one wave per SIMD:
+                                       // a load issued where it is needed is a stall of a full LDS round trip)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xc[m][r] = H1b[COL_OFF(m, r)];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
       }
-      float4 dOa[2][8];              // both halves' d_out rows up front, as for the positions below
-#pragma unroll
-      for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dOa[half][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 * half + e) >> 2) + 4 * hi + (e & 3)));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        if constexpr (HS) {            // the second half's rows: in flight under the first half's arithmetic (register pressure)
+          if (half == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dOa[1][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 + e) >> 2) + 4 * hi + (e & 3)));
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int r = 8 * half + e;
@@ -318,6 +472,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WAVE_SYNC();
+      if constexpr (HS) {
+        accl[0] = make_float4(dwo[0][0], dwo[0][1], dwo[0][2], dwo[0][3]);
+        accl[64] = make_float4(dwo[1][0], dwo[1][1], dwo[1][2], dwo[1][3]);
+        reinterpret_cast<float2*>(accl + 128)[0] = make_float2(dbh[L - 1][0], dbh[L - 1][1]);
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -345,6 +504,10 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       f32x16 dX[2];
       dgrad_b3(planes + LY::plane_slot(1) * 3 * PLANE_G, R, W0, lane, dX);
       TICK(7);
+      if constexpr (HS) {
+        const float2 b0 = reinterpret_cast<const float2*>(accl + 128)[1];
+        dbh[0][0] = b0.x; dbh[0][1] = b0.y;
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -354,6 +517,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
           dbh[0][m] += g;
         }
       WAVE_SYNC();
+      if constexpr (HS) reinterpret_cast<float2*>(accl + 128)[1] = make_float2(dbh[0][0], dbh[0][1]);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -375,13 +539,40 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     }
     TICK(8);
     const float4 encw[2] = {cenc[i], cenc[32 + i]};
-    float Eb[2][2][8];
     float4 ppa[2][8];                // both blocks' positions up front: the second block's read latency hides under the first's arithmetic
+#ifndef NGM_HS_NO_EARLY_ENC
+    constexpr bool EARLY = HS;       // the encoding was evaluated under the recompute's MFMAs
+#else
+    constexpr bool EARLY = false;
+#endif
+    if constexpr (!EARLY || ENC_GRAD) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+        for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+    }
+    if constexpr (HS && ENC_GRAD) {
+      const float4 f0 = accl[192], f1 = accl[256];
+      dwf[0][0] = f0.x; dwf[0][1] = f0.y; dwf[0][2] = f0.z;
+      dwf[1][0] = f1.x; dwf[1][1] = f1.y; dwf[1][2] = f1.z;
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EARLY) {
+      if constexpr (ENC_GRAD) {      // Fourier-matrix gradient: d sin(w.x)/d w = cos(w.x) x
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 p = ppa[b][e];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const float g = dE[m][8 * b + e] * Cb[b][m][e];
+              dwf[m][0] = fmaf(g, p.x, dwf[m][0]); dwf[m][1] = fmaf(g, p.y, dwf[m][1]); dwf[m][2] = fmaf(g, p.z, dwf[m][2]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const float inv2pi = 0.15915494309189535f;
@@ -406,6 +597,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
+    if constexpr (HS && ENC_GRAD) {
+      accl[192] = make_float4(dwf[0][0], dwf[0][1], dwf[0][2], 0.f);
+      accl[256] = make_float4(dwf[1][0], dwf[1][1], dwf[1][2], 0.f);
+    }
     // ---- next tile's transfers + this tile's last matrix work.  On gfx950 a wave's LDS instructions crawl while it
     // has HBM -> LDS transfers it has not waited for (tools/micro/dma_lds.hip: 8 ds_read_b128 behind 8 transfers cost
     // 1400 clocks instead of 250, whether the data has long arrived or not), and with one wave per SIMD nobody fills
@@ -425,10 +621,10 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       }
       const uint32_t u0 = nxt + fs.gb;
       if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
-        issue_tile32_fast(fs.act[L - 1], u0 >> 5, lane, wl_lds + LY::HL * 4);
+        if constexpr (!HS) issue_tile32_fast(fs.act[L - 1], u0 >> 5, lane, wl_lds + LY::HL * 4);
         if (L == 2) issue_tile32_fast(fs.act[0], u0 >> 5, lane, wl_lds + LY::H1 * 4);
       } else {
-        issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
+        if constexpr (!HS) issue_tile32(fs.act[L - 1], fs.gb, nxt, end, lane, wl_lds + LY::HL * 4);
         if (L == 2) issue_tile32(fs.act[0], fs.gb, nxt, end, lane, wl_lds + LY::H1 * 4);
       }
     }
@@ -450,6 +646,14 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     WAVE_SYNC();
   }
 #undef COL_OFF
+  if constexpr (HS) {                 // the per-feature sums back into registers before the staging area takes all of LDS
+    const float4 a0 = accl[0], a1 = accl[64], a2 = accl[128], f0 = accl[192], f1 = accl[256];
+    dwo[0][0] = a0.x; dwo[0][1] = a0.y; dwo[0][2] = a0.z; dwo[0][3] = a0.w;
+    dwo[1][0] = a1.x; dwo[1][1] = a1.y; dwo[1][2] = a1.z; dwo[1][3] = a1.w;
+    dbh[L - 1][0] = a2.x; dbh[L - 1][1] = a2.y; dbh[0][0] = a2.z; dbh[0][1] = a2.w;
+    dwf[0][0] = f0.x; dwf[0][1] = f0.y; dwf[0][2] = f0.z;
+    dwf[1][0] = f1.x; dwf[1][1] = f1.y; dwf[1][2] = f1.z;
+  }
   __syncthreads();
 
   // ---- epilogue: the four waves' accumulators are summed in fixed wave order (all of LDS is free now)
@@ -540,20 +744,20 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool HS>
 static int launch_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 #define NGM_LBB3(NC, EG)                                                                                              \
   do {                                                                                                                \
-    const size_t lds = (size_t)LdsB3b<L, EG>::TOTAL * sizeof(float);                                                  \
+    const size_t lds = (size_t)LdsB3b<L, EG, HS>::TOTAL * sizeof(float);                                              \
     if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;                                                                   \
     if (a.fused_comp) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG, true, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                            \
-      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG, true>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);             \
+      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG, true, HS>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);         \
     } else {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+      (void)hipFuncSetAttribute((const void*)k_field_bwd_b3<L, NC, EG, false, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                            \
-      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);                   \
+      hipLaunchKernelGGL((k_field_bwd_b3<L, NC, EG, false, HS>), dim3(blocks), dim3(B3B_THREADS), lds, st, a);        \
     }                                                                                                                 \
   } while (0)
   if (a.fc.encoding == NGM_ENC_FOURIER) NGM_LBB3(false, true);
@@ -580,9 +784,10 @@ int ngm_launch_field_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
   if (!ngm_field_bwd_b3_applies(a)) return NGM_E_UNSUPPORTED;
   if (a.fused_comp && (a.per_block % (B3B_WAVES * 32) || !a.rayseed)) return NGM_E_INVALID;
   NgmProfScope prof_(NGM_K_FIELD_BWD, st);
-  if (L == 2) return launch_bwd_b3<2>(a, blocks, st);
+  if (a.act_half && L != 2) return NGM_E_INVALID;
+  if (L == 2) return a.act_half ? launch_bwd_b3<2, true>(a, blocks, st) : launch_bwd_b3<2, false>(a, blocks, st);
 #ifndef NGM_FAST_BUILD
-  if (L == 1) return launch_bwd_b3<1>(a, blocks, st);
+  if (L == 1) return launch_bwd_b3<1, false>(a, blocks, st);
 #endif
   return NGM_E_UNSUPPORTED;
 }

@@ -4,14 +4,13 @@
 // HBM-bound integer/byte work: three streaming passes over the (nx, ny, nz) volume, no atomics, deterministic
 // output order (vertices by (grid point, axis) of the crossed edge, faces by cell) through two exclusive scans:
 //   k_mc_classify : per grid point the three "edge crossed" flags + per cell the triangle count of its corner case
-//   rocPRIM scans : vertex / face offsets (the +1'th element holds the totals)
+//   k_scan_*      : vertex / face offsets, hand-written reduce-then-scan (the +1'th element holds the totals)
 //   k_mc_emit     : vertices (linear interpolation along the edge) and faces (indices through the vertex offsets)
 // The 256-case triangulation table is derived from the cube topology at first use (no typed-in table): face
 // segments -> closed loops -> a triangulation without in-face diagonals; ambiguous faces cut off the inside corners,
 // a rule both neighbours of a face evaluate identically, so the mesh is watertight.  PARITY UNPINNED against
 // pytorch3d (not vendored); the CPU restatement is oracle/mesh_oracle.py.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <array>
 #include <cstring>
@@ -281,12 +280,107 @@ __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
 
 }  // namespace
 
-// workspace: vflag (3N+1) + tcnt (cells+1) int32 + the scans' temporary storage
-static int64_t mc_scan_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
-  return (int64_t)bytes;
+// ---- exclusive prefix sum of int32, in place (vertex / face offsets).  Hand-written reduce-then-scan, three launches:
+//   k_scan_sums    one workgroup per 4096-element chunk: the chunk's sum
+//   k_scan_chunks  ONE workgroup: exclusive scan of the chunk sums (a 201^3 block has 5 950 of them)
+//   k_scan_apply   one workgroup per chunk: 16 consecutive elements per thread (four 16-byte loads), thread-local scan, wave scan
+//                  by lane shifts, the four waves' totals through LDS, + the chunk's offset; written back over the input
+// 12 bytes of traffic per element (read twice, written once) -- HBM-bound integer work, no atomics, fixed order.
+constexpr int SCAN_T = 256, SCAN_V = 16, SCAN_CHUNK = SCAN_T * SCAN_V;
+
+__device__ __forceinline__ int4 scan_load4(const int32_t* __restrict__ d, int64_t i, int64_t n) {
+  if (i + 3 < n) return *reinterpret_cast<const int4*>(d + i);
+  int4 v = make_int4(0, 0, 0, 0);
+  if (i < n) v.x = d[i];
+  if (i + 1 < n) v.y = d[i + 1];
+  if (i + 2 < n) v.z = d[i + 2];
+  return v;
 }
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const int32_t* __restrict__ d, int64_t n, int32_t* __restrict__ csum) {
+  __shared__ int sh[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_V / 4; ++j) {              // striped: a wave reads 1 KB contiguous per instruction
+    const int4 v = scan_load4(d, base + ((int64_t)j * SCAN_T + threadIdx.x) * 4, n);
+    s += v.x + v.y + v.z + v.w;
+  }
+  const int t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) csum[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void k_scan_chunks(int32_t* __restrict__ csum, int nc) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < nc; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nc ? csum[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (i < nc) csum[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + inc;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_apply(int32_t* __restrict__ d, int64_t n, const int32_t* __restrict__ coff) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_V;
+  int4 v[SCAN_V / 4];
+#pragma unroll
+  for (int j = 0; j < SCAN_V / 4; ++j) v[j] = scan_load4(d, i0 + 4 * j, n);
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_V / 4; ++j) {              // thread-local exclusive scan
+    const int4 x = v[j];
+    v[j].x = run; run += x.x;
+    v[j].y = run; run += x.y;
+    v[j].z = run; run += x.z;
+    v[j].w = run; run += x.w;
+  }
+  int inc = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int off = coff[blockIdx.x] + inc - run;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+  for (int j = 0; j < SCAN_V / 4; ++j) {
+    const int64_t i = i0 + 4 * j;
+    const int4 o4 = make_int4(v[j].x + off, v[j].y + off, v[j].z + off, v[j].w + off);
+    if (i + 3 < n) *reinterpret_cast<int4*>(d + i) = o4;
+    else {
+      if (i < n) d[i] = o4.x;
+      if (i + 1 < n) d[i + 1] = o4.y;
+      if (i + 2 < n) d[i + 2] = o4.z;
+    }
+  }
+}
+static void exclusive_scan_inplace(int32_t* d, int64_t n, int32_t* chunk_sums, hipStream_t st) {
+  const int nc = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nc), dim3(SCAN_T), 0, st, d, n, chunk_sums);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, st, chunk_sums, nc);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nc), dim3(SCAN_T), 0, st, d, n, chunk_sums);
+}
+
+// workspace: vflag (3N+1) + tcnt (cells+1) int32 + the scans' chunk sums
+static int64_t mc_scan_temp_bytes(int64_t n) { return 4 * ((n + SCAN_CHUNK - 1) / SCAN_CHUNK) + 256; }
 static inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
 
 int64_t ngm_mc_workspace_bytes(int nx, int ny, int nz) {
@@ -322,10 +416,9 @@ int ngm_launch_mc_count(const float* vol, int nx, int ny, int nz, float iso, int
   a.counts = counts;
   const int64_t N = (int64_t)nx * ny * nz, cells = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
   hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, a);
-  size_t bytes = (size_t)tb;
-  if (hipcub::DeviceScan::ExclusiveSum(temp, bytes, a.vflag, a.vflag, (int)(3 * N + 1), st) != hipSuccess) return NGM_E_HIP;
-  bytes = (size_t)tb;
-  if (hipcub::DeviceScan::ExclusiveSum(temp, bytes, a.tcnt, a.tcnt, (int)(cells + 1), st) != hipSuccess) return NGM_E_HIP;
+  (void)tb;
+  exclusive_scan_inplace(a.vflag, 3 * N + 1, reinterpret_cast<int32_t*>(temp), st);
+  exclusive_scan_inplace(a.tcnt, cells + 1, reinterpret_cast<int32_t*>(temp), st);
   hipLaunchKernelGGL(k_mc_totals, dim3(1), dim3(1), 0, st, a);
   return NGM_OK;
 }

@@ -49,6 +49,31 @@ def grad_close(a, b, tol=2e-3, name=""):
     assert err < tol, (name, err)
 
 
+# Gradient bars of the HASH network, set from what the comparisons measured (profiles/r05_parity_margins.txt: the whole -m gpu
+# suite, worst case per tensor) times a margin of two, instead of round 4's blanket 1e-2:
+#   table gradient, against the GLOBAL max |grad|        measured 2.96e-3  -> 6e-3
+#   table gradient of levels 0-4, against the LEVEL's max measured 2.8e-3   -> 6e-3
+#   table gradient of levels 5-15, against the LEVEL's max measured 1.0e-1  -> 2e-1: sigma_l <= 6e-3 there, the fp32 position
+#       error (~5e-7) is up to 5e-3 in lattice coordinates, i.e. in a barycentric weight, and an entry few samples touch with
+#       opposite signs inherits it relative to ITS scale -- in the oracle as in the kernels (and in the reference's CUDA
+#       package); these levels carry < 1 % of the table gradient's norm
+#   first layer's weight (it multiplies the features)      measured 1.83e-3  -> 4e-3
+#   every other MLP tensor                                  measured 6.6e-4   -> 2e-3 (the Fourier bar)
+HASH_BARS = dict(lattice=6e-3, lattice_coarse_level=6e-3, lattice_fine_level=2e-1, first_weight=4e-3, other=2e-3)
+
+
+def hash_grad_close(a, b, name):
+    if name == "_encoding.lattice_values" and b.dim() == 4:
+        grad_close(a, b, HASH_BARS["lattice"], name)
+        for l, e in enumerate(lattice_level_errors(a, b)):
+            bar = HASH_BARS["lattice_coarse_level"] if l < 5 else HASH_BARS["lattice_fine_level"]
+            assert e < bar, (name, "level", l, e, bar)
+    elif name == "_linears.0.weight":
+        grad_close(a, b, HASH_BARS["first_weight"], name)
+    else:
+        grad_close(a, b, HASH_BARS["other"], name)
+
+
 def away_from_relu_boundaries(q, pos, quat, params, fs, margin=1e-5, tries=20):
     """Resample query points whose fp64 pre-activations come within `margin` of a ReLU kink, where the
     derivative is discontinuous and fp32 implementations may legitimately disagree."""
@@ -112,8 +137,8 @@ def make_renderer(fkw, ckw, num_fields, params=None):
     model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
         encoding_type=et, encoding_kwargs=ek, num_layers=fkw["num_layers"], dim_out=4, neus_initial_sd=1.0,
         skip_mode=fkw.get("skip_mode", "no")), num_knn=2,
-        distance_factor=10.0, outside_value=1.0, field_radius=1.0, scale_mode="unit_cube",
-        weight_dtype=fkw.get("weight_dtype")).to(DEV)
+        distance_factor=10.0, outside_value=1.0, field_radius=float(ckw.get("field_radius", 1.0)), scale_mode="unit_cube",
+        weight_dtype=fkw.get("weight_dtype")).to(DEV)                 # one radius for model and map, like the shipped YAML's anchor
     cfg = dict(geometry_mode="nrgbd", geometry_factor=20.0, color_factor=1.0, truncation_distance=0.1, field_radius=1.0,
                termination_weight=0.0, photometric_weight=1.0, photometric_loss="l1", depth_weight=1.0, depth_loss="huber",
                freespace_weight=40.0, tsdf_weight=50.0,

@@ -20,7 +20,7 @@ from neural_graph_mapping_amd import ops  # noqa: E402
 from neural_graph_mapping_amd import renderer as Rr  # noqa: E402
 from oracle import ngm_oracle as O  # noqa: E402
 from gpu_common import (CASES, DEV, NRGBD, NRGBD_KW, away_from_relu_boundaries, close, cu, grad_close,  # noqa: E402
-                        kink_free_draws, make_renderer, make_target, ragged_case, synth_target)
+                        hash_grad_close, kink_free_draws, make_renderer, make_target, ragged_case, synth_target)
 
 def test_device_is_gfx950_and_library_loaded():
     n = C.c_int(0)
@@ -218,7 +218,7 @@ def test_field_eval_forward_backward_vs_oracle(kw, P):
     close(out, out_o.detach(), rtol=tol, atol=tol * 0.2)
     (out * d_out.to(DEV)).sum().backward()
     for k in po:
-        grad_close(pg[k].grad, po[k].grad, 2e-3 if kw["encoding"] == "fourier" else 1e-2, k)
+        grad_close(pg[k].grad, po[k].grad, 2e-3, k)              # NeRF octaves too (measured <= 3.4e-4; was 1e-2)
 
 
 def test_neural_field_set_module_matches_oracle():
@@ -547,7 +547,7 @@ def test_skip_with_other_encodings_golden(name):
     mode, enc = name.split("_")[2], name.split("_")[3]
     if enc == "nerf":
         fc = K.field_cfg(encoding="nerf", num_octaves=8, num_layers=2, skip_mode=mode)
-        ftol, gtol = dict(rtol=2e-3, atol=3e-4), 1e-2             # arguments up to 2^7 pi: the NeRF tolerances of G4 / G6
+        ftol, gtol = dict(rtol=2e-3, atol=3e-4), 2e-3             # arguments up to 2^7 pi: forward looser; gradients at the common bar
     else:
         fc = K.field_cfg(encoding="triplane", resolution=12, num_components=32, tri_mode="sum", num_layers=2, skip_mode=mode,
                          scale_mode="unit_ball")
@@ -603,7 +603,10 @@ def test_skip_other_encodings_fused_train_step_vs_oracle(enc, mode):
     loss["combined"].backward()
     for k in po:
         if po[k].grad is not None:
-            grad_close(res["grads"][k], po[k].grad, 1e-2 if loose else 2e-3, k)
+            if enc == "permuto":
+                hash_grad_close(res["grads"][k], po[k].grad, k)
+            else:            # NeRF octaves: measured worst 3.4e-4 over the suite (profiles/r05_parity_margins.txt); was 1e-2
+                grad_close(res["grads"][k], po[k].grad, 2e-3, k)
     out = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=True)   # fused Adam
     assert torch.isfinite(out["combined"])
 
@@ -661,7 +664,7 @@ def test_fused_train_step_golden(name):
     for k, v in ref_loss.items():
         close(res[k], v, rtol=1e-3 if nerf else 2e-4, atol=1e-5)
     for k, v in split_prefix(g, "g::").items():
-        grad_close(res["grads"][k], v, 1e-2 if nerf else 2e-3, k)
+        grad_close(res["grads"][k], v, 2e-3, k)                  # NeRF octaves too: measured 3.4e-4 (was 1e-2)
 
 
 @pytest.mark.parametrize("name", ["g6_train_cfg0", "g6_train_3field", "g18_train_l2", "g20_train_gnll_gnll", "g20_train_l1_lnll",
@@ -1001,7 +1004,7 @@ def test_permuto_field_eval_vs_oracle(L_, P):
     (out * d_out.to(DEV)).sum().backward()
     for k in po:
         if po[k].grad is not None:
-            grad_close(pg[k].grad, po[k].grad, 1e-2, k)              # hash: fp32 lattice coordinates at sigma = 1e-4
+            hash_grad_close(pg[k].grad, po[k].grad, k)               # hash: measured bars per tensor / level group (gpu_common.HASH_BARS)
     # table gradient: every touched entry matches, untouched entries are exactly zero
     gl, rl = pg["_encoding.lattice_values"].grad.cpu(), po["_encoding.lattice_values"].grad
     assert torch.equal(gl == 0, rl == 0) or float(((gl == 0) != (rl == 0)).float().mean()) < 1e-3
@@ -1060,7 +1063,7 @@ def _permuto_train_case(F, R, n_c, n_g, mm, max_neutralised=0.15):
     close(res["combined"], loss["combined"].detach(), rtol=2e-3, atol=1e-5)
     for k in po:
         if po[k].grad is not None:
-            grad_close(res["grads"][k], po[k].grad, 1e-2, k)          # hash: fp32 lattice coordinates at sigma = 1e-4
+            hash_grad_close(res["grads"][k], po[k].grad, k)           # hash: measured bars per tensor / level group (gpu_common.HASH_BARS)
     first = {k: v.clone() for k, v in res["grads"].items()}            # (the renderer reuses its gradient buffers)
     again = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
     for k in first:

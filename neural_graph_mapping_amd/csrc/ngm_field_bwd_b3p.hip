@@ -149,6 +149,24 @@ __device__ __forceinline__ void dy_store_cells(char* tile, int lane, int b, cons
   }
 }
 
+// ... and back: the lane's OWN cells are its weight-gradient A operands (no transposition: lane = feature on both sides)
+__device__ __forceinline__ void dy_load_cells(const char* tile, int lane, int b, B3Op (&A)[2]) {
+  const int i = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    v2u h[2], mm[2], l[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int sg = 4 * b + 2 * w + hi;
+      const int off = (sg * 64 + ((32 * m + i) ^ (4 * (sg & 3)))) * 8;
+      h[w] = *reinterpret_cast<const v2u*>(tile + off);
+      mm[w] = *reinterpret_cast<const v2u*>(tile + 4096 + off);
+      l[w] = *reinterpret_cast<const v2u*>(tile + 8192 + off);
+    }
+    A[m].h = bf8(h[0], h[1]); A[m].m = bf8(mm[0], mm[1]); A[m].l = bf8(l[0], l[1]);
+  }
+}
+
 // weight-gradient blocks with the two B operands (feature tiles mi = 0, 1) passed separately
 __device__ __forceinline__ void wgrad_b3_block_free(const B3Op (&A)[2], const B3Op& B0, const B3Op& B1, f32x16 (&acc)[2][2]) {
   const B3Op Bx[2] = {B0, B1};
@@ -215,21 +233,87 @@ __device__ __forceinline__ void dgrad_cells(const char* tile, const char* w1c, c
   }
 }
 
-// H2^T = H1 W1^T (48 MFMAs) with both operands read as planes -- rows of the H1 tile (A), rows of W1's cells (B) -- and the
-// tile's ENCODING evaluated in the shadows of those MFMAs: one (sample, feature-tile) pair of the encoding (~9 vector
-// instructions) behind each of 8 of a k-block's 12 MFMAs, every step fenced; each slice's results are pinned to their slice by
-// an empty volatile asm, its input and the MFMA's A operand likewise (pure instructions otherwise float to their uses / to
-// where their operands became ready).
-template <bool NEED_COS, bool ENC_GRAD>
-__device__ __forceinline__ void recompute_planes_with_encoding(const char* __restrict__ w1c, const char* __restrict__ tile,
-                                                               const float* __restrict__ pb, const float4 (&encw)[2], int lane,
-                                                               f32x16 (&Hc)[2], float (&Eb)[2][2][8], float (&Cb)[2][2][8]) {
+// ---- GEMM phases "by steps": every MFMA is followed by one slice of INDEPENDENT vector work and a full scheduling fence.
+// One wave per SIMD: an MFMA holds the matrix pipe 32 clocks but the issue port 4; only this wave's own instructions can use
+// the rest, and only if they stand between two MFMAs in program order (the sequencer is in order: vector work behind a block
+// of MFMAs overlaps with the last one alone).  sched_group_barrier pipelines proved unreliable for work whose uses are a
+// phase away (instruction selection sinks pure instructions to their uses), so the order is built by construction: the
+// A operand of the step is pinned (the MFMA cannot float up), the slice pins its own inputs and results.
+template <class F>
+__device__ __forceinline__ void wgrad_steps(const B3Op (&Ain)[2], const B3Op& B0, const B3Op& B1, f32x16 (&acc)[2][2], int j0, F&& work) {
+  const B3Op A[2] = {Ain[0], Ain[1]};
+  const B3Op Bx[2] = {B0, B1};
+  int j = j0;
+#define NGM_WS_PRODUCT(PA, PB_)                                                          \
+  _Pragma("unroll") for (int mo = 0; mo < 2; ++mo)                                        \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                    \
+      acc[mo][mi] = mfma_bf16(A[mo].PA, Bx[mi].PB_, acc[mo][mi]);                         \
+      asm volatile("" : "+a"(acc[mo][mi]));     /* the MFMA stays in its step: its accumulator (an AGPR tuple in this kernel) is pinned */ \
+      work(j++);                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+  NGM_WS_PRODUCT(l, h)
+  NGM_WS_PRODUCT(h, l)
+  NGM_WS_PRODUCT(m, m)
+  NGM_WS_PRODUCT(m, h)
+  NGM_WS_PRODUCT(h, m)
+  NGM_WS_PRODUCT(h, h)
+#undef NGM_WS_PRODUCT
+}
+template <bool W1T, class F>
+__device__ __forceinline__ void dgrad_cells_steps(const char* tile, const char* w1c, const ngm_u32x4* P, const P3Lane& pl, int lane,
+                                                  f32x16 (&dX)[2], F&& work) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  TrOps o[2];
+  dgrad_cells_load<W1T>(tile, w1c, P, pl, lane, 0, o[0]);
+  int j = 0;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    if (kb < 3) dgrad_cells_load<W1T>(tile, w1c, P, pl, lane, kb + 1, o[(kb + 1) & 1]);
+    const TrOps& c = o[kb & 1];
+    __builtin_amdgcn_sched_barrier(0);
+#define NGM_DS_PRODUCT(PA, PB_, Z)                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                    \
+      dX[nt] = mfma_bf16(c.PA, c.PB_[nt], (Z) ? zero : dX[nt]);                           \
+      asm volatile("" : "+a"(dX[nt]));                                                    \
+      work(j++);                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    NGM_DS_PRODUCT(al, bh, kb == 0)
+    NGM_DS_PRODUCT(ah, bl, false)
+    NGM_DS_PRODUCT(am, bm, false)
+    NGM_DS_PRODUCT(am, bh, false)
+    NGM_DS_PRODUCT(ah, bm, false)
+    NGM_DS_PRODUCT(ah, bh, false)
+#undef NGM_DS_PRODUCT
+  }
+}
+// slice of a three-way split: one PAIR of values -> one dword of each plane (11 vector instructions), pinned to its slice
+struct SplitAcc { uint32_t h[2][2][4], m[2][2][4], l[2][2][4]; };     // [feature tile][k-block][dword]
+__device__ __forceinline__ void split_pair_slice(float x0, float x1, SplitAcc& S, int mt, int b, int q) {
+  asm volatile("" : "+v"(x0), "+v"(x1));
+  uint32_t hp, mp, lp;
+  b3_split2(x0, x1, hp, mp, lp);
+  asm volatile("" : "+v"(hp), "+v"(mp), "+v"(lp));
+  S.h[mt][b][q] = hp; S.m[mt][b][q] = mp; S.l[mt][b][q] = lp;
+}
+__device__ __forceinline__ B3Op split_op(const SplitAcc& S, int mt, int b) {
+  B3Op o;
+  o.h = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{S.h[mt][b][0], S.h[mt][b][1], S.h[mt][b][2], S.h[mt][b][3]});
+  o.m = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{S.m[mt][b][0], S.m[mt][b][1], S.m[mt][b][2], S.m[mt][b][3]});
+  o.l = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{S.l[mt][b][0], S.l[mt][b][1], S.l[mt][b][2], S.l[mt][b][3]});
+  return o;
+}
+
+// H2^T = H1 W1^T (48 MFMAs) with both operands read as planes -- rows of the H1 tile (A), rows of W1's cells (B) -- by steps:
+// work(j), j = 0..47, is the slice of independent vector work behind MFMA j.
+template <class F>
+__device__ __forceinline__ void recompute_planes_steps(const char* __restrict__ w1c, const char* __restrict__ tile, int lane,
+                                                       f32x16 (&Hc)[2], F&& work) {
   const int n = lane & 31, hi = lane >> 5;
-  const float inv2pi = 0.15915494309189535f;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   struct Ops { ngm_bf16x8 ah, am, al, bh[2], bm[2], bl[2]; };
   Ops o[2];
-  float4 pq[2][4];
   auto ldo = [&](int kb, Ops& d) __attribute__((always_inline)) {
     d.ah = cells_row<32>(tile, kb, hi, n);
     d.am = cells_row<32>(tile + 4096, kb, hi, n);
@@ -241,58 +325,41 @@ __device__ __forceinline__ void recompute_planes_with_encoding(const char* __res
       d.bl[nt] = cells_row<64>(w1c + 16384, kb, hi, 32 * nt + n);
     }
   };
-  auto ldq = [&](int q) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int b = q >> 1, e = 4 * (q & 1) + j;
-      pq[q & 1][j] = *reinterpret_cast<const float4*>(pb + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
-    }
-  };
   ldo(0, o[0]);
-  ldq(0);
   __builtin_amdgcn_sched_barrier(0);
+  int j = 0;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     Ops& c = o[kb & 1];
-    if (kb < 3) { ldo(kb + 1, o[(kb + 1) & 1]); ldq(kb + 1); }
-    auto enc = [&](int idx) __attribute__((always_inline)) {           // element idx of quarter kb: sample j, feature tile m
-      const int j = idx >> 1, m = idx & 1, b = kb >> 1, e = 4 * (kb & 1) + j;
-      float4 p = pq[kb & 1][j];
-      asm volatile("" : "+v"(p.x));
-      const float4 w = encw[m];
-      const float arg = fmaf(w.z, p.z, fmaf(w.y, p.y, w.x * p.x));
-      const float rev = __builtin_amdgcn_fractf(arg * inv2pi);
-      const float sn = __builtin_amdgcn_sinf(rev);
-      float v = sn;
-      if (NEED_COS) v = (w.w == NGM_FK_COS) ? __builtin_amdgcn_cosf(rev) : sn;
-      if (m == 0) v = (w.w == NGM_FK_RAW) ? arg : v;                    // raw coordinates are features 0..2
-      asm volatile("" : "+v"(v));
-      Eb[b][m][e] = v;
-      if (ENC_GRAD) {
-        float cs = __builtin_amdgcn_cosf(rev);
-        asm volatile("" : "+v"(cs));
-        Cb[b][m][e] = cs;
-      }
-    };
-#define NGM_HP_STEP(PA, PB_, NT_, Z, WORK)                                                                      \
-    asm volatile("" : "+v"(c.PA));                                                                              \
-    Hc[NT_] = mfma_bf16(c.PA, c.PB_[NT_], (Z) ? zero : Hc[NT_]);                                                \
-    WORK;                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);
-    NGM_HP_STEP(al, bh, 0, kb == 0, enc(0))
-    NGM_HP_STEP(al, bh, 1, kb == 0, enc(1))
-    NGM_HP_STEP(ah, bl, 0, false, enc(2))
-    NGM_HP_STEP(ah, bl, 1, false, (void)0)
-    NGM_HP_STEP(am, bm, 0, false, enc(3))
-    NGM_HP_STEP(am, bm, 1, false, enc(4))
-    NGM_HP_STEP(am, bh, 0, false, (void)0)
-    NGM_HP_STEP(am, bh, 1, false, enc(5))
-    NGM_HP_STEP(ah, bm, 0, false, enc(6))
-    NGM_HP_STEP(ah, bm, 1, false, (void)0)
-    NGM_HP_STEP(ah, bh, 0, false, enc(7))
-    NGM_HP_STEP(ah, bh, 1, false, (void)0)
-#undef NGM_HP_STEP
+    if (kb < 3) ldo(kb + 1, o[(kb + 1) & 1]);
+#define NGM_HP_PRODUCT(PA, PB_, Z)                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                    \
+      Hc[nt] = mfma_bf16(c.PA, c.PB_[nt], (Z) ? zero : Hc[nt]);                           \
+      asm volatile("" : "+a"(Hc[nt]));                                                    \
+      work(j++);                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    NGM_HP_PRODUCT(al, bh, kb == 0)
+    NGM_HP_PRODUCT(ah, bl, false)
+    NGM_HP_PRODUCT(am, bm, false)
+    NGM_HP_PRODUCT(am, bh, false)
+    NGM_HP_PRODUCT(ah, bm, false)
+    NGM_HP_PRODUCT(ah, bh, false)
+#undef NGM_HP_PRODUCT
   }
+}
+// one value of the encoding (positional_encodings.py:197-201 / 262-276): v = raw coordinate | sin | cos of w . p, rev = the
+// argument in revolutions (for the cosine of the Fourier-matrix gradient); the hardware sine / cosine of k_field_bwd_b3
+template <bool NEED_COS>
+__device__ __forceinline__ float enc_value(const float4& w, float x, float y, float z, bool first_tile, float& rev) {
+  const float inv2pi = 0.15915494309189535f;
+  const float arg = fmaf(w.z, z, fmaf(w.y, y, w.x * x));
+  rev = __builtin_amdgcn_fractf(arg * inv2pi);
+  const float sn = __builtin_amdgcn_sinf(rev);
+  float v = sn;
+  if (NEED_COS) v = (w.w == NGM_FK_COS) ? __builtin_amdgcn_cosf(rev) : sn;
+  if (first_tile) v = (w.w == NGM_FK_RAW) ? arg : v;                    // raw coordinates are features 0..2
+  return v;
 }
 
 // (the structure of k_field_bwd_b3<2, .., HS = true>; the differences are marked "planes")
@@ -553,161 +620,197 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3p(FieldBwdArgs a) {
       WAVE_SYNC();
     }
     TICK(1);
-    // ---- output layer, lane = feature: dY = relu'(H) * (Wout^T d_out); output-weight and bias gradients.
-    // Every LDS read of a phase is issued at its top (sched_barrier keeps it there): one wave per SIMD, so the latency
-    // is hidden by this wave's own arithmetic or not at all.
-    f32x16 dY[2];
-    B3Op Xp[2][2];                   // planes: layer 1's input columns as weight-gradient operands (m, k-block), straight from LDS
-    float Eb[2][2][8];               // the tile's encoding, weight-gradient operand layout (lane = feature, 8 samples per k-block)
-    float Cb[2][2][8];               // Fourier: cos of the same arguments, for the Fourier-matrix gradient
+    // ---- phase A: H2 = relu(W1 H1 + b1) recomputed transposed, both operands READ as planes (no split).  In the shadows of
+    // its 48 MFMAs: dh = Wout^T d_out (what the output layer's gradient needs and H2 does not enter: 8 fma per sample) and, for
+    // the networks without a Fourier matrix, the tile's encoding (with one, the encoding is evaluated where it is split: phase F)
+    f32x16 dY[2], Hc[2];
+    B3Op Xp[2][2];                   // layer 1's input columns as weight-gradient operands (feature tile, k-block), straight from LDS
+    float Eb[2][2][8];               // (no Fourier matrix) the tile's encoding, weight-gradient operand layout
+    const float4 encw[2] = {cenc[i], cenc[32 + i]};
     {
-      f32x16 Hc[2];
       const float4 wout[2] = {cwout[i], cwout[32 + i]};
-      float4 dOa[2][8];              // both halves' d_out rows
-      {
-        // recompute H2 = relu(W1 H1 + b1) transposed: A = the H1 tile's rows (lane = sample), B = W1's cells (lane = output),
-        // C fragment = lane = output feature, registers = samples.  Both operands are READ as planes: no split.  The tile's
-        // encoding runs in the shadows of the 48 MFMAs (recompute_planes_with_encoding).
-        const float4 encw[2] = {cenc[i], cenc[32 + i]};
-        recompute_planes_with_encoding<NEED_COS, ENC_GRAD>(w1c, tile, pb_c, encw, lane, Hc, Eb, Cb);
-        // layer 1's input columns (transpose reads of the H1 planes) and the first d_out rows: in flight under the bias / ReLU
+      float4 dq[2], pq[2];
+      dq[0] = *reinterpret_cast<const float4*>(ob_c + 4 * (4 * hi));
+      if constexpr (!ENC_GRAD) pq[0] = *reinterpret_cast<const float4*>(pb_c + 4 * (4 * hi));
+      recompute_planes_steps(w1c, tile, lane, Hc, [&](int j) __attribute__((always_inline)) {
+        const int kb = j / 12, st = j % 12;
+        if (st == 3 || st == 6 || st == 9 || st == 11) {                 // dh of sample r, both feature tiles
+          const int r = 4 * kb + (st == 3 ? 0 : st == 6 ? 1 : st == 9 ? 2 : 3);
+          float4 d = dq[r & 1];
+          asm volatile("" : "+v"(d.x));
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const char* c0 = tile + pl.col_h1 + 2048 * m + 128 * b;
-            const char* c1 = tile + (pl.col_h1 ^ 64) + 2048 * m + 128 * b;
-            Xp[m][b].h = bf8(lds_tr(c0), lds_tr(c1));
-            Xp[m][b].m = bf8(lds_tr(c0 + 4096), lds_tr(c1 + 4096));
-            Xp[m][b].l = bf8(lds_tr(c0 + 8192), lds_tr(c1 + 8192));
+          for (int m = 0; m < 2; ++m) {
+            float dh = fmaf(wout[m].w, d.w, fmaf(wout[m].z, d.z, fmaf(wout[m].y, d.y, wout[m].x * d.x)));
+            asm volatile("" : "+v"(dh));
+            dY[m][r] = dh;
           }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dOa[0][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * (e >> 2) + 4 * hi + (e & 3)));
-        const float b1v[2] = {sm[LY::CONSTS + 512 + i], sm[LY::CONSTS + 512 + 32 + i]};
-        {
-          const float4 a0 = accl[0], a1 = accl[64];
-          const float2 a2 = reinterpret_cast<const float2*>(accl + 128)[0];
-          dwo[0][0] = a0.x; dwo[0][1] = a0.y; dwo[0][2] = a0.z; dwo[0][3] = a0.w;
-          dwo[1][0] = a1.x; dwo[1][1] = a1.y; dwo[1][2] = a1.z; dwo[1][3] = a1.w;
-          dbh[L - 1][0] = a2.x; dbh[L - 1][1] = a2.y;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if ((st == 4 || st == 7 || st == 10 || st == 0) && !(kb == 0 && st == 0)) {   // the next d_out row: a slice ahead
+          const int r = 4 * kb + (st == 4 ? 1 : st == 7 ? 2 : st == 10 ? 3 : 0);
+          if (r < 16) dq[r & 1] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * (r >> 2) + 4 * hi + (r & 3)));
+        }
+        if constexpr (!ENC_GRAD) {                                        // encoding: sample r = 4 kb + st / 3 (two feature tiles: st % 3 = 0, 1)
+          if (st % 3 != 2 && st < 12) {
+            const int r = 4 * kb + st / 3, m = st % 3;
+            float4 p = pq[r & 1];
+            asm volatile("" : "+v"(p.x));
+            float rev;
+            float v = enc_value<NEED_COS>(encw[m], p.x, p.y, p.z, m == 0, rev);
+            asm volatile("" : "+v"(v));
+            Eb[r >> 3][m][r & 7] = v;
+          }
+          if (st % 3 == 2 && 4 * kb + st / 3 + 1 < 16) {
+            const int r = 4 * kb + st / 3 + 1;
+            pq[r & 1] = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * (r >> 2) + 4 * hi + (r & 3)));
+          }
+        }
+      });
+      TICK(6);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Hc[m][r] = fmaxf(Hc[m][r] + b1v[m], 0.f);
-      }
+        for (int b = 0; b < 2; ++b) {
+          const char* c0 = tile + pl.col_h1 + 2048 * m + 128 * b;
+          const char* c1 = tile + (pl.col_h1 ^ 64) + 2048 * m + 128 * b;
+          Xp[m][b].h = bf8(lds_tr(c0), lds_tr(c1));
+          Xp[m][b].m = bf8(lds_tr(c0 + 4096), lds_tr(c1 + 4096));
+          Xp[m][b].l = bf8(lds_tr(c0 + 8192), lds_tr(c1 + 8192));
+        }
+      const float b1v[2] = {sm[LY::CONSTS + 512 + i], sm[LY::CONSTS + 512 + 32 + i]};
+      const float2 a2 = reinterpret_cast<const float2*>(accl + 128)[0];
+      dbh[1][0] = a2.x; dbh[1][1] = a2.y;
       __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B (exposed): bias, ReLU, dY1 = relu'(H2) dh, hidden-bias gradient.  (The output-WEIGHT gradient d_out x H2
+      // does not feed dY1: deferred into the shadows of layer 1's data gradient, phase C.)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if constexpr (HS) {            // the second half's rows: in flight under the first half's arithmetic (register pressure)
-          if (half == 0) {
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dOa[1][e] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * ((8 + e) >> 2) + 4 * hi + (e & 3)));
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float h = fmaxf(Hc[m][r] + b1v[m], 0.f);
+          Hc[m][r] = h;
+          const float g = (h > 0.f) ? dY[m][r] : 0.f;
+          dY[m][r] = g;
+          dbh[1][m] += g;
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int r = 8 * half + e;
-          const float4 d = dOa[half][e];
+      reinterpret_cast<float2*>(accl + 128)[0] = make_float2(dbh[1][0], dbh[1][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(4);
+    // ---- phase B2 (exposed): dY1 is split ONCE (lane = feature: the weight gradient's A operands); the planes go to the tile
+    // as cells and come back transposed (lane = sample) as the data gradient's A operand
+    WAVE_SYNC();                       // every read of the H1 planes has been issued (in-order LDS queue): overwrite them
+    { const B3Op t0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])}; dy_store_cells(tile, lane, 0, t0); }
+    { const B3Op t1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])}; dy_store_cells(tile, lane, 1, t1); }
+    WAVE_SYNC();                       // (the weight gradient re-reads its own cells in phase E: the planes need not stay in registers)
+    // ---- phase C: layer 1's data gradient (48 MFMAs, both operands transposed reads) with the output-weight gradient in its
+    // shadows: one sample per slice (8 fma), every third step
+    f32x16 dX[2];
+    {
+      const float4 a0 = accl[0], a1 = accl[64];
+      dwo[0][0] = a0.x; dwo[0][1] = a0.y; dwo[0][2] = a0.z; dwo[0][3] = a0.w;
+      dwo[1][0] = a1.x; dwo[1][1] = a1.y; dwo[1][2] = a1.z; dwo[1][3] = a1.w;
+      float4 dq[2];                    // the d_out row of the slice in work / of the next one (re-read from LDS: 64 registers less)
+      dq[0] = *reinterpret_cast<const float4*>(ob_c + 4 * (4 * hi));
+      dgrad_cells_steps<true>(tile, w1c, nullptr, pl, lane, dX, [&](int j) __attribute__((always_inline)) {
+        if (j % 3 == 1 && j / 3 < 15) {
+          const int r = j / 3 + 1;
+          dq[r & 1] = *reinterpret_cast<const float4*>(ob_c + 4 * (8 * (r >> 2) + 4 * hi + (r & 3)));
+        }
+        if (j % 3 == 0) {
+          const int r = j / 3;
+          float4 d = dq[r & 1];
+          asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const float h = Hc[m][r];
-            const float dh = fmaf(wout[m].w, d.w, fmaf(wout[m].z, d.z, fmaf(wout[m].y, d.y, wout[m].x * d.x)));
-            const float g = (h > 0.f) ? dh : 0.f;
-            dY[m][r] = g;
-            dbh[L - 1][m] += g;
             dwo[m][0] = fmaf(d.x, h, dwo[m][0]); dwo[m][1] = fmaf(d.y, h, dwo[m][1]);
             dwo[m][2] = fmaf(d.z, h, dwo[m][2]); dwo[m][3] = fmaf(d.w, h, dwo[m][3]);
+            asm volatile("" : "+v"(dwo[m][0]), "+v"(dwo[m][1]), "+v"(dwo[m][2]), "+v"(dwo[m][3]));
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       accl[0] = make_float4(dwo[0][0], dwo[0][1], dwo[0][2], dwo[0][3]);
       accl[64] = make_float4(dwo[1][0], dwo[1][1], dwo[1][2], dwo[1][3]);
-      reinterpret_cast<float2*>(accl + 128)[0] = make_float2(dbh[L - 1][0], dbh[L - 1][1]);
-    }
-    TICK(4);
-    // ---- layer 1: dY is split ONCE (the weight gradient's A operands); the same planes go to the tile as cells and come back
-    // transposed as the data gradient's A operand
-    f32x16 dX[2];
-    {
-      B3Op A0[2] = {b3_regs<0>(dY[0]), b3_regs<0>(dY[1])};
-      WAVE_SYNC();                     // every transpose read of the H1 planes has been issued (in-order LDS queue): overwrite them
-      dy_store_cells(tile, lane, 0, A0);
-      __builtin_amdgcn_sched_barrier(0);
-      B3Op A1[2] = {b3_regs<1>(dY[0]), b3_regs<1>(dY[1])};
-      wgrad_b3_block_free(A0, Xp[0][0], Xp[1][0], acc[1]);
-      NGM_INTERLEAVE(24, 4)
-      __builtin_amdgcn_sched_barrier(0);
-      dy_store_cells(tile, lane, 1, A1);
-      WAVE_SYNC();
-      wgrad_b3_block2(A1, Xp[0][1], Xp[1][1], acc[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      TICK(6);
-      dgrad_cells<true>(tile, w1c, nullptr, pl, lane, dX);
     }
     TICK(7);
+    // ---- phase D (exposed): ReLU mask of layer 0 (from the hi plane of H1: post-ReLU, so positive <=> leading bf16 non-zero)
     {
       const float2 b0 = reinterpret_cast<const float2*>(accl + 128)[1];
       dbh[0][0] = b0.x; dbh[0][1] = b0.y;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t hw = __builtin_bit_cast(ngm_u32x4, Xp[m][r >> 3].h)[(r & 7) >> 1];
+          const bool pos = (hw & ((r & 1) ? 0xffff0000u : 0x0000ffffu)) != 0u;
+          const float g = pos ? dX[m][r] : 0.f;
+          dY[m][r] = g;
+          dbh[0][m] += g;
+        }
+      reinterpret_cast<float2*>(accl + 128)[1] = make_float2(dbh[0][0], dbh[0][1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase E: layer 1's weight gradient (48 MFMAs, operands in registers) with the ONE split of dY0 in its shadows (16
+    // pair slices; without a Fourier matrix there is no phase F and the encoding's split rides here as well)
+    SplitAcc S0, SE;
+    {
+      auto work = [&](int j) __attribute__((always_inline)) {
+        if (ENC_GRAD) {
+          if (j % 3 == 0) { const int p = j / 3, m = p >> 3, b = (p >> 2) & 1, q = p & 3; split_pair_slice(dY[m][8 * b + 2 * q], dY[m][8 * b + 2 * q + 1], S0, m, b, q); }
+        } else {
+          if (j % 3 == 0) { const int p = j / 3, m = p >> 3, b = (p >> 2) & 1, q = p & 3; split_pair_slice(dY[m][8 * b + 2 * q], dY[m][8 * b + 2 * q + 1], S0, m, b, q); }
+          if (j % 3 == 1) { const int p = j / 3, m = p >> 3, b = (p >> 2) & 1, q = p & 3; split_pair_slice(Eb[b][m][2 * q], Eb[b][m][2 * q + 1], SE, m, b, q); }
+        }
+      };
+      B3Op A0[2], A1[2];
+      dy_load_cells(tile, lane, 0, A0);
+      dy_load_cells(tile, lane, 1, A1);
+      __builtin_amdgcn_sched_barrier(0);
+      wgrad_steps(A0, Xp[0][0], Xp[1][0], acc[1], 0, work);
+      wgrad_steps(A1, Xp[0][1], Xp[1][1], acc[1], 24, work);
+    }
+    B3Op Y0[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // ReLU mask of layer 0 from the hi plane of H1 (post-ReLU, so non-negative: positive <=> its leading bf16 is non-zero)
-        const uint32_t hw = __builtin_bit_cast(ngm_u32x4, Xp[m][r >> 3].h)[(r & 7) >> 1];
-        const bool pos = (hw & ((r & 1) ? 0xffff0000u : 0x0000ffffu)) != 0u;
-        const float g = pos ? dX[m][r] : 0.f;
-        dY[m][r] = g;
-        dbh[0][m] += g;
-      }
-    reinterpret_cast<float2*>(accl + 128)[1] = make_float2(dbh[0][0], dbh[0][1]);
-    B3Op Y0[2][2];                     // dY of layer 0, split once: weight-gradient operands (m, k-block) + the cells for its data gradient
-#pragma unroll
-    for (int m = 0; m < 2; ++m) { Y0[m][0] = b3_regs<0>(dY[m]); Y0[m][1] = b3_regs<1>(dY[m]); }
+    for (int m = 0; m < 2; ++m) { Y0[m][0] = split_op(S0, m, 0); Y0[m][1] = split_op(S0, m, 1); }
+    TICK(9);
+    // ---- phase F (Fourier): dY0's cells; layer 0's data gradient (48 MFMAs, A transposed from the cells, B = W0's planes) with
+    // the ENCODING in its shadows: a slice evaluates one pair of sines and splits it (no fp32 copy of the encoding is kept)
+    f32x16 dE[2];
+    float px[16], py[16], pz[16];      // this lane's 16 sample positions: phase F (arguments), phase G (Fourier-matrix gradient)
     if constexpr (ENC_GRAD) {
       WAVE_SYNC();
       { const B3Op t0[2] = {Y0[0][0], Y0[1][0]}, t1[2] = {Y0[0][1], Y0[1][1]}; dy_store_cells(tile, lane, 0, t0); dy_store_cells(tile, lane, 1, t1); }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 p = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * (r >> 2) + 4 * hi + (r & 3)));
+        px[r] = p.x; py[r] = p.y; pz[r] = p.z;
+      }
       WAVE_SYNC();
+      dgrad_cells_steps<false>(tile, nullptr, planes, pl, lane, dE, [&](int j) __attribute__((always_inline)) {
+        if (j % 3 == 0) {
+          const int p = j / 3, m = p >> 3, b = (p >> 2) & 1, q = p & 3, r = 8 * b + 2 * q;
+          float x0 = px[r], x1 = px[r + 1];
+          asm volatile("" : "+v"(x0), "+v"(x1));
+          float rev;
+          const float v0 = enc_value<NEED_COS>(encw[m], x0, py[r], pz[r], m == 0, rev);
+          const float v1 = enc_value<NEED_COS>(encw[m], x1, py[r + 1], pz[r + 1], m == 0, rev);
+          split_pair_slice(v0, v1, SE, m, b, q);
+        }
+      });
     }
-    TICK(9);
-    // ---- layer 0.  Data gradient first (only dY's rows are needed), so that cos(.) never has to be kept: the encoding
-    // is then evaluated k-block by k-block, each value feeding the Fourier-matrix gradient and the weight-gradient operand
-    f32x16 dE[2];
-    if constexpr (ENC_GRAD) dgrad_cells<false>(tile, nullptr, planes, pl, lane, dE);
     TICK(8);
-    if constexpr (ENC_GRAD) {          // Fourier-matrix gradient: d sin(w.x)/d w = cos(w.x) x (the sines / cosines: recompute_planes_with_encoding)
-      float4 ppa[2][8];
+    B3Op EbP[2][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ppa[b][e] = *reinterpret_cast<const float4*>(pb_c + 4 * (8 * ((8 * b + e) >> 2) + 4 * hi + (e & 3)));
+    for (int m = 0; m < 2; ++m) { EbP[m][0] = split_op(SE, m, 0); EbP[m][1] = split_op(SE, m, 1); }
+    // ---- phase G: the next tile's transfers, then layer 0's weight gradient (48 MFMAs, operands in registers) with the
+    // Fourier-matrix gradient d sin(w.x)/d w = cos(w.x) x in its shadows (one (sample, feature tile) per slice, the cosine
+    // re-evaluated from the position: keeping 32 of them from phase F spilled).  No LDS instruction between the transfers'
+    // issue and their wait: a wave's LDS instructions crawl while it has HBM -> LDS transfers it has not waited for.
+    if constexpr (ENC_GRAD) {
       const float4 f0 = accl[192], f1 = accl[256];
       dwf[0][0] = f0.x; dwf[0][1] = f0.y; dwf[0][2] = f0.z;
       dwf[1][0] = f1.x; dwf[1][1] = f1.y; dwf[1][2] = f1.z;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float4 p = ppa[b][e];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const float g = dE[m][8 * b + e] * Cb[b][m][e];
-            dwf[m][0] = fmaf(g, p.x, dwf[m][0]); dwf[m][1] = fmaf(g, p.y, dwf[m][1]); dwf[m][2] = fmaf(g, p.z, dwf[m][2]);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      accl[192] = make_float4(dwf[0][0], dwf[0][1], dwf[0][2], 0.f);
-      accl[256] = make_float4(dwf[1][0], dwf[1][1], dwf[1][2], 0.f);
     }
-    // ---- next tile's transfers + this tile's last matrix work.  On gfx950 a wave's LDS instructions crawl while it
-    // has HBM -> LDS transfers it has not waited for (tools/micro/dma_lds.hip: 8 ds_read_b128 behind 8 transfers cost
-    // 1400 clocks instead of 250, whether the data has long arrived or not), and with one wave per SIMD nobody fills
-    // such holes.  So the transfers are issued where every landing buffer is free and NO LDS instruction follows until
-    // the wait: under the layer-0 weight gradient (48 MFMAs + operand splits, registers only).
     WAVE_SYNC();
     TICK(3);
     if constexpr (FC) {
@@ -720,25 +823,35 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3p(FieldBwdArgs a) {
         issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
         issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
       }
-      issue_plane_tile(fs.act[0], nxt >> 5, lane, wl_lds);       // planes: 12 linear 1 KB copies, tiles aligned per field
+      issue_plane_tile(fs.act[0], nxt >> 5, lane, wl_lds);       // 12 linear 1 KB copies, tiles aligned per field
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(5);
     {
-      const B3Op B00 = b3_arr(Eb[0][0]), B01 = b3_arr(Eb[0][1]);
-      const B3Op A0[2] = {Y0[0][0], Y0[1][0]};
-      __builtin_amdgcn_sched_barrier(0);
-      const B3Op B10 = b3_arr(Eb[1][0]), B11 = b3_arr(Eb[1][1]);
-      wgrad_b3_block_free(A0, B00, B01, acc[0]);
-      NGM_INTERLEAVE(24, 4)
-      __builtin_amdgcn_sched_barrier(0);
-      const B3Op A1[2] = {Y0[0][1], Y0[1][1]};
-      wgrad_b3_block2(A1, B10, B11, acc[0]);
+      auto work = [&](int j) __attribute__((always_inline)) {
+        if (ENC_GRAD && j % 3 != 2) {
+          const int r = j / 3, m = j % 3;
+          float x = px[r];
+          asm volatile("" : "+v"(x));
+          const float4 w = encw[m];
+          const float rev = __builtin_amdgcn_fractf(fmaf(w.z, pz[r], fmaf(w.y, py[r], w.x * x)) * 0.15915494309189535f);
+          const float g = dE[m][r] * __builtin_amdgcn_cosf(rev);
+          dwf[m][0] = fmaf(g, x, dwf[m][0]); dwf[m][1] = fmaf(g, py[r], dwf[m][1]); dwf[m][2] = fmaf(g, pz[r], dwf[m][2]);
+          asm volatile("" : "+v"(dwf[m][0]), "+v"(dwf[m][1]), "+v"(dwf[m][2]));
+        }
+      };
+      const B3Op A0[2] = {Y0[0][0], Y0[1][0]}, A1[2] = {Y0[0][1], Y0[1][1]};
+      wgrad_steps(A0, EbP[0][0], EbP[1][0], acc[0], 0, work);
+      wgrad_steps(A1, EbP[0][1], EbP[1][1], acc[0], 24, work);
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(10);
     DMA_WAIT(0);
     TICK(2);
+    if constexpr (ENC_GRAD) {
+      accl[192] = make_float4(dwf[0][0], dwf[0][1], dwf[0][2], 0.f);
+      accl[256] = make_float4(dwf[1][0], dwf[1][1], dwf[1][2], 0.f);
+    }
     WAVE_SYNC();
   }
 #undef COL_OFF

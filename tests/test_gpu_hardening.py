@@ -393,7 +393,11 @@ def test_stash_modes_ragged_train_step_vs_oracle(stash_mode, shape):
     F, R, n_c, n_g = shape
     ragged_case(F, R, n_c, n_g, dict(FOURIER))
     L = K.lib()
-    assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_stash_mode() == stash_mode
+    ran = L.ngm_debug_last_stash_mode()
+    # planes need the forward on the split arithmetic (it stores the planes it forms anyway): a batch shape whose LDS plan keeps
+    # the forward on exact-fp32 MFMA gets the fp32 half stash instead
+    fwd_b3 = L.ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
+    assert L.ngm_debug_last_bwd_variant() == 3 and ran == (stash_mode if (stash_mode != 2 or fwd_b3) else 1), (ran, fwd_b3)
 
 
 @pytest.mark.parametrize("stash_mode", [1, 2], indirect=True, ids=lambda m: STASH[m])
@@ -401,7 +405,8 @@ def test_stash_modes_ragged_train_step_vs_oracle(stash_mode, shape):
 def test_stash_modes_other_encodings(stash_mode, enc):
     fkw = dict(encoding="nerf", num_octaves=8, num_layers=2) if enc == "nerf" else dict(encoding="fourier", dim_enc=61, num_layers=2)
     ragged_case(3, 70, 6, 7, fkw)
-    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
+    fwd_b3 = K.lib().ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
+    assert K.lib().ngm_debug_last_stash_mode() == (stash_mode if (stash_mode != 2 or fwd_b3) else 1)
 
 
 @pytest.mark.parametrize("stash_mode", [1, 2], indirect=True, ids=lambda m: STASH[m])
@@ -420,7 +425,7 @@ def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
         g = r.optimization_iteration(tgt, seed=9, update=False)["grads"]
         for k in first:
             assert torch.equal(g[k], first[k]), k
-    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
+    assert K.lib().ngm_debug_last_stash_mode() in (stash_mode, 1)
     K.lib().ngm_debug_stash_mode(0)
     r0 = make_renderer(FOURIER, ckw, F)
     for k, v in r._model.all_fields_params.items():

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libngm_hip.so")
-SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_field_bwd16.hip", "ngm_field_bwd16s.hip", "ngm_field_bwd_b3.hip", "ngm_field_bwd_b3p.hip", "ngm_hash_bwd.hip", "ngm_target.hip", "ngm_composite.hip",
+SOURCES = ["ngm_api.hip", "ngm_field_fwd.hip", "ngm_field_bwd.hip", "ngm_field_bwd16.hip", "ngm_field_bwd16s.hip", "ngm_field_bwd_b3.hip", "ngm_hash_bwd.hip", "ngm_target.hip", "ngm_composite.hip",
            "ngm_knn.hip", "ngm_mesh.hip", "ngm_peer.hip"]
 def _headers():
     """Every header any source may include: all of csrc/*.h + the public C ABI header (the digest of an

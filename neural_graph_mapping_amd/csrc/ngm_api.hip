@@ -154,8 +154,7 @@ static int launch_bwd_any(FieldBwdArgs& a, int blocks, hipStream_t st) {
   static const bool no_b3 = getenv("NGM_NO_BWD_B3") != nullptr;
   int e = NGM_E_UNSUPPORTED;
   g_last_stash_mode = a.act ? a.act_half : -1;
-  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act && a.act_half == 2) { e = ngm_launch_field_bwd_b3p(a, blocks, st); g_last_bwd_variant = 3; }
-  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act && a.act_half != 2) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
+  if (e == NGM_E_UNSUPPORTED && !force32 && !no_b3 && a.act) { e = ngm_launch_field_bwd_b3(a, blocks, st); g_last_bwd_variant = 3; }
   if (a.act_half && e == NGM_E_UNSUPPORTED) {                   // no other kernel reads a half stash: never fall through
     snprintf(g_err, sizeof(g_err), "render_bwd: the forward stashed one hidden layer (split path) but k_field_bwd_b3 does not take this problem");
     return NGM_E_INVALID;
@@ -595,8 +594,7 @@ struct RenderPlan {
   int64_t p_pad;
   int64_t off_rayseed;             // (F*R, 8) per-ray loss derivatives without the normalisers (fused compositing backward)
   int64_t off_raytab, off_stashA, off_stashB, off_losspart, off_gradpart, off_hash, off_act, act_layer_stride, total;
-  int stash_mode;                  // 0: every hidden layer, fp32; 1: layer 0 only, fp32 (half stash); 2: layer 0 only, bf16 planes
-  int64_t planes_field_stride;     // stash_mode 2: bytes per field
+  int stash_mode;                  // 0: every hidden layer's output; 1: layer 0's only (half stash, k_field_bwd_b3<HS>)
   int64_t off_dout, off_disd;      // neus: separate per-sample gradient buffer, per-ray d loss / d isd
 };
 // The training forward stashes the hidden activations (64 floats per sample and layer) when the backward
@@ -616,7 +614,7 @@ static int act_stash_kind(const ngm_field_cfg* fc) {
 }
 
 #ifndef NGM_STASH_DEFAULT
-#define NGM_STASH_DEFAULT 2
+#define NGM_STASH_DEFAULT 0
 #endif
 // Half stash (round 5): with two hidden layers on the split path the forward stashes layer 0's output only and
 // k_field_bwd_b3<.., HS> recomputes the output layer's input from it on the matrix pipe: 256 instead of 512 bytes of stash per
@@ -631,7 +629,7 @@ static int stash_pref() {
     const char* e = getenv("NGM_STASH");
     if (getenv("NGM_FULL_STASH")) return 0;
     if (!e) return NGM_STASH_DEFAULT;
-    return !strcmp(e, "full") ? 0 : !strcmp(e, "half") ? 1 : !strcmp(e, "planes") ? 2 : NGM_STASH_DEFAULT;
+    return !strcmp(e, "full") ? 0 : !strcmp(e, "half") ? 1 : NGM_STASH_DEFAULT;
   }();
   return pref;
 }
@@ -721,15 +719,8 @@ static RenderPlan plan_render(const ngm_field_cfg* fc, const ngm_render_cfg* rc,
     if (kind == 1) {
       p.act_layer_stride = align_up(NS, 32) * 64 + 2048;      // floats: whole 32-sample tiles (+1: a field may start mid-tile)
       const bool half = half_stash_applies(fc, (int64_t)R * p.S);                              // half stash: layer 0's output only
-      // ... as bf16 planes when the forward runs the split arithmetic (it forms them anyway) and the planes backward is compiled
-      p.stash_mode = !half ? 0 : (stash_pref() == 2 && p.b3 && ngm_field_bwd_b3p_compiled(fc)) ? 2 : 1;
-      p.off_act = o;
-      if (p.stash_mode == 2) {
-        p.planes_field_stride = (((int64_t)R * p.S + 31) / 32) * 12288;
-        o = align_up(o + (int64_t)F * p.planes_field_stride + 64, 256);
-      } else {
-        o = align_up(o + (half ? 1 : fc->num_layers) * p.act_layer_stride * 4 + 64, 256);
-      }
+      p.stash_mode = half ? 1 : 0;
+      p.off_act = o; o = align_up(o + (half ? 1 : fc->num_layers) * p.act_layer_stride * 4 + 64, 256);
     } else if (kind == 2) {
       p.act_layer_stride = align_up(NS, 32) * 32 + 1024;      // one "layer": the 32-feature encoding
       p.off_act = o; o = align_up(o + p.act_layer_stride * 4 + 64, 256);
@@ -815,8 +806,6 @@ int ngm_render_fwd(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const 
     a.loss_partials = reinterpret_cast<float*>(ws + p.off_losspart);
     if (p.act_layer_stride) { a.act = reinterpret_cast<float*>(ws + p.off_act); a.act_layer_stride = p.act_layer_stride; }
     a.act_layers = (a.act && p.stash_mode) ? 1 : 0;
-    a.act_planes = (a.act && p.stash_mode == 2) ? 1 : 0;
-    a.act_planes_field_stride = p.planes_field_stride;
     note_forward_stash(workspace, p.stash_mode);
     static const bool timing = getenv("NGM_PHASE_TIMING") != nullptr;
     if (timing) {
@@ -872,7 +861,6 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   {
     const int rec = forward_stash_layers(workspace);       // what the forward on THIS workspace wrote (-1: no record: the plan's mode)
     a.act_half = a.act ? (rec < 0 ? p.stash_mode : rec) : 0;
-    a.act_planes_field_stride = p.planes_field_stride;
   }
   // Compositing backward inside the MLP backward (k_field_bwd_b3<FC>, k_hash_mlp_bwd<FC>): loss seeds, pointwise geometry
   // modes, and a kernel that implements it about to be chosen.  Otherwise k_stash_bwd runs first and leaves
@@ -1186,7 +1174,7 @@ int ngm_ipc_close(void* ptr) {
 int ngm_debug_last_stash_mode(void) { return g_last_stash_mode; }
 int ngm_debug_stash_mode(int mode) {
   const int prev = stash_pref();
-  if (mode >= 0 && mode <= 2) g_stash_override = mode;
+  if (mode >= 0 && mode <= 1) g_stash_override = mode;
   else if (mode == -2) g_stash_override = -1;
   return prev;
 }

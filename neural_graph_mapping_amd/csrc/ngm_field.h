@@ -689,20 +689,12 @@ struct ActStash {
   int nvalid;             // samples of this step that exist (lanes >= nvalid store nothing)
   int nlayers;            // hidden layers whose output is stashed: layers 0 .. nlayers - 1 (half stash: 1 of 2, the split
                           // backward recomputes the other; RenderFwdArgs::act_layers)
-  // PLANES stash (RenderFwdArgs::act_planes; two hidden layers on the split path): layer 0's output is stored not as fp32 but as
-  // the three bf16 planes layer 1's matrix products split it into anyway -- the backward (k_field_bwd_b3p) then reads both
-  // operand orientations of H1 straight from LDS (rows: two 8-byte cells; columns: ds_read_b64_tr_b16) and never splits it.
-  // 12 KB per 32-sample tile, tiles aligned per FIELD: [plane 3][feature group fg 16][sample 32] cells of 8 bytes = the four
-  // features 4 fg .. 4 fg + 3 of one sample, sample s of group fg at position s ^ 4 (fg & 3) (conflict-free transpose reads).
-  char* pbase;            // plane stash of this field (NULL: fp32 stash), byte address of its tile 0
-  int64_t pl0;            // sample index WITHIN THE FIELD of lane 0 of this 64-sample step
 };
-#define NGM_PLANE_TILE_BYTES 12288
 
 // Y = relu(W X + b) like layer_fwd, through the six-product bf16 split
 template <int MIN, int MOUT, int NT>
 __device__ __forceinline__ void layer_fwd_b3(const ngm_u32x4* __restrict__ P, const float* __restrict__ B, int lane,
-                                             const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT], const ActStash* pst = nullptr) {
+                                             const f32x16 (&X)[NT][MIN], f32x16 (&Y)[NT][MOUT]) {
   using PL = B3Planes<MIN, MOUT>;
   const int io = lane & 31, hi = lane >> 5;
   // The accumulators START from the bias (loaded from LDS), not from the inline constant 0: with a constant SrcC the
@@ -738,29 +730,6 @@ __device__ __forceinline__ void layer_fwd_b3(const ngm_u32x4* __restrict__ P, co
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = X[nt][mi][8 * b + e];
       b3_split8(x, bh[nt], bm[nt], bl[nt]);
-      if (pst && pst->pbase) {
-        // the planes of the INPUT (= the previous layer's output) to the stash: registers 8 b .. 8 b + 3 are the features
-        // 32 mi + 16 b + 4 hi + {0..3} of this lane's sample (cell fg = 8 mi + 4 b + hi), 8 b + 4 .. + 7 the cell fg + 2
-        const int s = 32 * nt + io;
-        if (s < pst->nvalid) {
-          typedef unsigned v2u __attribute__((ext_vector_type(2)));
-          const int64_t gl = pst->pl0 + s;
-          char* tp = pst->pbase + (gl >> 5) * NGM_PLANE_TILE_BYTES;
-          const int sp = (int)(gl & 31);
-          const int fg0 = 8 * mi + 4 * b + hi;
-          const ngm_u32x4 h4 = __builtin_bit_cast(ngm_u32x4, bh[nt]), m4 = __builtin_bit_cast(ngm_u32x4, bm[nt]),
-                          l4 = __builtin_bit_cast(ngm_u32x4, bl[nt]);
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const int fg = fg0 + 2 * w;
-            const int off = (fg * 32 + (sp ^ (4 * (fg & 3)))) * 8;
-            const v2u ch = {h4[2 * w], h4[2 * w + 1]}, cm = {m4[2 * w], m4[2 * w + 1]}, cl = {l4[2 * w], l4[2 * w + 1]};
-            __builtin_nontemporal_store(ch, reinterpret_cast<v2u*>(tp + off));
-            __builtin_nontemporal_store(cm, reinterpret_cast<v2u*>(tp + 4096 + off));
-            __builtin_nontemporal_store(cl, reinterpret_cast<v2u*>(tp + 8192 + off));
-          }
-        }
-      }
     }
     // product-major: consecutive MFMAs go to DIFFERENT accumulators (MOUT * NT independent chains), so no MFMA
     // waits for (or depends on the forwarding of) the one issued right before it; small terms first
@@ -893,7 +862,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
   else layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
   if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
   PTICK(pc, 5);
-  if (st && st->base && !(B3 && L == 2 && st->pbase)) act_store<MH, NT>(*st, 0, lane, Hlast);
+  if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
   PTICK(pc, 6);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
@@ -910,8 +879,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
       }
       layer_fwd<MH + MI, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Xc, T);
     } else if constexpr (B3) {
-      layer_fwd_b3<MH, MH, NT>(b3w + B3Lds<MI, MH, L>::off(l), sm + LY::b_off(l), lane, Hlast, T,
-                               (L == 2 && l == 1 && st && st->pbase) ? st : nullptr);
+      layer_fwd_b3<MH, MH, NT>(b3w + B3Lds<MI, MH, L>::off(l), sm + LY::b_off(l), lane, Hlast, T);
     } else {
       layer_fwd<MH, MH, NT>(sm + LY::w_off(l), sm + LY::b_off(l), lane, Hlast, T);
     }

@@ -500,8 +500,6 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #endif
       ast.g0 = ((int64_t)f * R + rb) * S + base; ast.nvalid = nsamp - base;
       ast.nlayers = a.act_layers > 0 ? a.act_layers : NGM_MAX_LAYERS;
-      ast.pbase = (a.act_planes && ast.base) ? reinterpret_cast<char*>(a.act) + (int64_t)f * a.act_planes_field_stride : nullptr;
-      ast.pl0 = (int64_t)rb * S + base;
 #ifdef NGM_ABLF_NOMLP
       const float4 o = make_float4(x, y, z, x * y);
 #else

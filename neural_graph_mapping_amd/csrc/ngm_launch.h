@@ -44,8 +44,6 @@ struct RenderFwdArgs {
   float* act;             // hidden-activation stash [L][F*R*S][64] (train, 64-wide hidden layers) or NULL
   int64_t act_layer_stride;  // floats
   int act_layers;         // how many of the hidden layers' outputs are stashed (half stash: 1 of 2; 0 = all)
-  int act_planes;         // half stash as bf16 PLANES (ActStash, ngm_field.h): 12 KB per 32-sample tile, tiles aligned per field
-  int64_t act_planes_field_stride;   // bytes between the plane stashes of consecutive fields = ceil(P / 32) * 12288
   const float* neus_sd;   // neus: "_neus_sd" (N,) rows like the other parameters (field_index), else NULL
   int64_t neus_sd_stride;
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase shader-clock cycles of one wave
@@ -92,8 +90,7 @@ struct FieldBwdArgs {
   const float* act;       // hidden-activation stash written by the forward (ray mode) or NULL = recompute
   int64_t act_layer_stride;
   int act_half;           // two hidden layers, split path: the forward stashed layer 0's output ONLY (k_field_bwd_b3<.., HS> recomputes
-                          // the output layer's input); no other kernel reads such a stash.  2: as bf16 planes (k_field_bwd_b3p)
-  int64_t act_planes_field_stride;    // act_half == 2: bytes between consecutive fields' plane stashes
+                          // the output layer's input); no other kernel reads such a stash
   unsigned long long* debug_cycles;   // optional (NGM_PHASE_TIMING): per-phase s_memtime cycles of wave 0 / block 0
   GradAdam lattice_adam;              // optional (tensors != NULL, num == 1): k_hash_reduce applies Adam to the hash tables
   // Fused compositing backward (k_field_bwd_b3<FC> and k_hash_mlp_bwd<FC>, pointwise geometry modes, loss seeds written by the
@@ -109,8 +106,6 @@ struct FieldBwdArgs {
   float* sums_out; float* loss_out; unsigned long long* counter;   // as StashBwdArgs
 };
 bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a);   // would ngm_launch_field_bwd_b3 take this problem
-bool ngm_field_bwd_b3p_compiled(const ngm_field_cfg* fc);       // is there a planes-stash backward for this network (ngm_field_bwd_b3p.hip)
-int ngm_launch_field_bwd_b3p(const FieldBwdArgs& a, int blocks, hipStream_t st);
 bool ngm_hash_mlp_bwd_applies(const FieldBwdArgs& a);   // would ngm_launch_hash_mlp_bwd (given positions, or fused_comp)
 int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr);
 

@@ -371,7 +371,7 @@ def test_standalone_encode_backward_stage_vs_oracle_autograd(enc, P):
 
 
 # ------------------------------------------------------------------------------------------------ activation stash modes (round 5)
-STASH = {0: "full", 1: "half", 2: "planes"}
+STASH = {0: "full", 1: "half"}
 
 
 @pytest.fixture
@@ -382,34 +382,28 @@ def stash_mode(request):
     L.ngm_debug_stash_mode(-2)
 
 
-@pytest.mark.parametrize("stash_mode", [0, 1, 2], indirect=True, ids=lambda m: STASH[m])
+@pytest.mark.parametrize("stash_mode", [0, 1], indirect=True, ids=lambda m: STASH[m])
 @pytest.mark.parametrize("shape", [(1, 256, 16, 16), (3, 41, 9, 5), (2, 96, 8, 16), (1, 7, 64, 64), (4, 130, 2, 5)])
 def test_stash_modes_ragged_train_step_vs_oracle(stash_mode, shape):
-    """The three activation-stash formats of the two-hidden-layer split path (include/ngm_hip.h, ngm_debug_stash_mode): both
-    layers fp32 / layer 0 fp32 with layer 1 recomputed / layer 0 as bf16 planes read transposed from LDS -- each against the
-    oracle at the usual bars on ragged shapes (rays of 7 .. 128 samples against 32-sample tiles, fields whose sample count is
-    not a multiple of 32: the planes stash aligns its tiles per field and sanitises the last one), and the mode that really
-    ran is read back from the library."""
+    """The two activation-stash modes of the two-hidden-layer split path (include/ngm_hip.h, ngm_debug_stash_mode): both layers'
+    outputs / layer 0's only with layer 1 recomputed on the matrix pipe (k_field_bwd_b3<HS>) -- each against the oracle at the
+    usual bars on ragged shapes (rays of 7 .. 128 samples against 32-sample tiles, fields whose sample count is not a multiple
+    of 32), and the mode that really ran is read back from the library."""
     F, R, n_c, n_g = shape
     ragged_case(F, R, n_c, n_g, dict(FOURIER))
     L = K.lib()
-    ran = L.ngm_debug_last_stash_mode()
-    # planes need the forward on the split arithmetic (it stores the planes it forms anyway): a batch shape whose LDS plan keeps
-    # the forward on exact-fp32 MFMA gets the fp32 half stash instead
-    fwd_b3 = L.ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
-    assert L.ngm_debug_last_bwd_variant() == 3 and ran == (stash_mode if (stash_mode != 2 or fwd_b3) else 1), (ran, fwd_b3)
+    assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_stash_mode() == stash_mode
 
 
-@pytest.mark.parametrize("stash_mode", [1, 2], indirect=True, ids=lambda m: STASH[m])
+@pytest.mark.parametrize("stash_mode", [1], indirect=True, ids=lambda m: STASH[m])
 @pytest.mark.parametrize("enc", ["nerf", "none61"])
 def test_stash_modes_other_encodings(stash_mode, enc):
     fkw = dict(encoding="nerf", num_octaves=8, num_layers=2) if enc == "nerf" else dict(encoding="fourier", dim_enc=61, num_layers=2)
     ragged_case(3, 70, 6, 7, fkw)
-    fwd_b3 = K.lib().ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
-    assert K.lib().ngm_debug_last_stash_mode() == (stash_mode if (stash_mode != 2 or fwd_b3) else 1)
+    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
 
 
-@pytest.mark.parametrize("stash_mode", [1, 2], indirect=True, ids=lambda m: STASH[m])
+@pytest.mark.parametrize("stash_mode", [1], indirect=True, ids=lambda m: STASH[m])
 def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
     """200 launches of a ragged batch give bitwise the same gradients; the gradients agree with the full-stash kernel's to
     fp32 round-off (the recomputed layer is the same arithmetic in another summation order)."""
@@ -425,7 +419,7 @@ def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
         g = r.optimization_iteration(tgt, seed=9, update=False)["grads"]
         for k in first:
             assert torch.equal(g[k], first[k]), k
-    assert K.lib().ngm_debug_last_stash_mode() in (stash_mode, 1)
+    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
     K.lib().ngm_debug_stash_mode(0)
     r0 = make_renderer(FOURIER, ckw, F)
     for k, v in r._model.all_fields_params.items():

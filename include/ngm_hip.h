@@ -382,7 +382,7 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
- * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 4; N_f unbounded (the centres are binned into a
+ * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 8; N_f unbounded (the centres are binned into a
  * uniform grid in the workspace per call; exact K nearest, distance ties to the lower field index).
  * mask_radius: the `field_radius` ARGUMENT of NeuralFieldSet.forward (models.py:293, 368): a point is evaluated when its
  * nearest field centre is closer than this; the local coordinates are still scaled with fcfg->field_radius
@@ -402,7 +402,8 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
  * the samples are drawn inside the neighbour assignment, the blend happens inside the quadrature, the grid over the field
  * centres is built once per call.  rays: rays->F * rays->R rays in all (field_pos / field_quat / pose_index unused); block b
  * draws its jitter from u_coarse, or from the Philox stream (philox_seed + b * ray_block, ray index within the block).
- * pred: (F*R, .) outputs, any may be NULL.  K, mask_radius as in ngm_field_eval_knn; S <= 1024. */
+ * pred: (F*R, .) outputs, any may be NULL.  mask_radius as in ngm_field_eval_knn; K <= 4 here (5..8: the three staged entry
+ * points per block -- NGM_E_UNSUPPORTED says so); S <= 1024. */
 int64_t ngm_render_eval_knn_workspace(const ngm_render_cfg* rcfg, int32_t num_fields, int32_t ray_block, int32_t num_knn);
 int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
                         int32_t num_fields, const float* field_pos, const float* field_quat, const ngm_rays* rays,

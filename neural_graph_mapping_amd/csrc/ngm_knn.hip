@@ -5,7 +5,7 @@
 //   k_knn_grid    : field centres binned into a uniform grid on the device (cell = the cover-grid spacing 2 r / sqrt 3 of
 //                   rm.py:299, never smaller than the mask radius; one workgroup: bounding box, counts, scan, fill), then per
 //                   cell of the grid extended by one ring the list of centres a point of that cell can be inside of
-//   k_knn_assign  : exact K-nearest (K <= 4) per point: the cell's list decides the inside test (most samples of an image
+//   k_knn_assign  : exact K-nearest (K <= 8) per point: the cell's list decides the inside test (most samples of an image
 //                   fall on an empty list and stop there) and seeds the neighbour list; where fewer than K centres are within
 //                   the radius the block of cells around the point grows ring by ring until the K-th neighbour found is
 //                   provably the K-th nearest; softmax weights; per-workgroup LDS histogram -> one global atomic per field
@@ -34,7 +34,7 @@
 #ifndef KNN_TILE
 #define KNN_TILE 512
 #endif
-#define KNN_MAXK 4
+#define KNN_MAXK 8
 // copies of the per-field pair counters: 4096 workgroups flushing their histograms into ~100 addresses serialise on the
 // device-scope atomics; sixteen copies, summed by k_knn_offsets
 #ifndef KNN_COUNT_REPL
@@ -750,7 +750,8 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
       if (grid_in_lds) hipLaunchKernelGGL((k_knn_assign<true, KK_>), dim3(std::max(pb, 1)), dim3(256), lds_grid, st, a);  \
       else hipLaunchKernelGGL((k_knn_assign<false, KK_>), dim3(std::max(pb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a); \
     } while (0)
-    if (K == 1) NGM_KL(1); else if (K == 2) NGM_KL(2); else if (K == 3) NGM_KL(3); else if (K == 4) NGM_KL(4); else return NGM_E_UNSUPPORTED;
+    if (K == 1) NGM_KL(1); else if (K == 2) NGM_KL(2); else if (K == 3) NGM_KL(3); else if (K == 4) NGM_KL(4);
+    else if (K == 5) NGM_KL(5); else if (K == 6) NGM_KL(6); else if (K == 7) NGM_KL(7); else if (K == 8) NGM_KL(8); else return NGM_E_UNSUPPORTED;
 #undef NGM_KL
   }
   if (hipGetLastError() != hipSuccess) return NGM_E_HIP;      // an over-sized LDS request fails here, not four launches later

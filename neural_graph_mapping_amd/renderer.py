@@ -113,6 +113,13 @@ class NeuralGraphRenderer:
         # 16x the matrix rate; fails loudly where not compiled); "auto" (default) = the split wherever it is compiled
         mm = config.get("mlp_matmul", "auto")
         self._fc.matmul_mode = K.MATMUL[mm]
+        # activation stash of two-hidden-layer networks on the split path (include/ngm_hip.h, ngm_debug_stash_mode): "full"
+        # (default: both hidden layers' outputs, 512 B per sample, fastest) or "half" (layer 0's only, 256 B per sample: half
+        # the stash memory and HBM traffic -- a 4096 x 128 x 32-field batch needs 4.3 instead of 8.6 GB --, the backward
+        # recomputes the other layer on the matrix pipe: step + 1.5-4 %).  PROCESS-wide switch of the library (it sizes the
+        # workspaces): set by the first renderer that names it, renderers that do not name it leave it alone.
+        if config.get("activation_stash") is not None:
+            K.lib().ngm_debug_stash_mode({"full": 0, "half": 1}[config["activation_stash"]])
         fc = self._fc
         compiled = (fc.encoding in (K.ENC["fourier"], K.ENC["none"]) and fc.skip_mode == K.SKIP["no"] and 1 <= fc.num_layers <= 2
                     and 32 < fc.dim_enc <= 64 and 32 < fc.dim_hidden <= 64)

@@ -188,7 +188,8 @@ __device__ __forceinline__ float occ_at(const CompositeArgs& a, int64_t ray, int
   const int mode = a.rc.geometry_mode;
   const int64_t g = ray * S + k;
   const float gm = gself ? *gself : geom_at(a, ray, g);
-  if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY) return occ_pointwise(mode, a.rc.geometry_factor, gm, docc);
+  if (mode == NGM_GEO_NRGBD || mode == NGM_GEO_OCCUPANCY)
+    return docc ? occ_pointwise(mode, a.rc.geometry_factor, gm, docc) : occ_pointwise_fwd(mode, a.rc.geometry_factor, gm);   // forward: one form everywhere
   if (k >= S - 1) return 0.f;   // density / neus drop the last sample (rm.py:749,758)
   if (mode == NGM_GEO_DENSITY) return occ_density(gm, a.dists[g + 1] - a.dists[g], docc);
   const float isd = a.isds ? a.isds[ray] : 1.0f;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
   // most wave steps of an image lie outside every field: all 64 geometry values are the constant outside value, and so is
   // their occupancy -- computed once here (two expf, two IEEE divisions otherwise, per sample)
   const float gm_ref = a.outside_value;
-  const float occ_ref = occ_pointwise(mode, a.rc.geometry_factor, gm_ref, nullptr);
+  const float occ_ref = occ_pointwise_fwd(mode, a.rc.geometry_factor, gm_ref);
   for (int64_t ray = r_beg; ray < r_end; ++ray) {
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;       // running sums (wave-uniform)
     float carry = 1.0f;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
         const int k = base0 + 64 * c + lane;
         if (base0 + 64 * c < S) {
           const bool all_ref = __builtin_amdgcn_ballot_w64(in[c].gm != gm_ref) == 0ull;      // (wave-uniform; same function, same input)
-          const float occ = all_ref ? occ_ref : occ_pointwise(mode, a.rc.geometry_factor, in[c].gm, nullptr);
+          const float occ = all_ref ? occ_ref : occ_pointwise_fwd(mode, a.rc.geometry_factor, in[c].gm);
           float q = wave_scan_mul(1.0f - occ);
           q *= carry;                                              // (carry = 1 in the ray's first step)
           const float up = lane_prev(q, carry);

@@ -616,6 +616,17 @@ __device__ __forceinline__ float occ_pointwise_fast(int mode, float gamma, float
   return s;
 }
 
+// The forward's form of the same (no derivative): round 5 -- the compositing kernels are bound by their vector instruction
+// stream (profiles/r05_pmc_stages_sq.json), and the two IEEE divisions + two expf of the exact form are a seventh of it.
+// ~3e-7 from the exact form (hardware exp2 / rcp: 1 ulp each), far inside the forward tolerance (2e-4 / 2e-5); exactly 1 at
+// g = 0 (nrgbd) like the exact form.
+__device__ __forceinline__ float occ_pointwise_fwd(int mode, float gamma, float g) {
+  const float x = fminf(fmaxf(gamma * g, -80.0f), 80.0f);
+  const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  return (mode == NGM_GEO_NRGBD) ? 4.0f * e * s * s : s;
+}
+
 // occupancy probability of one sample (rm.py:746-762) and its derivative w.r.t. the geometry value.
 // density/neus need the neighbouring sample and are handled by the callers.
 __device__ __forceinline__ float occ_pointwise(int mode, float gamma, float g, float* docc_dg) {

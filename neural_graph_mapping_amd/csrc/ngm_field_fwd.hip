@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       if (mode == NGM_GEO_DENSITY) {                                       // rm.py:746-749, last sample dropped
         const float o_d = occ_density(geom, wl.tbuf[min(ci + 1, nsamp - 1)] - t, nullptr);
         occ = (k < S - 1) ? o_d : 0.f;
-      } else occ = occ_pointwise(mode, gamma, geom, nullptr);
+      } else occ = occ_pointwise_fwd(mode, gamma, geom);
       occ = valid ? occ : 0.f;
         composite(idx, valid, ci, rl, k, t, c0, c1, c2, depth, geom, occ, carry);
       }

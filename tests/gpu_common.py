@@ -246,7 +246,7 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
     raise AssertionError("kink_free_draws did not converge")
 
 
-def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0, max_neutralised=0.15, **ckw_extra):
+def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0, max_neutralised=0.15, fwd_tol=None, grad_tol=2e-3, **ckw_extra):
     torch.manual_seed(F * 1000 + R)
     ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode=geometry_mode,
                geometry_factor=geometry_factor, **ckw_extra)
@@ -265,17 +265,17 @@ def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV) if n_g else None,
                                    update=False)
-    close(res["prediction"].rgbds, pred["rgbds"].detach())
-    close(res["prediction"].term_probs, pred["term_probs"].detach())
+    close(res["prediction"].rgbds, pred["rgbds"].detach(), **(fwd_tol or {}))
+    close(res["prediction"].term_probs, pred["term_probs"].detach(), **(fwd_tol or {}))
     n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
     n_fs, n_ts, n_t = pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())
     if min(n_m, n_fs, n_ts, n_t) == 0:
         return                        # reference yields NaN for empty selections; we contribute 0 (documented)
     loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
-    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4 if fwd_tol is None else 10 * fwd_tol["rtol"], atol=1e-6)
     loss["combined"].backward()
     for k in po:
-        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+        grad_close(res["grads"][k], po[k].grad, grad_tol, k)
 
 
 from _philox_host import host_philox_draws, host_philox_uniform  # noqa: E402,F401  (numpy-only: also imported by the CPU tests)

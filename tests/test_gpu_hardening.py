@@ -398,8 +398,10 @@ def test_stash_modes_ragged_train_step_vs_oracle(stash_mode, shape):
 @pytest.mark.parametrize("stash_mode", [1], indirect=True, ids=lambda m: STASH[m])
 @pytest.mark.parametrize("enc", ["nerf", "none61"])
 def test_stash_modes_other_encodings(stash_mode, enc):
-    fkw = dict(encoding="nerf", num_octaves=8, num_layers=2) if enc == "nerf" else dict(encoding="fourier", dim_enc=61, num_layers=2)
-    ragged_case(3, 70, 6, 7, fkw)
+    # (ten octaves: 60 features -- the stash exists for 49..64-wide layers; eight octaves = 48 run the recompute kernels)
+    fkw = dict(encoding="nerf", num_octaves=10, num_layers=2) if enc == "nerf" else dict(encoding="fourier", dim_enc=61, num_layers=2)
+    # ten octaves put arguments up to 2^9 pi into fp32 sines: the forward tolerance of the NeRF fixtures (G4 / G6), not 2e-4
+    ragged_case(3, 70, 6, 7, fkw, fwd_tol=dict(rtol=5e-3, atol=5e-4) if enc == "nerf" else None, grad_tol=5e-3 if enc == "nerf" else 2e-3)
     assert K.lib().ngm_debug_last_stash_mode() == stash_mode
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 8 /* 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 9 /* 9: ngm_sample_rays_weighted; 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -192,7 +192,9 @@ typedef struct ngm_rays {
   const float* gt;         /* (F,R) or NULL; 0.0 = no depth                                  */
   float near_const, far_const;
   const float* field_pos;  /* (F,3) field positions in the world frame                       */
-  const float* field_quat; /* (F,4) real-first quaternions                                   */
+  const float* field_quat; /* (F,4) real-first UNIT quaternions (rotations: what the reference's orientations  */
+                           /* are, made from rotation matrices; its raw Hamilton products, models.py:338-339,   */
+                           /* would scale the local frame by |q|^2 for any other norm -- the kernels do not)    */
   const float* u_coarse;   /* (F,R,S_c) torch.rand draws of camera.py:274, or NULL -> Philox */
   const float* u_guided;   /* (F,R,S_g) or NULL -> Philox                                    */
   const float* lin_coarse; /* (S_c+1) torch.linspace(0,1) table of camera.py:271 or NULL     */
@@ -236,6 +238,16 @@ int ngm_sample_rays(const ngm_render_cfg* cfg, const ngm_rays* rays, float* poin
  * rm.py:547): points_world (F,R,S,3) = R(c2w) p_cam + t(c2w). */
 int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float* points_cam,
                           float* points_world, float* distances, float* dirs, void* stream);
+/* Camera.sample_ijs_uniform with `weights` / `boundaries` (camera.py:227-244, 277-289; no caller inside run_mapping.py, part of
+ * the Camera interface): weighted sampling from distance bins given per ray by sorted boundaries (F,R,num_bins+1) and bin
+ * probabilities weights (F,R,num_bins): bin = searchsorted(cumsum(weights) + 1e-3, u_bin), distance = boundaries[bin] +
+ * (boundaries[bin+1] - boundaries[bin]) * u_off; cfg->num_samples_coarse samples per ray, in DRAW order (the reference does
+ * not sort this branch).  rays->u_coarse = the first torch.rand draw (bins), rays->u_guided = the second (offsets), both
+ * (F,R,S), or both NULL = Philox streams 0 / 1; rays->near / far / gt are not read.  The running sum is torch.cumsum's on the
+ * CPU (sequential, fp64 accumulator, every prefix rounded to fp32); a draw beyond the last cumulative weight takes the last bin (the reference's gather is out
+ * of range there).  Outputs as ngm_sample_rays (any may be NULL). */
+int ngm_sample_rays_weighted(const ngm_render_cfg* cfg, const ngm_rays* rays, int32_t num_bins, const float* boundaries,
+                             const float* weights, float* points_cam, float* distances, float* dirs, void* stream);
 
 /* ---- K2+K3: NeuralFieldSet.forward(use_vmap=True) -----------------------------------------
  * models.py:329-345: world -> field-local transform, scaling, encoding, MLP; points (F,P,3)

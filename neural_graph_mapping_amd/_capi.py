@@ -129,6 +129,8 @@ def lib():
     L.ngm_device_info.argtypes = [P(C.c_int), C.c_char_p, C.c_int]
     L.ngm_sample_rays.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp]
     L.ngm_sample_rays_world.argtypes = [P(RenderCfg), P(Rays), vp, vp, vp, vp, vp]
+    L.ngm_sample_rays_weighted.argtypes = [P(RenderCfg), P(Rays), i32, vp, vp, vp, vp, vp, vp]
+    L.ngm_sample_rays_weighted.restype = C.c_int
     L.ngm_composite_fwd_packed.argtypes = [P(RenderCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ngm_sample_rays_world.restype = C.c_int
     L.ngm_composite_fwd_packed.restype = C.c_int
@@ -209,7 +211,7 @@ def lib():
     return L
 
 
-EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto_fill_scales", "ngm_sample_rays", "ngm_sample_rays_world",
+EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto_fill_scales", "ngm_sample_rays", "ngm_sample_rays_world", "ngm_sample_rays_weighted",
             "ngm_composite_fwd_packed",
             "ngm_field_eval_fwd", "ngm_encode_fwd", "ngm_encode_bwd", "ngm_encode_bwd_workspace", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",

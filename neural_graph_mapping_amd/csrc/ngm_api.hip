@@ -8,6 +8,8 @@
 #include "../../include/ngm_hip.h"
 #include "ngm_launch.h"
 
+int ngm_launch_sampler_weighted(const ngm_render_cfg* rc, const ngm_rays* rays, int S, int B, const float* boundaries,
+                                const float* weights, float* points_cam, float* distances, float* dirs, hipStream_t st);
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
                        float* dirs, float* points_world, hipStream_t st);
 int ngm_launch_loss_values(const ngm_render_cfg* rc, const float* sums, float* out, hipStream_t st);
@@ -372,6 +374,19 @@ int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float
   if (S < 1) return fail(NGM_E_INVALID, "no samples");
   ngm_launch_sampler(cfg, rays, S, points_cam, distances, dirs, points_world, (hipStream_t)stream);
   return check_launch("ngm_sample_rays_world");
+}
+
+int ngm_sample_rays_weighted(const ngm_render_cfg* cfg, const ngm_rays* rays, int32_t num_bins, const float* boundaries,
+                             const float* weights, float* points_cam, float* distances, float* dirs, void* stream) {
+  if (!cfg || !rays || !rays->ijs || !boundaries || !weights) return fail(NGM_E_INVALID, "ngm_sample_rays_weighted: NULL argument");
+  // camera.py:260-261: "Either both or none of weights and boundaries must be None" -- both are required here; one draw array
+  // without the other would mix the reference's two torch.rand streams with the Philox stream
+  if ((rays->u_coarse == nullptr) != (rays->u_guided == nullptr))
+    return fail(NGM_E_INVALID, "ngm_sample_rays_weighted: u_coarse (bin draws) and u_guided (offset draws) must both be given or both be NULL");
+  const int S = cfg->num_samples_coarse;
+  if (S < 1 || num_bins < 1) return fail(NGM_E_INVALID, "ngm_sample_rays_weighted: no samples / no bins");
+  ngm_launch_sampler_weighted(cfg, rays, S, num_bins, boundaries, weights, points_cam, distances, dirs, (hipStream_t)stream);
+  return check_launch("ngm_sample_rays_weighted");
 }
 
 // ------------------------------------------------------------------------------------------------

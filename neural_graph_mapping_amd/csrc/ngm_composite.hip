@@ -127,6 +127,55 @@ int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, fl
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Camera.sample_ijs_uniform, weighted-bin branch (camera.py:277-289): per sample, a bin drawn from the ray's bin weights
+// (bin = first index whose running sum + 1e-3 reaches the first draw: torch.cumsum, torch.searchsorted(right=False)), then
+// a uniform position inside it (second draw).  The running sum is torch.cumsum's on the CPU: accumulated sequentially in
+// fp64, each prefix rounded to fp32 (ATen's cumsum_cpu_kernel, acc_type<float> = double) -- the reference's CUDA scan sums
+// in fp32 in tree order; the bin of a sample changes only when its draw falls within that rounding of a cumulative weight.  NOT sorted: the reference does not sort this branch's output either.  One lane per sample; the
+// lanes of a wave read the same ray's weights (broadcast loads).  A draw beyond the last cumulative weight (weights that do
+// not sum to 1 - 1e-3 or more: torch.gather is out of range there and raises) takes the last bin.
+// ------------------------------------------------------------------------------------------------
+struct WeightedSamplerArgs {
+  ngm_render_cfg rc;
+  ngm_rays rays;
+  int S, B;
+  const float* boundaries; const float* weights;
+  float* points_cam; float* distances; float* dirs;
+};
+__global__ void k_sample_rays_weighted(WeightedSamplerArgs a) {
+#pragma clang fp contract(off)
+  const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
+  const uint64_t poff = philox_launch_offset(a.rays);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = g / a.S;
+    const int e = (int)(g - ray * a.S);
+    const RayGeom rg = ray_geom(a.rc, a.rays, ray, false);
+    const float u_bin = jitter(a.rays, poff, 0, ray, a.S, e), u_off = jitter(a.rays, poff, 1, ray, a.S, e);
+    const float* w = a.weights + ray * a.B;
+    const float* bd = a.boundaries + ray * (a.B + 1);
+    double cum = 0.0;
+    int bin = a.B - 1;
+    for (int b = 0; b < a.B; ++b) {
+      cum += (double)w[b];
+      if ((float)cum + 1e-3f >= u_bin) { bin = b; break; }
+    }
+    const float start = bd[bin], size = bd[bin + 1] - start;
+    const float t = start + size * u_off;
+    if (a.distances) a.distances[g] = t;
+    if (a.points_cam) { a.points_cam[3 * g] = rg.dx * t; a.points_cam[3 * g + 1] = rg.dy * t; a.points_cam[3 * g + 2] = rg.dz * t; }
+    if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
+  }
+}
+int ngm_launch_sampler_weighted(const ngm_render_cfg* rc, const ngm_rays* rays, int S, int B, const float* boundaries,
+                                const float* weights, float* points_cam, float* distances, float* dirs, hipStream_t st) {
+  WeightedSamplerArgs a{*rc, *rays, S, B, boundaries, weights, points_cam, distances, dirs};
+  const int64_t total = (int64_t)rays->F * rays->R * S;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_sample_rays_weighted, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
+  return 0;
+}
+
 // ================================================================================================
 // K4 quadrature forward (rm.py:709-799), all four geometry modes.
 // Each wave owns a contiguous run of rays and walks their flat samples 64 at a time; transmittance

@@ -50,8 +50,9 @@ class PositionalEncodingFourier(PositionalEncoding):
 
     def __init__(self, dim_in: int, dim_out: int, mu: float, sigma: float, raw_coords: bool) -> None:
         super().__init__()
-        if dim_in != 3:
-            raise NotImplementedError("only 3D fields are supported")
+        if dim_in not in (2, 3):
+            raise NotImplementedError("only 2D and 3D fields are supported")
+        self._dim_in = dim_in
         self._linear = torch.nn.Linear(dim_in, dim_out - dim_in if raw_coords else dim_out, False)
         self._dim_out = dim_out
         self._raw_coords = raw_coords
@@ -61,7 +62,10 @@ class PositionalEncodingFourier(PositionalEncoding):
         return self._dim_out
 
     def spec(self):
-        return dict(encoding="fourier", dim_enc=self._dim_out, raw_coords=self._raw_coords)
+        # a 2-D encoding is evaluated as the 3-D one with a zero third matrix column (and, raw_coords, one more raw feature
+        # whose layer-0 weights are zero): Embed2D below
+        extra = 1 if (self._dim_in == 2 and self._raw_coords) else 0
+        return dict(encoding="fourier", dim_enc=self._dim_out + extra, raw_coords=self._raw_coords)
 
 
 class PositionalEncodingNeRF(PositionalEncoding):
@@ -69,8 +73,8 @@ class PositionalEncodingNeRF(PositionalEncoding):
 
     def __init__(self, dim_in: int, num_octaves: int = 8, start_octave: int = 0) -> None:
         super().__init__()
-        if dim_in != 3:
-            raise NotImplementedError("only 3D fields are supported")
+        if dim_in not in (2, 3):
+            raise NotImplementedError("only 2D and 3D fields are supported")
         self.num_octaves, self.start_octave, self.dim_in = num_octaves, start_octave, dim_in
 
     def get_out_dim(self) -> int:
@@ -167,11 +171,76 @@ class NeuralField(torch.nn.Module):
         return sum(p.numel() for p in self.parameters())
 
     def forward(self, query_points: torch.Tensor) -> torch.Tensor:
-        """Single field, points already in the field frame: (...,3) -> (...,dim_out)."""
+        """Single field, points already in the field frame: (...,3) -> (...,dim_out)  ((...,2) with a 2-D encoding)."""
         fc = self.field_cfg()
         lead = query_points.shape[:-1]
         params = {k: v.unsqueeze(0) for k, v in self.state_dict(keep_vars=True).items() if k != "_neus_sd"}
+        if query_points.shape[-1] == 2:
+            e2 = Embed2D(self)
+            params, query_points = e2.params(params), e2.points(query_points)
         return ops.field_eval(fc, params, query_points.reshape(1, -1, 3)).view(*lead, self._dim_out)
+
+
+# ------------------------------------------------------------------------------------------------
+class Embed2D:
+    """`dim_points == 2` (models.py:236-238: complex numbers as orientations, `complex_apply` :48-62) on the 3-D kernels.
+
+    A planar field set IS a 3-D one restricted to z = 0: points and centres get a zero third coordinate (distances, the
+    kNN ranking and the inside test are unchanged: + 0^2 is exact), the orientation c = cos t + i sin t becomes the unit
+    quaternion (q_w, 0, 0, q_z) with (q_w + i q_z)^2 = c, whose inverse rotation maps (x, y, 0) to (a x + b y, a y - b x, 0)
+    = conj(c) (x + iy), the reference's `complex_apply(complex_invert(c), .)`, and every place where the encoding of the
+    third coordinate would enter the network carries a ZERO weight: the third column of the Fourier matrix, and the layer-0
+    columns of the raw z feature (Fourier, `raw_coords`) or of the z octaves (NeRF).  A zero weight times a finite feature
+    is exactly 0 on every matmul path (fp32 MFMA and the bf16 split alike), so the result differs from the reference's 2-D
+    arithmetic only by the rounding of the rotation (fixture G22, from the real reference).  The zero blocks are inserted
+    with differentiable torch ops, so gradients arrive at the 2-D parameters; the blocks' own gradients are dropped.
+    Orientations are taken as ROTATIONS, as the kernels take the 3-D path's quaternions (unit norm: the reference's raw
+    products would scale the local coordinates by a modulus; its orientations come from rotation matrices): c is
+    normalised before the square root."""
+
+    def __init__(self, proto: "NeuralField") -> None:
+        enc = proto._encoding
+        if proto._skip_mode != "no":
+            raise NotImplementedError("dim_points=2: skip connections are not built for planar field sets (the encoding "
+                                      "width of the embedded 3-D problem differs from the 2-D one)")
+        d2 = enc.get_out_dim()
+        if isinstance(enc, PositionalEncodingFourier) and enc._dim_in == 2:
+            cols = [0, 1, -1] + list(range(2, d2)) if enc._raw_coords else list(range(d2))
+        elif isinstance(enc, PositionalEncodingNeRF) and enc.dim_in == 2:
+            n = enc.num_octaves                       # sines (x octaves, y octaves), cosines likewise (positional_encodings.py:268-274)
+            cols = list(range(0, 2 * n)) + [-1] * n + list(range(2 * n, 4 * n)) + [-1] * n
+        else:
+            raise NotImplementedError("dim_points=2 needs a 2-D Fourier or NeRF-octave encoding (dim_in=2); the permutohedral "
+                                      "and triplane encodings are 3-D constructions")
+        self._d2 = d2
+        self._cols = [c if c >= 0 else d2 for c in cols]          # d2 = the appended zero column
+
+    def params(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        out = dict(params)
+        w0 = params["_linears.0.weight"]
+        idx = torch.as_tensor(self._cols, device=w0.device)
+        out["_linears.0.weight"] = torch.cat((w0, w0.new_zeros(*w0.shape[:-1], 1)), -1).index_select(-1, idx)
+        k = "_encoding._linear.weight"
+        if k in params:
+            out[k] = torch.cat((params[k], params[k].new_zeros(*params[k].shape[:-1], 1)), -1)
+        return out
+
+    @staticmethod
+    def points(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if p is None else torch.cat((p, p.new_zeros(*p.shape[:-1], 1)), -1)
+
+    @staticmethod
+    def orientations(c: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """principal square root of c / |c|, in fp64: q_w = sqrt((1 + a) / 2), q_z = sign(b) sqrt((1 - a) / 2)"""
+        if c is None:
+            return None
+        a, b = c[..., 0].double(), c[..., 1].double()
+        r = torch.sqrt(a * a + b * b)
+        a, b = a / r, b / r
+        qw = torch.sqrt(torch.clamp((1.0 + a) * 0.5, min=0.0))
+        qz = torch.where(b < 0, -1.0, 1.0) * torch.sqrt(torch.clamp((1.0 - a) * 0.5, min=0.0))
+        z = torch.zeros_like(qw)
+        return torch.stack((qw, z, z, qz), -1).to(c.dtype)
 
 
 class NeuralFieldSet(torch.nn.Module):
@@ -193,8 +262,8 @@ class NeuralFieldSet(torch.nn.Module):
         self.lp_fields_params: Optional[Dict[str, torch.Tensor]] = None
         if scale_mode != "no" and field_radius is None:
             raise ValueError(f"{scale_mode=} requires field_radius to be specified.")
-        if dim_points != 3:
-            raise NotImplementedError("Only 3D spaces are supported by the HIP path.")
+        if dim_points not in (2, 3):
+            raise NotImplementedError("Only 2D and 3D spaces are supported.")      # models.py:236-243
         if scale_mode not in K.SCALE:
             raise NotImplementedError(f"{scale_mode=} is not available.")
         if not 1 <= int(num_knn) <= 8:
@@ -204,6 +273,10 @@ class NeuralFieldSet(torch.nn.Module):
         self._scale_mode, self._field_radius, self._dim_points = scale_mode, field_radius, dim_points
         self._num_knn, self._distance_factor, self._outside_value = num_knn, distance_factor, outside_value
         self._prototype_field = str_to_object(field_type)(**field_kwargs)
+        # planar sets run on the 3-D kernels (Embed2D); the render / training path (rays) is 3-D only, as in the reference
+        self._embed2d = Embed2D(self._prototype_field) if dim_points == 2 else None
+        if self._embed2d is not None and self._weight_dtype is not None:
+            raise NotImplementedError("weight_dtype (16-bit weight storage) is not built for dim_points=2")
         if self._weight_dtype is not None and isinstance(getattr(self._prototype_field, "_encoding", None), TriplaneEncoding):
             # the plane gradient is a fixed-point scatter into fp32 planes and their Adam launch has no 16-bit copy to
             # refresh: fail here, not at the first kernel call
@@ -265,8 +338,14 @@ class NeuralFieldSet(torch.nn.Module):
         the argument at all (models.py:336-345).  Caller that relies on it: the colour pass of `_extract_mesh`,
         run_mapping.py:2320-2332 (`field_radius=self._field_radius + 0.1`)."""
         fc = self.field_cfg()                       # scaling: the set's own radius, whatever the argument says
+        e2 = self._embed2d
+        if e2 is not None:
+            query_points, field_positions = e2.points(query_points), e2.points(field_positions)
+            field_orientations = e2.orientations(field_orientations)
         if use_vmap:
             params = {k: v for k, v in self.vmap_fields_params.items() if k != "_neus_sd"}
+            if e2 is not None:
+                params = e2.params(params)
             return ops.field_eval(fc, params, query_points, field_positions, field_orientations)
         if field_radius is None:
             field_radius = self._field_radius
@@ -275,7 +354,7 @@ class NeuralFieldSet(torch.nn.Module):
             raise TypeError("forward(use_vmap=False) needs a field radius (constructor or argument): the reference's "
                             "inside test `knn_dists[:, 0] < field_radius` fails on None (models.py:368)")
         lead = query_points.shape[:-1]
-        params = self.kernel_params()
+        params = self.kernel_params() if e2 is None else e2.params(self.kernel_params())
         out = ops.field_eval_knn(fc, params, query_points.reshape(-1, 3), field_positions, field_orientations,
                                  self._num_knn, self._distance_factor, self._outside_value, field_ids,
                                  mask_radius=float(field_radius))

@@ -394,6 +394,49 @@ def sample_rays_world(rc: K.RenderCfg, ijs, c2ws, near=None, far=None, gt=None, 
     return pc, pw, dist
 
 
+@_op("sample_rays_weighted")
+def _sample_rays_weighted_op(rcfg: torch.Tensor, ijs: torch.Tensor, boundaries: torch.Tensor, weights: torch.Tensor,
+                             u_bin: Optional[torch.Tensor], u_off: Optional[torch.Tensor], seed: int) -> List[torch.Tensor]:
+    """[points_cam (F,R,S,3), distances (F,R,S), dirs (F,R,3)]"""
+    rc = _render_cfg(rcfg)
+    dev = ijs.device
+    F, R, S, B = ijs.shape[0], ijs.shape[1], rc.num_samples_coarse, weights.shape[-1]
+    pos, quat = torch.zeros(F, 3, device=dev), torch.zeros(F, 4, device=dev)
+    keep = []
+    rays = make_rays(rc, ijs, torch.eye(4, device=dev), None, None, None, pos, quat, u_bin, u_off, seed, keep=keep)
+    bd, w = _f32c(boundaries), _f32c(weights)
+    pc = torch.empty(F, R, S, 3, device=dev)
+    dist = torch.empty(F, R, S, device=dev)
+    dirs = torch.empty(F, R, 3, device=dev)
+    K.check(K.lib().ngm_sample_rays_weighted(C.byref(rc), C.byref(rays), B, _ptr(bd), _ptr(w), _ptr(pc), _ptr(dist), _ptr(dirs),
+                                             _stream()), "ngm_sample_rays_weighted")
+    return [pc, dist, dirs]
+
+
+@_sample_rays_weighted_op.register_fake
+def _(rcfg, ijs, boundaries, weights, u_bin, u_off, seed):
+    F, R, S = ijs.shape[0], ijs.shape[1], _render_cfg(rcfg).num_samples_coarse
+    f = lambda *shape: torch.empty(*shape, device=ijs.device, dtype=torch.float32)
+    return [f(F, R, S, 3), f(F, R, S), f(F, R, 3)]
+
+
+def sample_rays_weighted(rc: K.RenderCfg, ijs, boundaries, weights, u_bin=None, u_off=None, seed=0):
+    """Camera.sample_ijs_uniform(ijs, num_samples, weights=..., boundaries=...) (camera.py:277-289): weighted sampling from
+    per-ray distance bins -> (points_cam (F,R,S,3), distances (F,R,S) in draw order, dirs (F,R,3)); S = rc.num_samples_coarse.
+    ijs (F,R,2) int64, boundaries (F,R,B+1) sorted, weights (F,R,B); u_bin / u_off (F,R,S): the reference's two torch.rand
+    draws, in its order, or both None = in-kernel Philox."""
+    _require_gpu(ijs, boundaries, weights, u_bin, u_off)
+    if (weights is None) != (boundaries is None):
+        raise ValueError("Either both or none of weights and boundaries must be None.")       # camera.py:260-261
+    if ijs.dim() == 2:
+        ijs, boundaries, weights = ijs[None], boundaries[None], weights[None]
+        u_bin, u_off = (None if u_bin is None else u_bin[None]), (None if u_off is None else u_off[None])
+    if boundaries.shape[:-1] != ijs.shape[:-1] or weights.shape[:-1] != ijs.shape[:-1] or boundaries.shape[-1] != weights.shape[-1] + 1:
+        raise ValueError("boundaries (..., num_bins + 1) and weights (..., num_bins) must match the leading dims of ijs")
+    pc, dist, dirs = torch.ops.ngm355.sample_rays_weighted(cfg_blob(rc), ijs, boundaries, weights, u_bin, u_off, int(seed))
+    return pc, dist, dirs
+
+
 @_op("composite_packed")
 def _composite_packed_op(rcfg: torch.Tensor, field_out4: torch.Tensor, dists: torch.Tensor,
                          points_cam: torch.Tensor) -> List[torch.Tensor]:

@@ -181,6 +181,18 @@ def sample_rays(ijs, cam: CameraSpec, near, far, gt, spec: RenderSpec, u_coarse,
     return pts, t, dirs
 
 
+def sample_rays_weighted(ijs, cam: CameraSpec, boundaries, weights, u_bin, u_off):
+    """Camera.sample_ijs_uniform with weights / boundaries (camera.py:277-289): the bin of a sample is the first whose
+    cumulative weight + 1e-3 reaches the first draw, its distance a uniform position inside that bin (second draw);
+    no sorting.  Returns points_cam (...,S,3), distances (...,S), dirs (...,3)."""
+    dirs = ijs_to_directions(ijs, cam, boundaries.dtype)
+    cum = torch.cumsum(weights, dim=-1) + 1e-3
+    bins = torch.searchsorted(cum, u_bin)
+    deltas = boundaries[..., 1:] - boundaries[..., :-1]
+    t = torch.gather(boundaries, -1, bins) + torch.gather(deltas, -1, bins) * u_off
+    return dirs.unsqueeze(-2) * t.unsqueeze(-1), t, dirs
+
+
 def transform_points(p, T, inv=False):
     """p_w = R p + t, or with inv: p_c = R^T (p - t) (utils.py:276-286)."""
     if inv:
@@ -211,6 +223,21 @@ def quat_apply(q, p):
     return quat_mul(quat_mul(q, p4), quat_invert(q))[..., 1:]
 
 
+def complex_mul(a, b):
+    """(models.py:27-45) raw complex product, real part first"""
+    ar, ai = a.unbind(-1)
+    br, bi = b.unbind(-1)
+    return torch.stack((ar * br - ai * bi, ar * bi + br * ai), -1)
+
+
+def orientation_apply_inverse(orient, p):
+    """`_orientation_apply(_orientation_invert(o), p)` (models.py:236-243): quaternions for 3-D points, complex numbers
+    (conjugate = models.py:12-24, `complex_apply` :48-62) for 2-D points"""
+    if p.shape[-1] == 2:
+        return complex_mul(orient * orient.new_tensor([1.0, -1.0]), p)
+    return quat_apply(quat_invert(orient), p)
+
+
 def scale_local(p, radius, scale_mode):
     if scale_mode == "unit_cube":
         return p / (2 * radius) + 0.5
@@ -222,9 +249,9 @@ def scale_local(p, radius, scale_mode):
 
 
 def world_to_field(p_world, pos, quat, radius, scale_mode):
-    """p_world (F,P,3), pos (F,3), quat (F,4) real-first -> local scaled (F,P,3)."""
+    """p_world (F,P,3), pos (F,3), quat (F,4) real-first -> local scaled (F,P,3)  (2-D: (F,P,2), (F,2), complex (F,2))."""
     local = p_world - pos.unsqueeze(-2)
-    local = quat_apply(quat_invert(quat).unsqueeze(-2), local)
+    local = orientation_apply_inverse(quat.unsqueeze(-2), local)
     return scale_local(local, radius, scale_mode)
 
 
@@ -400,7 +427,7 @@ def field_set_forward_knn(points, pos, quat, params, fs: FieldSpec, radius=1.0,
         acc = torch.zeros(pi.shape[0], fs.dim_out, dtype=points.dtype)
         for k in range(K):
             fk = ii[:, k]
-            loc = quat_apply(quat_invert(quat[fk]), pi - pos[fk])
+            loc = orientation_apply_inverse(quat[fk], pi - pos[fk])
             loc = scale_local(loc, radius, scale_mode)
             # evaluate each point with its own field's parameters
             pk = {n: v[fk] for n, v in params.items()}

@@ -795,11 +795,77 @@ def g21_field_radius_override():
          out_knn=out_knn, out_knn_default=out_knn_default, vmap_ids=ids, query=q, out_vmap=out_vmap, **arrays)
 
 
+def g22_fields_2d():
+    """`NeuralFieldSet(dim_points=2)` (models.py:236-238): complex orientations (`complex_apply` :48-62), 2-D Fourier
+    (raw coordinates) and NeRF-octave encodings, both branches of `forward`.  Orientations are rotations (unit modulus), as
+    the quaternions of the 3-D path are (the reference multiplies raw complex numbers / quaternions: a modulus would scale
+    the local coordinates; its orientations come from rotation matrices, utils.py / pytorch3d matrix_to_quaternion)."""
+    gen = torch.Generator().manual_seed(22)
+    NF, P, r = 5, 300, 0.8
+    pos = torch.tensor([[0.0, 0.0], [0.9, 0.1], [0.2, 1.0], [-0.7, 0.6], [3.0, 3.0]])
+    ang = 2 * torch.pi * torch.rand(NF, generator=gen)
+    comp = torch.stack((torch.cos(ang), torch.sin(ang)), -1)
+    comp[1] = torch.tensor([-1.0, 0.0])                      # the branch cut of the complex square root
+    for enc in ("fourier", "nerf"):
+        if enc == "fourier":
+            et, ek = "neural_graph_mapping.positional_encodings.PositionalEncodingFourier", dict(
+                dim_in=2, dim_out=40, mu=0.0, sigma=4.0, raw_coords=True)
+        else:
+            et, ek = "neural_graph_mapping.positional_encodings.PositionalEncodingNeRF", dict(dim_in=2, num_octaves=6, start_octave=0)
+        torch.manual_seed(220)
+        model = models.NeuralFieldSet(
+            dim_points=2, field_type="neural_graph_mapping.models.NeuralField",
+            field_kwargs=dict(encoding_type=et, encoding_kwargs=ek, num_layers=2, dim_out=4, dim_mlp_out=64, skip_mode="no",
+                              initial_geometry_bias=0.0, neus_initial_sd=None),
+            num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=r, scale_mode="unit_cube")
+        model.add_fields(NF)
+        for k, v in model.all_fields_params.items():
+            if v.dim() > 1:
+                v.add_(0.05 * torch.randn(v.shape, generator=gen))
+        c = torch.randint(0, NF, (P,), generator=gen)
+        d = torch.nn.functional.normalize(torch.randn(P, 2, generator=gen), dim=-1)
+        rad = torch.cat((r * torch.rand(2 * P // 3, generator=gen), r + 0.4 * torch.rand(P - 2 * P // 3, generator=gen)))
+        pts = pos[c] + rad[:, None] * d
+        with torch.no_grad():
+            out_knn = model(pts, pos, comp, None, use_vmap=False)
+            ids = torch.tensor([3, 0, 2])
+            model.set_vmap_fields(ids)
+            q = pos[ids][:, None, :] + 0.5 * torch.randn(3, 50, 2, generator=gen)
+            out_vmap = model(q, pos[ids], comp[ids], ids, use_vmap=True)
+            out_local = model(q, None, None, ids, use_vmap=True)       # points already local (models.py:344-345)
+        assert int((out_knn[:, 3] == 1.0).sum()) > P // 8              # some points are outside every field
+        arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+        save(f"g22_fields_2d_{enc}", points=pts, pos=pos, comp=comp, radius=np.float32(r), out_knn=out_knn, vmap_ids=ids, query=q,
+             out_vmap=out_vmap, out_local=out_local, **arrays)
+
+
+def g23_weighted_bins():
+    """`Camera.sample_ijs_uniform(ijs, S, weights=..., boundaries=...)` (camera.py:277-289): the weighted-bin branch, with the
+    two `torch.rand` draws recorded in the reference's order (bins first, offsets second).  Bin weights like a coarse pass
+    produces them (a few dominant bins, many near-empty ones, exact zeros), uneven boundaries."""
+    gen = torch.Generator().manual_seed(23)
+    cam = camera.Camera(**NRGBD_CAMERA)
+    F, R, S, B = 2, 37, 24, 15
+    ijs = torch.stack((torch.randint(0, 480, (F, R), generator=gen), torch.randint(0, 640, (F, R), generator=gen)), -1)
+    edges = torch.sort(torch.rand(F, R, B + 1, generator=gen) * 6.0 + 0.2, dim=-1).values
+    w = torch.rand(F, R, B, generator=gen) ** 6
+    w[torch.rand(F, R, B, generator=gen) < 0.2] = 0.0
+    w[..., 7] += 0.05                                          # never all zero
+    w = w / w.sum(-1, keepdim=True)
+    torch.manual_seed(2300)
+    u_bin = torch.rand(F, R, S)
+    u_off = torch.rand(F, R, S)
+    torch.manual_seed(2300)
+    pts, dist = cam.sample_ijs_uniform(ijs, S, weights=w, boundaries=edges)
+    save("g23_weighted_bins", ijs=ijs, boundaries=edges, weights=w, u_bin=u_bin, u_off=u_off, points=pts, distances=dist,
+         cam=np.array([NRGBD_CAMERA[k] for k in ("width", "height", "fx", "fy", "cx", "cy")], dtype=np.float64))
+
+
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
              g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings, g20_train_nll,
-             g21_field_radius_override]
+             g21_field_radius_override, g22_fields_2d, g23_weighted_bins]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -52,6 +52,63 @@ def test_sampler_golden_bit_exact():
     close(dirs[0], g1["dirs"], rtol=1e-6, atol=1e-7)
 
 
+def test_weighted_bin_sampler_golden_bit_exact():
+    """Camera.sample_ijs_uniform's weighted-bin branch (camera.py:277-289): fixture G23 from the real reference, distances
+    bit for bit (torch.cumsum's CPU arithmetic: sequential, fp64 accumulator, fp32 prefixes; first bin whose sum + 1e-3 reaches the draw, start + size * offset draw)"""
+    g = load_golden("g23_weighted_bins")
+    S = g["u_bin"].shape[-1]
+    rc = K.render_cfg(num_samples_coarse=S, num_samples_guided=0, **NRGBD_KW)
+    d = cu({k: g[k] for k in ("ijs", "boundaries", "weights", "u_bin", "u_off")})
+    pts, t, dirs = ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"], d["weights"], d["u_bin"], d["u_off"])
+    assert torch.equal(t.cpu(), g["distances"])
+    close(pts, g["points"], rtol=1e-6, atol=1e-6)
+    close(dirs, O.ijs_to_directions(g["ijs"], NRGBD), rtol=1e-6, atol=1e-7)
+    # flat (R,2) pixel lists are accepted like the reference's `...` leading dims
+    pts1, t1, _ = ops.sample_rays_weighted(rc, d["ijs"][0], d["boundaries"][0], d["weights"][0], d["u_bin"][0], d["u_off"][0])
+    assert torch.equal(t1[0], t[0])
+    with pytest.raises(ValueError):
+        ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"][..., :-1], d["weights"], d["u_bin"], d["u_off"])
+    with pytest.raises(K.NgmError):                            # one draw array without the other
+        ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"], d["weights"], d["u_bin"], None)
+
+
+@pytest.mark.parametrize("S,B", [(1, 1), (64, 7), (200, 128)])
+def test_weighted_bin_sampler_vs_oracle_random(S, B):
+    """random bins incl. zero-weight ones, weights that stop short of 1 (the draw beyond the last cumulative weight takes the
+    last bin -- the reference's gather is out of range there -- so such draws are excluded from the comparison), and the
+    in-kernel Philox draws: every distance inside a bin the weights allow, histogram of bins ~ the weights"""
+    torch.manual_seed(S * 1000 + B)
+    F, R = 3, 41
+    ijs = torch.stack([torch.randint(0, 480, (F, R)), torch.randint(0, 640, (F, R))], -1)
+    edges = torch.sort(torch.rand(F, R, B + 1) * 5 + 0.1, dim=-1).values
+    w = torch.rand(F, R, B) ** 3
+    w[torch.rand(F, R, B) < 0.3] = 0.0
+    w[..., 0] += 0.01
+    w = w / w.sum(-1, keepdim=True)
+    w[0, 0] *= 0.5                                         # sums to 0.5: half the draws are beyond the last cumulative weight
+    u_bin, u_off = torch.rand(F, R, S), torch.rand(F, R, S)
+    cum = torch.cumsum(w, -1) + 1e-3
+    ok = u_bin <= cum[..., -1:]
+    pts_o, t_o, _ = O.sample_rays_weighted(ijs, NRGBD, edges, w, torch.where(ok, u_bin, torch.zeros(())), u_off)
+    rc = K.render_cfg(num_samples_coarse=S, num_samples_guided=0, **NRGBD_KW)
+    pts, t, _ = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), u_bin.to(DEV), u_off.to(DEV))
+    assert torch.equal(t.cpu()[ok], t_o[ok])
+    close(pts.cpu()[ok], pts_o[ok], rtol=1e-6, atol=1e-6)
+    assert int((~ok).sum()) > 0 or S == 1
+    last = edges[..., -2:-1].expand_as(t_o)
+    assert bool((t.cpu()[~ok] >= last[~ok]).all())         # beyond the last cumulative weight: the last bin
+    # Philox: deterministic, seed-dependent, distributed like the weights
+    p1 = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), seed=5)[1]
+    p2 = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), seed=5)[1]
+    p3 = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), seed=6)[1]
+    assert torch.equal(p1, p2) and (S * B == 1 or not torch.equal(p1, p3))
+    assert bool(((p1.cpu() >= edges[..., :1]) & (p1.cpu() <= edges[..., -1:])).all())
+    if S >= 200:
+        bins = (torch.searchsorted(edges[1:].contiguous(), p1.cpu()[1:].contiguous(), right=True) - 1).clamp(0, B - 1)
+        hist = torch.zeros(F - 1, R, B).scatter_add_(-1, bins, torch.ones_like(p1.cpu()[1:])) / S
+        assert float((hist - w[1:]).abs().max()) < 0.2
+
+
 @pytest.mark.parametrize("n_c,n_g", [(24, 0), (7, 5), (64, 64), (1, 1)])
 def test_sampler_vs_oracle_random(n_c, n_g):
     torch.manual_seed(n_c * 100 + n_g)
@@ -281,6 +338,71 @@ def test_module_forward_field_radius_argument_golden():
     out_v = fs(q, pos[ids], quat[ids], ids, use_vmap=True, field_radius=mr)
     close(out_v, g["out_vmap"], rtol=2e-4, atol=2e-5)
     assert torch.equal(out_v, fs(q, pos[ids], quat[ids], ids, use_vmap=True))           # bitwise: the argument is unread
+
+
+def _g22_module(g, enc):
+    et = "PositionalEncodingFourier" if enc == "fourier" else "PositionalEncodingNeRF"
+    ek = dict(dim_in=2, dim_out=40, mu=0.0, sigma=4.0, raw_coords=True) if enc == "fourier" else dict(dim_in=2, num_octaves=6, start_octave=0)
+    fs = M.NeuralFieldSet(dim_points=2, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
+        encoding_type="neural_graph_mapping.positional_encodings." + et, encoding_kwargs=ek, num_layers=2, dim_out=4,
+        dim_mlp_out=64, skip_mode="no"), num_knn=2, distance_factor=10.0, outside_value=1.0, field_radius=float(g["radius"]),
+        scale_mode="unit_cube").to(DEV)
+    fs.add_fields(g["pos"].shape[0])
+    for k, v in split_prefix(g, "p::").items():
+        assert fs.all_fields_params[k].shape == v.shape, k          # the 2-D parameter shapes ARE the reference's
+        fs.all_fields_params[k].copy_(v.to(DEV))
+    return fs
+
+
+@pytest.mark.parametrize("enc", ["fourier", "nerf"])
+def test_module_forward_planar_field_set_golden(enc):
+    """`NeuralFieldSet(dim_points=2)` (models.py:236-238): fixture G22 from the real reference (complex orientations, one on the
+    square root's branch cut) through the drop-in class, both branches of `forward` and
+    the already-local call; the kernels see the z = 0 embedding (`models.Embed2D`)."""
+    g = load_golden(f"g22_fields_2d_{enc}")
+    fs = _g22_module(g, enc)
+    pts, pos, comp = g["points"].to(DEV), g["pos"].to(DEV), g["comp"].to(DEV)
+    out = fs(pts, pos, comp, None, use_vmap=False)
+    close(out, g["out_knn"], rtol=2e-4, atol=3e-5)
+    outside = (g["out_knn"] == 1.0).all(-1)
+    assert int(outside.sum()) > 30 and torch.equal(out.cpu()[outside], torch.ones(int(outside.sum()), 4))
+    assert fs(pts.view(3, -1, 2), pos, comp, None, use_vmap=False).shape == (3, pts.shape[0] // 3, 4)
+    ids = g["vmap_ids"].long().to(DEV)
+    fs.set_vmap_fields(ids)
+    q = g["query"].to(DEV)
+    close(fs(q, pos[ids], comp[ids], ids, use_vmap=True), g["out_vmap"], rtol=2e-4, atol=2e-5)
+    close(fs(q, None, None, ids, use_vmap=True), g["out_local"], rtol=2e-4, atol=2e-5)
+    # one field through the prototype class (models.py:143-182 with a 2-D encoding)
+    proto = fs._prototype_field.to(DEV)
+    sd = {k: v[0] for k, v in fs.vmap_fields_params.items()}
+    proto.load_state_dict(sd)
+    x_local = q[0] / (2 * float(g["radius"])) + 0.5
+    close(proto(x_local), fs(q[:1], None, None, ids[:1], use_vmap=True)[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("enc", ["fourier", "nerf"])
+def test_module_planar_field_set_gradients_vs_oracle(enc):
+    """autograd through the planar set: gradients of every 2-D parameter against the oracle's native 2-D restatement
+    (float64 autograd); the zero blocks of the embedding take no part"""
+    g = load_golden(f"g22_fields_2d_{enc}")
+    fs = _g22_module(g, enc)
+    ids = g["vmap_ids"].long()
+    fs.set_vmap_fields(ids.to(DEV))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in fs.vmap_fields_params.items()}
+    fs.vmap_fields_params = leaves
+    q, pos, comp = g["query"].to(DEV), g["pos"][ids].to(DEV), g["comp"][ids].to(DEV)
+    wgt = torch.randn(3, 50, 4, generator=torch.Generator().manual_seed(5))
+    (fs(q, pos, comp, ids.to(DEV), use_vmap=True) * wgt.to(DEV)).sum().backward()
+    fs2 = (O.FieldSpec(encoding="fourier", dim_enc=40, num_layers=2, dim_hidden=64) if enc == "fourier"
+           else O.FieldSpec(encoding="nerf", num_octaves=6, num_layers=2, dim_hidden=64))
+    po = {k: v[ids].double().requires_grad_(True) for k, v in split_prefix(g, "p::").items()}
+    (O.field_set_forward_vmap(g["query"].double(), g["pos"][ids].double(), g["comp"][ids].double(), po, fs2,
+                              radius=float(g["radius"])) * wgt.double()).sum().backward()
+    for k, v in po.items():
+        assert leaves[k].grad is not None and leaves[k].grad.shape == v.shape, k
+        ref = v.grad.float()
+        err = float((leaves[k].grad.cpu() - ref).abs().max())
+        assert err <= 2e-3 * float(ref.abs().max()) + 1e-6, (k, err, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("scale_mode,r", [("unit_cube", 0.7), ("unit_ball", 1.3), ("no", 0.9)])

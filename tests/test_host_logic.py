@@ -57,6 +57,41 @@ def test_unsupported_variants_raise():
         M.NeuralFieldSet(**{**SET_KW, "num_knn": 9})
 
 
+def test_planar_field_sets_wiring(monkeypatch):
+    """dim_points = 2 (models.py:236-238): what the kernels are handed is the z = 0 embedding; parameter shapes stay the
+    reference's 2-D ones; what the embedding cannot express raises at construction (arithmetic: fixture G22, CPU + GPU)"""
+    enc2 = dict(dim_in=2, dim_out=40, mu=0.0, sigma=4.0, raw_coords=True)
+    kw = {**SET_KW, "dim_points": 2, "field_kwargs": {**FIELD_KW, "encoding_kwargs": enc2, "dim_mlp_out": 64, "neus_initial_sd": None}}
+    fs = M.NeuralFieldSet(**kw)
+    fs.add_fields(3)
+    fs.set_vmap_fields(None)
+    assert fs.all_fields_params["_encoding._linear.weight"].shape == (3, 38, 2)
+    assert fs.all_fields_params["_linears.0.weight"].shape == (3, 64, 40)
+    fc = fs.field_cfg()
+    assert (fc.dim_enc, fc.dim_hidden, fc.raw_coords) == (41, 64, 1)
+    seen = {}
+
+    def vmap(fc, params, q, pos=None, quat=None):
+        seen.update(q=q, pos=pos, quat=quat, w0=params["_linears.0.weight"], we=params["_encoding._linear.weight"])
+        return torch.zeros(*q.shape[:-1], 4)
+    monkeypatch.setattr(M.ops, "field_eval", vmap)
+    comp = torch.tensor([[0.0, 1.0], [-1.0, 0.0], [0.6, -0.8]])
+    fs(torch.ones(3, 5, 2), torch.ones(3, 2), comp, None, use_vmap=True)
+    assert seen["q"].shape == (3, 5, 3) and float(seen["q"][..., 2].abs().max()) == 0.0 and seen["pos"].shape == (3, 3)
+    q = seen["quat"]
+    assert q.shape == (3, 4) and float(q[:, 1:3].abs().max()) == 0.0
+    torch.testing.assert_close(torch.stack((q[:, 0] ** 2 - q[:, 3] ** 2, 2 * q[:, 0] * q[:, 3]), -1), comp, rtol=1e-6, atol=1e-7)
+    assert seen["w0"].shape == (3, 64, 41) and float(seen["w0"][..., 2].abs().max()) == 0.0
+    assert torch.equal(seen["w0"][..., 3:], fs.all_fields_params["_linears.0.weight"][..., 2:])
+    assert seen["we"].shape == (3, 38, 3) and float(seen["we"][..., 2].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError, match="skip"):
+        M.NeuralFieldSet(**{**kw, "field_kwargs": {**kw["field_kwargs"], "skip_mode": "concat"}})
+    with pytest.raises(NotImplementedError, match="2-D Fourier or NeRF"):
+        M.NeuralFieldSet(**{**kw, "field_kwargs": FIELD_KW})          # a 3-D encoding in a planar set
+    with pytest.raises(NotImplementedError):
+        M.NeuralFieldSet(**{**SET_KW, "dim_points": 4})
+
+
 def test_forward_field_radius_argument_reaches_the_kernel_as_mask_radius_only(monkeypatch):
     """models.py:333-337, 367-378: the argument is the inside test's radius; scaling keeps the constructor's (host wiring only:
     the ops are replaced by recorders, the arithmetic is tested on the GPU against fixture G21)"""

@@ -192,9 +192,8 @@ typedef struct ngm_rays {
   const float* gt;         /* (F,R) or NULL; 0.0 = no depth                                  */
   float near_const, far_const;
   const float* field_pos;  /* (F,3) field positions in the world frame                       */
-  const float* field_quat; /* (F,4) real-first UNIT quaternions (rotations: what the reference's orientations  */
-                           /* are, made from rotation matrices; its raw Hamilton products, models.py:338-339,   */
-                           /* would scale the local frame by |q|^2 for any other norm -- the kernels do not)    */
+  const float* field_quat; /* (F,4) real-first quaternions, applied like pytorch3d's quaternion_apply (raw        */
+                           /* Hamilton products, models.py:338-339: a norm != 1 scales the local frame by |q|^2) */
   const float* u_coarse;   /* (F,R,S_c) torch.rand draws of camera.py:274, or NULL -> Philox */
   const float* u_guided;   /* (F,R,S_g) or NULL -> Philox                                    */
   const float* lin_coarse; /* (S_c+1) torch.linspace(0,1) table of camera.py:271 or NULL     */

@@ -237,13 +237,16 @@ struct Vec3 { float x, y, z; };
 __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
   return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-// rotate v by the INVERSE of unit quaternion (w, u): v' = v + 2w(v x u)... written for q^-1 = (w,-u)
+// pytorch3d's quaternion_apply(quaternion_invert(q), v) for q = (w, u), models.py:338-339: the RAW Hamilton products
+// q' (0, v) q'* with q' = (w, a), a = -u, i.e. (w^2 - a.a) v + 2 (a.v) a + 2 w (a x v) = |q|^2 v + w t + a x t, t = 2 (a x v):
+// the rotation for a unit quaternion, and -- like the reference, which never normalises -- |q|^2 times it otherwise
 __device__ __forceinline__ Vec3 quat_rotate_inv(float w, float ux, float uy, float uz, Vec3 v) {
   const Vec3 u{-ux, -uy, -uz};
+  const float n2 = w * w + ux * ux + uy * uy + uz * uz;
   Vec3 t = cross3(u, v);
   t.x *= 2.0f; t.y *= 2.0f; t.z *= 2.0f;
   const Vec3 c = cross3(u, t);
-  return Vec3{v.x + w * t.x + c.x, v.y + w * t.y + c.y, v.z + w * t.z + c.z};
+  return Vec3{n2 * v.x + w * t.x + c.x, n2 * v.y + w * t.y + c.y, n2 * v.z + w * t.z + c.z};
 }
 // world point -> field-local -> scaled coordinates (models.py:329-339, 278-285) for the STANDALONE evaluation kernels (vmap-style
 // k_field_points_fwd and the kNN path's k_knn_eval), every operation rounded separately: the two then give the same bits for
@@ -255,10 +258,11 @@ __device__ __forceinline__ Vec3 scaled_local_point(Vec3 p, bool posed, float px,
   if (posed) {
     v = Vec3{p.x - px, p.y - py, p.z - pz};
     const Vec3 u{-qx, -qy, -qz};
+    const float n2 = qw * qw + qx * qx + qy * qy + qz * qz;      // quat_rotate_inv's arithmetic, rounded op by op
     Vec3 t{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
     t.x *= 2.0f; t.y *= 2.0f; t.z *= 2.0f;
     const Vec3 c{u.y * t.z - u.z * t.y, u.z * t.x - u.x * t.z, u.x * t.y - u.y * t.x};
-    v = Vec3{v.x + qw * t.x + c.x, v.y + qw * t.y + c.y, v.z + qw * t.z + c.z};
+    v = Vec3{n2 * v.x + qw * t.x + c.x, n2 * v.y + qw * t.y + c.y, n2 * v.z + qw * t.z + c.z};
   }
   return Vec3{v.x / div + off, v.y / div + off, v.z / div + off};
 }

@@ -186,17 +186,16 @@ class Embed2D:
     """`dim_points == 2` (models.py:236-238: complex numbers as orientations, `complex_apply` :48-62) on the 3-D kernels.
 
     A planar field set IS a 3-D one restricted to z = 0: points and centres get a zero third coordinate (distances, the
-    kNN ranking and the inside test are unchanged: + 0^2 is exact), the orientation c = cos t + i sin t becomes the unit
-    quaternion (q_w, 0, 0, q_z) with (q_w + i q_z)^2 = c, whose inverse rotation maps (x, y, 0) to (a x + b y, a y - b x, 0)
-    = conj(c) (x + iy), the reference's `complex_apply(complex_invert(c), .)`, and every place where the encoding of the
-    third coordinate would enter the network carries a ZERO weight: the third column of the Fourier matrix, and the layer-0
-    columns of the raw z feature (Fourier, `raw_coords`) or of the z octaves (NeRF).  A zero weight times a finite feature
-    is exactly 0 on every matmul path (fp32 MFMA and the bf16 split alike), so the result differs from the reference's 2-D
-    arithmetic only by the rounding of the rotation (fixture G22, from the real reference).  The zero blocks are inserted
-    with differentiable torch ops, so gradients arrive at the 2-D parameters; the blocks' own gradients are dropped.
-    Orientations are taken as ROTATIONS, as the kernels take the 3-D path's quaternions (unit norm: the reference's raw
-    products would scale the local coordinates by a modulus; its orientations come from rotation matrices): c is
-    normalised before the square root."""
+    kNN ranking and the inside test are unchanged: + 0^2 is exact), the orientation c = a + ib becomes the quaternion
+    (q_w, 0, 0, q_z) with (q_w + i q_z)^2 = c -- pytorch3d's un-normalised `quaternion_apply(quaternion_invert(q), v)`, which
+    is what the kernels compute (ngm_device.h: quat_rotate_inv), then maps (x, y, 0) to (a x + b y, a y - b x, 0) =
+    conj(c) (x + iy), the reference's `complex_apply(complex_invert(c), .)`, for any modulus -- and every place where the
+    encoding of the third coordinate would enter the network carries a ZERO weight: the third column of the Fourier matrix,
+    and the layer-0 columns of the raw z feature (Fourier, `raw_coords`) or of the z octaves (NeRF).  A zero weight times
+    a finite feature is exactly 0 on every matmul path (fp32 MFMA and the bf16 split alike), so the result differs from
+    the reference's 2-D arithmetic only by the rounding of the rotation (fixture G22, from the real reference).  The zero
+    blocks are inserted with differentiable torch ops, so gradients arrive at the 2-D parameters; the blocks' own
+    gradients are dropped."""
 
     def __init__(self, proto: "NeuralField") -> None:
         enc = proto._encoding
@@ -231,14 +230,13 @@ class Embed2D:
 
     @staticmethod
     def orientations(c: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-        """principal square root of c / |c|, in fp64: q_w = sqrt((1 + a) / 2), q_z = sign(b) sqrt((1 - a) / 2)"""
+        """principal complex square root, in fp64: q_w = sqrt((|c| + a) / 2), q_z = sign(b) sqrt((|c| - a) / 2)"""
         if c is None:
             return None
         a, b = c[..., 0].double(), c[..., 1].double()
         r = torch.sqrt(a * a + b * b)
-        a, b = a / r, b / r
-        qw = torch.sqrt(torch.clamp((1.0 + a) * 0.5, min=0.0))
-        qz = torch.where(b < 0, -1.0, 1.0) * torch.sqrt(torch.clamp((1.0 - a) * 0.5, min=0.0))
+        qw = torch.sqrt(torch.clamp((r + a) * 0.5, min=0.0))
+        qz = torch.where(b < 0, -1.0, 1.0) * torch.sqrt(torch.clamp((r - a) * 0.5, min=0.0))
         z = torch.zeros_like(qw)
         return torch.stack((qw, z, z, qz), -1).to(c.dtype)
 

@@ -797,14 +797,14 @@ def g21_field_radius_override():
 
 def g22_fields_2d():
     """`NeuralFieldSet(dim_points=2)` (models.py:236-238): complex orientations (`complex_apply` :48-62), 2-D Fourier
-    (raw coordinates) and NeRF-octave encodings, both branches of `forward`.  Orientations are rotations (unit modulus), as
-    the quaternions of the 3-D path are (the reference multiplies raw complex numbers / quaternions: a modulus would scale
-    the local coordinates; its orientations come from rotation matrices, utils.py / pytorch3d matrix_to_quaternion)."""
+    (raw coordinates) and NeRF-octave encodings, both branches of `forward`.  Orientations are NOT all of unit modulus
+    (the reference multiplies raw complex numbers: a modulus scales the local coordinates)."""
     gen = torch.Generator().manual_seed(22)
     NF, P, r = 5, 300, 0.8
     pos = torch.tensor([[0.0, 0.0], [0.9, 0.1], [0.2, 1.0], [-0.7, 0.6], [3.0, 3.0]])
     ang = 2 * torch.pi * torch.rand(NF, generator=gen)
-    comp = torch.stack((torch.cos(ang), torch.sin(ang)), -1)
+    mod = torch.tensor([1.0, 1.0, 0.9, 1.1, 1.0])
+    comp = torch.stack((mod * torch.cos(ang), mod * torch.sin(ang)), -1)
     comp[1] = torch.tensor([-1.0, 0.0])                      # the branch cut of the complex square root
     for enc in ("fourier", "nerf"):
         if enc == "fourier":

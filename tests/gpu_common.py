@@ -183,7 +183,8 @@ def synth_target(F, R, seed=0):
                            term_probs=(gt < far).float(), term_mask=(gt > near) & (gt != 0))
 
 
-def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=40, seed=4321, max_neutralised=0.15):
+def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=40, seed=4321, max_neutralised=0.15,
+                    neus_isds=None, geometry_margin=2e-7):
     """Redraw the jitter of every SAMPLE whose fp64 hidden pre-activations come within `margin` of a ReLU kink.
     The loss gradient is discontinuous there, so two correct fp32 implementations (different summation order) may put
     the sample on different sides and differ by that sample's whole contribution; away from the kinks the strict
@@ -191,6 +192,10 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
     A few samples cannot be moved out of the band (a hidden unit whose pre-activation stays near zero across a whole
     stratum): their rays first get a narrower band (down to margin / 8), and the rays that still hold such samples are taken
     out of the loss (gt = 0, masks false: no term of rm.py:1769-1872 sees them), so a flip there cannot matter.
+    The geometry modes with a kink of their own are covered the same way (fp64, band `geometry_margin`): neus clamps
+    (tno_k - tno_k+1) / (tno_k + 1e-5) at 0 (rm.py:753-758; pass `neus_isds`) -- a pair of neighbouring samples whose
+    transformed geometries agree to within fp32 rounding sits on either side of the clamp depending on the last bit of a
+    position (pairs deep in the sigmoid's saturation are left alone: the clamp switches nothing there) -- and density applies a ReLU to the geometry output (rm.py:746-749).
     Returns (u_coarse, u_guided, t) with the offending elements redrawn (t: copy with those rays neutralised).  The share of
     neutralised rays is recorded (KINK -> gpurun_out/parity_margins.txt) and bounded by `max_neutralised` (the metric-size
     comparisons pass 0.02: "M1-size vs oracle" must mean at least 98 % of the batch)."""
@@ -212,11 +217,24 @@ def kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, margin=5e-5, tries=4
         pts_w = O.transform_points(pts_cam, c2ws.unsqueeze(-3)).double().reshape(F, R * S, 3)
         x = O.world_to_field(pts_w, pos.double(), quat.double(), rs.field_radius, rs.scale_mode)
         pres = []
-        O.field_mlp(O.encode(x, p64, fs), p64, fs, pre_out=pres)
+        out64 = O.field_mlp(O.encode(x, p64, fs), p64, fs, pre_out=pres)
         near0 = torch.full((F, R * S), float("inf"), dtype=torch.float64)
         for pre in pres:
             near0 = torch.minimum(near0, pre.abs().min(-1).values)
         bad = (near0.view(F, R, S) < mar[..., None]) & ~dead[..., None]
+        geo = out64[..., 3].view(F, R, S)
+        if rs.geometry_mode == "neus" and neus_isds is not None and S > 1:
+            k_ = neus_isds.double().view(F, 1, 1) * rs.geometry_factor
+            tno = torch.sigmoid(k_ * geo)
+            slope = k_ * tno * (1 - tno)          # what a flip of the clamp switches on or off; ~0 where the sigmoid is saturated
+            smax = torch.maximum(slope[..., :-1], slope[..., 1:])
+            # the band in which the clamp's side is undecided between two fp32 evaluations: an ulp or two of tno (6e-8) plus the
+            # difference of the two geometry outputs' errors through the sigmoid's slope (neighbouring samples of one ray round
+            # almost alike: measured, kernels and oracle agree on such pairs to ~1e-7)
+            pair = ((tno[..., :-1] - tno[..., 1:]).abs() < geometry_margin * smax + 1.5e-7) & (smax > 1e-4)
+            bad[..., :-1] |= pair & ~dead[..., None]
+        elif rs.geometry_mode == "density":
+            bad |= (geo.abs() < geometry_margin) & ~dead[..., None]
         if not bad.any():
             frac = float(dead.float().mean())
             KINK.append(dict(test=_test_id(), rays=int(dead.numel()), samples_per_ray=int(S), neutralised_rays=int(dead.sum()),

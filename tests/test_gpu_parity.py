@@ -193,6 +193,52 @@ def test_skip_concat_golden(name):
     close(a, b, rtol=1e-5, atol=1e-6)
 
 
+def test_non_unit_quaternions_scale_the_local_frame_like_the_reference():
+    """`quaternion_apply(quaternion_invert(q), .)` (models.py:338-339, 377-379) is two raw Hamilton products: for |q| != 1
+    the local coordinates come out scaled by |q|^2 -- the reference never normalises, and neither do the kernels (standalone
+    evaluation, kNN evaluation, the fused training step's ray set-up).  Against the oracle's restatement of the raw products."""
+    torch.manual_seed(12)
+    F, P = 3, 600
+    norms = torch.tensor([0.85, 1.0, 1.2])
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=2)
+    fs = O.FieldSpec(**fkw)
+    params = O.init_params(fs, F, seed=5, sigma=3.0)
+    pos = torch.randn(F, 3)
+    unit = torch.nn.functional.normalize(torch.randn(F, 4), dim=-1)
+    quat = unit * norms[:, None]
+    q = pos[:, None, :] + 0.35 * torch.randn(F, P, 3)
+    fc = K.field_cfg(field_radius=1.0, **fkw)
+    ref = O.field_set_forward_vmap(q, pos, quat, params, fs, radius=1.0)
+    out = ops.field_eval(fc, cu(params), q.to(DEV), pos.to(DEV), quat.to(DEV))
+    close(out, ref, rtol=2e-4, atol=3e-5)
+    normalised = O.field_set_forward_vmap(q, pos, unit, params, fs, radius=1.0)
+    assert float((normalised[0] - ref[0]).abs().max()) > 1e-2 and float((normalised[1] - ref[1]).abs().max()) < 1e-4
+    pts = q.reshape(-1, 3)
+    ref_k = O.field_set_forward_knn(pts, pos, quat, params, fs, radius=1.0)
+    out_k = ops.field_eval_knn(fc, cu(params), pts.to(DEV), pos.to(DEV), quat.to(DEV), 2, 10.0, 1.0)
+    close(out_k, ref_k, rtol=2e-4, atol=3e-5)
+    # the fused training step: rays set up in the (scaled) local frame
+    R, n_c, n_g = 40, 8, 8
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    pos2, quat2, t = synth_target(F, R, seed=6)
+    quat2 = quat2 * norms[:, None]
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3)
+    params[f"_linears.2.weight"] *= 2.0
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos2, quat2, params, fs, rs, u_c, u_g)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos2, quat2, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g)
+    r = make_renderer(fkw, ckw, F, params)
+    r.set_field_poses(pos2.to(DEV), quat2.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    loss["combined"].backward()
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+
+
 @pytest.mark.parametrize("D,layers", [(64, 2), (32, 1), (61, 2)])
 def test_skip_concat_fused_train_step_vs_oracle(D, layers):
     """skip_mode "concat" through the fused render / train step (forward kernel + 32-sample-tile backward)."""
@@ -356,8 +402,8 @@ def _g22_module(g, enc):
 
 @pytest.mark.parametrize("enc", ["fourier", "nerf"])
 def test_module_forward_planar_field_set_golden(enc):
-    """`NeuralFieldSet(dim_points=2)` (models.py:236-238): fixture G22 from the real reference (complex orientations, one on the
-    square root's branch cut) through the drop-in class, both branches of `forward` and
+    """`NeuralFieldSet(dim_points=2)` (models.py:236-238): fixture G22 from the real reference (complex orientations, two
+    of non-unit modulus, one on the square root's branch cut) through the drop-in class, both branches of `forward` and
     the already-local call; the kernels see the z = 0 embedding (`models.Embed2D`)."""
     g = load_golden(f"g22_fields_2d_{enc}")
     fs = _g22_module(g, enc)
@@ -549,7 +595,7 @@ def test_neus_staged_train_step_vs_oracle():
     params["_linears.2.weight"] *= 3.0
     sd = torch.tensor([0.4, 0.8, 1.5])
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
-    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, neus_isds=1.0 / sd.abs())
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     sdo = sd.clone().requires_grad_()
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g,
@@ -598,7 +644,7 @@ def test_neus_fused_train_step_vs_oracle(F, R, n_c, n_g, layers):
     params[f"_linears.{layers}.weight"] *= 3.0
     sd = torch.tensor([0.4, 0.8, -1.5, 1.1])[:F]                      # a negative one: isd = 1 / |sd| (rm.py:641-644)
     u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
-    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, neus_isds=1.0 / sd.abs())
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     sdo = sd.clone().requires_grad_()
     pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g,

@@ -916,6 +916,30 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     // training: the encoding itself is what the backward cannot cheaply recompute (simplex search + 64 table
     // gathers per sample) -> stash it (128 B per sample); the one hidden layer is recomputed there
     if (st && st->base) act_store<MI, 2>(*st, 0, lane, E);
+#ifdef NGM_ABLF_HASHCELLS   // timing ablation (results meaningless): what stashing the lattice search for k_hash_grad would cost the
+                            // forward -- 24 bytes (4 x 16-bit slots + 4 fp32 weights) per (sample, level), level-major, written over
+                            // the encoding stash's memory (wrapped: the backward then reads garbage)
+    if (st && st->base) {
+      const int64_t span = (1ll << (63 - __clzll((unsigned long long)(st->layer_stride / 4 - 64)))) - 1;   // float4 slots of the stash area (power of two - 1)
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      v4f* w4 = reinterpret_cast<v4f*>(st->base);
+      v2u* i2 = reinterpret_cast<v2u*>(st->base);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int level = 4 * (k >> 1) + 2 * hi + (k & 1);
+          const int64_t g = (st->g0 + 32 * nt + (lane & 31)) + (int64_t)level * 524288;
+          if (32 * nt + (lane & 31) < st->nvalid) {
+            const v4f wv = {E[nt][0][2 * k], E[nt][0][2 * k + 1], x, y};
+            const v2u iv = {__float_as_uint(E[nt][0][2 * k]), (unsigned)lane};
+            __builtin_nontemporal_store(wv, w4 + (g & span));
+            __builtin_nontemporal_store(iv, i2 + ((2 * g + 1) & span));
+          }
+        }
+    }
+#endif
   } else {
     if constexpr (!NEED_COS) {
       const ngm_v2f X = {hi ? ox : x, hi ? x : ox}, Y = {hi ? oy : y, hi ? y : oy}, Z = {hi ? oz : z, hi ? z : oz};

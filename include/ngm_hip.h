@@ -242,7 +242,7 @@ int ngm_sample_rays_world(const ngm_render_cfg* cfg, const ngm_rays* rays, float
  * probabilities weights (F,R,num_bins): bin = searchsorted(cumsum(weights) + 1e-3, u_bin), distance = boundaries[bin] +
  * (boundaries[bin+1] - boundaries[bin]) * u_off; cfg->num_samples_coarse samples per ray, in DRAW order (the reference does
  * not sort this branch).  rays->u_coarse = the first torch.rand draw (bins), rays->u_guided = the second (offsets), both
- * (F,R,S), or both NULL = Philox streams 0 / 1; rays->near / far / gt are not read.  The running sum is torch.cumsum's on the
+ * (F,R,S), or both NULL = words 0 / 1 of Philox block (ray * S + sample, stream 0); rays->near / far / gt are not read.  The running sum is torch.cumsum's on the
  * CPU (sequential, fp64 accumulator, every prefix rounded to fp32); a draw beyond the last cumulative weight takes the last bin (the reference's gather is out
  * of range there).  Outputs as ngm_sample_rays (any may be NULL). */
 int ngm_sample_rays_weighted(const ngm_render_cfg* cfg, const ngm_rays* rays, int32_t num_bins, const float* boundaries,
@@ -509,7 +509,8 @@ enum ngm_kernel_id {
   NGM_K_LOSS_REDUCE = 10,
   NGM_K_KNN_ASSIGN = 11, /* evaluation path: exact K nearest fields per point                                       */
   NGM_K_KNN_EVAL = 12,   /* evaluation path: per-field MLP tiles over the (point, neighbour) pairs (dominant there) */
-  NGM_K_COUNT = 13
+  NGM_K_SAMPLER = 13,    /* standalone ray sampler (k_sample_rays / k_sample_rays_elem / k_sample_rays_weighted)            */
+  NGM_K_COUNT = 14
 };
 int ngm_profile_enable(int32_t on);
 int ngm_profile_reset(void);

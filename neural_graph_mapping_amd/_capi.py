@@ -226,7 +226,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
 NO_GRAD_PARAMS = frozenset({"_encoding.random_shift_per_level"})
 
 KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4, points_fwd=5, composite_fwd=6,
-                  composite_bwd=7, hash_grad=8, hash_reduce=9, loss_reduce=10, knn_assign=11, knn_eval=12)
+                  composite_bwd=7, hash_grad=8, hash_reduce=9, loss_reduce=10, knn_assign=11, knn_eval=12, sampler=13)
 
 
 class NgmError(RuntimeError):

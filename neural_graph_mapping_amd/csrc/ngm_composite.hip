@@ -113,6 +113,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_sample_rays(SamplerArgs a, int ra
 static int comp_grid(int64_t N, int S, int* rays_per_wave);
 int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, float* points_cam, float* distances,
                        float* dirs, float* points_world, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_SAMPLER, st);
   SamplerArgs a{*rc, *rays, S, points_cam, distances, dirs, points_world};
   const int64_t N = (int64_t)rays->F * rays->R;
   if (S <= SR_MAXS) {
@@ -132,9 +133,13 @@ int ngm_launch_sampler(const ngm_render_cfg* rc, const ngm_rays* rays, int S, fl
 // (bin = first index whose running sum + 1e-3 reaches the first draw: torch.cumsum, torch.searchsorted(right=False)), then
 // a uniform position inside it (second draw).  The running sum is torch.cumsum's on the CPU: accumulated sequentially in
 // fp64, each prefix rounded to fp32 (ATen's cumsum_cpu_kernel, acc_type<float> = double) -- the reference's CUDA scan sums
-// in fp32 in tree order; the bin of a sample changes only when its draw falls within that rounding of a cumulative weight.  NOT sorted: the reference does not sort this branch's output either.  One lane per sample; the
-// lanes of a wave read the same ray's weights (broadcast loads).  A draw beyond the last cumulative weight (weights that do
-// not sum to 1 - 1e-3 or more: torch.gather is out of range there and raises) takes the last bin.
+// in fp32 in tree order; the bin of a sample changes only when its draw falls within that rounding of a cumulative weight.
+// NOT sorted: the reference does not sort this branch's output either.  A draw beyond the last cumulative weight (weights
+// that do not sum to 1 - 1e-3 or more: torch.gather is out of range there and raises) takes the last bin.
+// A wave per batch of whole rays: lane = ray builds the ray's direction, its cumulative weights (+ 1e-3) and its boundaries
+// in LDS once; lane = sample then draws (in-kernel: ONE Philox block per sample, words 0 and 1), finds its bin by bisection
+// (= searchsorted's lower bound on a non-decreasing sequence) and reads the bin from LDS.  Rays with more bins than the
+// LDS budget holds go through the one-thread-per-sample kernel below (sequential search of the running sum).
 // ------------------------------------------------------------------------------------------------
 struct WeightedSamplerArgs {
   ngm_render_cfg rc;
@@ -143,7 +148,11 @@ struct WeightedSamplerArgs {
   const float* boundaries; const float* weights;
   float* points_cam; float* distances; float* dirs;
 };
-__global__ void k_sample_rays_weighted(WeightedSamplerArgs a) {
+__device__ __forceinline__ void weighted_draws(const ngm_rays& rays, uint64_t poff, int64_t ray, int S, int e, float* u_bin, float* u_off) {
+  if (rays.u_coarse) { *u_bin = rays.u_coarse[ray * S + e]; *u_off = rays.u_guided[ray * S + e]; }
+  else philox_uniform2(rays.philox_seed, poff, (uint64_t)(ray * S + e), 0u, u_bin, u_off);
+}
+__global__ void k_sample_rays_weighted_elem(WeightedSamplerArgs a) {
 #pragma clang fp contract(off)
   const int64_t total = (int64_t)a.rays.F * a.rays.R * a.S;
   const uint64_t poff = philox_launch_offset(a.rays);
@@ -151,7 +160,8 @@ __global__ void k_sample_rays_weighted(WeightedSamplerArgs a) {
     const int64_t ray = g / a.S;
     const int e = (int)(g - ray * a.S);
     const RayGeom rg = ray_geom(a.rc, a.rays, ray, false);
-    const float u_bin = jitter(a.rays, poff, 0, ray, a.S, e), u_off = jitter(a.rays, poff, 1, ray, a.S, e);
+    float u_bin, u_off;
+    weighted_draws(a.rays, poff, ray, a.S, e, &u_bin, &u_off);
     const float* w = a.weights + ray * a.B;
     const float* bd = a.boundaries + ray * (a.B + 1);
     double cum = 0.0;
@@ -167,12 +177,83 @@ __global__ void k_sample_rays_weighted(WeightedSamplerArgs a) {
     if (a.dirs && e == 0) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
   }
 }
+// per wave: [RB][B] cumulative weights + 1e-3, [RB][B + 1] boundaries, [RB][4] directions
+__global__ __launch_bounds__(NGM_BLOCK) void k_sample_rays_weighted(WeightedSamplerArgs a, int rays_per_wave, int RB) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float sw_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, B = a.B;
+  float* const cw = sw_lds + (size_t)wave * RB * (2 * B + 1 + 4);
+  float* const bdl = cw + (size_t)RB * B;
+  float* const dir = bdl + (size_t)RB * (B + 1);
+  const int64_t N = (int64_t)a.rays.F * a.rays.R;
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(N, gw * rays_per_wave), r_end = min(N, r_beg + rays_per_wave);
+  const float inv_s = 1.0f / (float)S;
+  const uint64_t poff = philox_launch_offset(a.rays);
+  for (int64_t rb = r_beg; rb < r_end; rb += RB) {
+    const int nb = (int)min<int64_t>(RB, r_end - rb);
+    if (lane < nb) {
+      const int64_t ray = rb + lane;
+      const RayGeom rg = ray_geom(a.rc, a.rays, ray, false);
+      dir[4 * lane] = rg.dx; dir[4 * lane + 1] = rg.dy; dir[4 * lane + 2] = rg.dz;
+      if (a.dirs) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
+      const float* w = a.weights + ray * B;
+      const float* bd = a.boundaries + ray * (B + 1);
+      double cum = 0.0;
+      for (int b = 0; b < B; ++b) {
+        cum += (double)w[b];
+        cw[lane * B + b] = (float)cum + 1e-3f;
+        bdl[lane * (B + 1) + b] = bd[b];
+      }
+      bdl[lane * (B + 1) + B] = bd[B];
+    }
+    WAVE_SYNC();
+    const int nsamp = nb * S;
+    for (int idx = lane; idx < nsamp; idx += 64) {
+      const int rl = fdiv_idx2(idx, inv_s, S), e = idx - rl * S;
+      const int64_t ray = rb + rl;
+      float u_bin, u_off;
+      weighted_draws(a.rays, poff, ray, S, e, &u_bin, &u_off);
+      const float* c = cw + rl * B;
+      int lo = 0, hi = B;                       // lower bound: first b with c[b] >= u_bin
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] < u_bin) lo = mid + 1; else hi = mid;
+      }
+      const int bin = min(lo, B - 1);
+      const float start = bdl[rl * (B + 1) + bin], size = bdl[rl * (B + 1) + bin + 1] - start;
+      const float t = start + size * u_off;
+      const int64_t g = ray * S + e;
+      if (a.distances) a.distances[g] = t;
+      if (a.points_cam) {
+        const float dx = dir[4 * rl], dy = dir[4 * rl + 1], dz = dir[4 * rl + 2];
+        a.points_cam[3 * g] = dx * t; a.points_cam[3 * g + 1] = dy * t; a.points_cam[3 * g + 2] = dz * t;
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+static int comp_grid(int64_t N, int S, int* rays_per_wave);
 int ngm_launch_sampler_weighted(const ngm_render_cfg* rc, const ngm_rays* rays, int S, int B, const float* boundaries,
                                 const float* weights, float* points_cam, float* distances, float* dirs, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_SAMPLER, st);
   WeightedSamplerArgs a{*rc, *rays, S, B, boundaries, weights, points_cam, distances, dirs};
-  const int64_t total = (int64_t)rays->F * rays->R * S;
+  const int64_t N = (int64_t)rays->F * rays->R;
+  const int64_t per_ray = 2 * (int64_t)B + 1 + 4;                 // floats of LDS per ray
+  const int64_t budget = 4096;                                    // floats per wave (16 KB; 4 waves per block, 2+ blocks per CU)
+  if (per_ray <= budget) {
+    int RB = (int)std::min<int64_t>(64, budget / per_ray);
+    int rpw;
+    const int blocks = comp_grid(N, S, &rpw);
+    if (rpw < RB) RB = std::max(1, rpw);
+    const size_t lds = (size_t)NGM_WAVES_PER_BLOCK * RB * per_ray * sizeof(float);
+    hipLaunchKernelGGL(k_sample_rays_weighted, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw, RB);
+    return 0;
+  }
+  const int64_t total = N * S;
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_sample_rays_weighted, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_sample_rays_weighted_elem, dim3(std::max(blocks, 1)), dim3(256), 0, st, a);
   return 0;
 }
 

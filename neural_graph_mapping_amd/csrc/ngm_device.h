@@ -229,6 +229,22 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
   }
   return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0,1)
 }
+// the first TWO output words of the same block as two uniforms (k_sample_rays_weighted: bin draw, offset draw)
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t stream_id, float* u0, float* u1) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = (uint32_t)offset;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t pr0 = (uint64_t)0xD2511F53u * c0, pr1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(pr0 >> 32), lo0 = (uint32_t)pr0;
+    const uint32_t hi1 = (uint32_t)(pr1 >> 32), lo1 = (uint32_t)pr1;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  *u0 = (float)(c0 >> 8) * (1.0f / 16777216.0f);
+  *u1 = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+}
 
 // ------------------------------------------------------------------------------------------------
 // quaternion / pose helpers (models.py:329-339 with pytorch3d's Hamilton convention, real first)

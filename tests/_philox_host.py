@@ -26,11 +26,13 @@ def philox4x32_10(ctr, key):
     return tuple(int(w[0]) for w in out)
 
 
-def host_philox_uniform(seed, offset, idx, stream):
+def host_philox_uniform(seed, offset, idx, stream, word=0):
+    """`word`: which of the block's four output words (0: every sampler; 1: the offset draw of k_sample_rays_weighted, whose bin
+    draw is word 0 of the same block -- ngm_device.h philox_uniform2)"""
     idx = np.asarray(idx, dtype=np.uint64)
     c0 = philox4x32_10_words(idx & _M, idx >> np.uint64(32), np.full_like(idx, np.uint64(stream)),
                              np.full_like(idx, np.uint64(int(offset) & 0xFFFFFFFF)), int(seed) & 0xFFFFFFFF,
-                             (int(seed) >> 32) & 0xFFFFFFFF)[0]
+                             (int(seed) >> 32) & 0xFFFFFFFF)[word]
     return (c0 >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 

@@ -20,7 +20,7 @@ from neural_graph_mapping_amd import ops  # noqa: E402
 from neural_graph_mapping_amd import renderer as Rr  # noqa: E402
 from oracle import ngm_oracle as O  # noqa: E402
 from gpu_common import (CASES, DEV, NRGBD, NRGBD_KW, away_from_relu_boundaries, close, cu, grad_close,  # noqa: E402
-                        hash_grad_close, kink_free_draws, make_renderer, make_target, ragged_case, synth_target)
+                        hash_grad_close, host_philox_uniform, kink_free_draws, make_renderer, make_target, ragged_case, synth_target)
 
 def test_device_is_gfx950_and_library_loaded():
     n = C.c_int(0)
@@ -72,7 +72,7 @@ def test_weighted_bin_sampler_golden_bit_exact():
         ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"], d["weights"], d["u_bin"], None)
 
 
-@pytest.mark.parametrize("S,B", [(1, 1), (64, 7), (200, 128)])
+@pytest.mark.parametrize("S,B", [(1, 1), (64, 7), (200, 128), (16, 3000)])
 def test_weighted_bin_sampler_vs_oracle_random(S, B):
     """random bins incl. zero-weight ones, weights that stop short of 1 (the draw beyond the last cumulative weight takes the
     last bin -- the reference's gather is out of range there -- so such draws are excluded from the comparison), and the
@@ -103,6 +103,14 @@ def test_weighted_bin_sampler_vs_oracle_random(S, B):
     p3 = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), seed=6)[1]
     assert torch.equal(p1, p2) and (S * B == 1 or not torch.equal(p1, p3))
     assert bool(((p1.cpu() >= edges[..., :1]) & (p1.cpu() <= edges[..., -1:])).all())
+    # ... and pinned: sample e of ray r draws words 0 (bin) and 1 (offset) of Philox4x32-10 block (r S + e, stream 0) -- the host
+    # generator (itself pinned to the Random123 vectors) reproduces the in-kernel draws bit for bit
+    import numpy as np
+    idx = np.arange(F * R * S, dtype=np.uint64)
+    hb = torch.from_numpy(host_philox_uniform(5, 0, idx, 0, word=0)).view(F, R, S)
+    ho = torch.from_numpy(host_philox_uniform(5, 0, idx, 0, word=1)).view(F, R, S)
+    ph = ops.sample_rays_weighted(rc, ijs.to(DEV), edges.to(DEV), w.to(DEV), hb.to(DEV), ho.to(DEV))[1]
+    assert torch.equal(ph, p1)
     if S >= 200:
         bins = (torch.searchsorted(edges[1:].contiguous(), p1.cpu()[1:].contiguous(), right=True) - 1).clamp(0, B - 1)
         hist = torch.zeros(F - 1, R, B).scatter_add_(-1, bins, torch.ones_like(p1.cpu()[1:])) / S

@@ -36,6 +36,25 @@ def timeit(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3      # seconds
 
 
+def kernel_us(fn, kid, iters=10):
+    """average duration of the library's launches of kernel class `kid` inside fn(): HIP events around every launch on the
+    launch stream (the library's own profile scopes, as bench.py's kernels_us) -- the op-level time next to it also holds
+    torch's allocator, the dispatcher and, for backward stages, autograd's bookkeeping"""
+    import ctypes as C
+    L = K.lib()
+    fn()
+    torch.cuda.synchronize()
+    L.ngm_profile_reset()
+    L.ngm_profile_enable(1)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    L.ngm_profile_enable(0)
+    ms, n = C.c_double(0), C.c_int64(0)
+    L.ngm_profile_read(K.KERNEL_IDS[kid], C.byref(ms), C.byref(n))
+    return (ms.value / max(n.value, 1)) * 1e3, int(n.value) // iters
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=262144)
@@ -48,8 +67,14 @@ def main():
     F, R = 64, N // 64
     res = dict(device=torch.cuda.get_device_name(0), rays=N, samples_per_ray=S, stages={})
 
-    def add(name, secs, bytes_=None, flops=None, note=""):
+    def add(name, secs, bytes_=None, flops=None, note="", kern=None):
         d = dict(us=round(secs * 1e6, 1), note=note)
+        if kern is not None:          # (us per launch, launches per call): the kernel alone
+            kus, per_call = kern
+            d.update(kernel_us=round(kus * per_call, 1), launches_per_call=per_call)
+            if bytes_ is not None:
+                d.update(kernel_GBps=round(bytes_ / (kus * per_call * 1e-6) / 1e9, 1),
+                         kernel_frac_of_hbm_peak=round(bytes_ / (kus * per_call * 1e-6) / 1e9 / HBM_PEAK_GBS, 3))
         if bytes_ is not None:
             d.update(algorithmic_MB=round(bytes_ / 1e6, 1), GBps=round(bytes_ / secs / 1e9, 1),
                      frac_of_hbm_peak=round(bytes_ / secs / 1e9 / HBM_PEAK_GBS, 3))
@@ -65,14 +90,15 @@ def main():
     dists = torch.sort(torch.rand(N, S, device=dev) * 3 + 0.5, -1)[0]
     depths = dists * 0.9
     add("composite_fwd", timeit(lambda: ops.quadrature(rc, colors, geoms, dists, depths)), bytes_=N * S * 24 + N * (36 + 4 * S),
-        note="k_composite_fwd incl. the (N,S) weights output")
+        note="k_composite_fwd incl. the (N,S) weights output", kern=kernel_us(lambda: ops.quadrature(rc, colors, geoms, dists, depths), "composite_fwd"))
     cg, gg = colors.clone().requires_grad_(), geoms.clone().requires_grad_()
     Cc, D, _, _, T, _ = ops.quadrature(rc, cg, gg, dists, depths)
     seeds = (torch.randn_like(Cc), torch.randn_like(D), torch.randn_like(T))
 
     def comp_bwd():
         torch.autograd.grad((Cc, D, T), (cg, gg), seeds, retain_graph=True)
-    add("composite_bwd", timeit(comp_bwd), bytes_=N * S * 40 + N * 36, note="k_composite_bwd via autograd (includes torch's grad bookkeeping)")
+    add("composite_bwd", timeit(comp_bwd), bytes_=N * S * 40 + N * 36, note="k_composite_bwd via autograd (includes torch's grad bookkeeping)",
+        kern=kernel_us(comp_bwd, "composite_bwd"))
     del colors, geoms, depths, cg, gg, Cc, D, T
 
     # ---- sampler (k_sample_rays): ~(104 + 4S)/S B read + 16 B written per sample
@@ -82,7 +108,16 @@ def main():
     far = near + 2.0
     gt = near + 2.0 * torch.rand(F, R, device=dev)
     add("sample_rays", timeit(lambda: ops.sample_rays(rcs, ijs, near, far, gt, seed=1)), bytes_=N * S * 16 + N * 44,
-        note="k_sample_rays, in-kernel Philox jitter, rank merge of the two strata; includes the output allocation")
+        note="k_sample_rays, in-kernel Philox jitter, rank merge of the two strata; includes the output allocation",
+        kern=kernel_us(lambda: ops.sample_rays(rcs, ijs, near, far, gt, seed=1), "sampler"))
+    B = 32
+    edges = torch.sort(torch.rand(F, R, B + 1, device=dev) * 4 + 0.2, -1)[0]
+    wts = torch.softmax(4 * torch.randn(F, R, B, device=dev), -1)
+    rcw = K.render_cfg(num_samples_coarse=S, num_samples_guided=0)
+    add("sample_rays_weighted", timeit(lambda: ops.sample_rays_weighted(rcw, ijs, edges, wts, seed=1)),
+        bytes_=N * S * 16 + N * (12 + 8 * B + 4),
+        note="k_sample_rays_weighted (camera.py:277-289): 32 bins per ray, two Philox draws per sample, sequential search of the fp64 running sum",
+        kern=kernel_us(lambda: ops.sample_rays_weighted(rcw, ijs, edges, wts, seed=1), "sampler"))
 
     # ---- field evaluation (encode + MLP), forward and backward on flat points
     fc = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2)

@@ -595,7 +595,9 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
   const float gm_ref = a.outside_value;
   const float occ_ref = occ_pointwise_fwd(mode, a.rc.geometry_factor, gm_ref);
   for (int64_t ray = r_beg; ray < r_end; ++ray) {
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;       // running sums (wave-uniform)
+    // per-LANE partial sums over the ray's steps, ONE cross-lane reduction per ray and sum (a DPP scan per step and sum was a
+    // third of this kernel's vector instructions: it is VALU-bound, profiles/r05_pmc_stages_sq.json)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     float carry = 1.0f;
     for (int base0 = 0; base0 < S; base0 += 64 * CH) {
       StepIn in[CH];
@@ -614,23 +616,25 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
           const float w = occ * T_excl;
           pw[k] = w; p0[k] = in[c].c0; p1[k] = in[c].c1; p2[k] = in[c].c2; p3[k] = in[c].dp;
           if (a.weights) a.weights[ray * S + k] = w;
-          float sv[5] = {w * in[c].c0, w * in[c].c1, w * in[c].c2, w * in[c].dp, w};
-          wave_scan_add_n<5>(sv);
-          m0 += lane_value(sv[0], 63); m1 += lane_value(sv[1], 63); m2 += lane_value(sv[2], 63); m3 += lane_value(sv[3], 63);
-          m4 += lane_value(sv[4], 63);
+          s0 = fmaf(w, in[c].c0, s0); s1 = fmaf(w, in[c].c1, s1); s2 = fmaf(w, in[c].c2, s2); s3 = fmaf(w, in[c].dp, s3);
+          s4 += w;
         }
       }
     }
+    float mv[5] = {s0, s1, s2, s3, s4};
+    wave_scan_add_n<5>(mv);
+    const float m0 = lane_value(mv[0], 63), m1 = lane_value(mv[1], 63), m2 = lane_value(mv[2], 63), m3 = lane_value(mv[3], 63),
+                m4 = lane_value(mv[4], 63);
     WAVE_SYNC();
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                  // variances around the finished means (rm.py:781-790)
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};                            // variances around the finished means (rm.py:781-790)
     for (int base = 0; base < S; base += 64) {
       const int k = base + lane;
       const float w = pw[k];
       const float e0 = m0 - p0[k], e1 = m1 - p1[k], e2 = m2 - p2[k], e3 = m3 - p3[k];
-      float sv[4] = {w * (e0 * e0), w * (e1 * e1), w * (e2 * e2), w * (e3 * e3)};
-      wave_scan_add_n<4>(sv);
-      v0 += lane_value(sv[0], 63); v1 += lane_value(sv[1], 63); v2 += lane_value(sv[2], 63); v3 += lane_value(sv[3], 63);
+      sv[0] = fmaf(w * e0, e0, sv[0]); sv[1] = fmaf(w * e1, e1, sv[1]); sv[2] = fmaf(w * e2, e2, sv[2]); sv[3] = fmaf(w * e3, e3, sv[3]);
     }
+    wave_scan_add_n<4>(sv);
+    const float v0 = lane_value(sv[0], 63), v1 = lane_value(sv[1], 63), v2 = lane_value(sv[2], 63), v3 = lane_value(sv[3], 63);
     if (lane == 0) {
       if (a.rgbd) reinterpret_cast<float4*>(a.rgbd)[ray] = make_float4(m0, m1, m2, m3);
       if (a.C) { a.C[3 * ray] = m0; a.C[3 * ray + 1] = m1; a.C[3 * ray + 2] = m2; }

@@ -281,6 +281,7 @@ __device__ __forceinline__ Rgb3 load_rgb(const float* colors, int64_t g) { retur
 // packed sources (eval path = _render_ijs(use_vmap=False)): the (N,S,4) field outputs, or -- fused with the kNN blend
 // (k_knn_blend, models.py:384-401) -- the (point, neighbour) pair records it would have been formed from
 __device__ __forceinline__ bool comp_packed(const CompositeArgs& a) { return a.out4 || a.pair_field; }
+static inline bool comp_packed_host(const CompositeArgs& a) { return a.out4 || a.pair_field; }
 __device__ __forceinline__ float4 packed_out4(const CompositeArgs& a, int64_t g) {
   if (!a.pair_field) return a.out4[g];
   const int K = a.pair_K;
@@ -810,11 +811,91 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd(CompositeArgs a, in
   }
 }
 
+
+// Whole-ray steps (S = 64 NST, pointwise geometry modes, separate tensors): no segment bookkeeping, the ray's transmittances /
+// occupancies / derivatives stay in registers between the two sweeps, every load of a ray is issued before its first use,
+// one exp + one rcp per occupancy (occ_pointwise_fast, as the backward fused into the MLP backward).  The generic kernel above
+// spends 288 vector instructions per 64 samples on a stream that is VALU-bound (profiles/r05_pmc_stages_sq.json).
+__device__ __forceinline__ void wave_rscan_affine64(float& A, float& B) {
+  // unsegmented reverse scan of affine maps x -> A + B x over the 64 lanes (lanes beyond a row's end read the identity)
+#define NGM_WRS_STEP(d)                                                                  \
+  {                                                                                       \
+    const float oA = dpp_take<NGM_DPP_ROW_SHL(d), 0xf>(0.f, A), oB = dpp_take<NGM_DPP_ROW_SHL(d), 0xf>(1.f, B); \
+    A = fmaf(B, oA, A); B = B * oB;                                                       \
+  }
+  NGM_WRS_STEP(1) NGM_WRS_STEP(2) NGM_WRS_STEP(4) NGM_WRS_STEP(8)
+#undef NGM_WRS_STEP
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int row = 2; row >= 0; --row) {
+    const int head = 16 * (row + 1);
+    const float An = lane_value(A, head), Bn = lane_value(B, head);
+    if ((lane >> 4) == row) { A = fmaf(B, An, A); B = B * Bn; }
+  }
+}
+template <int NST>
+__global__ __launch_bounds__(NGM_BLOCK) void k_composite_bwd_whole(CompositeArgs a, int rays_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
+  const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
+  constexpr int S = 64 * NST;
+  const int mode = a.rc.geometry_mode;
+  const float gamma = a.rc.geometry_factor;
+  for (int64_t ray = r_beg; ray < r_end; ++ray) {
+    const int64_t g0 = ray * S + lane;
+    float T[NST], oc[NST], dg[NST], dp[NST];
+    Rgb3 col[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) dg[st] = a.geoms[g0 + 64 * st];          // (geometry values, replaced by the derivatives below)
+#pragma unroll
+    for (int st = 0; st < NST; ++st) { col[st] = load_rgb(a.colors, g0 + 64 * st); dp[st] = a.depths[g0 + 64 * st]; }
+    const float dC0 = a.dC ? a.dC[3 * ray] : 0.f, dC1 = a.dC ? a.dC[3 * ray + 1] : 0.f, dC2 = a.dC ? a.dC[3 * ray + 2] : 0.f;
+    const float dD = a.dD ? a.dD[ray] : 0.f, dT = a.dterm ? a.dterm[ray] : 0.f;
+    float carry = 1.0f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float d_;
+      const float occ = occ_pointwise_fast(mode, gamma, dg[st], &d_);
+      float q = wave_scan_mul(1.0f - occ);
+      q *= carry;
+      const float up = lane_prev(q, carry);
+      T[st] = (st == 0 && lane == 0) ? 1.0f : (lane == 0 ? carry : up);
+      carry = lane_value(q, 63);
+      oc[st] = occ; dg[st] = d_;
+    }
+    float carryQ = 0.f;
+#pragma unroll
+    for (int st = NST - 1; st >= 0; --st) {
+      const float ak = dC0 * col[st].x + dC1 * col[st].y + dC2 * col[st].z + dD * dp[st] + dT;
+      float A = ak * oc[st], B = 1.0f - oc[st];
+      wave_rscan_affine64(A, B);
+      const float Qend = (st == NST - 1) ? 0.f : carryQ;
+      const float nA = lane_next(A, 0.f), nB = lane_next(B, 1.0f);
+      const float Qk = (lane < 63) ? fmaf(nB, Qend, nA) : Qend;
+      carryQ = lane_value(fmaf(B, Qend, A), 0);
+      const float w = oc[st] * T[st];
+      const int64_t g = g0 + 64 * st;
+      if (a.d_colors) *reinterpret_cast<Rgb3*>(a.d_colors + 3 * g) = Rgb3{w * dC0, w * dC1, w * dC2};
+      if (a.d_geoms) a.d_geoms[g] = T[st] * (ak - Qk) * dg[st];
+    }
+  }
+}
+
 int ngm_launch_composite_bwd(const CompositeArgs& a, hipStream_t st) {
   NgmProfScope prof_(NGM_K_COMPOSITE_BWD, st);
   if (a.S > CQ_MAXS || a.S < 1) return NGM_E_UNSUPPORTED;
   int rpw;
   const int blocks = comp_grid(a.N, a.S, &rpw);
+  const int gm = a.rc.geometry_mode;
+  static const bool no_whole = getenv("NGM_NO_WHOLE_COMP_BWD") != nullptr;       // A/B and test knob: the generic kernel
+  if (!no_whole && a.S % 64 == 0 && a.S <= 512 && (gm == NGM_GEO_NRGBD || gm == NGM_GEO_OCCUPANCY) && !comp_packed_host(a) &&
+      a.colors && a.geoms && a.depths) {
+#define NGM_CBW(N_) hipLaunchKernelGGL((k_composite_bwd_whole<N_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw)
+    switch (a.S / 64) { case 1: NGM_CBW(1); break; case 2: NGM_CBW(2); break; case 3: NGM_CBW(3); break; case 4: NGM_CBW(4); break;
+                        case 5: NGM_CBW(5); break; case 6: NGM_CBW(6); break; case 7: NGM_CBW(7); break; default: NGM_CBW(8); break; }
+#undef NGM_CBW
+    return 0;
+  }
   const size_t lds = sizeof(float) * CompBwdLds::floats(a.rc.geometry_mode == NGM_GEO_NEUS) * NGM_WAVES_PER_BLOCK;
   (void)hipFuncSetAttribute((const void*)k_composite_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_composite_bwd, dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw);

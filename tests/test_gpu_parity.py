@@ -503,7 +503,8 @@ def test_quadrature_golden(mode, S):
 
 
 @pytest.mark.parametrize("mode", ["nrgbd", "occupancy"])
-@pytest.mark.parametrize("lead,S", [((3, 5), 24), ((7,), 128), ((2, 3), 1), ((1,), 200), ((40,), 7)])
+@pytest.mark.parametrize("lead,S", [((3, 5), 24), ((7,), 128), ((2, 3), 1), ((1,), 200), ((40,), 7),
+                                    ((5,), 64), ((300,), 192), ((3,), 512), ((2,), 576)])      # 64 | S <= 512: the whole-ray kernels
 def test_quadrature_backward_vs_oracle(mode, lead, S):
     torch.manual_seed(S)
     colors = torch.rand(*lead, S, 3)

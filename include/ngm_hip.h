@@ -413,8 +413,7 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
  * the samples are drawn inside the neighbour assignment, the blend happens inside the quadrature, the grid over the field
  * centres is built once per call.  rays: rays->F * rays->R rays in all (field_pos / field_quat / pose_index unused); block b
  * draws its jitter from u_coarse, or from the Philox stream (philox_seed + b * ray_block, ray index within the block).
- * pred: (F*R, .) outputs, any may be NULL.  mask_radius as in ngm_field_eval_knn; K <= 4 here (5..8: the three staged entry
- * points per block -- NGM_E_UNSUPPORTED says so); S <= 1024. */
+ * pred: (F*R, .) outputs, any may be NULL.  mask_radius as in ngm_field_eval_knn; K <= 8; S <= 1024. */
 int64_t ngm_render_eval_knn_workspace(const ngm_render_cfg* rcfg, int32_t num_fields, int32_t ray_block, int32_t num_knn);
 int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, const ngm_params* params,
                         int32_t num_fields, const float* field_pos, const float* field_quat, const ngm_rays* rays,

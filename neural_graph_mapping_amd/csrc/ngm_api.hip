@@ -1109,8 +1109,7 @@ int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, c
     return fail(NGM_E_INVALID, "ngm_render_eval_knn: bad argument");
   if ((int64_t)rays->F * rays->R == 0) return NGM_OK;
   const int K = num_knn < num_fields ? num_knn : num_fields;
-  if (K < 1 || K > 4) return fail(NGM_E_UNSUPPORTED, "ngm_render_eval_knn: K must be in [1,4] (the blend inside the quadrature is compiled for up to 4 neighbours; "
-                                  "K = 5..8: ngm_sample_rays_world -> ngm_field_eval_knn -> ngm_composite_fwd_packed per block, which is what NeuralGraphRenderer falls back to)");
+  if (K < 1 || K > 8) return fail(NGM_E_UNSUPPORTED, "ngm_render_eval_knn: K must be in [1,8] (the neighbour assignment and the blend inside the quadrature are compiled for up to 8 neighbours)");
   e = ngm_launch_render_eval_knn(fcfg, rcfg, params, num_fields, field_pos, field_quat, rays, K, distance_factor, outside_value,
                                  mask_radius > 0.f ? mask_radius : fcfg->field_radius, ray_block, pred, workspace,
                                  workspace_bytes, (hipStream_t)stream);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd(CompositeArgs a, in
   const int S_eff = (mode == NGM_GEO_DENSITY || mode == NGM_GEO_NEUS) ? S - 1 : S;
   const float inv_s = 1.0f / (float)S;
   const bool packed = comp_packed(a);
-  constexpr int CH = PK > 0 ? 4 : 1;                 // wave steps gathered together (pair-record source)
+  constexpr int CH = PK > 4 ? 2 : PK > 0 ? 4 : 1;    // wave steps gathered together (pair-record source; 5..8 neighbours: registers)
   const int BR = max(1, min(CQ_BR, CompWaveLds<KEEP>::MAXS / S));
   for (int64_t rb = r_beg; rb < r_end; rb += BR) {
     const int nb = (int)min<int64_t>(BR, r_end - rb);
@@ -552,10 +552,10 @@ __device__ __forceinline__ void wave_scan_add_n(float (&v)[N]) {
 }
 
 struct StepIn { float c0, c1, c2, dp, gm; };
-// SRC 0: separate tensors; 1..4: pair records with SRC neighbours per point; 5: packed (N,S,4) outputs + camera-frame points
+// SRC 0: separate tensors; 1..8: pair records with SRC neighbours per point; 9: packed (N,S,4) outputs + camera-frame points
 template <int SRC, int CH>
 __device__ __forceinline__ void whole_gather(const CompositeArgs& a, int64_t ray, int S, int base0, int lane, StepIn (&in)[CH]) {
-  if constexpr (SRC >= 1 && SRC <= 4) {
+  if constexpr (SRC >= 1 && SRC <= 8) {
     float4 o4[CH];
     float pz[CH];
     pairs_gather<SRC, CH>(a, ray, S, 1.0f / (float)S, S, base0, lane, o4, pz);
@@ -568,7 +568,7 @@ __device__ __forceinline__ void whole_gather(const CompositeArgs& a, int64_t ray
     for (int c = 0; c < CH; ++c) {
       const int k = min(base0 + 64 * c + lane, S - 1);        // steps past the ray's end re-read its last sample (unused)
       const int64_t g = ray * S + k;
-      if constexpr (SRC == 5) {
+      if constexpr (SRC == 9) {
         const float4 o = a.out4[g];
         const float pz = a.pcam[3 * g + 2];
         in[c] = StepIn{a.rc.color_factor * o.x, a.rc.color_factor * o.y, a.rc.color_factor * o.z, -pz, packed_geom(a, o, pz)};
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_composite_fwd_whole(CompositeArgs
   const int64_t gw = (int64_t)blockIdx.x * NGM_WAVES_PER_BLOCK + wave;
   const int64_t r_beg = min(a.N, gw * rays_per_wave), r_end = min(a.N, r_beg + rays_per_wave);
   const int mode = a.rc.geometry_mode;
-  constexpr int CH = (SRC >= 1 && SRC <= 4) ? 5 : 4;
+  constexpr int CH = (SRC >= 1 && SRC <= 4) ? 5 : (SRC >= 5 && SRC <= 8) ? 2 : 4;
   // most wave steps of an image lie outside every field: all 64 geometry values are the constant outside value, and so is
   // their occupancy -- computed once here (two expf, two IEEE divisions otherwise, per sample)
   const float gm_ref = a.outside_value;
@@ -666,23 +666,24 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
   const int blocks = comp_grid(a.N, a.S, &rpw);
   const bool keep = a.S <= CompWaveLds<true>::MAXS;
   const int pk = a.pair_field ? a.pair_K : 0;
-  if (pk && (pk > 4 || !a.pair_w || !a.pair_out || !a.ray_dir || !a.dists || a.pcam || a.out4)) return NGM_E_INVALID;
+  if (pk && (pk > 8 || !a.pair_w || !a.pair_out || !a.ray_dir || !a.dists || a.pcam || a.out4)) return NGM_E_INVALID;
   const int gm = a.rc.geometry_mode;
   if (a.S % 64 == 0 && (gm == NGM_GEO_NRGBD || gm == NGM_GEO_OCCUPANCY)) {
     // whole-ray steps: the specialised kernel (same sums, a fifth of the instructions)
     const size_t lds = (size_t)NGM_WAVES_PER_BLOCK * 5 * a.S * sizeof(float);
-    const int src = pk ? pk : (a.out4 ? 5 : 0);
+    const int src = pk ? pk : (a.out4 ? 9 : 0);
     static const hipError_t attr = [] {
       hipError_t e = hipSuccess;
 #define NGM_CWA(SRC_) do { const hipError_t x = hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_fwd_whole<SRC_>), hipFuncAttributeMaxDynamicSharedMemorySize, NGM_WAVES_PER_BLOCK * 5 * CQ_MAXS * 4); if (x != hipSuccess) e = x; } while (0)
-      NGM_CWA(0); NGM_CWA(1); NGM_CWA(2); NGM_CWA(3); NGM_CWA(4); NGM_CWA(5);
+      NGM_CWA(0); NGM_CWA(1); NGM_CWA(2); NGM_CWA(3); NGM_CWA(4); NGM_CWA(5); NGM_CWA(6); NGM_CWA(7); NGM_CWA(8); NGM_CWA(9);
 #undef NGM_CWA
       return e;
     }();
     if (attr != hipSuccess) return NGM_E_HIP;
 #define NGM_CW(SRC_) hipLaunchKernelGGL((k_composite_fwd_whole<SRC_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), lds, st, a, rpw)
     switch (src) { case 0: NGM_CW(0); break; case 1: NGM_CW(1); break; case 2: NGM_CW(2); break; case 3: NGM_CW(3); break;
-                   case 4: NGM_CW(4); break; default: NGM_CW(5); break; }
+                   case 4: NGM_CW(4); break; case 5: NGM_CW(5); break; case 6: NGM_CW(6); break; case 7: NGM_CW(7); break;
+                   case 8: NGM_CW(8); break; default: NGM_CW(9); break; }
 #undef NGM_CW
     return 0;
   }
@@ -691,7 +692,8 @@ int ngm_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
     if (keep) hipLaunchKernelGGL((k_composite_fwd<true, PK_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);  \
     else hipLaunchKernelGGL((k_composite_fwd<false, PK_>), dim3(std::max(blocks, 1)), dim3(NGM_BLOCK), 0, st, a, rpw);      \
   } while (0)
-  if (pk == 0) NGM_CF(0); else if (pk == 1) NGM_CF(1); else if (pk == 2) NGM_CF(2); else if (pk == 3) NGM_CF(3); else NGM_CF(4);
+  if (pk == 0) NGM_CF(0); else if (pk == 1) NGM_CF(1); else if (pk == 2) NGM_CF(2); else if (pk == 3) NGM_CF(3); else if (pk == 4) NGM_CF(4);
+  else if (pk == 5) NGM_CF(5); else if (pk == 6) NGM_CF(6); else if (pk == 7) NGM_CF(7); else NGM_CF(8);
 #undef NGM_CF
   return 0;
 }

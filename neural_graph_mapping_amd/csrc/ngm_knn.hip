@@ -723,6 +723,8 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
 #define NGM_KA(G, KK_, B) do { const hipError_t x = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_assign<G, KK_>), hipFuncAttributeMaxDynamicSharedMemorySize, B); if (x != hipSuccess) e = x; } while (0)
     NGM_KA(false, 1, 150 * 1024); NGM_KA(false, 2, 150 * 1024); NGM_KA(false, 3, 150 * 1024); NGM_KA(false, 4, 150 * 1024);
     NGM_KA(true, 1, 64 * 1024); NGM_KA(true, 2, 64 * 1024); NGM_KA(true, 3, 64 * 1024); NGM_KA(true, 4, 64 * 1024);
+    NGM_KA(false, 5, 150 * 1024); NGM_KA(false, 6, 150 * 1024); NGM_KA(false, 7, 150 * 1024); NGM_KA(false, 8, 150 * 1024);
+    NGM_KA(true, 5, 64 * 1024); NGM_KA(true, 6, 64 * 1024); NGM_KA(true, 7, 64 * 1024); NGM_KA(true, 8, 64 * 1024);
 #undef NGM_KA
     return e;
   }();

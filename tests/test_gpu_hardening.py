@@ -433,10 +433,11 @@ def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
         grad_close(first[k], full[k], 2e-5, "vs full stash " + k)
 
 
-def test_image_path_with_more_than_four_neighbours_runs_the_staged_entry_points():
-    """K = 5..8 (round 5): the assignment / evaluation kernels take up to 8 neighbours; the ONE-call image path blends up to 4
-    inside its quadrature and says NGM_E_UNSUPPORTED beyond -- render_pixels then runs the three staged entry points per block
-    (the same image as eval_fused = False, bit for bit) and says which path ran."""
+@pytest.mark.parametrize("num_knn,S", [(6, 64), (8, 640), (5, 40)])
+def test_image_path_with_more_than_four_neighbours(num_knn, S):
+    """K = 5..8: assignment, evaluation and -- since the end of round 5 -- the blend inside the one-call image path's quadrature
+    take up to 8 neighbours (whole-ray and generic quadrature kernels, two wave steps gathered at a time instead of five):
+    the fused call runs and equals the three staged entry points per block bit for bit."""
     from neural_graph_mapping_amd import models as M
     from neural_graph_mapping_amd import renderer as Rr
     torch.manual_seed(3)
@@ -447,16 +448,16 @@ def test_image_path_with_more_than_four_neighbours_runs_the_staged_entry_points(
     model = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(
         encoding_type="neural_graph_mapping.positional_encodings.PositionalEncodingFourier",
         encoding_kwargs=dict(dim_in=3, dim_out=32, mu=0.0, sigma=3.0, raw_coords=True), num_layers=1, dim_out=4),
-        num_knn=6, distance_factor=10.0, outside_value=1.0, field_radius=0.6, scale_mode="unit_cube").to(DEV)
+        num_knn=num_knn, distance_factor=10.0, outside_value=1.0, field_radius=0.6, scale_mode="unit_cube").to(DEV)
     cam = Rr.Camera(64, 48, 55.0, 55.0, 31.5, 23.5, pixel_center=0.0)
-    r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(field_radius=0.6, eval_num_samples=64, eval_far_distance=4.0,
-                                                           pixel_block_size=1000), device=DEV)
+    r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(field_radius=0.6, eval_num_samples=S, eval_far_distance=4.0,
+                                                           pixel_block_size=1000, eval_ray_block=1000), device=DEV)
     r.add_fields(NF)
     _perturb(r)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     c2w = torch.eye(4, device=DEV)
     img, dv = r.render_image(c2w, seed=5)
-    assert r.last_eval_path.startswith("staged") and any("K must be in [1,4]" in m for m in r.eval_fallbacks)
+    assert r.last_eval_path.startswith("fused") and not r.eval_fallbacks
     r.eval_fused = False
     img2, dv2 = r.render_image(c2w, seed=5)
     assert torch.equal(img, img2) and torch.equal(dv, dv2)

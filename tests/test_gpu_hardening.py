@@ -130,7 +130,7 @@ def test_in_kernel_philox_equals_host_philox(n_c, n_g):
 
 # ------------------------------------------------------------------------------------------------ kNN evaluation, large maps
 @pytest.mark.parametrize("NF,K_,P,layout", [(10000, 2, 6000, "cover_grid"), (10000, 4, 4000, "random"), (5000, 2, 6000, "two_rooms"),
-                                            (40000, 2, 3000, "cover_grid")])
+                                            (40000, 2, 3000, "cover_grid"), (20000, 6, 3000, "cover_grid")])      # K > 4 with a histogram of more than 64 KB of LDS
 def test_knn_assignment_large_maps_vs_oracle(NF, K_, P, layout):
     """The nearest-field assignment bins the centres into a uniform grid on the device and grows the block of cells around a
     point until the K-th neighbour is provably exact -- no limit on the number of fields (round 3: 4096).  10 000 fields on

@@ -691,6 +691,52 @@ def test_neus_fused_train_step_vs_oracle(F, R, n_c, n_g, layers):
     assert bool((after[:F] != before[:F]).all()) and bool(after[F] == before[F]) and r._step == 3
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("NGM_FUZZ_SEEDS_NEUS", "5")))))      # NGM_FUZZ_SEEDS_NEUS=200: a longer sweep
+def test_neus_fused_train_random_shapes_vs_oracle(seed):
+    """geometry_mode = neus on random batch shapes, sample counts (incl. S = 2), layer counts, per-field standard deviations of
+    either sign: prediction, loss and every gradient incl. `_neus_sd` against the oracle; the clamp's kinks are kept out of the
+    comparison by kink_free_draws."""
+    g = torch.Generator().manual_seed(9000 + seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    F, R, n_c, n_g, layers = ri(1, 5), ri(1, 80), ri(1, 20), ri(1, 20), ri(1, 2)
+    torch.manual_seed(seed)
+    fkw = dict(encoding="fourier", dim_enc=64, num_layers=layers)
+    ckw = dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode="neus", geometry_factor=5.0)
+    pos, quat, t = synth_target(F, R, seed=seed)
+    fs = O.FieldSpec(**fkw)
+    rs = O.RenderSpec(num_samples_coarse=n_c, num_samples_depth_guided=n_g, termination_weight=0.3, geometry_mode="neus",
+                      geometry_factor=5.0)
+    params = O.init_params(fs, F, seed=seed, sigma=3.0)
+    params[f"_linears.{layers}.weight"] *= 3.0
+    sd = (0.3 + 1.5 * torch.rand(F, generator=g)) * torch.where(torch.rand(F, generator=g) < 0.3, -1.0, 1.0)
+    u_c, u_g = torch.rand(F, R, n_c), torch.rand(F, R, n_g)
+    u_c, u_g, t = kink_free_draws(t, pos, quat, params, fs, rs, u_c, u_g, neus_isds=1.0 / sd.abs(), max_neutralised=0.5)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    sdo = sd.clone().requires_grad_()
+    pred = O.render_ijs(t["ijs"], t["c2ws"], NRGBD, pos, quat, po, fs, rs, t["near"], t["far"], t["gt"], u_c, u_g,
+                        neus_isds=1.0 / sdo.abs().view(-1, 1, 1))
+    r = make_renderer(fkw, ckw, F, None)
+    with torch.no_grad():
+        for k, v in params.items():
+            r._model.all_fields_params[k].copy_(v.to(DEV))
+        r._model.all_fields_params["_neus_sd"].copy_(sd.to(DEV))
+    r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    res = r.optimization_iteration(make_target(t, torch.arange(F)), u_c.to(DEV), u_g.to(DEV), update=False)
+    close(res["prediction"].rgbds, pred["rgbds"].detach())
+    close(res["prediction"].term_probs, pred["term_probs"].detach())
+    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
+    if min(n_m, pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())) == 0:
+        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    loss["combined"].backward()
+    close(res["combined"], loss["combined"].detach(), rtol=3e-4, atol=1e-6)
+    for k in po:
+        grad_close(res["grads"][k], po[k].grad, 2e-3, k)
+    grad_close(res["grads"]["_neus_sd"].view(-1), sdo.grad, 2e-3, "_neus_sd")
+
+
 # ------------------------------------------------------------------------- triplane encoding (G15)
 @pytest.mark.parametrize("name", ["g15_triplane_sum_C32", "g15_triplane_product_C32", "g15_triplane_concat_C20",
                                   "g15_triplane_sum_C64"])

@@ -75,6 +75,9 @@ def main():
             if bytes_ is not None:
                 d.update(kernel_GBps=round(bytes_ / (kus * per_call * 1e-6) / 1e9, 1),
                          kernel_frac_of_hbm_peak=round(bytes_ / (kus * per_call * 1e-6) / 1e9 / HBM_PEAK_GBS, 3))
+            if flops is not None:
+                d.update(kernel_TFLOPs=round(flops / (kus * per_call * 1e-6) / 1e12, 1),
+                         kernel_frac_of_f32_mfma_peak=round(flops / (kus * per_call * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 3))
         if bytes_ is not None:
             d.update(algorithmic_MB=round(bytes_ / 1e6, 1), GBps=round(bytes_ / secs / 1e9, 1),
                      frac_of_hbm_peak=round(bytes_ / secs / 1e9 / HBM_PEAK_GBS, 3))
@@ -132,7 +135,13 @@ def main():
     nsamp = F * P
     with torch.no_grad():
         add("field_eval_fwd", timeit(lambda: ops.field_eval(fc, params, pts, pos, quat)), flops=nsamp * 16896,
-            bytes_=nsamp * 28, note="k_field_points_fwd: Fourier(64) + 2x64 MLP, 16 896 flop/sample")
+            bytes_=nsamp * 28, note="k_field_points_fwd: Fourier(64) + 2x64 MLP, 16 896 flop/sample, mlp_matmul f32 (exact-fp32 MFMA)",
+            kern=kernel_us(lambda: ops.field_eval(fc, params, pts, pos, quat), "points_fwd"))
+        fca = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, matmul_mode="auto")
+        add("field_eval_fwd_auto", timeit(lambda: ops.field_eval(fca, params, pts, pos, quat)), flops=nsamp * 16896,
+            bytes_=nsamp * 28, note="the same with mlp_matmul auto (what the renderer uses): exact three-way bf16 split on the bf16 matrix pipe; "
+            "algorithmic fp32 flops against the fp32 MFMA peak",
+            kern=kernel_us(lambda: ops.field_eval(fca, params, pts, pos, quat), "points_fwd"))
     out = ops.field_eval(fc, params, pts, pos, quat)
     go = torch.randn_like(out)
 

@@ -8,6 +8,8 @@
     in-kernel draws bit for bit (sample distances and predictions) for three offsets;
   * which arithmetic the hash network's forward and backward resolved to."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -245,10 +247,20 @@ def test_nll_loss_modes_ragged_vs_oracle(F, R, n_c, n_g, photo, depth, geom):
 
 
 # ------------------------------------------------------------------------------------------------ fused image path
-@pytest.mark.parametrize("geo,S,K_,block,explicit_u,net", [("nrgbd", 24, 2, 1000, True, "fourier"), ("nrgbd", 640, 2, 700, False, "fourier"),
-                                                           ("density", 96, 3, 4096, False, "fourier"), ("occupancy", 64, 1, 333, True, "fourier"),
-                                                           ("neus", 40, 2, 512, False, "fourier"), ("nrgbd", 128, 4, 600, False, "hash"),
-                                                           ("nrgbd", 64, 2, 2048, True, "fourier_f32")])
+def _image_cases():
+    cases = [("nrgbd", 24, 2, 1000, True, "fourier"), ("nrgbd", 640, 2, 700, False, "fourier"),
+             ("density", 96, 3, 4096, False, "fourier"), ("occupancy", 64, 1, 333, True, "fourier"),
+             ("neus", 40, 2, 512, False, "fourier"), ("nrgbd", 128, 4, 600, False, "hash"),
+             ("nrgbd", 64, 2, 2048, True, "fourier_f32"), ("occupancy", 192, 7, 900, False, "fourier"), ("nrgbd", 50, 5, 640, True, "fourier")]
+    import random
+    rnd = random.Random(77)                       # NGM_FUZZ_IMAGE=40: that many random combinations on top
+    for _ in range(int(os.environ.get("NGM_FUZZ_IMAGE", "0"))):
+        cases.append((rnd.choice(["nrgbd", "occupancy", "density", "neus"]), rnd.choice([1, 7, 33, 64, 100, 128, 256, 320, 640]),
+                      rnd.randint(1, 8), rnd.choice([257, 512, 1000, 4096]), rnd.random() < 0.4, rnd.choice(["fourier", "fourier", "hash"])))
+    return cases
+
+
+@pytest.mark.parametrize("geo,S,K_,block,explicit_u,net", _image_cases())
 def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, explicit_u, net):
     """render_pixels as ONE call (ngm_render_eval_knn: samples drawn inside the neighbour assignment, blend inside the
     quadrature, grid over the centres built once) against the staged per-block entry points (ngm_sample_rays_world ->

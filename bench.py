@@ -304,6 +304,7 @@ def aux_render_image_line(dev):
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
     r.add_fields(NF)
     r.set_field_poses(pos.to(dev), quat.to(dev))
+    r.eval()                                # rm.py:1978: the evaluation's sampling parameters
     c2w = torch.eye(4, device=dev)
     r.render_image(c2w)
     times = []

@@ -95,7 +95,9 @@ def main(iters=300, device="cuda:0", quiet=False):
             if not quiet:
                 print(f"iter {it:4d}  loss {losses[-1]:.4f}  (photo {float(out['photometric_l1']):.4f} depth {float(out['depth_huber']):.4f} "
                       f"fs {float(out['freespace']):.4f} tsdf {float(out['tsdf']):.4f})")
+    r.eval()                                                        # as rm.py:1978 before an evaluation render
     rgbd, _ = r.render_image(c2ws[0], camera=cam)
+    r.train()
     ref = store[0]
     valid = torch.isfinite(ref[..., 3]) & (rgbd[..., 3] > 0.1)      # pixels whose ray meets a trained field
     mse = ((rgbd[..., :3].clamp(0, 1) - ref[..., :3]) ** 2)[valid].mean()

@@ -229,14 +229,21 @@ KERNEL_IDS = dict(render_fwd=0, stash_bwd=1, field_bwd=2, grad_reduce=3, adam=4,
                   composite_bwd=7, hash_grad=8, hash_reduce=9, loss_reduce=10, knn_assign=11, knn_eval=12, sampler=13)
 
 
+NGM_OK, NGM_E_INVALID, NGM_E_UNSUPPORTED, NGM_E_WORKSPACE, NGM_E_HIP = 0, -1, -2, -3, -4     # include/ngm_hip.h ngm_status
+
+
 class NgmError(RuntimeError):
-    pass
+    """A C-ABI call returned a negative status; `code` = the NGM_E_* value (None: raised by the host layer itself)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 def check(rc, what=""):
     if rc != 0:
         msg = lib().ngm_last_error().decode(errors="replace")
-        raise NgmError(f"{what} failed with status {rc}: {msg}")
+        raise NgmError(f"{what} failed with status {rc}: {msg}", code=int(rc))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -126,7 +126,8 @@ class NeuralGraphRenderer:
         # what the library resolves "auto" to for batch shapes whose LDS plan has room for the weight planes
         self.mlp_matmul = ("bf16x3" if compiled else "f32") if mm == "auto" else mm
         self._rc_train = make_render_cfg(camera, config, guided=True)
-        self._rc_plain = make_render_cfg(camera, config, guided=False)
+        self._rc_cache = {}
+        self._mode = "train"               # rm.py:114: a new map is in train mode
         self._global_map_dict = None       # supplied by the mapping loop: positions / orientations
         self._learning_rate = config.get("learning_rate", 1e-3)
         self._adam_eps = config.get("adam_eps", 1e-15)
@@ -215,22 +216,62 @@ class NeuralGraphRenderer:
         return ops.quadrature(self._rc_train, sample_colors, sample_geometries, sample_distances, sample_depths,
                               neus_isds)
 
-    def render_ijs(self, ijs, c2ws, camera=None, field_ids=None, use_vmap=True, near_distances=None,
+    # -- train / eval sampling parameters (rm.py:1966-1974) ------------------------------------------
+    def eval(self) -> None:
+        """NeuralGraphMap.eval (rm.py:1966-1969): render_ijs / render_image sample `eval_num_samples` (configured, or derived
+        from the training sample spacing, rm.py:199-207) in [eval_near_distance, eval_far_distance]."""
+        self._mode = "eval"
+
+    def train(self) -> None:
+        """NeuralGraphMap.train (rm.py:1971-1974; the state a new map is in, :114): `num_samples_coarse` samples in
+        [near_distance, far_distance]."""
+        self._mode = "train"
+
+    def _mode_sampling(self):
+        """(_num_samples, _near_distance, _far_distance) of the current mode"""
+        cfg = self._config
+        if self._mode == "eval":
+            return self.eval_num_samples(), cfg.get("eval_near_distance", 0.0), cfg.get("eval_far_distance", 8.0)
+        return int(cfg["num_samples_coarse"]), cfg.get("near_distance", 0.0), cfg.get("far_distance", 8.0)
+
+    def _rc_for(self, camera: Optional[Camera], guided: bool, overwrite: bool = True) -> K.RenderCfg:
+        """ngm_render_cfg for `camera` (None: the constructor's) in the current mode; cached per (intrinsics, samples, flags)"""
+        cam = camera or self._camera
+        S, _, _ = self._mode_sampling()
+        key = (cam.fx, cam.fy, cam.cx, cam.cy, S, bool(guided), bool(overwrite))
+        rc = self._rc_cache.get(key)
+        if rc is None:
+            rc = make_render_cfg(cam, {**self._config, "num_samples_coarse": S}, guided=guided)
+            rc.overwrite_behind_camera = int(bool(overwrite))
+            self._rc_cache[key] = rc
+        return rc
+
+    def render_ijs(self, ijs, c2ws, camera=None, field_ids=None, use_vmap=False, near_distances=None,
                    far_distances=None, gt_distances=None, overwrite_samples_behind_camera=True, u_coarse=None,
                    u_guided=None, seed=0) -> Prediction:
-        """_render_ijs(use_vmap=True) (rm.py:439-666); differentiable w.r.t. vmap_fields_params."""
-        if not use_vmap or field_ids is None:
-            raise NotImplementedError("render_ijs: only the training path (use_vmap=True, field_ids given) is fused; "
-                                      "use render_image for the kNN evaluation path")
+        """NeuralGraphMap._render_ijs (rm.py:439-666), same arguments, same default branch.
+
+        use_vmap=False (the default, rm.py:445): rays `ijs` (N,2) or (F,R,2) through the kNN-blended map -- all fields, or
+        the subset `field_ids` (rm.py:502-508) --, `c2ws` (4,4) or per ray, optional per-ray near / far; with `gt_distances`
+        and depth-guided samples configured, the second stratum + the free-space / TSDF vectors (rm.py:521-545, 624-639).
+        Runs without autograd (stacked parameters are plain tensors in the reference too).
+        use_vmap=True: the training branch, each ray row against ITS field; differentiable w.r.t. vmap_fields_params.
+        `camera` is honoured on both (None = the constructor's camera); sample count and scalar near / far follow
+        train() / eval().  Beyond the reference: `u_coarse` / `u_guided` replay the torch.rand draws of camera.py:274
+        (shape (..., S)); otherwise the kernels draw from Philox with `seed`."""
+        if use_vmap and field_ids is None:
+            raise ValueError("field_ids=None only supported for use_vmap=False")                  # rm.py:497-498
+        if not use_vmap:
+            return self._render_ijs_knn(ijs, c2ws, camera, field_ids, near_distances, far_distances, gt_distances,
+                                        overwrite_samples_behind_camera, u_coarse, u_guided, seed)
         self._model.set_vmap_fields(field_ids)
         for n, v in self._model.vmap_fields_params.items():
             if n not in K.NO_GRAD_PARAMS:                 # constants (hash shifts): no gradient, no Adam, no weight decay
                 v.requires_grad_()
+        _, near_c, far_c = self._mode_sampling()
         guided = gt_distances is not None and self._rc_train.num_samples_guided > 0
-        rc = self._rc_train if guided else self._rc_plain
-        if not overwrite_samples_behind_camera:                      # default True (rm.py:450); checked per sample
-            rc = K.RenderCfg.from_buffer_copy(rc)
-            rc.overwrite_behind_camera = 0
+        # default True (rm.py:450); checked per sample
+        rc = self._rc_for(camera, guided, overwrite_samples_behind_camera)
         pos = self._global_map_dict["positions"][field_ids]
         quat = self._global_map_dict["orientations"][field_ids]
         params = self._model.vmap_fields_params
@@ -240,8 +281,7 @@ class NeuralGraphRenderer:
                                            u_guided if guided else None, seed, overwrite_samples_behind_camera)
         rgbds, cvars, dvars, term, geoms, dists = ops.render_ijs_fused(
             self._fc, rc, params, ijs, c2ws, near_distances, far_distances, gt_distances if guided else None, pos, quat,
-            u_coarse, u_guided if guided else None, seed, self._config.get("near_distance", 0.0),
-            self._config.get("far_distance", 8.0))
+            u_coarse, u_guided if guided else None, seed, near_c, far_c)
         fs = ts = None
         tau = rc.truncation_distance
         if gt_distances is not None and geoms is not None:
@@ -253,6 +293,127 @@ class NeuralGraphRenderer:
                 m = (deltas.abs() < tau) & (gt != 0.0)
                 ts = geoms[m] * tau - deltas[m]                                         # rm.py:632-639
         return Prediction(rgbds, cvars, dvars, term, fs, ts)
+
+    @torch.no_grad()
+    def _render_ijs_knn(self, ijs, c2ws, camera, field_ids, near, far, gt, overwrite, u_coarse, u_guided, seed,
+                        params: Optional[dict] = None) -> Prediction:
+        """_render_ijs(use_vmap=False) (rm.py:439-666 with :586-595): the rays are flattened to one row; without gt the
+        whole call is ngm_render_eval_knn (samples, neighbour blend and quadrature in one pass over blocks of rays); with gt
+        the per-sample geometry is needed for the free-space / TSDF vectors, so the staged entry points run
+        (ngm_sample_rays_world -> ngm_field_eval_knn -> ngm_composite_fwd_packed), in blocks of `block_size` samples like
+        the reference's batched_evaluation (rm.py:587-594)."""
+        cfg, m, dev = self._config, self._model, self._device
+        if self._rc_train.geometry_mode == K.GEO["neus"]:
+            # rm.py:641-647 hands neus_isds=None to _quadrature on this branch, whose `None * float` raises (rm.py:754)
+            raise TypeError("render_ijs(use_vmap=False) in geometry mode 'neus': the reference has no kNN branch for it "
+                            "(neus_isds is None there, rm.py:641-647, 753-754); render with use_vmap=True")
+        if ijs.dtype != torch.int64:
+            raise TypeError("ijs must be int64 (row, col)")
+        S, near_c, far_c = self._mode_sampling()
+        n_g = int(cfg["num_samples_depth_guided"])
+        guided = gt is not None and n_g > 0
+        if guided and (near is None or far is None):
+            # rm.py:522-526 compares the per-ray tensors with gt: None raises there as well
+            raise TypeError("render_ijs: gt_distances with depth-guided samples needs per-ray near_distances and far_distances")
+        lead = tuple(ijs.shape[:-1])
+        N = 1
+        for d in lead:
+            N *= d
+        flat = lambda t, *tail: None if t is None else t.reshape(N, *tail)
+        ij, nr, fr, g = ijs.reshape(N, 2), flat(near), flat(far), flat(gt)
+        if c2ws.dim() == 2:
+            cw = c2ws
+        else:
+            cw = c2ws.expand(*lead, 4, 4).reshape(N, 4, 4)
+        num = self._global_map_dict["num"]
+        if field_ids is not None:                                                            # rm.py:502-508
+            fids = field_ids.to(dev)
+            pos, quat = self._global_map_dict["positions"][fids], self._global_map_dict["orientations"][fids]
+        else:
+            fids = None
+            pos, quat = self._global_map_dict["positions"][:num], self._global_map_dict["orientations"][:num]
+        if params is None:
+            params = m.kernel_params()
+        params = {k: v for k, v in params.items() if k != "_neus_sd"}
+        rc = self._rc_for(camera, guided, overwrite)
+        empty = lambda *shape: torch.empty(*shape, device=dev)
+        if N == 0:
+            fs = ts = None
+            if gt is not None:
+                fs = empty(0) if rc.w_freespace != 0.0 else None
+                ts = empty(0) if rc.w_tsdf != 0.0 else None
+            return Prediction(empty(*lead, 4), empty(*lead, 3), empty(*lead), empty(*lead), fs, ts)
+        if gt is None and self.eval_fused:
+            block = int(cfg.get("pixel_block_size", 8192))
+            rb = int(cfg.get("eval_ray_block") or max(block, 32768))
+            pred = self._fused_eval(lambda ray_block: ops.render_eval_knn(
+                self._fc, rc, params, ij, cw, pos, quat, m._num_knn, m._distance_factor, m._outside_value, near=nr, far=fr,
+                u=flat(u_coarse, S), seed=seed, near_const=near_c, far_const=far_c, field_index=fids, ray_block=ray_block),
+                rb, block)
+            if pred is not None:
+                rgbd, cv, dv, term = pred
+                return Prediction(rgbd.view(*lead, 4), cv.view(*lead, 3), dv.view(*lead), term.view(*lead), None, None)
+        else:
+            self.last_eval_path = "staged"
+        St = S + (n_g if guided else 0)
+        rays_per_block = max(1, int(cfg.get("block_size", 3000000)) // St)
+        tau = rc.truncation_distance
+        want_fs = gt is not None and rc.w_freespace != 0.0
+        want_ts = gt is not None and rc.w_tsdf != 0.0
+        behind = -100.0 if rc.geometry_mode in (K.GEO["occupancy"], K.GEO["density"]) else 1.0      # rm.py:614-622
+        check_behind = overwrite and nr is not None and not bool((nr >= 0).all())                   # rm.py:494-495
+        outs, fss, tss = [], [], []
+        for s0 in range(0, N, rays_per_block):
+            sl = slice(s0, s0 + rays_per_block)
+            sub = lambda t: None if t is None else t[sl][None]
+            pc, pw, dist = ops.sample_rays_world(rc, ij[sl][None], cw if cw.dim() == 2 else cw[sl][None], sub(nr), sub(fr),
+                                                 sub(g) if guided else None, sub(flat(u_coarse, S)),
+                                                 sub(flat(u_guided, n_g)) if guided else None, seed + s0,
+                                                 near_const=near_c, far_const=far_c)
+            out4 = ops.field_eval_knn(self._fc, params, pw.view(-1, 3), pos, quat, m._num_knn, m._distance_factor,
+                                      m._outside_value, field_index=fids)
+            dist, pc = dist.view(-1, St), pc.view(-1, St, 3)
+            outs.append(ops.composite_packed(rc, out4, dist, pc))            # applies the behind-camera constant itself
+            if want_fs or want_ts:
+                geoms = out4.view(-1, St, 4)[..., 3]
+                if check_behind:
+                    geoms = torch.where(pc[..., 2] > 0, torch.full_like(geoms, behind), geoms)
+                gg = g[sl][:, None]
+                if want_fs:
+                    fss.append(geoms[dist < (gg - tau) * (gg != 0.0)] * tau)             # rm.py:624-630
+                if want_ts:
+                    deltas = gg - dist
+                    msk = (deltas.abs() < tau) & (gg != 0.0)
+                    tss.append(geoms[msk] * tau - deltas[msk])                           # rm.py:632-639
+        rgbd, cv, dv, term = (torch.cat([o[i] for o in outs]) for i in range(4))
+        return Prediction(rgbd.view(*lead, 4), cv.view(*lead, 3), dv.view(*lead), term.view(*lead),
+                          torch.cat(fss) if want_fs else None, torch.cat(tss) if want_ts else None)
+
+    def _fused_eval(self, call, ray_block: int, min_block: int):
+        """Run the fused evaluation call `call(ray_block)`; a block that does not fit (torch OOM, NGM_E_WORKSPACE) is halved
+        down to `min_block`.  Returns None when the staged entry points must serve the call: the block cannot shrink
+        further, or the library reports a shape the fused call does not support (NGM_E_UNSUPPORTED).  Every other error is
+        raised.  Each distinct reason is recorded once in `eval_fallbacks`; `last_eval_path` names what ran."""
+        rb = ray_block
+        while True:
+            try:
+                out = call(rb)
+                self.last_eval_path = f"fused, ray_block {rb}"
+                return out
+            except (K.NgmError, torch.cuda.OutOfMemoryError) as e:
+                oom = isinstance(e, torch.cuda.OutOfMemoryError)
+                code = getattr(e, "code", None)
+                if not oom and code not in (K.NGM_E_WORKSPACE, K.NGM_E_UNSUPPORTED):
+                    raise
+                note = f"ray_block {rb}: {type(e).__name__}: {str(e)[:200]}"
+                if note not in self.eval_fallbacks and len(self.eval_fallbacks) < 64:
+                    self.eval_fallbacks.append(note)
+                if oom:
+                    torch.cuda.empty_cache()
+                if rb <= min_block or code == K.NGM_E_UNSUPPORTED:
+                    self.last_eval_path = "staged (fused call failed, see eval_fallbacks)"
+                    return None
+                rb = max(min_block, rb // 2)
 
     def _render_ijs_staged(self, rc, ijs, c2ws, field_ids, near, far, gt_sampler, gt, u_coarse, u_guided, seed,
                            overwrite_behind) -> Prediction:
@@ -294,7 +455,7 @@ class NeuralGraphRenderer:
         """The training iteration for configurations outside the fused kernels (geometry mode neus): staged render,
         torch loss, autograd through the stage kernels, the same sparse Adam (incl. `_neus_sd`)."""
         fids = target.field_ids
-        pred = self.render_ijs(target.ijs, target.c2ws, field_ids=fids, near_distances=target.near_distances,
+        pred = self.render_ijs(target.ijs, target.c2ws, field_ids=fids, use_vmap=True, near_distances=target.near_distances,
                                far_distances=target.far_distances, gt_distances=target.gt_distances,
                                u_coarse=u_coarse, u_guided=u_guided, seed=seed)
         loss = self.compute_losses(target, pred)
@@ -476,13 +637,14 @@ class NeuralGraphRenderer:
     @torch.no_grad()
     def render_pixels(self, c2w: torch.Tensor, begin: int, end: int, params: Optional[dict] = None,
                       camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None, seed: int = 0):
-        """Pixels [begin, end) of the flattened (row-major) image, eval-style single stratum, kNN-blended fields
-        (the loop body of render_image, rm.py:402-437).  `params` overrides the model's stacked parameters (the
+        """Pixels [begin, end) of the flattened (row-major) image, single stratum, kNN-blended fields (the loop body of
+        render_image, rm.py:402-437 = _render_ijs(x, c2w, camera) per block); sample count and near / far of the current
+        mode (call eval() first, as rm.py:1879, 1978 do).  `params` overrides the model's stacked parameters (the
         all-gathered set on a sharded map).  Returns (rgbds (n,4), depth_vars (n,))."""
         cam = camera or self._camera
         cfg = self._config
-        S = self.eval_num_samples()
-        rc = make_render_cfg(cam, {**cfg, "num_samples_coarse": S, "num_samples_depth_guided": 0}, guided=False)
+        S, near_c, far_c = self._mode_sampling()
+        rc = self._rc_for(cam, False)
         w = cam.width
         dev = self._device
         idx = torch.arange(begin, end, device=dev)
@@ -505,26 +667,16 @@ class NeuralGraphRenderer:
             # unaffected); with eval_ray_block = pixel_block_size the image equals the staged loop below bit for bit.
             # Memory: the transient workspace grows with the block (about 1.2 GB at S = 640, K = 2; 3.7 GB at S = 1024, K = 4).  A
             # block that does not fit (torch OOM, NGM_E_WORKSPACE) is halved down to the reference's pixel_block_size; if even
-            # that fails -- or the library reports a shape the fused call does not support -- the staged loop below runs, as
-            # it would have with eval_fused = False.  The fall-back is reported once (`eval_fallbacks`), never silent about
-            # WHICH path ran: `last_eval_path`.
+            # that fails -- or the library reports a shape the fused call does not support (NGM_E_UNSUPPORTED) -- the staged
+            # loop below runs, as it would have with eval_fused = False; any other error is raised.  A fall-back is recorded
+            # once per reason (`eval_fallbacks`), never silent about WHICH path ran: `last_eval_path`.
             rb = int(cfg.get("eval_ray_block") or max(block, 32768))
-            while True:
-                try:
-                    rgbd, _, dv, _ = ops.render_eval_knn(
-                        self._fc, rc, params, ijs, c2w, pos, quat, m._num_knn, m._distance_factor, m._outside_value,
-                        u=None if u is None else u[begin:end], seed=seed + begin, near_const=cfg.get("eval_near_distance", 0.0),
-                        far_const=cfg.get("eval_far_distance", 8.0), ray_block=rb)
-                    self.last_eval_path = f"fused, ray_block {rb}"
-                    return rgbd, dv
-                except (K.NgmError, torch.cuda.OutOfMemoryError) as e:
-                    self.eval_fallbacks.append(f"ray_block {rb}: {type(e).__name__}: {str(e)[:200]}")
-                    if isinstance(e, torch.cuda.OutOfMemoryError):
-                        torch.cuda.empty_cache()
-                    if rb <= block or (isinstance(e, K.NgmError) and "workspace" not in str(e).lower()):
-                        break                                   # staged loop
-                    rb = max(block, rb // 2)
-            self.last_eval_path = "staged (fused call failed, see eval_fallbacks)"
+            pred = self._fused_eval(lambda ray_block: ops.render_eval_knn(
+                self._fc, rc, params, ijs, c2w, pos, quat, m._num_knn, m._distance_factor, m._outside_value,
+                u=None if u is None else u[begin:end], seed=seed + begin, near_const=near_c, far_const=far_c,
+                ray_block=ray_block), rb, block)
+            if pred is not None:
+                return pred[0], pred[2]
         else:
             self.last_eval_path = "staged"
         rgbds, dvars = [], []
@@ -532,8 +684,7 @@ class NeuralGraphRenderer:
             ij = ijs[s0:s0 + block]
             ub = None if u is None else u[begin + s0:begin + s0 + block][None]
             pc, pw, dist = ops.sample_rays_world(rc, ij, c2w, None, None, None, ub, None, seed + begin + s0,
-                                                 near_const=cfg.get("eval_near_distance", 0.0),
-                                                 far_const=cfg.get("eval_far_distance", 8.0))
+                                                 near_const=near_c, far_const=far_c)
             out4 = ops.field_eval_knn(self._fc, params, pw.view(-1, 3), pos, quat, m._num_knn, m._distance_factor,
                                       m._outside_value)
             rgbd, _, dv, _ = ops.composite_packed(rc, out4, dist.view(-1, S), pc.view(-1, S, 3))
@@ -546,7 +697,9 @@ class NeuralGraphRenderer:
     @torch.no_grad()
     def render_image(self, c2w: torch.Tensor, camera: Optional[Camera] = None, u: Optional[torch.Tensor] = None,
                      seed: int = 0):
-        """render_image (rm.py:402-437): every pixel, eval-style single stratum, kNN-blended fields.
+        """render_image (rm.py:402-437): every pixel of `camera`, single stratum, kNN-blended fields, in the current mode
+        like the reference: its callers switch to eval() first (rm.py:1879-1906, 1978-2019); in train mode this renders
+        with `num_samples_coarse` samples in [near_distance, far_distance], as the reference would.
 
         Returns (rgbds (H,W,4), depth_vars (H,W)).  `u` (H*W, S) optionally supplies the torch.rand draws."""
         cam = camera or self._camera

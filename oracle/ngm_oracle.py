@@ -512,6 +512,55 @@ def render_ijs(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs:
     return pred
 
 
+def render_ijs_knn(ijs, c2ws, cam: CameraSpec, pos, quat, params, fs: FieldSpec, rs: RenderSpec, num_samples: int,
+                   near=None, far=None, gt=None, u_coarse=None, u_guided=None, field_ids=None, near_const=0.0,
+                   far_const=8.0, num_knn=2, distance_factor=10.0, outside_value=1.0,
+                   overwrite_samples_behind_camera=True):
+    """`_render_ijs(use_vmap=False)` (rm.py:439-666; the default of the signature, :445): arbitrary rays, every field --
+    or the subset `field_ids` (:502-508; the model then blends among THOSE centres and reads parameter rows
+    `field_ids[k]`, models.py:390-394) --, `num_samples` = the map's current `_num_samples` (train / eval, :1966-1974),
+    scalar near / far from the same mode where no per-ray tensors are given (:513-519), depth-guided second stratum when
+    `gt` is given and the config has guided samples (:521-545; the reference's gather needs (F,R,2) rays there),
+    kNN-blended evaluation (:586-595), behind-camera overwrite (:494-495, 614-622), free-space / TSDF vectors (:624-639),
+    quadrature without neus_isds (:641-647: the neus mode has no kNN branch).
+
+    ijs (...,2); c2ws (4,4) or (...,4,4); pos / quat / params: ALL fields of the map.  Returns the Prediction dict."""
+    lead = ijs.shape[:-1]
+    dtype = pos.dtype
+    near_t = torch.full(lead, near_const, dtype=dtype) if near is None else near           # camera.py:264-267
+    far_t = torch.full(lead, far_const, dtype=dtype) if far is None else far
+    if near is None or bool((near >= 0).all()):                                            # rm.py:494-495
+        overwrite_samples_behind_camera = False
+    if field_ids is not None:                                                              # rm.py:502-508
+        pos, quat = pos[field_ids], quat[field_ids]
+        params = {n: v[field_ids] for n, v in params.items()}
+    if c2ws.dim() == 2:
+        c2ws = c2ws[None]
+    guided = gt is not None and rs.num_samples_depth_guided > 0
+    pts_cam, t, _ = sample_rays(ijs, cam, near_t, far_t, gt if guided else None, rs, u_coarse, u_guided if guided else None,
+                                num_samples)
+    pts_w = transform_points(pts_cam, c2ws.unsqueeze(-3))
+    out = field_set_forward_knn(pts_w.reshape(-1, 3), pos, quat, params, fs, rs.field_radius, rs.scale_mode, num_knn,
+                                distance_factor, outside_value).view(*t.shape, 4)
+    colors = rs.color_factor * out[..., :3]
+    geoms = out[..., 3]
+    depths = -pts_cam[..., 2]
+    if overwrite_samples_behind_camera:
+        const = -100.0 if rs.geometry_mode in ("occupancy", "density") else 1.0
+        geoms = torch.where(pts_cam[..., 2] > 0, torch.full_like(geoms, const), geoms)
+    tau = rs.truncation_distance
+    fs_vec = ts_vec = None
+    if rs.freespace_weight != 0.0 and gt is not None:
+        fs_vec = geoms[t < (gt[..., None] - tau) * (gt[..., None] != 0.0)] * tau
+    if rs.tsdf_weight != 0.0 and gt is not None:
+        deltas = gt[..., None] - t
+        m = (deltas.abs() < tau) & (gt[..., None] != 0.0)
+        ts_vec = geoms[m] * tau - deltas[m]
+    C, D, Cv, Dv, term, _ = quadrature(rs.geometry_mode, colors, geoms, t, depths, rs.geometry_factor, None)
+    return dict(rgbds=torch.cat([C, D[..., None]], -1), color_vars=Cv, depth_vars=Dv, term_probs=term,
+                freespace_geometry=fs_vec, tsdf_residuals=ts_vec, sample_distances=t)
+
+
 # ----------------------------------------------------------------------------------------
 # training-target sampler (rm.py:1259-1459, SURVEY 8f.2)
 # ----------------------------------------------------------------------------------------

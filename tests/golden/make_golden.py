@@ -861,11 +861,81 @@ def g23_weighted_bins():
          cam=np.array([NRGBD_CAMERA[k] for k in ("width", "height", "fx", "fy", "cx", "cy")], dtype=np.float64))
 
 
+def g24_render_ijs_knn():
+    """`NeuralGraphMap._render_ijs` on its DEFAULT branch `use_vmap=False` (rm.py:440-451, 502-545, 586-595; the call
+    `vis_blender.py:236-238` makes): arbitrary pixels, a camera that is not the training one, a `field_ids` subset, and the
+    optional per-ray near / far / gt.  Three calls of the real method on one 6-field map:
+      a  ijs (500,2), one c2w, camera = a preview-style camera, field_ids = [0,2,3,5], train mode (16 samples in [0, 5])
+      b  ijs (3,40,2), per-ray c2ws, per-ray near / far / gt -> depth-guided second stratum + free-space / TSDF vectors
+      c  eval mode (48 samples), field_ids=None, per-ray near with negative entries -> behind-camera overwrite"""
+    gen = torch.Generator().manual_seed(24)
+    cam_kw = dict(width=96, height=72, fx=83.1, fy=81.7, cx=47.2, cy=36.4, pixel_center=0.0)
+    cam = camera.Camera(**cam_kw)
+    NF = 6
+    pos = torch.tensor([[0.0, 0.0, -2.5], [0.9, 0.1, -2.8], [-0.7, 0.3, -2.2], [0.3, -0.8, -3.1], [1.5, 0.9, -3.6],
+                        [-0.2, 0.5, -3.3]])
+    quat = rand_quats(NF, gen)
+    cfg = make_config(far_distance=5.0, eval_far_distance=4.5, eval_num_samples=48, num_samples_coarse=16,
+                      num_samples_depth_guided=12)
+    ngm = build_map(rm, cfg, NF, pos, quat, seed=240)
+    model = ngm._model
+    for k, v in model.all_fields_params.items():
+        if v.dim() > 1:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    model.all_fields_params["_linears.2.weight"].mul_(3.0)
+    arrays = {"p::" + k: v for k, v in model.all_fields_params.items()}
+    out = dict(pos=pos, quat=quat, cam=np.array([cam_kw[k] for k in ("width", "height", "fx", "fy", "cx", "cy")]),
+               train_far=np.float32(5.0), eval_far=np.float32(4.5), eval_num_samples=np.int64(48),
+               num_samples_coarse=np.int64(16), num_samples_depth_guided=np.int64(12))
+
+    def rec(tag, pred, **inputs):
+        for k, v in inputs.items():
+            out[f"{tag}::{k}"] = v
+        for k, v in pred._asdict().items():
+            if v is not None:
+                out[f"{tag}::pred::{k}"] = v
+
+    with torch.no_grad():
+        # a: the vis_blender call
+        N = 500
+        ijs = torch.stack([torch.randint(0, cam.height, (N,), generator=gen), torch.randint(0, cam.width, (N,), generator=gen)], -1)
+        c2w = look_at_c2w(torch.tensor([0.4, 0.2, 0.3]), torch.tensor([0.2, 0.0, -2.8]), gen)
+        fids = torch.tensor([0, 2, 3, 5])
+        torch.manual_seed(2400)
+        u = torch.rand(N, 16)
+        torch.manual_seed(2400)
+        pred = ngm._render_ijs(ijs=ijs, c2ws=c2w, camera=cam, field_ids=fids)
+        rec("a", pred, ijs=ijs, c2w=c2w, field_ids=fids, u=u)
+        # b: (F,R,2) rays with per-ray poses and bounds, depth-guided samples on the kNN branch
+        F, R = 3, 40
+        t = synth_target(F, R, cam, pos[:F] * 0.0 + pos[[0, 1, 3]], gen, radius=1.0)
+        fids_b = torch.tensor([0, 1, 3, 5])
+        torch.manual_seed(2401)
+        u_c = torch.rand(F, R, 16)
+        u_g = torch.rand(F, R, 12)
+        torch.manual_seed(2401)
+        pred = ngm._render_ijs(ijs=t["ijs"], c2ws=t["c2ws"], camera=cam, field_ids=fids_b, use_vmap=False,
+                               near_distances=t["near"], far_distances=t["far"], gt_distances=t["gt"].clone())
+        rec("b", pred, ijs=t["ijs"], c2ws=t["c2ws"], near=t["near"], far=t["far"], gt=t["gt"], field_ids=fids_b, u_c=u_c, u_g=u_g)
+        # c: eval mode, all fields, cameras inside the map with negative near distances
+        ngm.eval()
+        ti = synth_target(1, 300, cam, pos[:1], gen, radius=1.0, inside=True)
+        ijs_c, c2ws_c, near_c, far_c = ti["ijs"][0], ti["c2ws"][0], ti["near"][0], ti["far"][0]
+        assert bool((near_c < 0).any())
+        torch.manual_seed(2402)
+        u_e = torch.rand(300, 48)
+        torch.manual_seed(2402)
+        pred = ngm._render_ijs(ijs=ijs_c, c2ws=c2ws_c, camera=cam, near_distances=near_c, far_distances=far_c)
+        rec("c", pred, ijs=ijs_c, c2ws=c2ws_c, near=near_c, far=far_c, u=u_e)
+        ngm.train()
+    save("g24_render_ijs_knn", **out, **arrays)
+
+
 if __name__ == "__main__":
     import sys
     cases = [g1_directions, g2_g3_sampling, g4_field_forward, g5_quadrature, g6_train, g7_adam, g8_knn, g9_render_image,
              g10_behind_camera, g11_target_sampler, g12_skip_modes, g13_training_run, g15_triplane, g16_target_sampler_sv, g17_extract_mesh, g18_train_l2, g19_skip_other_encodings, g20_train_nll,
-             g21_field_radius_override, g22_fields_2d, g23_weighted_bins]
+             g21_field_radius_override, g22_fields_2d, g23_weighted_bins, g24_render_ijs_knn]
     only = set(sys.argv[1:])            # e.g. `python make_golden.py g10_behind_camera` regenerates one group
     for fn in cases:
         if not only or fn.__name__ in only:

@@ -232,7 +232,7 @@ def test_eval_style_fused_render_640_samples_vs_oracle():
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     ids = torch.arange(F, device=DEV)
     with torch.no_grad():
-        p = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, field_ids=ids, near_distances=t["near"].to(DEV),
+        p = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, field_ids=ids, use_vmap=True, near_distances=t["near"].to(DEV),
                          far_distances=t["far"].to(DEV), gt_distances=None, u_coarse=u.to(DEV))
     close(p.rgbds, pred["rgbds"])
     close(p.term_probs, pred["term_probs"])
@@ -247,7 +247,7 @@ def test_eval_style_fused_render_4096_rays_x_640_samples_properties():
     pos, quat, t = synth_target(F, R, seed=6)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     ids = torch.arange(F, device=DEV)
-    kw = dict(field_ids=ids, near_distances=t["near"].to(DEV), far_distances=t["far"].to(DEV), gt_distances=None)
+    kw = dict(field_ids=ids, use_vmap=True, near_distances=t["near"].to(DEV), far_distances=t["far"].to(DEV), gt_distances=None)
     with torch.no_grad():
         a = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, seed=5, **kw)
         b = r.render_ijs(t["ijs"].to(DEV), t["c2ws"].to(DEV), None, seed=5, **kw)

@@ -167,6 +167,7 @@ def _g9_renderer(g, own=None):
     NF = next(iter(p.values())).shape[0]
     r = make_renderer(fkw, ckw, NF, p)
     r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))          # poses are replicated on every rank
+    r.eval()                                                         # rm.py:1978: evaluation switches the sampling parameters
     w, h, fx, fy, cx, cy = [float(x) for x in g["cam"]]
     return r, Rr.Camera(int(w), int(h), fx, fy, cx, cy, pixel_center=0.0)
 

@@ -282,6 +282,7 @@ def test_fused_image_path_equals_the_staged_entry_points(geo, S, K_, block, expl
     r._model._num_knn = K_
     _perturb(r)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    r.eval()
     c2w = torch.eye(4)
     c2w[:3, 3] = torch.tensor([0.1, -0.2, 0.3])
     begin, end = 640 * 200 + 17, 640 * 200 + 17 + 2500                      # not aligned to anything
@@ -467,6 +468,7 @@ def test_image_path_with_more_than_four_neighbours(num_knn, S):
     r.add_fields(NF)
     _perturb(r)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
+    r.eval()
     c2w = torch.eye(4, device=DEV)
     img, dv = r.render_image(c2w, seed=5)
     assert r.last_eval_path.startswith("fused") and not r.eval_fallbacks

@@ -1186,6 +1186,7 @@ def test_render_image_and_psnr_golden():
     r = make_renderer(fkw, ckw, NF, split_prefix(g, "p::"))
     r.set_field_poses(g["pos"].to(DEV), g["quat"].to(DEV))
     cam = Rr.Camera(int(w), int(h), fx, fy, cx, cy, pixel_center=0.0)
+    r.eval()                                                          # make_golden.g9_render_image: ngm.eval() first
     rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
     close(rgbd, g["rgbd"], rtol=5e-4, atol=5e-5)
     close(dvar, g["dvar"], rtol=5e-4, atol=5e-5)
@@ -1436,12 +1437,14 @@ def test_checkpoint_in_reference_layout_renders_the_reference_image(tmp_path):
     r = make_renderer(dict(encoding="fourier", dim_enc=64, num_layers=2), ckw, 1)     # holds one unrelated field
     r.load_model(os.path.join(GOLDEN, "g14_checkpoint_reference_layout.pt"))
     assert r._global_map_dict["num"] == 3 and r._model.all_fields_params["_linears.0.weight"].is_cuda
+    r.eval()
     rgbd, dvar = r.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
     close(rgbd, g["rgbd"], rtol=5e-4, atol=5e-5)
     close(dvar, g["dvar"], rtol=5e-4, atol=5e-5)
     r.save_model(str(tmp_path / "again.pt"))
     r2 = make_renderer(dict(encoding="fourier", dim_enc=64, num_layers=2), ckw, 0)
     r2.load_model(str(tmp_path / "again.pt"))
+    r2.eval()
     rgbd2, _ = r2.render_image(g["c2w"].to(DEV), cam, u=g["u"].to(DEV))
     assert torch.equal(rgbd, rgbd2)
     # a loaded map trains: moments start from zero (the reference does not checkpoint them either)

@@ -108,7 +108,7 @@ def test_ensemble_psnr_within_a_tenth_of_a_db_of_the_reference():
         losses.append(r.optimization_iteration(make_target(t, ids), u_c, u_g, update=True)["combined"].clone())
         if it + 1 >= scene.B_EVAL_FROM and (it + 1) % scene.B_EVAL_EVERY == 0:
             with torch.no_grad():
-                p = r.render_ijs(th_dev["ijs"], th_dev["c2ws"], None, field_ids=ids_dev, near_distances=th_dev["near"],
+                p = r.render_ijs(th_dev["ijs"], th_dev["c2ws"], None, field_ids=ids_dev, use_vmap=True, near_distances=th_dev["near"],
                                  far_distances=th_dev["far"], gt_distances=th_dev["gt"], u_coarse=hu_c, u_guided=hu_g)
             ps, de = scene.held_out_scores(p.rgbds, th)
             psnr.append(ps)

@@ -130,6 +130,7 @@ def test_fused_image_call_falls_back_instead_of_failing(monkeypatch):
     r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(eval_num_samples=16, pixel_block_size=1024), device="cpu")
     r.add_fields(2)
     r.set_field_poses(torch.zeros(2, 3), torch.tensor([[1.0, 0, 0, 0]] * 2))
+    r.eval()
     calls = []
 
     def fused(fc, rc, params, ijs, c2w, pos, quat, *a, ray_block=0, **kw):
@@ -137,7 +138,7 @@ def test_fused_image_call_falls_back_instead_of_failing(monkeypatch):
         if ray_block > 8192:
             raise torch.cuda.OutOfMemoryError("fake")
         if ray_block > 1024:
-            raise K.NgmError("ngm_render_eval_knn failed with status -3: ngm_render_eval_knn: workspace too small")
+            raise K.NgmError("ngm_render_eval_knn failed with status -3: ngm_render_eval_knn: workspace too small", code=K.NGM_E_WORKSPACE)
         n = ijs.shape[0]
         return torch.zeros(n, 4), None, torch.zeros(n), None
     monkeypatch.setattr(Rr.ops, "render_eval_knn", fused)
@@ -147,7 +148,7 @@ def test_fused_image_call_falls_back_instead_of_failing(monkeypatch):
     assert r.last_eval_path == "fused, ray_block 1024" and len(r.eval_fallbacks) == 5
 
     staged = []
-    monkeypatch.setattr(Rr.ops, "render_eval_knn", lambda *a, **k: (_ for _ in ()).throw(K.NgmError("status -4: unsupported shape")))
+    monkeypatch.setattr(Rr.ops, "render_eval_knn", lambda *a, **k: (_ for _ in ()).throw(K.NgmError("status -2: unsupported shape", code=K.NGM_E_UNSUPPORTED)))
     monkeypatch.setattr(Rr.ops, "sample_rays_world", lambda rc, ij, *a, **k: (staged.append(ij.shape[0]),
                         (torch.zeros(ij.shape[0], 16, 3), torch.zeros(ij.shape[0], 16, 3), torch.zeros(ij.shape[0], 16)))[1])
     monkeypatch.setattr(Rr.ops, "field_eval_knn", lambda fc, p, pts, *a, **k: torch.zeros(pts.shape[0], 4))
@@ -362,3 +363,31 @@ def test_recorded_bench_line_carries_the_contract():
     assert d["cpu_baseline"]["kind"] == "port"
     samples = 8 * 512 * 128
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_render_ijs_signature_is_the_reference_one():
+    """rm.py:440-451: argument order and defaults of `_render_ijs` -- `use_vmap` defaults to False (the kNN branch), so
+    vis_blender.py:236-238's call without it lands there; use_vmap=True without field_ids raises the reference's ValueError.
+    train() / eval() switch sample count and scalar bounds like rm.py:1966-1974 (a new map is in train mode, :114)."""
+    import inspect
+    sig = inspect.signature(Rr.NeuralGraphRenderer.render_ijs)
+    names = list(sig.parameters)[1:10]
+    assert names == ["ijs", "c2ws", "camera", "field_ids", "use_vmap", "near_distances", "far_distances", "gt_distances",
+                     "overwrite_samples_behind_camera"]
+    assert sig.parameters["use_vmap"].default is False and sig.parameters["field_ids"].default is None
+    assert sig.parameters["overwrite_samples_behind_camera"].default is True
+    model = M.NeuralFieldSet(**SET_KW)
+    cam = Rr.Camera(64, 48, 50.0, 50.0, 31.5, 23.5, pixel_center=0.0)
+    r = Rr.NeuralGraphRenderer(model, cam, Rr.shipped_config(eval_num_samples=40, eval_far_distance=6.0, far_distance=5.0,
+                                                           near_distance=0.1), device="cpu")
+    assert r._mode_sampling() == (8, 0.1, 5.0)
+    r.eval()
+    assert r._mode_sampling() == (40, 0.0, 6.0)
+    r.train()
+    assert r._mode_sampling() == (8, 0.1, 5.0)
+    with pytest.raises(ValueError, match="field_ids=None only supported for use_vmap=False"):
+        r.render_ijs(torch.zeros(1, 4, 2, dtype=torch.long), torch.eye(4), cam, None, True)
+    # the render configuration follows the camera that is handed in, not the constructor's
+    other = Rr.Camera(32, 24, 27.7, 26.0, 15.5, 11.5, pixel_center=0.0)
+    rc = r._rc_for(other, False)
+    assert (round(rc.fx, 3), round(rc.fy, 3), rc.cx, rc.cy) == (27.7, 26.0, 15.5, 11.5) and r._rc_for(None, False).fx == 50.0

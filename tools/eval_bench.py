@@ -34,6 +34,7 @@ def main():
         r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
         r.add_fields(NF)
         r.set_field_poses(pos.to(dev), quat.to(dev))
+        r.eval()
         c2w = torch.eye(4, device=dev)
         r.render_image(c2w)
         torch.cuda.synchronize()
@@ -91,6 +92,7 @@ def main():
         r = Rr.NeuralGraphRenderer(model, cam, cfg, device=dev)
         r.add_fields(NF)
         r.set_field_poses(pos.to(dev), quat.to(dev))
+        r.eval()
         c2w = torch.eye(4, device=dev)
         r.render_image(c2w)
         torch.cuda.synchronize()

@@ -206,7 +206,7 @@ def main():
     near2, far2 = torch.full((F2, R2), 1.5, device=dev), torch.full((F2, R2), 3.5, device=dev)
     ids = torch.arange(F2, device=dev)
     with torch.no_grad():
-        secs = timeit(lambda: r.render_ijs(ijs2, c2w, field_ids=ids, near_distances=near2, far_distances=far2, seed=3))
+        secs = timeit(lambda: r.render_ijs(ijs2, c2w, field_ids=ids, use_vmap=True, near_distances=near2, far_distances=far2, seed=3))
     add("M2_render_ijs_nograd", secs, flops=F2 * R2 * S2 * 16896,
         note="8 fields x 512 rays x 128 samples, render only (k_render_fwd without stash), incl. the Python layer of render_ijs")
     res["stages"]["M2_render_ijs_nograd"]["ray_samples_per_s"] = round(F2 * R2 * S2 / secs / 1e6, 1) * 1e6

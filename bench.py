@@ -68,7 +68,7 @@ def synth_target(F, Rn, seed, field_offset=0):
     return pos, quat, tgt
 
 
-def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, matmul="auto"):
+def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, matmul="auto", hash_atomics="exact"):
     from neural_graph_mapping_amd import models as M
     from neural_graph_mapping_amd import renderer as Rr
     torch.manual_seed(0)
@@ -88,7 +88,7 @@ def build_renderer(device, num_fields, variant="fourier", s_c=None, s_g=None, ma
                freespace_weight=40.0, tsdf_weight=50.0,
                learning_rate=1e-3, adam_eps=1e-15, adam_weight_decay=1e-5, near_distance=0.0, far_distance=8.0,
                num_samples_coarse=S_C if s_c is None else s_c, num_samples_depth_guided=S_G if s_g is None else s_g,
-               mlp_matmul=matmul)
+               mlp_matmul=matmul, hash_grad_atomics=hash_atomics)
     cam = Rr.Camera(640, 480, 554.2562584220408, 554.2562584220408, 319.5, 239.5, pixel_center=0.0)
     r = Rr.NeuralGraphRenderer(model, cam, cfg, device=device)
     r.add_fields(num_fields)
@@ -218,13 +218,13 @@ def hash_rooflines(kern, n_local, scale_note="", pmc_scale=1.0):
                                    achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                                    traffic=(pv["hbm_bytes"] * pmc_scale) if pv.get("hbm_bytes") is not None else None,
                                    traffic_source=src if pv else None, l2_hit_rate=pv.get("l2_hit_rate"),
-                                   l2_gather_ceiling=dict(useful_GBs=GATHER_L2_USEFUL_GBS, frac=ach / GATHER_L2_USEFUL_GBS,
-                                                          peak_l2_GBs=PEAK_L2_GBS,
-                                                          note="the tables are L2-resident (l2_hit_rate), so the ceiling of the gathers is "
-                                                               "L2 -> L1, not HBM: a micro-benchmark of random 8-byte gathers from a 512 KB "
-                                                               "table reads 2.2 TB/s of USEFUL bytes (16 x that in 128-byte lines = the L2 "
-                                                               "peak); frac > 1 = the kernel's gathers hit the vector L1 more often than the "
-                                                               "micro-benchmark's (coarse levels: neighbouring samples share vertices)"),
+                                   l2_gather_microbench=dict(useful_GBs=GATHER_L2_USEFUL_GBS, ratio=ach / GATHER_L2_USEFUL_GBS,
+                                                             peak_l2_GBs=PEAK_L2_GBS,
+                                                             note="NOT a bound (the kernel exceeds it): random 8-byte gathers from a 512 KB, "
+                                                                  "L2-resident table read 2.2 TB/s of useful bytes in tools/micro/gather_rate; "
+                                                                  "the kernel's gathers also hit the vector L1 (coarse levels: neighbouring "
+                                                                  "samples share vertices).  The honest statement is `frac` of the HBM peak "
+                                                                  "at `l2_hit_rate`, with no established ceiling for the gather path"),
                                    avg_launch_us=ff["avg_us"], launches_timed=ff["launches"], algorithmic_bytes_per_launch=algo,
                                    note="algorithmic gather bytes (512 B/sample, SURVEY 8d) against the HBM peak as the survey asks")
     return out
@@ -267,7 +267,7 @@ def aux_default_line(dev, args, use_graph):
     """The iteration the reference actually runs by default (config/neural_graph_map.yaml:6-20, 60-63): 32 active fields x
     512 rays x (8 coarse + 16 depth-guided) samples, permutohedral hash 16 levels x 2 features + ONE hidden layer of 32."""
     Fd, Sc, Sg = 32, 8, 16
-    r = build_renderer(dev, Fd, "hash", s_c=Sc, s_g=Sg, matmul=args.matmul)
+    r = build_renderer(dev, Fd, "hash", s_c=Sc, s_g=Sg, matmul=args.matmul, hash_atomics=args.hash_atomics)
     pos, quat, t = synth_target(Fd, R, seed=4242)
     r.set_field_poses(pos.to(dev), quat.to(dev))
     tgt = type(t)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in t])
@@ -279,6 +279,7 @@ def aux_default_line(dev, args, use_graph):
                          "2^12 entries) + 1x32 MLP: the reference's default iteration (config/neural_graph_map.yaml:6-20, 60-63; "
                          "parity of the hash encoding unpinned: third-party CUDA package absent)",
                 value=n * args.steps / dth, unit="ray-samples/s", ms_per_step=1e3 * dth / args.steps, final_loss=lh, bwd_variant=bvh,
+                hash_grad_atomics=args.hash_atomics,
                 launch="hipGraph replay" if use_graph else "eager", kernels_us={k: round(v["avg_us"], 2) for k, v in kh.items()}, **roof)
 
 
@@ -333,7 +334,7 @@ def aux_m2_line(dev, variant, matmul="auto", launches=200):
     S = S_C + S_G
     r = build_renderer(dev, F_PER_GPU, variant, s_c=S, s_g=0, matmul=matmul)
     pos, quat, t = synth_target(F_PER_GPU, R, seed=1000)
-    fc, rc = r._fc, r._rc_plain
+    fc, rc = r._fc, r._rc_for(None, False)
     keep = []
     rays = ops.make_rays(rc, t.ijs.to(dev), t.c2ws.to(dev), t.near_distances.to(dev), t.far_distances.to(dev), None, pos.to(dev),
                          quat.to(dev), seed=11, keep=keep)
@@ -368,8 +369,8 @@ def aux_m2_line(dev, variant, matmul="auto", launches=200):
         ach = 512 * n_samp / (us * 1e-6) / 1e9
         roof = dict(bound="hbm", kernel="k_render_fwd<1,1,1,hash> (inference instance: no stash)", achieved=ach, peak=PEAK_HBM_GBS,
                     unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, algorithmic_bytes_per_launch=512 * n_samp,
-                    note="512 B of table gathers per sample (SURVEY 8d) against the HBM peak; the tables are L2-resident, the honest "
-                         "ceiling is the L2 -> L1 gather rate (aux_hash.roofline_fwd.l2_gather_ceiling)")
+                    note="512 B of table gathers per sample (SURVEY 8d) against the HBM peak; the tables are L2-resident "
+                         "(aux_hash.roofline_fwd.l2_hit_rate): no bound for the L2 -> L1 gather path is established")
     else:
         ach = FLOP_FWD * n_samp / (us * 1e-6) / 1e12
         roof = dict(bound="mfma", kernel="k_render_fwd<2,2,2> (inference instance: no stash)", achieved=ach, peak=PEAK_F32_MFMA_TF,
@@ -547,6 +548,9 @@ def main():
                     help="hidden layers of the forward kernels: auto (library default) = the exact three-way bf16 split with fp32 "
                          "accumulation where it is compiled (this workload), f32 = exact-fp32 MFMA everywhere; the line's `dtype` "
                          "says which ran, and the other one is measured next to it (`matmul_alternative`)")
+    ap.add_argument("--hash-atomics", choices=["exact", "float"], default="exact",
+                    help="accumulation of the hash-table gradient in the hash lines (ngm_hash_grad_atomics): exact = Q23.40 integer LDS "
+                         "atomics, bitwise reproducible (default, and what the lines report unless named); float = fp32 LDS atomics")
     ap.add_argument("--no-aux-hash", action="store_true",
                     help="skip the auxiliary measurement of the reference's default network (hash encoding + 1x32 MLP) that the "
                          "default line carries as `aux_hash`")
@@ -600,7 +604,7 @@ def main():
     if strong and args.fields_total % world:
         raise SystemExit("--fields-total must be a multiple of the number of GPUs")
     F_PER_GPU = args.fields_total // world if strong else globals()["F_PER_GPU"]
-    r = build_renderer(dev, F_PER_GPU, args.variant, matmul=args.matmul)
+    r = build_renderer(dev, F_PER_GPU, args.variant, matmul=args.matmul, hash_atomics=args.hash_atomics)
     pos, quat, tgt_cpu = synth_target(F_PER_GPU, R, seed=1000 + rank)
     r.set_field_poses(pos.to(dev), quat.to(dev))
     tgt = type(tgt_cpu)(*[v.to(dev) if isinstance(v, torch.Tensor) else v for v in tgt_cpu])
@@ -716,7 +720,7 @@ def main():
     # auxiliary: the reference's DEFAULT network (hash 16x2 + 1x32 MLP) on the same batch, in the same run
     aux_hash = None
     if world == 1 and args.variant == "fourier" and not strong and not args.no_aux_hash:
-        rh = build_renderer(dev, F_PER_GPU, "hash", matmul=args.matmul)
+        rh = build_renderer(dev, F_PER_GPU, "hash", matmul=args.matmul, hash_atomics=args.hash_atomics)
         rh.set_field_poses(pos.to(dev), quat.to(dev))
         dth, kh, lh, bvh = time_steps(rh, tgt, args.steps, args.warmup, 20, use_graph)
         n_h = F_PER_GPU * R * (S_C + S_G)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 9 /* 9: ngm_sample_rays_weighted; 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 10 /* 10: ngm_field_cfg.activation_stash / .hash_grad_atomics (per configuration, no process-wide switch), empty loss selections report NaN like the reference; 9: ngm_sample_rays_weighted; 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -101,7 +101,21 @@ typedef struct ngm_field_cfg {
    * combined per ngm_triplane_mode; dim_enc = C (sum, product) or 3 C (concat) */
   int32_t tri_resolution;
   int32_t tri_mode;
+  /* ABI 10: two choices that used to be process-wide switches, now part of the configuration (two renderers of one process
+   * may differ; ngm_render_workspace sizes the workspace for the configuration it is handed) */
+  int32_t activation_stash;   /* ngm_activation_stash: what the training forward of a two-hidden-layer network on the split
+                               * path stashes for the backward                                                            */
+  int32_t hash_grad_atomics;  /* ngm_hash_grad_atomics: accumulation of the hash-table gradient (k_hash_grad)               */
 } ngm_field_cfg;
+/* NGM_STASH_FULL: both hidden layers' outputs (512 B per sample; fastest).  NGM_STASH_HALF: layer 0's output only (256 B
+ * per sample: half the stash memory and HBM traffic); k_field_bwd_b3<HS> recomputes the output layer's input on the matrix
+ * pipe.  Same results at the same tolerances, each bitwise reproducible. */
+enum ngm_activation_stash { NGM_STASH_FULL = 0, NGM_STASH_HALF = 1 };
+/* NGM_HASH_ATOMICS_EXACT (default): Q23.40 fixed-point integer LDS atomics -- order-independent, the table gradient is
+ * bitwise reproducible.  NGM_HASH_ATOMICS_FLOAT (opt-in): fp32 LDS atomics, what the reference's CUDA package does with its
+ * global float atomics -- the same sums up to the rounding of the order the adds happen to land in (NOT reproducible run
+ * to run), half the LDS per workgroup, no fixed-point conversion. */
+enum ngm_hash_grad_atomics { NGM_HASH_ATOMICS_EXACT = 0, NGM_HASH_ATOMICS_FLOAT = 1 };
 
 /* fills cfg->level_scale from nr_levels / coarsest_scale / finest_scale (double precision) */
 int ngm_permuto_fill_scales(ngm_field_cfg* cfg);
@@ -539,12 +553,10 @@ int ngm_debug_last_matmul(int which);
  * k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */
 int ngm_debug_last_comp_fused(void);
 int ngm_debug_disable_fused_comp(int on);
-/* Which activation stash the training forward of two-hidden-layer networks on the split path writes for the backward
- * (the workspace is sized accordingly: set it BEFORE ngm_render_workspace): 0 = both hidden layers' outputs (512 B per
- * sample; the default: fastest), 1 = layer 0's output only (256 B per sample: half the stash traffic and memory;
- * k_field_bwd_b3<HS> recomputes the output layer's input on the matrix pipe: forward -8 us, backward +12..17 us on the
- * 4096 x 128 batch).  Same results at the same tolerances, each bitwise reproducible.  mode -1: query only; -2: back to
- * the default (environment NGM_STASH=full|half, else 0).  Returns the mode in force before the call. */
+/* DEVELOPER override of ngm_field_cfg.activation_stash for A/B timing of one library on one box (tools/): 0 / 1 force that
+ * mode for every configuration of the process, -1 queries, -2 removes the override (environment NGM_STASH=full|half does
+ * the same at load time).  The product path never calls it: the renderer sets ngm_field_cfg.activation_stash.
+ * Returns the override in force before the call (-1: none). */
 int ngm_debug_stash_mode(int mode);
 int ngm_debug_last_stash_mode(void);   /* the stash the last MLP backward actually read: 0 / 1 as above, -1 none (recompute kernels) */
   /* 1 = always launch k_stash_bwd (as NGM_NO_FUSED_COMP=1); returns the previous setting */

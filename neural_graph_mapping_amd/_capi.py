@@ -39,7 +39,8 @@ class FieldCfg(C.Structure):
                 ("field_radius", C.c_float), ("nr_levels", C.c_int32), ("nr_feat_per_level", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("coarsest_scale", C.c_float), ("finest_scale", C.c_float),
                 ("level_scale", C.c_float * 48), ("skip_mode", C.c_int32), ("matmul_mode", C.c_int32),
-                ("tri_resolution", C.c_int32), ("tri_mode", C.c_int32)]
+                ("tri_resolution", C.c_int32), ("tri_mode", C.c_int32),
+                ("activation_stash", C.c_int32), ("hash_grad_atomics", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -250,6 +251,8 @@ def check(rc, what=""):
 # struct builders from plain python values / raw device addresses
 # ------------------------------------------------------------------------------------------------
 SKIP = {"no": 0, "add": 1, "concat": 2}
+STASH = {"full": 0, "half": 1}               # ngm_activation_stash
+HASH_ATOMICS = {"exact": 0, "float": 1}      # ngm_hash_grad_atomics
 MATMUL = {"f32": 0, "bf16x3": 1, "auto": 2}
 
 

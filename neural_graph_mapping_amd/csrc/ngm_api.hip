@@ -226,6 +226,10 @@ static int check_field_cfg(const ngm_field_cfg* fc) {
   // the encoding in the hidden units (the reference adds out[..., :D] += encoding: D <= H)
   if (fc->skip_mode == NGM_SKIP_ADD && fc->dim_hidden < fc->dim_enc)
     return fail(NGM_E_UNSUPPORTED, "skip_mode add: needs dim_hidden >= dim_enc");
+  if (fc->activation_stash != NGM_STASH_FULL && fc->activation_stash != NGM_STASH_HALF)
+    return fail(NGM_E_INVALID, "activation_stash: NGM_STASH_FULL / NGM_STASH_HALF (ABI 10: is the struct the caller built 276 bytes?)");
+  if (fc->hash_grad_atomics != NGM_HASH_ATOMICS_EXACT && fc->hash_grad_atomics != NGM_HASH_ATOMICS_FLOAT)
+    return fail(NGM_E_INVALID, "hash_grad_atomics: NGM_HASH_ATOMICS_EXACT / NGM_HASH_ATOMICS_FLOAT");
   return NGM_OK;
 }
 static int check_params(const ngm_field_cfg* fc, const ngm_params* pr) {
@@ -637,19 +641,21 @@ static int act_stash_kind(const ngm_field_cfg* fc) {
 // ngm_render_bwd* (which see the same fcfg and rays) agree; the forward's choice is also recorded per workspace.
 // NGM_FULL_STASH=1: both layers, as before (A/B, and what every other backward kernel reads).
 // NGM_STASH=full | half | planes overrides the default (A/B on one box); NGM_FULL_STASH=1 = NGM_STASH=full.
+// ABI 10: the mode is ngm_field_cfg.activation_stash; the override below is a developer A/B switch only (tools/)
 static int g_stash_override = -1;      // ngm_debug_stash_mode
-static int stash_pref() {
+static int stash_pref(const ngm_field_cfg* fc) {
   if (g_stash_override >= 0) return g_stash_override;
-  static const int pref = [] {
+  static const int env = [] {
     const char* e = getenv("NGM_STASH");
     if (getenv("NGM_FULL_STASH")) return 0;
-    if (!e) return NGM_STASH_DEFAULT;
-    return !strcmp(e, "full") ? 0 : !strcmp(e, "half") ? 1 : NGM_STASH_DEFAULT;
+    if (!e) return -1;
+    return !strcmp(e, "full") ? 0 : !strcmp(e, "half") ? 1 : -1;
   }();
-  return pref;
+  if (env >= 0) return env;
+  return fc->activation_stash == NGM_STASH_HALF ? 1 : NGM_STASH_DEFAULT;
 }
 static bool half_stash_applies(const ngm_field_cfg* fc, int64_t P) {
-  if (stash_pref() == 0 || !bwd_b3_is_default() || fc->num_layers != 2 || act_stash_kind(fc) != 1) return false;
+  if (stash_pref(fc) == 0 || !bwd_b3_is_default() || fc->num_layers != 2 || act_stash_kind(fc) != 1) return false;
   FieldBwdArgs probe;
   memset(&probe, 0, sizeof(probe));
   probe.fc = *fc; probe.P = P; probe.act = reinterpret_cast<const float*>(1);
@@ -850,6 +856,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   if (!workspace || workspace_bytes < p.total) return fail(NGM_E_WORKSPACE, "render_bwd: workspace too small");
   char* ws = reinterpret_cast<char*>(align_up((int64_t)workspace, 256));
   sb.rc = *rcfg; sb.F = rays->F; sb.R = rays->R; sb.S = p.S;
+  if (!rays->gt) sb.rc.w_freespace = sb.rc.w_tsdf = 0.f;       // no gt: the reference forms no free-space / TSDF terms (rm.py:624, 632)
   sb.stashA = reinterpret_cast<float4*>(ws + p.off_stashA);
   sb.stashB = reinterpret_cast<const float2*>(ws + p.off_stashB);
   sb.raytab = reinterpret_cast<const float*>(ws + p.off_raytab);
@@ -892,7 +899,7 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   int e = 0;
   const FieldBwdArgs a_plain = a;            // for the fall-back below: the launch records before the fused fields are set
   if (fuse) {
-    a.fused_comp = 1; a.rc = *rcfg;
+    a.fused_comp = 1; a.rc = sb.rc;
     a.rayseed = reinterpret_cast<const float*>(ws + p.off_rayseed);
     a.loss_sums = sb.loss_sums; a.loss_partials = sb.loss_partials; a.n_partials = sb.n_partials;
     a.sums_out = sb.sums_out; a.loss_out = sb.loss_out; a.counter = sb.counter;
@@ -1188,7 +1195,7 @@ int ngm_ipc_close(void* ptr) {
 }
 int ngm_debug_last_stash_mode(void) { return g_last_stash_mode; }
 int ngm_debug_stash_mode(int mode) {
-  const int prev = stash_pref();
+  const int prev = g_stash_override;
   if (mode >= 0 && mode <= 1) g_stash_override = mode;
   else if (mode == -2) g_stash_override = -1;
   return prev;

@@ -1169,7 +1169,7 @@ int ngm_launch_stash_bwd(const StashBwdArgs& a, hipStream_t st) {
 
 // ================================================================================================
 // loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination,
-// photometric, depth, freespace, tsdf.  Empty selections contribute 0 (the reference yields NaN).
+// photometric, depth, freespace, tsdf.  Empty selections: NaN, as the reference (loss_values_from_sums).
 // ================================================================================================
 __global__ void k_loss_values(ngm_render_cfg rc, const float* sums, float* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -584,24 +584,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // loss scalars from the global sums (rm.py:1803-1871); out[0..5] = combined, termination, photometric, depth, freespace,
-// tsdf.  Empty selections contribute 0 (the reference yields NaN).
+// tsdf.  An EMPTY selection gives NaN for its term and for `combined`, exactly as the reference's `.mean()` of an empty
+// tensor does (rm.py:1803-1835; 0 * NaN = NaN for a zero weight too) -- the VALUES only: the gradient of an empty mean is
+// empty, so the normalisers of the backward (k = 0 for an empty selection) already were the reference's.  The free-space /
+// TSDF terms exist only with a non-zero weight (rm.py:624, 632, 1847-1871; callers zero the weights when the rays carry no gt).
 // photometric gaussian_nll: the reference returns the L1 loss instead whenever the mean NLL exceeds 2 (losses.py:34-35) -- a
 // decision on the GLOBAL mean, i.e. on the (all-reduced) sums; loss value and gradient seeds both follow it
 __device__ __forceinline__ bool photo_nll_uses_l1(const ngm_render_cfg& rc, const float* sums) {
   const float n_m = sums[NGM_LS_PHOTO_CNT];
-  return rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL && n_m > 0 && sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) > 2.0f;
+  return rc.photometric_mode == NGM_PHOTO_GAUSSIAN_NLL && n_m > 0 && sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) > 2.0f;   // NaN > 2 is false
 }
 __device__ __forceinline__ void loss_values_from_sums(const ngm_render_cfg& rc, const float* sums, float* out) {
   const float n_m = sums[NGM_LS_PHOTO_CNT], n_d = sums[NGM_LS_DEPTH_CNT], n_t = sums[NGM_LS_TERM_CNT],
               n_fs = sums[NGM_LS_FS_CNT], n_ts = sums[NGM_LS_TSDF_CNT];
-  const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : 0.f;
-  float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : 0.f;
+  const float nan = __builtin_nanf("");
+  const float lt = n_t > 0 ? sums[NGM_LS_TERM_SUM] / n_t : nan;
+  float lp = n_m > 0 ? sums[NGM_LS_PHOTO_SUM] / (3.0f * n_m) : nan;
   if (photo_nll_uses_l1(rc, sums)) lp = sums[NGM_LS_PHOTO_L1_SUM] / (3.0f * n_m);       // losses.py:34-35
-  const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : 0.f;
-  const float lf = n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : 0.f;
-  const float ls = n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : 0.f;
+  const float ld = n_d > 0 ? sums[NGM_LS_DEPTH_SUM] / n_d : nan;
+  const bool has_fs = rc.w_freespace != 0.f, has_ts = rc.w_tsdf != 0.f;
+  const float lf = has_fs ? (n_fs > 0 ? sums[NGM_LS_FS_SUM] / n_fs : nan) : 0.f;
+  const float ls = has_ts ? (n_ts > 0 ? sums[NGM_LS_TSDF_SUM] / n_ts : nan) : 0.f;
   out[1] = lt; out[2] = lp; out[3] = ld; out[4] = lf; out[5] = ls;
-  out[0] = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld + rc.w_freespace * lf + rc.w_tsdf * ls;
+  float total = rc.w_termination * lt + rc.w_photometric * lp + rc.w_depth * ld;
+  if (has_fs) total += rc.w_freespace * lf;
+  if (has_ts) total += rc.w_tsdf * ls;
+  out[0] = total;
   out[6] = 0.f; out[7] = 0.f;
 }
 

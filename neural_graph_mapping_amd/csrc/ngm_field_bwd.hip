@@ -740,159 +740,213 @@ struct HashGradArgs {
   float ad_lr, ad_beta1, ad_beta2, ad_eps, ad_wd;
 };
 
-__global__ __launch_bounds__(512) void k_hash_grad(HashGradArgs a) {
-  // Q23.40 fixed point in LDS: integer LDS atomics run at full bank rate (fp32 LDS atomics measured ~2.5
-  // cycles per LANE regardless of address) and make the table gradient order-independent -> deterministic.
-  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
-  // 1-D grid, decoded so that blocks id and id + total / 2 -- which share a CU when total / 2 = the number of CUs, two
-  // blocks being resident per CU -- work on levels l and L - 1 - l: a coarse level (long runs: the segmented scans run)
-  // costs ~1.5x a fine one, and two coarse blocks on one CU set the kernel's time
-  int chunk, level, f;
+// FLT = false (NGM_HASH_ATOMICS_EXACT, the default): Q23.40 fixed point in LDS -- integer LDS atomics run at full bank rate
+// and make the table gradient order-independent -> bitwise reproducible.  FLT = true (NGM_HASH_ATOMICS_FLOAT, opt-in): plain
+// fp32 LDS atomics (ds_add_f32), what the reference's CUDA package does with global float atomics: no fixed-point conversion
+// (88 of ~300 vector instructions per sample-level), half the LDS per workgroup (32 KB per level: four workgroups per CU
+// instead of two), the sums in whatever order the adds land -- not reproducible run to run.
+template <bool FLT> struct HashAcc { using T = unsigned long long; };
+template <> struct HashAcc<true> { using T = float; };
+template <bool FLT>
+__device__ __forceinline__ float hash_acc_value(typename HashAcc<FLT>::T v) {
+  if constexpr (FLT) return v;
+  else return (float)((double)(long long)v * (1.0 / 1099511627776.0));
+}
+// NL = levels per workgroup.  NL = 2 (round 6 experiment, NGM_HASH_PAIR=1; NOT the default: 2 us slower): a workgroup of 1024
+// threads owns the level PAIR (l, L - 1 - l) of its (field, chunk) with both tables in LDS (2 x 64 KB): the position of a
+// sample is read once for two levels (384 -> 256 B per sample over the 16 levels) and a thread carries two independent
+// simplex searches.  Measured equal-to-slower than one level per workgroup: the loop is not bound by its loads.
+template <bool FLT, int NL, int NT = 512 * NL>
+__global__ __launch_bounds__(NT) void k_hash_grad(HashGradArgs a) {
+  using acc_t = typename HashAcc<FLT>::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tab_raw[];
+  acc_t* tab = reinterpret_cast<acc_t*>(tab_raw);
+  int chunk, f, level[NL];
   {
     const int nlev = a.fc.nr_levels, total = gridDim.x, id = blockIdx.x;
-    if ((nlev & 1) == 0) {
+    if constexpr (NL == 2) {
+      chunk = id % a.chunks;
+      const int r = id / a.chunks, lh = r % (nlev / 2);
+      f = r / (nlev / 2);
+      level[0] = lh; level[1] = nlev - 1 - lh;
+    } else if ((nlev & 1) == 0) {
+      // 1-D grid, decoded so that blocks id and id + total / 2 -- which share a CU when total / 2 = the number of CUs, two
+      // blocks being resident per CU -- work on levels l and L - 1 - l: a coarse level (long runs: the segmented scans run)
+      // costs ~1.5x a fine one, and two coarse blocks on one CU set the kernel's time
       const int half = id >= total / 2, j = id - half * (total / 2);
       chunk = j % a.chunks;
       const int r = j / a.chunks, lh = r % (nlev / 2);
       f = r / (nlev / 2);
-      level = half ? nlev - 1 - lh : lh;
+      level[0] = half ? nlev - 1 - lh : lh;
     } else {
       chunk = id % a.chunks;
-      level = (id / a.chunks) % nlev;
+      level[0] = (id / a.chunks) % nlev;
       f = id / (a.chunks * nlev);
     }
   }
   const int T = 1 << a.fc.log2_hashmap_size;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
-  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) tab[i] = 0ull;
-  // Adam's bias corrections (two double-precision pow) once per workgroup, up front, by one thread -- not by all 512 in the
-  // epilogue; read back after the barrier that ends the sample loop
+  for (int i = threadIdx.x; i < NL * 2 * T; i += blockDim.x) tab[i] = acc_t(0);
+  // Adam's bias corrections (two double-precision pow) once per workgroup, up front, by one thread -- not by every thread in
+  // the epilogue; read back after the barrier that ends the sample loop
   __shared__ float adam_c[2];
   if (a.chunks == 1 && a.ad_param && threadIdx.x == 0) {
     const double step = (double)(a.ad_step_dev ? *a.ad_step_dev : a.ad_step);
     adam_c[0] = (float)((double)a.ad_lr / (1.0 - pow((double)a.ad_beta1, step)));
     adam_c[1] = (float)(1.0 / sqrt(1.0 - pow((double)a.ad_beta2, step)));
   }
-  float lp[8];
-  {
-    const float* hs = a.pr.shift + row * a.pr.shift_stride + 3 * level;
-    lp[0] = a.fc.level_scale[3 * level]; lp[1] = a.fc.level_scale[3 * level + 1]; lp[2] = a.fc.level_scale[3 * level + 2];
-    lp[3] = 0.f; lp[4] = hs[0]; lp[5] = hs[1]; lp[6] = hs[2]; lp[7] = 0.f;
+  float lp[NL][8];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    const float* hs = a.pr.shift + row * a.pr.shift_stride + 3 * level[q];
+    lp[q][0] = a.fc.level_scale[3 * level[q]]; lp[q][1] = a.fc.level_scale[3 * level[q] + 1]; lp[q][2] = a.fc.level_scale[3 * level[q] + 2];
+    lp[q][3] = 0.f; lp[q][4] = hs[0]; lp[q][5] = hs[1]; lp[q][6] = hs[2]; lp[q][7] = 0.f;
   }
   __syncthreads();
   const int64_t NP = (int64_t)a.F * a.P;
   const int64_t beg = (int64_t)chunk * a.per_chunk, end = min(a.P, beg + a.per_chunk);
   const uint32_t mask = (uint32_t)T - 1u;
   const int lane = threadIdx.x & 63;
-  // the next iteration's position and gradient travel while this one is worked on (few waves per SIMD: a load issued
+  // the next iteration's position and gradients travel while this one is worked on (few waves per SIMD: a load issued
   // where it is used exposes the whole HBM latency once per iteration)
   float4 p_nx = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 d_nx = make_float2(0.f, 0.f);
+  float2 d_nx[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) d_nx[q] = make_float2(0.f, 0.f);
   if (beg + threadIdx.x < end) {
     const int64_t g = (int64_t)f * a.P + beg + threadIdx.x;
     p_nx = a.xyz[g];
-    d_nx = a.dE[level * NP + g];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) d_nx[q] = a.dE[level[q] * NP + g];
   }
   for (int64_t s0 = beg; s0 < end; s0 += blockDim.x) {      // trip count uniform across the wave (shuffles inside)
     const int64_t s = s0 + threadIdx.x;
     const bool valid = s < end;
-    uint32_t idx[4] = {0u, 0u, 0u, 0u}; float bw[4] = {0.f, 0.f, 0.f, 0.f};
-    float2 d = make_float2(0.f, 0.f);
     const float4 p = p_nx;
-    if (valid) d = d_nx;
+    float2 dq[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) dq[q] = valid ? d_nx[q] : make_float2(0.f, 0.f);
     if (s + blockDim.x < end) {
       const int64_t g = (int64_t)f * a.P + s + blockDim.x;
       p_nx = a.xyz[g];
-      d_nx = a.dE[level * NP + g];
+#pragma unroll
+      for (int q = 0; q < NL; ++q) d_nx[q] = a.dE[level[q] * NP + g];
     }
-    if (valid) {
+    uint32_t idxq[NL][4]; float bwq[NL][4];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { idxq[q][r] = 0u; bwq[q][r] = 0.f; }
+      if (valid) {
 #ifdef NGM_ABLH_NOSIMPLEX   // timing ablations of k_hash_grad (results meaningless when defined)
-      idx[0] = (uint32_t)(p.x * 1000.f) & mask; idx[1] = (idx[0] + 1) & mask; idx[2] = (idx[0] + 2) & mask; idx[3] = (idx[0] + 3) & mask;
-      bw[0] = p.x; bw[1] = p.y; bw[2] = p.z; bw[3] = 1.f - p.x;
+        idxq[q][0] = (uint32_t)(p.x * 1000.f) & mask; idxq[q][1] = (idxq[q][0] + 1) & mask; idxq[q][2] = (idxq[q][0] + 2) & mask; idxq[q][3] = (idxq[q][0] + 3) & mask;
+        bwq[q][0] = p.x; bwq[q][1] = p.y; bwq[q][2] = p.z; bwq[q][3] = 1.f - p.x;
 #else
-      permuto_simplex(p.x, p.y, p.z, lp, mask, idx, bw);
+        permuto_simplex(p.x, p.y, p.z, lp[q], mask, idxq[q], bwq[q]);
 #endif
+      }
     }
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      acc_t* tq = tab + (size_t)q * 2 * T;
+      const uint32_t (&idx)[4] = idxq[q];
+      const float (&bw)[4] = bwq[q];
+      const float2 d = dq[q];
 #ifdef NGM_ABLH_NOSCATTER
-    if (valid) { tab[threadIdx.x] += (unsigned long long)(idx[0] + idx[1] + idx[2] + idx[3]) + to_fix(d.x * bw[0] + d.y * bw[1] + bw[2] + bw[3]); }
-    continue;
+      if (valid) { tq[threadIdx.x] += acc_t(idx[0] + idx[1] + idx[2] + idx[3]) + acc_t(to_fix(d.x * bw[0] + d.y * bw[1] + bw[2] + bw[3])); }
+      continue;
 #endif
-    // consecutive lanes = consecutive samples of a ray: at coarse levels they sit in the same simplex in long
-    // runs, which would serialise the LDS atomic unit (measured 163 LDS cycles per ds_add_f32).  Reduce each run
-    // inside the wave first (segmented scans; a run = lanes whose four vertices all repeat the previous lane's, so
-    // one run structure serves the 8 sums) and let its last lane issue the atomics.
-    bool same = valid && lane > 0;
+      // consecutive lanes = consecutive samples of a ray: at coarse levels they sit in the same simplex in long
+      // runs, which would serialise the LDS atomic unit (measured 163 LDS cycles per ds_add_f32).  Reduce each run
+      // inside the wave first (segmented scans; a run = lanes whose four vertices all repeat the previous lane's, so
+      // one run structure serves the 8 sums) and let its last lane issue the atomics.
+      bool same = valid && lane > 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t key = valid ? idx[r] : 0xffffffffu;
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)key, NGM_DPP_WAVE_SHR1, 0xf, 0xf, false);
-      same = same && (key == prev);
-    }
-    const unsigned long long hm = __ballot(!same);
-    float v[8];
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t key = valid ? idx[r] : 0xffffffffu;
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)key, NGM_DPP_WAVE_SHR1, 0xf, 0xf, false);
+        same = same && (key == prev);
+      }
+      const unsigned long long hm = __ballot(!same);
+      float v[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v[2 * r] = d.x * bw[r]; v[2 * r + 1] = d.y * bw[r]; }
-    bool issue = valid;
-    if (__popcll(hm) <= 40) {                                   // wave-uniform
-      const unsigned long long below = hm & ((2ull << lane) - 1ull);
-      const int k = lane - (63 - __clzll(below));
-      seg_scan_add_n<8>(v, k, lane);
-      issue = valid && ((lane == 63) || ((hm >> (lane + 1)) & 1ull));
-    }
-    if (issue) {
+      for (int r = 0; r < 4; ++r) { v[2 * r] = d.x * bw[r]; v[2 * r + 1] = d.y * bw[r]; }
+      bool issue = valid;
+#ifdef NGM_ABLH_NOMERGE      // timing ablation: every lane issues its own atomics
+      if (false) {
+#else
+      if (__popcll(hm) <= 40) {                                   // wave-uniform
+#endif
+        const unsigned long long below = hm & ((2ull << lane) - 1ull);
+        const int k = lane - (63 - __clzll(below));
+        seg_scan_add_n<8>(v, k, lane);
+        issue = valid && ((lane == 63) || ((hm >> (lane + 1)) & 1ull));
+      }
+      if (issue) {
+        if constexpr (FLT) {
+          // no-return fp32 LDS atomics: ds_add_f32 (checked in the disassembly: no CAS loop)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { atomicAdd(&tab[idx[r]], to_fix(v[2 * r])); atomicAdd(&tab[T + idx[r]], to_fix(v[2 * r + 1])); }
+          for (int r = 0; r < 4; ++r) { atomicAdd(&tq[idx[r]], v[2 * r]); atomicAdd(&tq[T + idx[r]], v[2 * r + 1]); }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { atomicAdd(&tq[idx[r]], to_fix(v[2 * r])); atomicAdd(&tq[T + idx[r]], to_fix(v[2 * r + 1])); }
+        }
+      }
     }
   }
   __syncthreads();
   // LDS holds one plane per feature (8-byte stride: the 64 lanes of an atomic spread over 32 bank pairs; interleaved, 16-byte
   // entries reach only 16); tables are written in the parameter layout [entry][feature]
-  if (a.chunks == 1) {
-    // This workgroup saw EVERY sample of its (field, level): its LDS table is the gradient.  It is written where
-    // k_hash_reduce would have put it, and the sparse Adam of that table follows right here -- no partial table through HBM
-    // (2 x 32 KB per level and field), no k_hash_reduce launch.  (The reference's default iteration: 32 fields x 16 levels =
-    // 512 workgroups = two per CU; the M1 batch has 4 chunks per level and keeps the reduction kernel.)
-    float* gdst = a.gtab + (int64_t)f * a.gstride + (int64_t)level * T * 2;
-    float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
-    int64_t prow = 0;
-    if (a.ad_param) {
-      lr_bc1 = adam_c[0]; inv_sqrt_bc2 = adam_c[1];
-      prow = (a.ad_field_index ? a.ad_field_index[f] : f) * a.ad_stride + (int64_t)level * T * 2;
-    }
-    for (int i4 = threadIdx.x; i4 < T / 2; i4 += blockDim.x) {            // float4 = two entries x two features
-      const int e0 = 2 * i4;
-      float4 s4;
-      s4.x = (float)((double)(long long)tab[e0] * (1.0 / 1099511627776.0));
-      s4.y = (float)((double)(long long)tab[T + e0] * (1.0 / 1099511627776.0));
-      s4.z = (float)((double)(long long)tab[e0 + 1] * (1.0 / 1099511627776.0));
-      s4.w = (float)((double)(long long)tab[T + e0 + 1] * (1.0 / 1099511627776.0));
-      reinterpret_cast<float4*>(gdst)[i4] = s4;
-      if (a.ad_param) {                                                     // same arithmetic as k_hash_reduce / k_adam_multi
-        const int64_t o4 = prow / 4 + i4;                                   // tables are 16-byte aligned rows (checked by the launcher)
-        float4 p = reinterpret_cast<float4*>(a.ad_param)[o4], m = reinterpret_cast<float4*>(a.ad_m)[o4],
-               v = reinterpret_cast<float4*>(a.ad_v)[o4];
-        float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &s4.x;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float g = pg[c] + a.ad_wd * pp[c];
-          const float mn = a.ad_beta1 * pm[c] + (1.0f - a.ad_beta1) * g;
-          const float vn = a.ad_beta2 * pv[c] + (1.0f - a.ad_beta2) * g * g;
-          pm[c] = mn; pv[c] = vn;
-          pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.ad_eps));
-        }
-        reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
-        reinterpret_cast<float4*>(a.ad_param)[o4] = p;
-        if (a.ad_lp) {
+  for (int q = 0; q < NL; ++q) {
+    const acc_t* tq = tab + (size_t)q * 2 * T;
+    const int lv = level[q];
+    if (a.chunks == 1) {
+      // This workgroup saw EVERY sample of its (field, level): its LDS table is the gradient.  It is written where
+      // k_hash_reduce would have put it, and the sparse Adam of that table follows right here -- no partial table through HBM
+      // (2 x 32 KB per level and field), no k_hash_reduce launch.  (The reference's default iteration: 32 fields x 16 levels =
+      // one chunk per level; the M1 batch has 4 chunks per level and keeps the reduction kernel.)
+      float* gdst = a.gtab + (int64_t)f * a.gstride + (int64_t)lv * T * 2;
+      float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
+      int64_t prow = 0;
+      if (a.ad_param) {
+        lr_bc1 = adam_c[0]; inv_sqrt_bc2 = adam_c[1];
+        prow = (a.ad_field_index ? a.ad_field_index[f] : f) * a.ad_stride + (int64_t)lv * T * 2;
+      }
+      for (int i4 = threadIdx.x; i4 < T / 2; i4 += blockDim.x) {            // float4 = two entries x two features
+        const int e0 = 2 * i4;
+        float4 s4;
+        s4.x = hash_acc_value<FLT>(tq[e0]);
+        s4.y = hash_acc_value<FLT>(tq[T + e0]);
+        s4.z = hash_acc_value<FLT>(tq[e0 + 1]);
+        s4.w = hash_acc_value<FLT>(tq[T + e0 + 1]);
+        reinterpret_cast<float4*>(gdst)[i4] = s4;
+        if (a.ad_param) {                                                     // same arithmetic as k_hash_reduce / k_adam_multi
+          const int64_t o4 = prow / 4 + i4;                                   // tables are 16-byte aligned rows (checked by the launcher)
+          float4 p = reinterpret_cast<float4*>(a.ad_param)[o4], m = reinterpret_cast<float4*>(a.ad_m)[o4],
+                 v = reinterpret_cast<float4*>(a.ad_v)[o4];
+          float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &s4.x;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) ngm_stp(a.ad_lp, 4 * o4 + c, pp[c], a.ad_lp_dt);
+          for (int c = 0; c < 4; ++c) {
+            const float g = pg[c] + a.ad_wd * pp[c];
+            const float mn = a.ad_beta1 * pm[c] + (1.0f - a.ad_beta1) * g;
+            const float vn = a.ad_beta2 * pv[c] + (1.0f - a.ad_beta2) * g * g;
+            pm[c] = mn; pv[c] = vn;
+            pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.ad_eps));
+          }
+          reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
+          reinterpret_cast<float4*>(a.ad_param)[o4] = p;
+          if (a.ad_lp) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ngm_stp(a.ad_lp, 4 * o4 + c, pp[c], a.ad_lp_dt);
+          }
         }
       }
+    } else {
+      float* dst = a.part + (((int64_t)f * a.fc.nr_levels + lv) * a.chunks + chunk) * 2 * T;
+      for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) dst[i] = hash_acc_value<FLT>(tq[(i & 1) * T + (i >> 1)]);
     }
-    return;
   }
-  float* dst = a.part + (((int64_t)f * a.fc.nr_levels + level) * a.chunks + chunk) * 2 * T;
-  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x)
-    dst[i] = (float)((double)(long long)tab[(i & 1) * T + (i >> 1)] * (1.0 / 1099511627776.0));
 }
 
 // gtab[f][level][i] = sum over chunks (fixed order): overwrites -> no zero-fill of the gradient needed
@@ -939,11 +993,19 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
   a.fc = fb.fc; a.pr = fb.pr; a.F = fb.F; a.P = fb.P; a.dE = fb.hash_dE; a.xyz = fb.hash_xyz;
   a.gtab = fb.lattice_grad; a.gstride = fb.lattice_grad_stride;
   const int T = 1 << fb.fc.log2_hashmap_size;
-  const size_t lds = (size_t)2 * T * sizeof(unsigned long long);
-  if (lds > 150 * 1024) return NGM_E_UNSUPPORTED;
-  // 2 blocks per CU = exactly what is resident at a time (64 KB of LDS each), one round: with the coarse / fine level
-  // pairing of k_hash_grad's block decoding the CUs finish together (M1 hash batch, kernel time: 4 chunks 99 us, 6: 100,
-  // 8: 102, 5: 115; before the pairing 4 chunks cost 118 -- two coarse levels on one CU)
+  const bool flt = fb.fc.hash_grad_atomics == NGM_HASH_ATOMICS_FLOAT;
+  const size_t lds1 = (size_t)2 * T * (flt ? sizeof(float) : sizeof(unsigned long long));
+  if (lds1 > 150 * 1024) return NGM_E_UNSUPPORTED;
+  // level pairs (k_hash_grad<., 2>): both tables of a pair in one workgroup's LDS.  NGM_HASH_PAIR=0: one level per workgroup
+  // (the round-5 kernel; A/B inside one library)
+  static const bool pair_on = getenv("NGM_HASH_PAIR") != nullptr && atoi(getenv("NGM_HASH_PAIR")) == 1;
+  const bool pair = pair_on && (fb.fc.nr_levels & 1) == 0 && 2 * lds1 <= 150 * 1024;
+  const size_t lds = pair ? 2 * lds1 : lds1;
+  const int units = (int)fb.F * (pair ? fb.fc.nr_levels / 2 : fb.fc.nr_levels);      // (field, level) or (field, level pair)
+  // One level per workgroup: 2 blocks per CU = exactly what is resident at a time (64 KB of LDS each), one round: with the
+  // coarse / fine level pairing of the block decoding the CUs finish together (M1 hash batch, kernel time: 4 chunks 99 us,
+  // 6: 100, 8: 102, 5: 115; before the pairing 4 chunks cost 118 -- two coarse levels on one CU).  Level pairs: one
+  // 1024-thread workgroup per CU.
   int ncu = 256;
   {
     int dev = 0;
@@ -953,7 +1015,8 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
       cached = prop.multiProcessorCount;
     if (cached) ncu = cached;
   }
-  int chunks = (int)((2 * ncu + (int64_t)fb.F * fb.fc.nr_levels - 1) / ((int64_t)fb.F * fb.fc.nr_levels));
+  const int slots = pair ? ncu : 2 * ncu;
+  int chunks = (int)((slots + (int64_t)units - 1) / (int64_t)units);
   const int64_t max_chunks = (fb.P + 4095) / 4096;
   if (chunks > max_chunks) chunks = (int)max_chunks;
   if (chunks < 1) chunks = 1;
@@ -976,10 +1039,22 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
       a.ad_eps = fb.lattice_adam.eps; a.ad_wd = fb.lattice_adam.wd;
     }
   }
-  (void)hipFuncSetAttribute((const void*)k_hash_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   {
     NgmProfScope prof_(NGM_K_HASH_GRAD, st);
-    hipLaunchKernelGGL(k_hash_grad, dim3(chunks * fb.fc.nr_levels * fb.F), dim3(512), lds, st, a);
+#define NGM_HG(FLT_, NL_, NT_)                                                                                                  \
+    do {                                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)k_hash_grad<FLT_, NL_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((k_hash_grad<FLT_, NL_, NT_>), dim3(chunks * units), dim3(NT_), lds, st, a);                            \
+    } while (0)
+    // Round 6 A/B on one box (profiles/r06_hash_ablation.txt), M1 hash batch at 2397 MHz: one level per workgroup, 512 threads
+    // (two resident workgroups = 4 waves per SIMD) 76.7 us; 1024 threads (8 waves per SIMD) 84.9 us; level pairs 78.8 us.  More
+    // waves do not help (the LDS atomic unit is shared by them), sharing the position load does not either (the loop is bound
+    // by its own instructions, not by the loads).  NGM_HASH_THREADS=1024 / NGM_HASH_PAIR=1 reproduce the comparison.
+    static const bool wide = getenv("NGM_HASH_THREADS") != nullptr && atoi(getenv("NGM_HASH_THREADS")) == 1024;
+    if (pair) { if (flt) NGM_HG(true, 2, 1024); else NGM_HG(false, 2, 1024); }
+    else if (wide) { if (flt) NGM_HG(true, 1, 1024); else NGM_HG(false, 1, 1024); }
+    else { if (flt) NGM_HG(true, 1, 512); else NGM_HG(false, 1, 512); }
+#undef NGM_HG
   }
   if (chunks > 1) {        // one chunk: k_hash_grad wrote the gradient table and applied the update itself
     NgmProfScope prof_(NGM_K_HASH_REDUCE, st);

@@ -243,15 +243,20 @@ def loss_values_from_sums(s: torch.Tensor, w_term, w_photo, w_depth, w_fs, w_tsd
     """rm.py:1803-1871 from the global sums (slot layout: include/ngm_hip.h ngm_loss_slot); the photometric / depth
     keys carry the mode like rm.py:1827, 1837 (the sums already are of |e| or e^2, whichever the kernels were told)."""
     def mean(num, den, scale=1.0):
-        return torch.where(den > 0, num / (scale * den.clamp_min(1.0)), torch.zeros_like(num))
+        # an empty selection is NaN, as the reference's `.mean()` of an empty tensor (rm.py:1803-1835)
+        return torch.where(den > 0, num / (scale * den.clamp_min(1.0)), torch.full_like(num, float("nan")))
     pk, dk = "photometric_" + photometric_loss, "depth_" + depth_loss
     photo = mean(s[0], s[1], 3.0)
     if photometric_loss == "gaussian_nll":                 # losses.py:34-35: the L1 loss whenever the mean NLL exceeds 2
         photo = torch.where(photo > 2.0, mean(s[10], s[1], 3.0), photo)
-    out = {pk: photo, dk: mean(s[2], s[3]), "freespace": mean(s[4], s[5]),
-           "tsdf": mean(s[6], s[7]), "termination": mean(s[8], s[9])}
-    out["combined"] = (w_term * out["termination"] + w_photo * out[pk] + w_depth * out[dk]
-                       + w_fs * out["freespace"] + w_tsdf * out["tsdf"])
+    zero = torch.zeros_like(s[0])
+    out = {pk: photo, dk: mean(s[2], s[3]), "freespace": mean(s[4], s[5]) if w_fs != 0.0 else zero,
+           "tsdf": mean(s[6], s[7]) if w_tsdf != 0.0 else zero, "termination": mean(s[8], s[9])}
+    out["combined"] = w_term * out["termination"] + w_photo * out[pk] + w_depth * out[dk]
+    if w_fs != 0.0:                                        # the terms exist only with a non-zero weight (rm.py:1847-1871)
+        out["combined"] = out["combined"] + w_fs * out["freespace"]
+    if w_tsdf != 0.0:
+        out["combined"] = out["combined"] + w_tsdf * out["tsdf"]
     return out
 
 

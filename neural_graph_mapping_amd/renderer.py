@@ -113,13 +113,15 @@ class NeuralGraphRenderer:
         # 16x the matrix rate; fails loudly where not compiled); "auto" (default) = the split wherever it is compiled
         mm = config.get("mlp_matmul", "auto")
         self._fc.matmul_mode = K.MATMUL[mm]
-        # activation stash of two-hidden-layer networks on the split path (include/ngm_hip.h, ngm_debug_stash_mode): "full"
+        # activation stash of two-hidden-layer networks on the split path (include/ngm_hip.h, ngm_activation_stash): "full"
         # (default: both hidden layers' outputs, 512 B per sample, fastest) or "half" (layer 0's only, 256 B per sample: half
         # the stash memory and HBM traffic -- a 4096 x 128 x 32-field batch needs 4.3 instead of 8.6 GB --, the backward
-        # recomputes the other layer on the matrix pipe: step + 1.5-4 %).  PROCESS-wide switch of the library (it sizes the
-        # workspaces): set by the first renderer that names it, renderers that do not name it leave it alone.
-        if config.get("activation_stash") is not None:
-            K.lib().ngm_debug_stash_mode({"full": 0, "half": 1}[config["activation_stash"]])
+        # recomputes the other layer on the matrix pipe: step + 1.5-4 %).  Part of THIS renderer's field configuration
+        # (ABI 10): it sizes this renderer's workspaces; other renderers of the process are unaffected.
+        self._fc.activation_stash = K.STASH[config.get("activation_stash") or "full"]
+        # accumulation of the hash-table gradient (ngm_hash_grad_atomics): "exact" (default: Q23.40 integer LDS atomics, bitwise
+        # reproducible) or "float" (opt-in: fp32 LDS atomics like the reference's CUDA package -- not reproducible run to run)
+        self._fc.hash_grad_atomics = K.HASH_ATOMICS[config.get("hash_grad_atomics") or "exact"]
         fc = self._fc
         compiled = (fc.encoding in (K.ENC["fourier"], K.ENC["none"]) and fc.skip_mode == K.SKIP["no"] and 1 <= fc.num_layers <= 2
                     and 32 < fc.dim_enc <= 64 and 32 < fc.dim_hidden <= 64)

@@ -32,7 +32,7 @@ def golden():
 def pytest_sessionfinish(session, exitstatus):
     """-m gpu sessions: write what the oracle comparisons measured (gpu_common.MARGINS / KINK) to gpurun_out/parity_margins.txt"""
     gc = sys.modules.get("gpu_common")
-    if gc is None or not (gc.MARGINS or gc.KINK):
+    if gc is None or not (gc.MARGINS or gc.KINK or gc.SWEEPS):
         return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -49,6 +49,10 @@ def pytest_sessionfinish(session, exitstatus):
                      + ("  per_level=" + ",".join(f"{x:.2e}" for x in m["per_level"]) if "per_level" in m else "") + "\n")
             key = (m["name"], m["tol"])
             worst[key] = max(worst.get(key, 0.0), m["err"])
+        fh.write("# loss + gradient comparisons against the oracle per test function: instances run / instances that compared every loss "
+                 "term and every gradient / instances with an empty loss selection among them (NaN terms, as in the reference)\n")
+        for name, rec in sorted(gc.SWEEPS.items()):
+            fh.write(f"sweep {name}  compared={rec['compared']}/{rec['run']}  with_empty_selection={rec['empty']}\n")
         fh.write("# worst error per (tensor, bar) over the whole session\n")
         for (name, tol), e in sorted(worst.items()):
             fh.write(f"worst {name}  tol={tol:.1e}  err={e:.3e}  margin={tol / max(e, 1e-30):.1f}x\n")

@@ -15,8 +15,8 @@ def cu(d):
     return {k: v.to(DEV) for k, v in d.items()}
 
 
-def close(a, b, rtol=2e-4, atol=2e-5):
-    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol)
+def close(a, b, rtol=2e-4, atol=2e-5, equal_nan=False):
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol, equal_nan=equal_nan)
 
 
 # what the oracle comparisons actually measured, written by tests/conftest.py at the end of a -m gpu session to
@@ -24,6 +24,32 @@ def close(a, b, rtol=2e-4, atol=2e-5):
 # relative error next to its bar, and the share of rays kink_free_draws took out of a batch before the comparison
 MARGINS = []
 KINK = []
+SWEEPS = {}        # test function -> dict(run, compared, empty): parametrised sweep instances that reached the loss + gradient comparison
+
+
+def compare_losses(res, pred, t, rs, rtol=3e-4, atol=1e-6):
+    """Loss dict of the fused iteration against `O.compute_losses` on the oracle's prediction, term by term, and the bookkeeping
+    of the randomised sweeps.  A loss term whose selection is EMPTY is NaN in the reference (`.mean()` of an empty tensor,
+    rm.py:1803-1835) and makes `combined` NaN -- here too, compared as such --, while its gradient is empty: the gradients of
+    the other terms stay finite in the reference and are compared by the caller against the oracle's backward like in any other
+    case (no early return: every instance of a sweep compares its gradients).  Returns (oracle loss dict, empty term names)."""
+    n = dict(photometric=int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum()), termination=int(t["term_mask"].sum()))
+    if pred["freespace_geometry"] is not None:
+        n["freespace"] = pred["freespace_geometry"].numel()
+    if pred["tsdf_residuals"] is not None:
+        n["tsdf"] = pred["tsdf_residuals"].numel()
+    empty = sorted(k for k, v in n.items() if v == 0)
+    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
+    for k, v in loss.items():
+        sel = "photometric" if k.startswith(("photometric_", "depth_")) else k       # both read the selection m (rm.py:1787-1788)
+        assert bool(torch.isnan(v)) == (bool(empty) if k == "combined" else sel in empty), (k, empty)
+        close(res[k], v.detach(), rtol=rtol, atol=atol, equal_nan=True)
+    rec = SWEEPS.setdefault(_test_id().split("[")[0], dict(run=0, compared=0, empty=0))
+    rec["run"] += 1
+    rec["compared"] += 1
+    rec["empty"] += bool(empty)
+    return loss, empty
+
 
 
 def _test_id():
@@ -289,13 +315,8 @@ def ragged_case(F, R, n_c, n_g, fkw, geometry_mode="nrgbd", geometry_factor=20.0
                                    update=False)
     close(res["prediction"].rgbds, pred["rgbds"].detach(), **(fwd_tol or {}))
     close(res["prediction"].term_probs, pred["term_probs"].detach(), **(fwd_tol or {}))
-    n_m = int((t["depth_mask"] & (pred["term_probs"] > 0.8)).sum())
-    n_fs, n_ts, n_t = pred["freespace_geometry"].numel(), pred["tsdf_residuals"].numel(), int(t["term_mask"].sum())
-    if min(n_m, n_fs, n_ts, n_t) == 0:
-        return                        # reference yields NaN for empty selections; we contribute 0 (documented)
-    loss = O.compute_losses(pred, t["rgbds"], t["depth_mask"], t["term_mask"], t["term_probs"], rs)
-    close(res["combined"], loss["combined"].detach(), rtol=3e-4 if fwd_tol is None else 10 * fwd_tol["rtol"], atol=1e-6)
-    loss["combined"].backward()
+    loss, _ = compare_losses(res, pred, t, rs, rtol=3e-4 if fwd_tol is None else 10 * fwd_tol["rtol"])
+    loss["combined"].backward()        # NaN value or not: the oracle's backward is finite (an empty mean has an empty gradient)
     for k in po:
         grad_close(res["grads"][k], po[k].grad, grad_tol, k)
 

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(capi):
         assert hasattr(L, n), f"{n} declared in include/ngm_hip.h but not exported"
     assert sorted(capi.EXPORTED) == names
     want = int(re.search(r"#define\s+NGM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert L.ngm_abi_version() == want == 9
+    assert L.ngm_abi_version() == want == 10
     L.ngm_peer_set_timeout.restype, L.ngm_peer_set_timeout.argtypes = C.c_double, [C.c_double]
     prev = L.ngm_peer_set_timeout(5.0)
     assert prev > 0 and L.ngm_peer_set_timeout(prev) == 5.0 and L.ngm_peer_set_timeout(0.0) == prev     # <= 0 only reads
@@ -76,7 +76,7 @@ def test_integration_md_level3_snippet_matches_the_library(capi, tmp_path):
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sz_fc, sz_p, off_tri, off_neus = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert C.sizeof(ns["FieldCfg"]) == sz_fc == 268
+    assert C.sizeof(ns["FieldCfg"]) == sz_fc == 276
     assert C.sizeof(ns["Params"]) == sz_p
     assert ns["FieldCfg"].tri_mode.offset == off_tri and ns["Params"].neus_sd_stride.offset == off_neus
     for doc, mirror in ((ns["FieldCfg"], capi.FieldCfg), (ns["Params"], capi.Params)):

@@ -34,9 +34,11 @@ def test_m1_size_fourier_train_step_vs_oracle():
     assert L.ngm_debug_last_matmul(0) == K.MATMUL["bf16x3"]
 
 
-def test_m1_size_hash_train_step_vs_oracle():
-    """the reference's default network on the same batch (tolerances of the hash tests: forward 2e-3 / 2e-4, gradients per tensor / level group: gpu_common.HASH_BARS)"""
-    _permuto_train_case(8, 512, 64, 64, "auto", max_neutralised=0.02)
+@pytest.mark.parametrize("atomics", ["exact", "float"])
+def test_m1_size_hash_train_step_vs_oracle(atomics):
+    """the reference's default network on the same batch (tolerances of the hash tests: forward 2e-3 / 2e-4, gradients per tensor /
+    level group: gpu_common.HASH_BARS); `float`: the opt-in fp32 LDS atomics of the table gradient, at the same bars"""
+    _permuto_train_case(8, 512, 64, 64, "auto", max_neutralised=0.02, atomics=atomics)
     assert K.lib().ngm_debug_last_comp_fused() == 1
 
 
@@ -383,49 +385,43 @@ def test_standalone_encode_backward_stage_vs_oracle_autograd(enc, P):
         grad_close(got[name], ref, 2e-3, name)
 
 
-# ------------------------------------------------------------------------------------------------ activation stash modes (round 5)
+# ------------------------------------------------------------------------------------------------ activation stash modes
+# (round 5: a process-wide debug switch; ABI 10: `activation_stash` is part of a renderer's field configuration)
 STASH = {0: "full", 1: "half"}
 
 
-@pytest.fixture
-def stash_mode(request):
-    L = K.lib()
-    L.ngm_debug_stash_mode(request.param)
-    yield request.param
-    L.ngm_debug_stash_mode(-2)
-
-
-@pytest.mark.parametrize("stash_mode", [0, 1], indirect=True, ids=lambda m: STASH[m])
+@pytest.mark.parametrize("stash_mode", [0, 1], ids=lambda m: STASH[m])
 @pytest.mark.parametrize("shape", [(1, 256, 16, 16), (3, 41, 9, 5), (2, 96, 8, 16), (1, 7, 64, 64), (4, 130, 2, 5)])
 def test_stash_modes_ragged_train_step_vs_oracle(stash_mode, shape):
-    """The two activation-stash modes of the two-hidden-layer split path (include/ngm_hip.h, ngm_debug_stash_mode): both layers'
+    """The two activation-stash modes of the two-hidden-layer split path (include/ngm_hip.h, ngm_activation_stash): both layers'
     outputs / layer 0's only with layer 1 recomputed on the matrix pipe (k_field_bwd_b3<HS>) -- each against the oracle at the
     usual bars on ragged shapes (rays of 7 .. 128 samples against 32-sample tiles, fields whose sample count is not a multiple
     of 32), and the mode that really ran is read back from the library."""
     F, R, n_c, n_g = shape
-    ragged_case(F, R, n_c, n_g, dict(FOURIER))
+    ragged_case(F, R, n_c, n_g, dict(FOURIER), activation_stash=STASH[stash_mode])
     L = K.lib()
     assert L.ngm_debug_last_bwd_variant() == 3 and L.ngm_debug_last_stash_mode() == stash_mode
 
 
-@pytest.mark.parametrize("stash_mode", [1], indirect=True, ids=lambda m: STASH[m])
 @pytest.mark.parametrize("enc", ["nerf", "none61"])
-def test_stash_modes_other_encodings(stash_mode, enc):
+def test_stash_modes_other_encodings(enc):
     # (ten octaves: 60 features -- the stash exists for 49..64-wide layers; eight octaves = 48 run the recompute kernels)
     fkw = dict(encoding="nerf", num_octaves=10, num_layers=2) if enc == "nerf" else dict(encoding="fourier", dim_enc=61, num_layers=2)
     # ten octaves put arguments up to 2^9 pi into fp32 sines: the forward tolerance of the NeRF fixtures (G4 / G6), not 2e-4
-    ragged_case(3, 70, 6, 7, fkw, fwd_tol=dict(rtol=5e-3, atol=5e-4) if enc == "nerf" else None, grad_tol=5e-3 if enc == "nerf" else 2e-3)
-    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
+    ragged_case(3, 70, 6, 7, fkw, fwd_tol=dict(rtol=5e-3, atol=5e-4) if enc == "nerf" else None, grad_tol=5e-3 if enc == "nerf" else 2e-3,
+                activation_stash="half")
+    assert K.lib().ngm_debug_last_stash_mode() == 1
 
 
-@pytest.mark.parametrize("stash_mode", [1], indirect=True, ids=lambda m: STASH[m])
-def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
+def test_stash_modes_bitwise_deterministic_and_close_to_full():
     """200 launches of a ragged batch give bitwise the same gradients; the gradients agree with the full-stash kernel's to
-    fp32 round-off (the recomputed layer is the same arithmetic in another summation order)."""
+    fp32 round-off (the recomputed layer is the same arithmetic in another summation order).  The two renderers live in ONE
+    process with DIFFERENT stash modes and are used alternately (ABI 10: the mode travels in ngm_field_cfg, workspaces are
+    sized per configuration -- as a process-wide switch the second renderer's mode broke the first one's cached workspace)."""
     F, R = 3, 97
     pos, quat, t = synth_target(F, R, seed=5)
     ckw = dict(num_samples_coarse=11, num_samples_depth_guided=13, termination_weight=0.3)
-    r = make_renderer(FOURIER, ckw, F)
+    r = make_renderer(FOURIER, {**ckw, "activation_stash": "half"}, F)
     _perturb(r)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     tgt = make_target(t, torch.arange(F))
@@ -434,16 +430,26 @@ def test_stash_modes_bitwise_deterministic_and_close_to_full(stash_mode):
         g = r.optimization_iteration(tgt, seed=9, update=False)["grads"]
         for k in first:
             assert torch.equal(g[k], first[k]), k
-    assert K.lib().ngm_debug_last_stash_mode() == stash_mode
-    K.lib().ngm_debug_stash_mode(0)
-    r0 = make_renderer(FOURIER, ckw, F)
+    assert K.lib().ngm_debug_last_stash_mode() == 1
+    r0 = make_renderer(FOURIER, ckw, F)                                  # does not name a mode: the default, full
     for k, v in r._model.all_fields_params.items():
         r0._model.all_fields_params[k].copy_(v)
     r0.set_field_poses(pos.to(DEV), quat.to(DEV))
-    full = r0.optimization_iteration(tgt, seed=9, update=False)["grads"]
+    full = {k: v.clone() for k, v in r0.optimization_iteration(tgt, seed=9, update=False)["grads"].items()}
     assert K.lib().ngm_debug_last_stash_mode() == 0
     for k in first:
         grad_close(first[k], full[k], 2e-5, "vs full stash " + k)
+    ws_half, ws_full = r._workspace(F, R)["wsb"], r0._workspace(F, R)["wsb"]
+    assert ws_half < ws_full                                             # each sized for its own configuration
+    for _ in range(3):                                                    # alternate: cached workspaces, both modes, one process
+        g1 = r.optimization_iteration(tgt, seed=9, update=False)["grads"]
+        assert K.lib().ngm_debug_last_stash_mode() == 1
+        for k in first:
+            assert torch.equal(g1[k], first[k]), k
+        g0 = r0.optimization_iteration(tgt, seed=9, update=False)["grads"]
+        assert K.lib().ngm_debug_last_stash_mode() == 0
+        for k in first:
+            assert torch.equal(g0[k], full[k]), k
 
 
 @pytest.mark.parametrize("num_knn,S", [(6, 64), (8, 640), (5, 40)])

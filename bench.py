@@ -529,7 +529,7 @@ def main():
     ap.add_argument("--windows", type=int, default=11,
                     help="number of consecutive timed windows of --steps steps each (after ONE --warmup phase); the line's "
                          "ms_per_step / value are the median window, all windows are listed in ms_per_step_windows")
-    ap.add_argument("--min-seconds", type=float, default=2.0,
+    ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="keep adding timed windows of --steps steps (same protocol, median headline) until this much timed GPU "
                          "work has run, so that an external sampler (rocm-smi, the driver's gpu_busy) sees the load: 11 windows of "
                          "20 steps are 55 ms.  0: exactly --windows windows")

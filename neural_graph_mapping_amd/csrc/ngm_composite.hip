@@ -84,10 +84,8 @@ __global__ __launch_bounds__(NGM_BLOCK) void k_sample_rays(SamplerArgs a, int ra
       rt[0] = rg.dx; rt[1] = rg.dy; rt[2] = rg.dz; rt[3] = rg.near; rt[4] = rg.far; rt[5] = rg.gnear; rt[6] = rg.gfar; rt[7] = rg.gt;
       if (a.dirs) { a.dirs[3 * ray] = rg.dx; a.dirs[3 * ray + 1] = rg.dy; a.dirs[3 * ray + 2] = rg.dz; }
     }
-    for (int idx = lane; idx < nsamp; idx += 64) {
-      const int rl = fdiv_idx2(idx, inv_s, S), e = idx - rl * S;
-      wl.u[idx] = (e < S_c) ? jitter(a.rays, poff, 0, rb + rl, S_c, e) : jitter(a.rays, poff, 1, rb + rl, S_g, e - S_c);
-    }
+    jitter_fill(a.rays, poff, 0, rb, nb, S_c, wl.u, S, lane);                  // one Philox block per four elements
+    if (S_g > 0) jitter_fill(a.rays, poff, 1, rb, nb, S_g, wl.u + S_c, S, lane);
     WAVE_SYNC();
     for (int idx = lane; idx < nsamp; idx += 64) {
       const int rl = fdiv_idx2(idx, inv_s, S), e = idx - rl * S;

@@ -213,8 +213,9 @@ __device__ __forceinline__ ngm_v2f ngm_sinf2(ngm_v2f x) {
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (used when the caller passes no explicit torch.rand draws)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t stream_id) {
-  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = (uint32_t)offset;
+// One block = counter (ctr low 32, ctr high 32, stream id, offset low 32) under key (seed low 32, seed high 32) -> four words.
+__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uint64_t ctr, uint32_t stream_id, uint32_t (&w)[4]) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = stream_id, c3 = (uint32_t)offset;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -227,9 +228,20 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0,1)
+  w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
 }
-// the first TWO output words of the same block as two uniforms (k_sample_rays_weighted: bin draw, offset draw)
+__device__ __forceinline__ float philox_word_uniform(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }   // [0,1)
+// Element `idx` of stream `stream_id`: word idx & 3 of block idx >> 2 (round 6: all four words of a block are used -- rounds
+// 1-5 spent a whole block per element and threw three words away; tests/_philox_host.py restates this mapping on the host and
+// the in-kernel draws are compared with it bit for bit).  This form still computes a block per call: the samplers that draw
+// for whole rays use jitter_fill below, which shares a block between four elements.
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t stream_id) {
+  uint32_t w[4];
+  philox_block(seed, offset, idx >> 2, stream_id, w);
+  const uint32_t k = (uint32_t)idx & 3u;
+  return philox_word_uniform((k & 2u) ? ((k & 1u) ? w[3] : w[2]) : ((k & 1u) ? w[1] : w[0]));
+}
+// k_sample_rays_weighted: block = element (NOT idx >> 2), its first TWO words are the bin draw and the offset draw
 __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t stream_id, float* u0, float* u1) {
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = (uint32_t)offset;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -372,6 +384,45 @@ __device__ __forceinline__ float jitter(const ngm_rays& rays, uint64_t poff, int
   const float* u = which ? rays.u_guided : rays.u_coarse;
   if (u) return u[ray * n + i];
   return philox_uniform(rays.philox_seed, poff, (uint64_t)(ray * n + i), (uint32_t)which);
+}
+// idx / S for 0 <= idx < 2^24 by reciprocal multiplication, corrected at the segment borders
+__device__ __forceinline__ int fdiv_small(int idx, float inv_s, int S) {
+  int q = (int)(((float)idx + 0.5f) * inv_s);
+  if (q * S > idx) --q;
+  if ((q + 1) * S <= idx) ++q;
+  return q;
+}
+// The draws of stratum `which` for the `nrays` consecutive rays from `ray0` on, by one wave: element e of ray ray0 + rl goes to
+// out[rl * out_stride + e].  The elements of consecutive rays are consecutive indices of the stream (ray * n + e), so one
+// Philox block (~100 vector instructions) serves four of them; the block-per-element form was ~100 of the sampler's ~255
+// instructions per sample (profiles/r05_pmc_stages_sq.json).  Same values as jitter() element by element.
+__device__ __forceinline__ void jitter_fill(const ngm_rays& rays, uint64_t poff, int which, int64_t ray0, int nrays, int n,
+                                            float* out, int out_stride, int lane) {
+  const float* u = which ? rays.u_guided : rays.u_coarse;
+  const int total = nrays * n;
+  const float inv_n = 1.0f / (float)n;
+  if (u) {
+    const float* src = u + ray0 * n;
+    for (int j = lane; j < total; j += 64) {
+      const int rl = fdiv_small(j, inv_n, n);
+      out[rl * out_stride + (j - rl * n)] = src[j];
+    }
+    return;
+  }
+  const uint64_t i0 = (uint64_t)ray0 * (uint64_t)n, i1 = i0 + (uint64_t)total;
+  for (uint64_t blk = (i0 >> 2) + (uint64_t)lane; (blk << 2) < i1; blk += 64) {
+    uint32_t w[4];
+    philox_block(rays.philox_seed, poff, blk, (uint32_t)which, w);
+    const int j0 = (int)((int64_t)(blk << 2) - (int64_t)i0);            // may be -3..-1 for the first block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = j0 + k;
+      if (j >= 0 && j < total) {
+        const int rl = fdiv_small(j, inv_n, n);
+        out[rl * out_stride + (j - rl * n)] = philox_word_uniform(w[k]);
+      }
+    }
+  }
 }
 
 // number of elements of stratum (near,far,n) that are < x (strict=1) or <= x (strict=0).
@@ -629,10 +680,17 @@ __device__ __forceinline__ float occ_density(float g, float dl, float* docc_dg) 
 // every instruction of this phase is exposed: one v_exp_f32 and one v_rcp_f32 instead of two IEEE divisions and two expf
 // (~55 -> ~12 instructions).  With e = exp(-x), s = 1 / (1 + e): sigmoid(x) = s, sigmoid(-x) = e s, so
 // nrgbd: occ = 4 e s^2, d occ / d g = gamma occ (e - 1) s; occupancy: occ = s, d occ / d g = gamma e s^2.
-// |x| is clamped at 80 (e stays finite; the exact forms are 0 or 1 to fp32 there).  Agrees with occ_pointwise to ~3e-7
-// relative; the forward keeps the exact form.
+// |x| is clamped at 80 (e stays finite; the exact forms are 0 or 1 to fp32 there); a NaN geometry output stays NaN (fminf /
+// fmaxf return the non-NaN operand: unguarded, a diverged field would render a finite, saturated occupancy where the exact
+// form and the reference give NaN -- ADVICE r5).  Agrees with occ_pointwise to ~3e-7 relative.  The forward kernels use
+// occ_pointwise_fwd (this form without the derivative); k_composite_bwd / k_stash_bwd differentiate the exact form
+// occ_pointwise: the two differ by ~3e-7 relative, far inside the gradient bar (2e-3).
+__device__ __forceinline__ float occ_clamped_arg(float x) {
+  const float c = fminf(fmaxf(x, -80.0f), 80.0f);
+  return (x != x) ? x : c;
+}
 __device__ __forceinline__ float occ_pointwise_fast(int mode, float gamma, float g, float* docc_dg) {
-  const float x = fminf(fmaxf(gamma * g, -80.0f), 80.0f);
+  const float x = occ_clamped_arg(gamma * g);
   const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
   const float s = __builtin_amdgcn_rcpf(1.0f + e);
   if (mode == NGM_GEO_NRGBD) {
@@ -649,7 +707,7 @@ __device__ __forceinline__ float occ_pointwise_fast(int mode, float gamma, float
 // ~3e-7 from the exact form (hardware exp2 / rcp: 1 ulp each), far inside the forward tolerance (2e-4 / 2e-5); exactly 1 at
 // g = 0 (nrgbd) like the exact form.
 __device__ __forceinline__ float occ_pointwise_fwd(int mode, float gamma, float g) {
-  const float x = fminf(fmaxf(gamma * g, -80.0f), 80.0f);
+  const float x = occ_clamped_arg(gamma * g);
   const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
   const float s = __builtin_amdgcn_rcpf(1.0f + e);
   return (mode == NGM_GEO_NRGBD) ? 4.0f * e * s * s : s;

@@ -404,11 +404,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
     // ---- (2) sorted sample distances: closed-form rank of every source element (no sort).  The draws are made once
     // per element into the (still unused) weight plane; the ranking reads its neighbours' draws from there.
 #ifndef NGM_ABLF_NOSAMPLER
-    for (int idx = lane; idx < nsamp; idx += 64) {
-      const int rl = fdiv_idx(idx, inv_s, S), e = idx - rl * S;
-      const int64_t ray = (int64_t)f * R + rb + rl;
-      wl.wbuf[idx] = (e < S_c) ? jitter(a.rays, poff, 0, ray, S_c, e) : jitter(a.rays, poff, 1, ray, S_g, e - S_c);
-    }
+    // (one Philox block per FOUR elements: the batch's rays are consecutive, so are their elements in each stratum's stream)
+    jitter_fill(a.rays, poff, 0, (int64_t)f * R + rb, nb, S_c, wl.wbuf, S, lane);
+    if (S_g > 0) jitter_fill(a.rays, poff, 1, (int64_t)f * R + rb, nb, S_g, wl.wbuf + S_c, S, lane);
     WAVE_SYNC();
 #endif
     for (int idx = lane; idx < nsamp; idx += 64) {

@@ -17,8 +17,10 @@
 // bit 0 of a STICKY status word and returns NaN in every sum: the losses of that iteration and the parameters its update
 // touches become NaN on this rank -- visible in the same iteration, never a silently wrong normaliser (PeerExchange.check
 // raises on the status; the renderer calls it before checkpoints and every few iterations).  A slot that already carries a LATER sequence
-// number (possible only after such a time-out: the fast rank went on) is accepted and raises bit 1, so that a late rank
-// falls back into step instead of timing out on every following exchange.
+// number (possible only after such a time-out: the fast rank went on) is accepted and raises bit 1.  Once bit 0 is set the
+// exchange is dead on this rank: every later launch still delivers its own words (the peers are not made to wait) but does not
+// poll -- it returns NaN at once instead of waiting out another time-out per iteration until the host looks at the status
+// (a dead peer used to cost peer_check_interval x time-out of wedged GPU before the RuntimeError).
 #include "ngm_launch.h"
 
 __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, float* sums, uint32_t max_spins) {
@@ -37,15 +39,16 @@ __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, flo
     const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(px.mailbox[px.rank]) + (size_t)par * NGM_MAX_PEERS * 16;
     float total = 0.f;
     bool late = false, skew = false;
-    for (int p = 0; p < W; ++p) {
+    const bool dead = (__hip_atomic_load(px.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) != 0;   // an earlier exchange timed out
+    for (int p = 0; p < W && !dead; ++p) {
       unsigned long long w = 0;
-      int spins = 0;
+      uint32_t spins = 0;
       for (;;) {
         w = __hip_atomic_load(mine + p * 16 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const int32_t ahead = (int32_t)((uint32_t)(w >> 32) - seq);
         if (ahead == 0) break;
         if (ahead > 0 && ahead < (1 << 30)) { skew = true; break; }   // the writer is past this exchange: resynchronise, flag it
-        if ((uint32_t)++spins > max_spins) { late = true; w = 0; break; }   // x ~1 us of s_sleep; the slot still holds the word of
+        if (++spins > max_spins) { late = true; w = 0; break; }   // x ~1 us of s_sleep; the slot still holds the word of
                                                                             // two exchanges ago: contribute nothing, not that
         __builtin_amdgcn_s_sleep(32);
       }
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(128) void k_loss_exchange(ngm_peer_exchange px, flo
     }
     if (late) atomicOr(px.status, 1);
     if (skew) atomicOr(px.status, 2);
-    sums[t] = late ? __uint_as_float(0x7fc00000u) : total;      // a time-out poisons the iteration instead of mis-normalising it
+    sums[t] = (late || dead) ? __uint_as_float(0x7fc00000u) : total;      // a time-out poisons the iteration instead of mis-normalising it
   }
   if (t == 0) *px.seq = (unsigned long long)seq;
 }

@@ -425,14 +425,22 @@ def sample_rays_weighted(rc: K.RenderCfg, ijs, boundaries, weights, u_bin=None, 
     per-ray distance bins -> (points_cam (F,R,S,3), distances (F,R,S) in draw order, dirs (F,R,3)); S = rc.num_samples_coarse.
     ijs (F,R,2) int64, boundaries (F,R,B+1) sorted, weights (F,R,B); u_bin / u_off (F,R,S): the reference's two torch.rand
     draws, in its order, or both None = in-kernel Philox."""
-    _require_gpu(ijs, boundaries, weights, u_bin, u_off)
     if (weights is None) != (boundaries is None):
         raise ValueError("Either both or none of weights and boundaries must be None.")       # camera.py:260-261
+    if weights is None:
+        raise ValueError("sample_rays_weighted: boundaries and weights are required (the stratified branch is sample_rays)")
+    if (u_bin is None) != (u_off is None):
+        raise ValueError("sample_rays_weighted: u_bin and u_off go together (both None = in-kernel Philox)")
+    _require_gpu(ijs, boundaries, weights, u_bin, u_off)
     if ijs.dim() == 2:
         ijs, boundaries, weights = ijs[None], boundaries[None], weights[None]
         u_bin, u_off = (None if u_bin is None else u_bin[None]), (None if u_off is None else u_off[None])
     if boundaries.shape[:-1] != ijs.shape[:-1] or weights.shape[:-1] != ijs.shape[:-1] or boundaries.shape[-1] != weights.shape[-1] + 1:
         raise ValueError("boundaries (..., num_bins + 1) and weights (..., num_bins) must match the leading dims of ijs")
+    want = (*ijs.shape[:-1], int(rc.num_samples_coarse))            # the kernel indexes the draws as (F, R, S)
+    for name, u in (("u_bin", u_bin), ("u_off", u_off)):
+        if u is not None and tuple(u.shape) != want:
+            raise ValueError(f"sample_rays_weighted: {name} must have shape {want} (leading dims of ijs, num_samples), got {tuple(u.shape)}")
     pc, dist, dirs = torch.ops.ngm355.sample_rays_weighted(cfg_blob(rc), ijs, boundaries, weights, u_bin, u_off, int(seed))
     return pc, dist, dirs
 

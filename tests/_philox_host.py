@@ -1,7 +1,9 @@
-"""Host restatement (numpy, uint64 arithmetic) of the jitter generator of the kernels (csrc/ngm_device.h philox_uniform):
-the standard Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC11) with
-    counter = (idx low 32, idx high 32, stream id, offset low 32),  key = (seed low 32, seed high 32),
-first output word >> 8 scaled to [0, 1).  Test infrastructure: tests/test_host_logic.py pins it to the Random123 known-answer
+"""Host restatement (numpy, uint64 arithmetic) of the jitter generator of the kernels (csrc/ngm_device.h philox_block /
+philox_uniform / jitter_fill): the standard Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC11)
+with
+    counter = (block low 32, block high 32, stream id, offset low 32),  key = (seed low 32, seed high 32);
+element idx of a stream is word idx & 3 of block idx >> 2 (round 6: all four words of a block are used; rounds 1-5: block = idx,
+word 0), the word >> 8 scaled to [0, 1).  Test infrastructure: tests/test_host_logic.py pins it to the Random123 known-answer
 vectors on the CPU, tests/test_gpu_hardening.py compares the in-kernel draws with it bit for bit."""
 import numpy as np
 
@@ -26,14 +28,21 @@ def philox4x32_10(ctr, key):
     return tuple(int(w[0]) for w in out)
 
 
-def host_philox_uniform(seed, offset, idx, stream, word=0):
-    """`word`: which of the block's four output words (0: every sampler; 1: the offset draw of k_sample_rays_weighted, whose bin
-    draw is word 0 of the same block -- ngm_device.h philox_uniform2)"""
+def host_philox_uniform(seed, offset, idx, stream, word=None):
+    """Element `idx` of stream `stream`.  word=None: the samplers' mapping (block idx >> 2, word idx & 3: ngm_device.h
+    philox_uniform / jitter_fill).  word=0 / 1: the weighted-bin sampler's own mapping (ngm_device.h philox_uniform2): block =
+    idx, its first word is the bin draw, its second the offset draw."""
     idx = np.asarray(idx, dtype=np.uint64)
-    c0 = philox4x32_10_words(idx & _M, idx >> np.uint64(32), np.full_like(idx, np.uint64(stream)),
-                             np.full_like(idx, np.uint64(int(offset) & 0xFFFFFFFF)), int(seed) & 0xFFFFFFFF,
-                             (int(seed) >> 32) & 0xFFFFFFFF)[word]
-    return (c0 >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    blk = idx if word is not None else idx >> np.uint64(2)
+    words = philox4x32_10_words(blk & _M, blk >> np.uint64(32), np.full_like(blk, np.uint64(stream)),
+                                np.full_like(blk, np.uint64(int(offset) & 0xFFFFFFFF)), int(seed) & 0xFFFFFFFF,
+                                (int(seed) >> 32) & 0xFFFFFFFF)
+    if word is not None:
+        c = words[word]
+    else:
+        k = idx & np.uint64(3)
+        c = np.where(k == 0, words[0], np.where(k == 1, words[1], np.where(k == 2, words[2], words[3])))
+    return (c >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
 def host_philox_draws(seed, offset, F, R, n_c, n_g):

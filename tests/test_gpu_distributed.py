@@ -348,10 +348,20 @@ def _peer_timeout_worker(rank, world, port, out):
         except RuntimeError as e:
             raised = str(e)
         partial = bool(torch.isnan(y).all())
+        # the exchange is dead on this rank now: later launches do not wait out another time-out each (a dead peer
+        # used to stall the survivors for peer_check_interval x time-out), they return NaN at once
+        import time
+        t0 = time.perf_counter()
+        for _ in range(20):
+            z = torch.ones(16, device=DEV)
+            px.allreduce(z)
+        torch.cuda.synchronize()
+        fast_after = (time.perf_counter() - t0, bool(torch.isnan(z).all()))
     else:
-        partial = None
+        partial = fast_after = None
     dist.barrier()
-    torch.save(dict(healthy=healthy, raised=raised, status=px.status(), partial=partial), os.path.join(out, f"timeout{rank}.pt"))
+    torch.save(dict(healthy=healthy, raised=raised, status=px.status(), partial=partial, fast_after=fast_after),
+               os.path.join(out, f"timeout{rank}.pt"))
     px.close()
     dist.destroy_process_group()
 
@@ -366,4 +376,5 @@ def test_peer_exchange_timeout_is_reported_not_swallowed(tmp_path):
     assert r0["healthy"] == (0, 3.0) and r1["healthy"] == (0, 3.0)
     assert r0["status"] & 1 and r0["raised"] and "loss exchange failed" in r0["raised"]
     assert r0["partial"] is True                         # the sums of a timed-out exchange are NaN: the iteration is visibly dead
+    assert r0["fast_after"][1] and r0["fast_after"][0] < 1.0     # 20 further exchanges: NaN without another 20 x 2 s of waiting
     assert r1["status"] == 0

@@ -70,8 +70,10 @@ def test_weighted_bin_sampler_golden_bit_exact():
     assert torch.equal(t1[0], t[0])
     with pytest.raises(ValueError):
         ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"][..., :-1], d["weights"], d["u_bin"], d["u_off"])
-    with pytest.raises(K.NgmError):                            # one draw array without the other
+    with pytest.raises(ValueError, match="go together"):       # one draw array without the other (checked before the library is called)
         ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"], d["weights"], d["u_bin"], None)
+    with pytest.raises(ValueError, match="must have shape"):   # draws sized for another sample count would be read out of bounds
+        ops.sample_rays_weighted(rc, d["ijs"], d["boundaries"], d["weights"], d["u_bin"][..., :-1], d["u_off"][..., :-1])
 
 
 @pytest.mark.parametrize("S,B", [(1, 1), (64, 7), (200, 128), (16, 3000)])

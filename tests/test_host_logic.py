@@ -341,6 +341,18 @@ def test_host_philox_restatement_known_answers():
     assert f == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
     p = m.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0))
     assert p == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    # the element -> (block, word) mapping of the samplers (ngm_device.h philox_uniform / jitter_fill): element i of a stream is
+    # word i & 3 of block i >> 2, so eight consecutive elements are exactly the eight words of two consecutive blocks
+    import numpy as np
+    seed, off, stream = 0x299f31d0a4093822, 0x03707344, 7
+    u = m.host_philox_uniform(seed, off, np.arange(40, 48, dtype=np.uint64), stream)
+    exp = []
+    for blk in (10, 11):
+        exp += list(m.philox4x32_10((blk, 0, stream, off), (seed & 0xffffffff, seed >> 32)))
+    assert [int(x * 16777216.0) for x in u] == [w >> 8 for w in exp]
+    # the weighted-bin sampler keeps one block per element: word 0 = bin draw, word 1 = offset draw
+    ub = m.host_philox_uniform(seed, off, np.array([42], dtype=np.uint64), stream, word=1)
+    assert int(ub[0] * 16777216.0) == m.philox4x32_10((42, 0, stream, off), (seed & 0xffffffff, seed >> 32))[1] >> 8
 
 
 def test_recorded_bench_line_carries_the_contract():
@@ -391,3 +403,16 @@ def test_render_ijs_signature_is_the_reference_one():
     other = Rr.Camera(32, 24, 27.7, 26.0, 15.5, 11.5, pixel_center=0.0)
     rc = r._rc_for(other, False)
     assert (round(rc.fx, 3), round(rc.fy, 3), rc.cx, rc.cy) == (27.7, 26.0, 15.5, 11.5) and r._rc_for(None, False).fx == 50.0
+
+
+def test_sample_rays_weighted_argument_checks():
+    """None / half-given arguments raise the reference's ValueError (camera.py:260-261) before anything is indexed"""
+    from neural_graph_mapping_amd import ops
+    rc = K.render_cfg(num_samples_coarse=4, num_samples_guided=0)
+    ijs = torch.zeros(3, 2, dtype=torch.long)
+    with pytest.raises(ValueError, match="Either both or none"):
+        ops.sample_rays_weighted(rc, ijs, torch.zeros(3, 6), None)
+    with pytest.raises(ValueError, match="required"):
+        ops.sample_rays_weighted(rc, ijs, None, None)
+    with pytest.raises(ValueError, match="go together"):
+        ops.sample_rays_weighted(rc, ijs, torch.zeros(3, 6), torch.zeros(3, 5), u_bin=torch.zeros(3, 4))

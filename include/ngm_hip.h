@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGM_ABI_VERSION 10 /* 10: ngm_field_cfg.activation_stash / .hash_grad_atomics (per configuration, no process-wide switch), empty loss selections report NaN like the reference; 9: ngm_sample_rays_weighted; 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
+#define NGM_ABI_VERSION 11 /* 11: ngm_field_eval_stash_bytes / ngm_field_eval_fwd_train / ngm_field_eval_bwd_stash (training forward of the point evaluation writes the activation stash, its backward is the fused step's kernel); 10: ngm_field_cfg.activation_stash / .hash_grad_atomics (per configuration, no process-wide switch), empty loss selections report NaN like the reference; 9: ngm_sample_rays_weighted; 8: ngm_peer_set_timeout (a time-out now also poisons the sums with NaN); 7: ngm_encode_bwd; 6: ngm_render_eval_knn; 5: ngm_encode_fwd, ngm_render_bwd_seeded_vars, *_nll loss modes (+ loss-sum slot 10), peer status bits */
 #define NGM_MAX_LAYERS 4 /* hidden layers; +1 output layer */
 #define NGM_NUM_LOSS_SUMS 16
 
@@ -290,6 +290,24 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
                        const float* d_out, const ngm_grads* grads, void* workspace,
                        int64_t workspace_bytes, void* stream);
 int64_t ngm_field_eval_bwd_workspace(const ngm_field_cfg* fcfg, int32_t F, int64_t P);
+/* Training pair of the above (ABI 11; models.py:329-345 under autograd -- the path the reference's unchanged
+ * _optimization_iteration takes, rm.py:1164-1177).  ngm_field_eval_fwd_train computes what ngm_field_eval_fwd computes (same
+ * kernel, same bits) and also writes the hidden activations of every sample into the caller-owned `stash`
+ * (ngm_field_eval_stash_bytes: 256 B per sample and hidden layer + one tile); ngm_field_eval_bwd_stash reads them back instead
+ * of recomputing the hidden layers and runs the MLP backward of the fused training step (bf16-split matrix products, fp32
+ * accumulate) on the explicit points.  ngm_field_eval_stash_bytes returns 0 when the configuration has no stash-reading
+ * backward (anything but 33..64-wide encoding and hidden layers, 1-2 layers, Fourier / NeRF / no encoding, skip_mode no,
+ * matmul_mode auto / bf16x3): the pair then returns NGM_E_UNSUPPORTED and ngm_field_eval_fwd / ngm_field_eval_bwd serve the
+ * call.  `points`, poses and parameters passed to the backward must be those of the forward that wrote the stash.
+ * workspace of the backward: ngm_field_eval_bwd_workspace(). */
+int64_t ngm_field_eval_stash_bytes(const ngm_field_cfg* fcfg, int32_t F, int64_t P);
+int ngm_field_eval_fwd_train(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
+                             const float* points, const float* field_pos, const float* field_quat,
+                             float* out, void* stash, int64_t stash_bytes, void* stream);
+int ngm_field_eval_bwd_stash(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P,
+                             const float* points, const float* field_pos, const float* field_quat,
+                             const float* d_out, const ngm_grads* grads, const void* stash, int64_t stash_bytes,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- K4: volume renderer -------------------------------------------------------------------
  * NeuralGraphMap._quadrature (rm.py:709-799) on N rays x S samples: colors (N,S,3), geoms (N,S),

@@ -145,6 +145,12 @@ def lib():
     L.ngm_field_eval_bwd.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp]
     L.ngm_field_eval_bwd_workspace.argtypes = [P(FieldCfg), i32, i64]
     L.ngm_field_eval_bwd_workspace.restype = i64
+    L.ngm_field_eval_stash_bytes.argtypes = [P(FieldCfg), i32, i64]
+    L.ngm_field_eval_stash_bytes.restype = i64
+    L.ngm_field_eval_fwd_train.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, vp, i64, vp]
+    L.ngm_field_eval_fwd_train.restype = C.c_int
+    L.ngm_field_eval_bwd_stash.argtypes = [P(FieldCfg), P(Params), i32, i64, vp, vp, vp, vp, P(Grads), vp, i64, vp, i64, vp]
+    L.ngm_field_eval_bwd_stash.restype = C.c_int
     L.ngm_composite_fwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 11 + [vp]
     L.ngm_composite_bwd.argtypes = [P(RenderCfg), i64, i32] + [vp] * 11 + [vp]
     L.ngm_render_workspace.argtypes = [P(FieldCfg), P(RenderCfg), i32, i32, i32]
@@ -215,6 +221,7 @@ def lib():
 EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto_fill_scales", "ngm_sample_rays", "ngm_sample_rays_world", "ngm_sample_rays_weighted",
             "ngm_composite_fwd_packed",
             "ngm_field_eval_fwd", "ngm_encode_fwd", "ngm_encode_bwd", "ngm_encode_bwd_workspace", "ngm_field_eval_bwd", "ngm_field_eval_bwd_workspace",
+            "ngm_field_eval_stash_bytes", "ngm_field_eval_fwd_train", "ngm_field_eval_bwd_stash",
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_bwd_seeded_vars", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_render_eval_knn", "ngm_render_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",

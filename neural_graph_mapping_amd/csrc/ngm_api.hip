@@ -562,6 +562,86 @@ int ngm_field_eval_bwd(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   return check_launch("ngm_grad_reduce");
 }
 
+// ---- training forward / backward of the point evaluation with an activation stash (ABI 11) ---------------------------------
+// The reference's unchanged _optimization_iteration reaches NeuralFieldSet.forward(use_vmap=True) under autograd; its backward
+// used to be k_field_bwd16 alone (fp32 MFMA, every hidden layer recomputed: 0.45 of the fp32 MFMA peak).  With the stash the
+// forward writes what the fused training step's forward writes (ngm_field.h ActStash, 256 B per sample and hidden layer) and
+// the backward is the fused step's kernel, k_field_bwd_b3, in point mode.
+static int act_stash_kind(const ngm_field_cfg* fc);
+static bool field_eval_stash_applies(const ngm_field_cfg* fc, int32_t F, int64_t P) {
+  if (act_stash_kind(fc) != 1 || !bwd_b3_is_default()) return false;
+  FieldBwdArgs probe;
+  memset(&probe, 0, sizeof(probe));
+  probe.fc = *fc; probe.F = F; probe.P = P;
+  probe.act = reinterpret_cast<const float*>(1); probe.points = reinterpret_cast<const float*>(1);
+  return ngm_field_bwd_b3_applies(probe);
+}
+static int64_t field_eval_stash_stride(int32_t F, int64_t P) { return align_up((int64_t)F * P, 32) * 64 + 2048; }   // floats per layer
+int64_t ngm_field_eval_stash_bytes(const ngm_field_cfg* fcfg, int32_t F, int64_t P) {
+  if (check_field_cfg(fcfg) || F < 1 || P < 0) return NGM_E_INVALID;
+  if (P == 0 || !field_eval_stash_applies(fcfg, F, P)) return 0;
+  return align_up(fcfg->num_layers * field_eval_stash_stride(F, P) * 4 + 64, 256) + 256;
+}
+int ngm_field_eval_fwd_train(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                             const float* field_pos, const float* field_quat, float* out, void* stash, int64_t stash_bytes,
+                             void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !out || F < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_field_eval_fwd_train: bad argument");
+  if ((field_pos == nullptr) != (field_quat == nullptr)) return fail(NGM_E_INVALID, "pos/quat must both be given");
+  if (P == 0) return NGM_OK;
+  const int64_t need = ngm_field_eval_stash_bytes(fcfg, F, P);
+  if (need <= 0) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_fwd_train: no stash-reading backward for this configuration (ngm_field_eval_stash_bytes == 0): use ngm_field_eval_fwd / ngm_field_eval_bwd");
+  if (!stash || stash_bytes < need) return fail(NGM_E_WORKSPACE, "ngm_field_eval_fwd_train: stash too small (ngm_field_eval_stash_bytes)");
+  PointsFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = F; a.P = P; a.points = points; a.pos = field_pos; a.quat = field_quat; a.out = out;
+  a.act = reinterpret_cast<float*>(align_up((int64_t)stash, 256)); a.act_layer_stride = field_eval_stash_stride(F, P);
+  const int ncu = num_cus();
+  int64_t bpf = (ncu + F - 1) / F;
+  int64_t per = align_up((P + bpf - 1) / bpf, NGM_BLOCK);
+  bpf = (P + per - 1) / per;
+  a.per_block = per;
+  rc = ngm_launch_points_fwd(a, (int)(bpf * F), (hipStream_t)stream);
+  if (rc) return fail(rc, "ngm_field_eval_fwd_train: no kernel for this (D,H,L)");
+  return check_launch("ngm_field_eval_fwd_train");
+}
+int ngm_field_eval_bwd_stash(const ngm_field_cfg* fcfg, const ngm_params* params, int32_t F, int64_t P, const float* points,
+                             const float* field_pos, const float* field_quat, const float* d_out, const ngm_grads* grads,
+                             const void* stash, int64_t stash_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_field_cfg(fcfg);
+  if (rc) return rc;
+  rc = check_params(fcfg, params);
+  if (rc) return rc;
+  if (!points || !d_out || !grads || F < 1 || P < 1) return fail(NGM_E_INVALID, "ngm_field_eval_bwd_stash: bad argument");
+  if ((field_pos == nullptr) != (field_quat == nullptr)) return fail(NGM_E_INVALID, "pos/quat must both be given");
+  const int64_t need = ngm_field_eval_stash_bytes(fcfg, F, P);
+  if (need <= 0) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_bwd_stash: no stash-reading backward for this configuration");
+  if (!stash || stash_bytes < need) return fail(NGM_E_WORKSPACE, "ngm_field_eval_bwd_stash: stash too small");
+  if (workspace_bytes < ngm_field_eval_bwd_workspace(fcfg, F, P) || !workspace) return fail(NGM_E_WORKSPACE, "workspace too small");
+  FieldBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fc = *fcfg; a.pr = *params; a.F = F; a.P = P; a.points = points; a.pos = field_pos; a.quat = field_quat;
+  a.d_out = reinterpret_cast<const float4*>(d_out);
+  plan_bwd(F, P, &a.per_block, &a.blocks_per_field);
+  a.p_pad = param_pad(fcfg);
+  a.partials = reinterpret_cast<float*>(align_up((int64_t)workspace, 256));
+  a.act = reinterpret_cast<const float*>(align_up((int64_t)stash, 256)); a.act_layer_stride = field_eval_stash_stride(F, P);
+  a.debug_cycles = nullptr;
+  rc = ngm_launch_field_bwd_b3(a, a.blocks_per_field * F, (hipStream_t)stream);
+  g_last_bwd_variant = 3; g_last_stash_mode = 0; g_last_comp_fused = 0;
+  if (rc) return fail(rc, "ngm_field_eval_bwd_stash: k_field_bwd_b3 does not take this problem");
+  rc = check_launch("ngm_field_eval_bwd_stash");
+  if (rc) return rc;
+  GradReduceArgs g;
+  memset(&g.adam, 0, sizeof(g.adam));
+  g.fc = *fcfg; g.gr = *grads; g.F = F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
+  ngm_launch_grad_reduce(g, (hipStream_t)stream);
+  return check_launch("ngm_grad_reduce");
+}
+
 // ------------------------------------------------------------------------------------------------
 int ngm_composite_fwd(const ngm_render_cfg* cfg, int64_t N, int32_t S, const float* colors, const float* geoms,
                       const float* dists, const float* depths, const float* neus_isds, float* C, float* D, float* Cvar,

@@ -152,6 +152,35 @@ __device__ __forceinline__ void issue_inputs(const FieldStreams& fs, int S, uint
   dma16(src, lds);
 }
 
+// global_load_lds_dword: lane p's 4 bytes land at lds_base + 4 p (per-lane 64-bit pointer)
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+// Point mode (ngm_field_eval_bwd_stash: explicit (F,P,3) points, no ray table): inputs of tile [n0, n0+16) -- d_out of sample
+// j as piece 2 of the ray-mode layout (every lane group fetches it: all 64 lanes of a transfer move data), and the 48 floats
+// of the 16 points as one dword transfer to lds_pts (sample j's coordinates at floats 3 j .. 3 j + 2).
+__device__ __forceinline__ void issue_inputs_pts(const char* dout, const char* pts, uint32_t n0, uint32_t end, int lane, uint32_t lds,
+                                                 uint32_t lds_pts) {
+  asm volatile("" : "+v"(lane));
+  const int j = lane & 15;
+  uint32_t n = n0 + j;
+  if (n >= end) n = end - 1;
+  dma16(dout + 16 * (size_t)n, lds);
+  const uint32_t d = min((uint32_t)lane, 47u), jj = d / 3u, c = d - 3u * jj;
+  uint32_t m = n0 + jj;
+  if (m >= end) m = end - 1;
+  dma4(pts + 4 * (3 * (size_t)m + c), lds_pts);
+}
+
 #define B16_WAVES 8
 #define B16_THREADS 512
 #define B16_RS 17          // row stride of a 16x16 weight block in LDS ([k-row][out]), odd: transposed reads stay spread

@@ -186,11 +186,23 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     tstep = (int32_t)TSTRIDE;
   }
   FieldStreams fs;
+  // point mode (FC = false only): explicit points instead of ray table + distances; the field's pose for the world -> local map
+  const bool pts = !FC && a.points != nullptr;
+  const char* pts_base = pts ? reinterpret_cast<const char*>(a.points + (int64_t)f * a.P * 3) : nullptr;
+  __shared__ float s_pose[12];
+  if (pts && threadIdx.x == 0) {
+    float div, off;
+    scale_consts(a.fc.scale_mode, a.fc.field_radius, &div, &off);
+    const bool posed = a.pos != nullptr;
+    s_pose[0] = posed ? a.pos[3 * f] : 0.f; s_pose[1] = posed ? a.pos[3 * f + 1] : 0.f; s_pose[2] = posed ? a.pos[3 * f + 2] : 0.f;
+    s_pose[3] = posed ? a.quat[4 * f] : 1.f; s_pose[4] = posed ? a.quat[4 * f + 1] : 0.f; s_pose[5] = posed ? a.quat[4 * f + 2] : 0.f;
+    s_pose[6] = posed ? a.quat[4 * f + 3] : 0.f; s_pose[7] = div; s_pose[8] = off; s_pose[9] = posed ? 1.f : 0.f;
+  }
   {
     const int64_t g0 = (int64_t)f * a.P;
-    fs.raytab = reinterpret_cast<const char*>(a.raytab) + 32 * (g0 / a.S);
+    fs.raytab = pts ? nullptr : reinterpret_cast<const char*>(a.raytab) + 32 * (g0 / a.S);
     fs.dout = reinterpret_cast<const char*>(a.d_out + g0);
-    fs.tpair = reinterpret_cast<const char*>(a.stashB + (g0 & ~(int64_t)1));
+    fs.tpair = pts ? nullptr : reinterpret_cast<const char*>(a.stashB + (g0 & ~(int64_t)1));
     fs.par = (uint32_t)(g0 & 1);
     fs.gb = (uint32_t)(g0 & 31);
     fs.act[0] = reinterpret_cast<const char*>(a.act + (g0 >> 5) * 2048);
@@ -213,6 +225,9 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     if constexpr (FC) {
       issue_small(first, 0);
       if (ntiles > 1u) issue_small(first - 32u, 1);
+    } else if (pts) {
+      issue_inputs_pts(fs.dout, pts_base, first, end, lane, wl_lds + LY::INB * 4, wl_lds + LY::INB * 4 + 2048);
+      issue_inputs_pts(fs.dout, pts_base, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024, wl_lds + LY::INB * 4 + 2048 + 256);
     } else {
       issue_inputs(fs, a.S, first, end, lane, wl_lds + LY::INB * 4);
       issue_inputs(fs, a.S, first + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
@@ -362,7 +377,13 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
       const bool valid = n < end;
       const uint32_t nc = valid ? n : end - 1;
       const float t = ((nc + fs.par) & 1u) ? sp.z : sp.x;
-      const float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
+      float x = fmaf(t, r0.w, r0.x), y = fmaf(t, r1.x, r0.y), z = fmaf(t, r1.y, r0.z);
+      if (pts) {                       // the forward's own map world -> scaled field-local (k_field_points_fwd): same bits
+        const float* pw = inb + 512 + 64 * h + 3 * jj;
+        const Vec3 v = scaled_local_point(Vec3{pw[0], pw[1], pw[2]}, s_pose[9] != 0.f, s_pose[0], s_pose[1], s_pose[2], s_pose[3],
+                                          s_pose[4], s_pose[5], s_pose[6], s_pose[7], s_pose[8]);
+        x = v.x; y = v.y; z = v.z;
+      }
       const float4 dout = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
       WAVE_SYNC();
       if (hi == 0) {
@@ -616,8 +637,13 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     }
     if (more) {
       if constexpr (!FC) {
-        issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
-        issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+        if (pts) {
+          issue_inputs_pts(fs.dout, pts_base, nxt, end, lane, wl_lds + LY::INB * 4, wl_lds + LY::INB * 4 + 2048);
+          issue_inputs_pts(fs.dout, pts_base, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024, wl_lds + LY::INB * 4 + 2048 + 256);
+        } else {
+          issue_inputs(fs, a.S, nxt, end, lane, wl_lds + LY::INB * 4);
+          issue_inputs(fs, a.S, nxt + 16, end, lane, wl_lds + LY::INB * 4 + 1024);
+        }
       }
       const uint32_t u0 = nxt + fs.gb;
       if (((u0 & 31u) == 0u) && (nxt + 32u <= end)) {      // whole tile, aligned with the stash tiles: scalar addressing
@@ -769,7 +795,7 @@ static int launch_bwd_b3(const FieldBwdArgs& a, int blocks, hipStream_t st) {
 
 bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a) {
   const int MI = (a.fc.dim_enc + 31) / 32, MH = (a.fc.dim_hidden + 31) / 32, L = a.fc.num_layers;
-  if (!a.act || a.points || a.fc.skip_mode != NGM_SKIP_NO || a.fc.matmul_mode == NGM_MATMUL_F32 || MI != 2 || MH != 2 || L < 1 || L > 2)
+  if (!a.act || (a.points && (a.fused_comp || a.act_half)) || a.fc.skip_mode != NGM_SKIP_NO || a.fc.matmul_mode == NGM_MATMUL_F32 || MI != 2 || MH != 2 || L < 1 || L > 2)
     return false;
   if (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NERF && a.fc.encoding != NGM_ENC_NONE) return false;
   if ((a.P + 64) * 256 >= ((int64_t)1 << 32)) return false;   // 32-bit byte offsets inside a field

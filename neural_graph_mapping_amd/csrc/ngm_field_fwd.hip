@@ -59,7 +59,10 @@ __global__ __launch_bounds__(NT) void k_field_points_fwd(PointsFwdArgs a) {
       const Vec3 v = scaled_local_point(Vec3{p[0], p[1], p[2]}, posed, px, py, pz, qw, qx, qy, qz, div, off);
       x = v.x; y = v.y; z = v.z;
     }
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, nullptr, nullptr, b3w, &tc);
+    ActStash ast;
+    ast.base = (HASH == 0 && MH == 2 && SKIP == 0) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
+    ast.g0 = (int64_t)f * a.P + base; ast.nvalid = (int)min((int64_t)64, end - base); ast.nlayers = NGM_MAX_LAYERS;
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, ast.base ? &ast : nullptr, nullptr, b3w, &tc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }

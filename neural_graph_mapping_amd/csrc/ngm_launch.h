@@ -20,6 +20,10 @@ struct PointsFwdArgs {
   const float* pos;       // (F,3) or NULL
   const float* quat;      // (F,4) or NULL
   float* out;             // (F,P,4)
+  // training forward (ngm_field_eval_fwd_train): the hidden activations of every sample, in the tiled stash layout of the fused
+  // training step (ngm_field.h ActStash; global sample index = f * P + p), read by k_field_bwd_b3 in point mode
+  float* act;             // NULL: nothing is stashed
+  int64_t act_layer_stride;   // floats
 };
 
 struct RenderFwdArgs {

@@ -5,7 +5,7 @@ gfx950 kernel reached through ``_capi``.  There is NO CPU / eager fallback: tens
 ROCm device ("cuda" under PyTorch-ROCm) and the HIP library must be built, otherwise the call raises.
 """
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -209,13 +209,94 @@ def _field_eval_backward(ctx, d_out):
 _field_eval_op.register_autograd(_field_eval_backward, setup_context=_field_eval_setup)
 
 
+# ---- the same under autograd with an activation stash (ABI 11): the forward writes the hidden activations, the backward is the
+# fused training step's MLP backward (k_field_bwd_b3 in point mode) instead of the recomputing fp32 kernel
+@_op("field_eval_train")
+def _field_eval_train_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[torch.Tensor], quat: Optional[torch.Tensor],
+                         params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    fc = _field_cfg(fcfg)
+    pd = dict(zip(K.param_names(fc), params))
+    F, P, _ = points.shape
+    L = K.lib()
+    out = torch.empty(F, P, 4, device=points.device, dtype=torch.float32)
+    sb = int(L.ngm_field_eval_stash_bytes(C.byref(fc), F, P))
+    if sb <= 0:
+        raise K.NgmError("field_eval_train: this configuration has no stash-reading backward (ngm_field_eval_stash_bytes == 0)")
+    stash = torch.empty(sb, device=points.device, dtype=torch.uint8)      # an output: lives until the backward has run
+    ps = params_struct(fc, pd)
+    K.check(L.ngm_field_eval_fwd_train(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)), _ptr(out),
+                                       _ptr(stash), sb, _stream()), "ngm_field_eval_fwd_train")
+    return out, stash
+
+
+@_field_eval_train_op.register_fake
+def _(fcfg, points, pos, quat, params):
+    return points.new_empty(points.shape[0], points.shape[1], 4), points.new_empty(0, dtype=torch.uint8)
+
+
+@_op("field_eval_bwd_stash")
+def _field_eval_bwd_stash_op(fcfg: torch.Tensor, points: torch.Tensor, pos: Optional[torch.Tensor], quat: Optional[torch.Tensor],
+                             d_out: torch.Tensor, stash: torch.Tensor, params: List[torch.Tensor]) -> List[torch.Tensor]:
+    fc = _field_cfg(fcfg)
+    names = K.param_names(fc)
+    pd = dict(zip(names, params))
+    F, P, _ = points.shape
+    grads, gs = alloc_grads_separate(fc, F, points.device)
+    ps = params_struct(fc, pd)
+    L = K.lib()
+    wsb = L.ngm_field_eval_bwd_workspace(C.byref(fc), F, P)
+    ws = torch.empty(wsb, device=points.device, dtype=torch.uint8)
+    K.check(L.ngm_field_eval_bwd_stash(C.byref(fc), C.byref(ps), F, P, _ptr(points), _ptr(_f32c(pos)), _ptr(_f32c(quat)),
+                                       _ptr(_f32c(d_out, "d_out")), C.byref(gs), _ptr(stash), stash.numel(), _ptr(ws), wsb, _stream()),
+            "ngm_field_eval_bwd_stash")
+    return [grads[n] for n in names]
+
+
+@_field_eval_bwd_stash_op.register_fake
+def _(fcfg, points, pos, quat, d_out, stash, params):
+    return [torch.empty_like(p, dtype=torch.float32) for p in params]
+
+
+def _field_eval_train_setup(ctx, inputs, output):
+    fcfg, points, pos, quat, params = inputs
+    ctx.fcfg, ctx.has_pose, ctx.n = fcfg, pos is not None, len(params)
+    ctx.save_for_backward(points, output[1], *([pos, quat] if pos is not None else []), *params)
+    ctx.mark_non_differentiable(output[1])
+    ctx.set_materialize_grads(False)         # no zero "gradient" of the stash's size (a 2 GB fill per backward at 4 M points)
+
+
+def _field_eval_train_backward(ctx, d_out, _d_stash):
+    if d_out is None:
+        return None, None, None, None, None
+    points, stash, *rest = ctx.saved_tensors
+    pos, quat = (rest[0], rest[1]) if ctx.has_pose else (None, None)
+    params = rest[2:] if ctx.has_pose else rest
+    grads = torch.ops.ngm355.field_eval_bwd_stash(ctx.fcfg, points, pos, quat, d_out.contiguous(), stash, list(params))
+    return None, None, None, None, grads
+
+
+_field_eval_train_op.register_autograd(_field_eval_train_backward, setup_context=_field_eval_train_setup)
+
+# Above this many bytes of stash (256 B per point and hidden layer) a differentiable field_eval keeps the recomputing backward
+# (no stash is held between forward and backward).  The reference's own training batch (32 fields x 512 rays x 24 samples)
+# stashes 0.2 GB; the MI355X has 288 GB.
+FIELD_EVAL_STASH_MAX_BYTES = 16 << 30
+
+
 def field_eval(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None, quat=None):
     """(F,P,3) points -> (F,P,4); differentiable w.r.t. the parameters (not the points/poses).
-    Dispatches through torch.ops.ngm355.field_eval."""
+    Dispatches through torch.ops.ngm355.field_eval; when a gradient will be asked for and the network has a stash-reading
+    backward (ngm_field_eval_stash_bytes > 0) through torch.ops.ngm355.field_eval_train: same outputs bit for bit, the hidden
+    activations kept for the backward (k_field_bwd_b3 in point mode) instead of being recomputed there."""
     names = K.param_names(fc)
     plist = [params[n] for n in names]
     _require_gpu(points, pos, quat, *plist)
-    return torch.ops.ngm355.field_eval(cfg_blob(fc), _f32c(points, "points"), pos, quat, plist)
+    points = _f32c(points, "points")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in plist) and points.shape[1] > 0:
+        sb = int(K.lib().ngm_field_eval_stash_bytes(C.byref(fc), points.shape[0], points.shape[1]))
+        if 0 < sb <= FIELD_EVAL_STASH_MAX_BYTES:
+            return torch.ops.ngm355.field_eval_train(cfg_blob(fc), points, pos, quat, plist)[0]
+    return torch.ops.ngm355.field_eval(cfg_blob(fc), points, pos, quat, plist)
 
 
 def encode(fc: K.FieldCfg, params: Dict[str, torch.Tensor], points, pos=None, quat=None):

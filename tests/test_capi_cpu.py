@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(capi):
         assert hasattr(L, n), f"{n} declared in include/ngm_hip.h but not exported"
     assert sorted(capi.EXPORTED) == names
     want = int(re.search(r"#define\s+NGM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert L.ngm_abi_version() == want == 10
+    assert L.ngm_abi_version() == want == 11
     L.ngm_peer_set_timeout.restype, L.ngm_peer_set_timeout.argtypes = C.c_double, [C.c_double]
     prev = L.ngm_peer_set_timeout(5.0)
     assert prev > 0 and L.ngm_peer_set_timeout(prev) == 5.0 and L.ngm_peer_set_timeout(0.0) == prev     # <= 0 only reads

@@ -336,6 +336,59 @@ def test_field_eval_forward_backward_vs_oracle(kw, P):
         grad_close(pg[k].grad, po[k].grad, 2e-3, k)              # NeRF octaves too (measured <= 3.4e-4; was 1e-2)
 
 
+@pytest.mark.parametrize("kw,P,posed", [(dict(encoding="fourier", dim_enc=64, num_layers=2), 4133, True),
+                                        (dict(encoding="fourier", dim_enc=64, num_layers=2), 31, False),
+                                        (dict(encoding="fourier", dim_enc=64, num_layers=1, raw_coords=False), 1000, True),
+                                        (dict(encoding="nerf", num_octaves=9, num_layers=2), 777, True),
+                                        (dict(encoding="fourier", dim_enc=50, num_layers=2, dim_hidden=60), 515, True)])
+def test_field_eval_training_pair_with_activation_stash(kw, P, posed):
+    """ABI 11: under autograd the point evaluation writes the activation stash (ngm_field_eval_fwd_train) and its backward is the
+    fused step's MLP backward in point mode (ngm_field_eval_bwd_stash -> k_field_bwd_b3).  Same outputs as the plain forward bit
+    for bit; gradients against the oracle at the usual 2e-3 bar and against the recomputing backward; bitwise repeatable; fields
+    that start in the middle of a 32-sample stash tile (P not a multiple of 32); mlp_matmul f32 keeps the recomputing pair."""
+    torch.manual_seed(11)
+    F = 3
+    fs = O.FieldSpec(**kw)
+    fc = K.field_cfg(**kw, matmul_mode="auto")
+    assert K.lib().ngm_field_eval_stash_bytes(K.C.byref(fc), F, P) >= F * P * 256 * kw["num_layers"]
+    assert K.lib().ngm_field_eval_stash_bytes(K.C.byref(K.field_cfg(**kw)), F, P) == 0            # mlp_matmul f32: no stash-reading backward
+    params = O.init_params(fs, F, seed=5, sigma=3.0)
+    pos, quat = torch.randn(F, 3), torch.nn.functional.normalize(torch.randn(F, 4), dim=-1)
+    if not posed:
+        pos, quat = torch.zeros(F, 3), torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(F, 1)
+    q = away_from_relu_boundaries(pos[:, None] + 0.5 * torch.randn(F, P, 3), pos, quat, params, fs)
+    d_out = torch.randn(F, P, 4)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    out_o = O.field_set_forward_vmap(q, pos, quat, po, fs)
+    (out_o * d_out).sum().backward()
+    pose = (pos.to(DEV), quat.to(DEV)) if posed else (None, None)
+    with torch.no_grad():
+        plain = ops.field_eval(fc, cu(params), q.to(DEV), *pose)
+    runs = []
+    for _ in range(2):
+        pg = {k: v.to(DEV).requires_grad_() for k, v in params.items()}
+        out = ops.field_eval(fc, pg, q.to(DEV), *pose)
+        assert torch.equal(out, plain)
+        (out * d_out.to(DEV)).sum().backward()
+        assert K.lib().ngm_debug_last_bwd_variant() == 3
+        runs.append({k: v.grad.clone() for k, v in pg.items()})
+    for k in po:
+        grad_close(runs[0][k], po[k].grad, 2e-3, k)
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    # the recomputing backward (no stash kept) on the same inputs
+    keep = ops.FIELD_EVAL_STASH_MAX_BYTES
+    ops.FIELD_EVAL_STASH_MAX_BYTES = 0
+    try:
+        pg = {k: v.to(DEV).requires_grad_() for k, v in params.items()}
+        out = ops.field_eval(fc, pg, q.to(DEV), *pose)
+        (out * d_out.to(DEV)).sum().backward()
+        assert K.lib().ngm_debug_last_bwd_variant() != 3
+    finally:
+        ops.FIELD_EVAL_STASH_MAX_BYTES = keep
+    for k in po:
+        grad_close(pg[k].grad, runs[0][k], 2e-3, k)
+
+
 def test_neural_field_set_module_matches_oracle():
     torch.manual_seed(0)
     fs = M.NeuralFieldSet(dim_points=3, field_type="neural_graph_mapping.models.NeuralField", field_kwargs=dict(

@@ -149,7 +149,21 @@ def main():
         torch.autograd.grad(out, list(params.values()), go, retain_graph=True)
     add("field_eval_bwd", timeit(fbwd, iters=10), flops=nsamp * 33792, bytes_=nsamp * 28,
         note="point-mode backward (k_field_bwd16, recomputes the forward), 33 792 algorithmic flop/sample")
-    del out, go, params, pts
+    # the training pair with mlp_matmul auto (what the renderer's models use; round 6, ABI 11): the forward also writes the
+    # activation stash (512 B / sample), the backward is k_field_bwd_b3 in point mode reading it back
+    fca = K.field_cfg(encoding="fourier", dim_enc=64, num_layers=2, matmul_mode="auto")
+    add("field_eval_fwd_train_auto", timeit(lambda: ops.field_eval(fca, params, pts, pos, quat)), flops=nsamp * 16896, bytes_=nsamp * (28 + 512),
+        note="ngm_field_eval_fwd_train: the forward under autograd, mlp_matmul auto, + 512 B / sample of activation stash written",
+        kern=kernel_us(lambda: ops.field_eval(fca, params, pts, pos, quat), "points_fwd"))
+    out_a = ops.field_eval(fca, params, pts, pos, quat)
+
+    def fbwd_a():
+        torch.autograd.grad(out_a, list(params.values()), go, retain_graph=True)
+    add("field_eval_bwd_auto", timeit(fbwd_a, iters=10), flops=nsamp * 33792, bytes_=nsamp * (28 + 512),
+        note="ngm_field_eval_bwd_stash: point-mode backward with mlp_matmul auto = k_field_bwd_b3 (bf16 split, reads the forward's "
+             "activation stash, no recompute) + k_grad_reduce; 33 792 algorithmic flop/sample against the fp32 MFMA peak",
+        kern=kernel_us(fbwd_a, "field_bwd"))
+    del out, out_a, go, params, pts
     # ---- hash encode stage (SURVEY 8d "Hash encode gathers": 16 levels x 4 vertices x 2 features x 4 B = 512 B of table
     # gathers per sample): the reference's default field (hash 16 x 2 + 1 x 32 MLP, config/neural_graph_map.yaml:6-20) evaluated on
     # flat points; the MLP adds 2 304 flop per sample (1.4 % of the kernel's instructions), so this IS the encode stage's time

@@ -425,7 +425,7 @@ int ngm_step_advance(int64_t* step_dev, uint64_t* philox_offset_dev, void* strea
 
 /* ---- eval path: kNN-blended field evaluation (models.py:347-405) --------------------------
  * points (P,3) world; all N_f fields' poses; params cover all N_f fields (field_index optional,
- * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 8; N_f unbounded (the centres are binned into a
+ * maps field slot -> parameter row).  out (P,4).  K = min(num_knn, N_f) <= 16 (unrolled neighbour lists for K <= 8, one 16-slot instance above); N_f unbounded (the centres are binned into a
  * uniform grid in the workspace per call; exact K nearest, distance ties to the lower field index).
  * mask_radius: the `field_radius` ARGUMENT of NeuralFieldSet.forward (models.py:293, 368): a point is evaluated when its
  * nearest field centre is closer than this; the local coordinates are still scaled with fcfg->field_radius

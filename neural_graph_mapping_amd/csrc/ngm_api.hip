@@ -1169,7 +1169,7 @@ int ngm_field_eval_knn(const ngm_field_cfg* fcfg, const ngm_params* params, int3
   if (!points || !field_pos || !field_quat || !out || num_fields < 1 || P < 0) return fail(NGM_E_INVALID, "ngm_field_eval_knn: bad argument");
   if (P == 0) return NGM_OK;
   const int K = num_knn < num_fields ? num_knn : num_fields;
-  if (K < 1 || K > 8) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_knn: K must be in [1,8]");
+  if (K < 1 || K > 16) return fail(NGM_E_UNSUPPORTED, "ngm_field_eval_knn: K must be in [1,16]");
   e = ngm_launch_knn(fcfg, params, num_fields, P, points, field_pos, field_quat, K, distance_factor, outside_value,
                      mask_radius > 0.f ? mask_radius : fcfg->field_radius, out, workspace, workspace_bytes, (hipStream_t)stream);
   if (e == NGM_E_WORKSPACE) return fail(e, "ngm_field_eval_knn: workspace too small");
@@ -1196,7 +1196,7 @@ int ngm_render_eval_knn(const ngm_field_cfg* fcfg, const ngm_render_cfg* rcfg, c
     return fail(NGM_E_INVALID, "ngm_render_eval_knn: bad argument");
   if ((int64_t)rays->F * rays->R == 0) return NGM_OK;
   const int K = num_knn < num_fields ? num_knn : num_fields;
-  if (K < 1 || K > 8) return fail(NGM_E_UNSUPPORTED, "ngm_render_eval_knn: K must be in [1,8] (the neighbour assignment and the blend inside the quadrature are compiled for up to 8 neighbours)");
+  if (K < 1 || K > 8) return fail(NGM_E_UNSUPPORTED, "ngm_render_eval_knn: K must be in [1,8] (the blend inside the quadrature is compiled for up to 8 neighbours; K = 9..16: the staged entry points, ngm_sample_rays_world -> ngm_field_eval_knn -> ngm_composite_fwd_packed)");
   e = ngm_launch_render_eval_knn(fcfg, rcfg, params, num_fields, field_pos, field_quat, rays, K, distance_factor, outside_value,
                                  mask_radius > 0.f ? mask_radius : fcfg->field_radius, ray_block, pred, workspace,
                                  workspace_bytes, (hipStream_t)stream);

@@ -621,6 +621,12 @@ __device__ __forceinline__ void b3_split2(float x0, float x1, uint32_t& hp, uint
 }
 
 __device__ __forceinline__ void b3_split8(const float (&x)[8], ngm_bf16x8& H, ngm_bf16x8& M, ngm_bf16x8& Lo) {
+#ifdef NGM_ABLB_NOSPLIT   // timing ablation of k_field_bwd_b3 (results meaningless): operands straight from the fp32 bits, no split arithmetic
+  H = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])});
+  M = __builtin_bit_cast(ngm_bf16x8, ngm_u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])});
+  Lo = H;
+  return;
+#endif
   ngm_u32x4 h4, m4, l4;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -678,6 +684,11 @@ __device__ __forceinline__ void b3_build_planes(const float* sm, ngm_u32x4* plan
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(ngm_bf16x8 a, ngm_bf16x8 b, f32x16 c) {
+#ifdef NGM_ABLB_NOMFMA    // timing ablation of k_field_bwd_b3 (results meaningless): one vector instruction that keeps both operands alive
+  const ngm_u32x4 ua = __builtin_bit_cast(ngm_u32x4, a), ub = __builtin_bit_cast(ngm_u32x4, b);
+  c[0] += __uint_as_float((ua[0] ^ ub[1]) & 0x3fffffffu);
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 

@@ -344,6 +344,17 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
         const float dC0 = k_photo * q0.x, dC1 = k_photo * q0.y, dC2 = k_photo * q0.z, dD = k_depth * q0.w, dT = k_term * q1.x;
         const float depth = -(dzc * t);
         float dodg = 0.f;
+#ifdef NGM_ABLB_NOCOMP    // timing ablation (results meaningless): no compositing backward, the stash row is the gradient
+        {
+          WAVE_SYNC();
+          *reinterpret_cast<float4*>((hi ? pbuf : pbuf2) + 4 * j) = make_float4(x, y, z, 0.f);
+          *reinterpret_cast<float4*>((hi ? obuf : obuf2) + 4 * j) = valid ? dd : make_float4(0.f, 0.f, 0.f, 0.f);
+          WAVE_SYNC();
+        }
+        if (false) {
+#else
+        {
+#endif
         const float occ = occ_pointwise_fast(a.rc.geometry_mode, a.rc.geometry_factor, geom, &dodg);
         const float ak = dC0 * dd.x + dC1 * dd.y + dC2 * dd.z + dD * depth + dT;
         float A = valid ? ak * occ : 0.f, B = valid ? 1.0f - occ : 1.0f;
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
         *reinterpret_cast<float4*>((hi ? obuf : obuf2) + 4 * j) = dout;
         dbo[0] += dout.x; dbo[1] += dout.y; dbo[2] += dout.z; dbo[3] += dout.w;
         WAVE_SYNC();
+        }
       }
     } else {
       // (both halves compute, half 0 stores)
@@ -482,6 +494,10 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const float h = Hc[m][r];
+#ifdef NGM_ABLB_NOOUT     // timing ablation (results meaningless): no output-layer arithmetic
+            dY[m][r] = h + d.x;
+            continue;
+#endif
             const float dh = fmaf(wout[m].w, d.w, fmaf(wout[m].z, d.z, fmaf(wout[m].y, d.y, wout[m].x * d.x)));
             const float g = (h > 0.f) ? dh : 0.f;
             dY[m][r] = g;
@@ -603,6 +619,11 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           const float4 w = encw[m];
+#ifdef NGM_ABLB_NOENC     // timing ablation (results meaningless): no encoding arithmetic, no Fourier-matrix gradient
+          Eb[b][m][e] = p.x + w.x;
+          if (ENC_GRAD) dwf[m][0] += dE[m][8 * b + e];
+          continue;
+#endif
           const float arg = fmaf(w.z, p.z, fmaf(w.y, p.y, w.x * p.x));
           const float rev = __builtin_amdgcn_fractf(arg * inv2pi);
           const float sn = __builtin_amdgcn_sinf(rev);

@@ -324,7 +324,17 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
     cs = lcs; cc = lcc;
   }
   __syncthreads();
-  constexpr int K = KK;
+  // KK <= 8: K = KK, everything unrolled over the list.  KK = 16 (round 6): the instance for K = 9..16 -- the list has 16 slots,
+  // the run-time K says how many of them count (the reference takes any num_knn, models.py:354-366)
+  const int K = (KK > KNN_MAXK) ? a.K : KK;
+  auto kth = [&](const auto& arr) __attribute__((always_inline)) {       // arr[K - 1] without indexing registers by a run-time value
+    auto v = arr[KK - 1];
+    if constexpr (KK > KNN_MAXK) {
+#pragma unroll
+      for (int k = 0; k < KK; ++k) v = (k == K - 1) ? arr[k] : v;
+    }
+    return v;
+  };
   const int maxR = max(h.nx, max(h.ny, h.nz));
   const float c2 = h.c * h.c;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -351,7 +361,8 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
     }
     if (nj0 == nj1) {                                            // nowhere near a field: outside, no search
 #pragma unroll
-      for (int k = 0; k < KK; ++k) a.pair_field[p * KK + k] = -1;
+      for (int k = 0; k < KK; ++k)
+        if (k < K) a.pair_field[p * K + k] = -1;
       continue;
     }
     float bd[KK]; int bi[KK];
@@ -398,8 +409,8 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
                   const float td = bd[k]; const int ti = bi[k]; bd[k] = d; bi[k] = id; d = td; id = ti;
                 }
               }
-              worst = bd[KK - 1];
-              worst_i = bi[KK - 1];
+              worst = kth(bd);
+              worst_i = kth(bi);
             }
           }
         }
@@ -432,7 +443,12 @@ __global__ __launch_bounds__(256) void k_knn_assign(KnnArgs a) {
       bi[k] = (int)(unsigned)(key[k] & 0xffffffffull);
       bd[k] = (key[k] == ~0ull) ? INFINITY : __uint_as_float((unsigned)(key[k] >> 32));
     }
-    worst = bd[KK - 1]; worst_i = bi[KK - 1];
+    if constexpr (KK > KNN_MAXK) {       // slots beyond K are not part of the list (phase B's insertion never touches them)
+#pragma unroll
+      for (int k = 0; k < KK; ++k)
+        if (k >= K) { bd[k] = INFINITY; bi[k] = -1; }
+    }
+    worst = kth(bd); worst_i = kth(bi);
     const float dmin = bd[0];                                    // (no centre within the radius: infinity, outside)
     bool inside = sqrtf(dmin) < a.radius;                        // models.py:369 (the same squared distance as the list's bd[0])
     // every centre closer than the radius has been seen: a K-th neighbour inside the radius is the K-th nearest
@@ -725,6 +741,7 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
     NGM_KA(true, 1, 64 * 1024); NGM_KA(true, 2, 64 * 1024); NGM_KA(true, 3, 64 * 1024); NGM_KA(true, 4, 64 * 1024);
     NGM_KA(false, 5, 150 * 1024); NGM_KA(false, 6, 150 * 1024); NGM_KA(false, 7, 150 * 1024); NGM_KA(false, 8, 150 * 1024);
     NGM_KA(true, 5, 64 * 1024); NGM_KA(true, 6, 64 * 1024); NGM_KA(true, 7, 64 * 1024); NGM_KA(true, 8, 64 * 1024);
+    NGM_KA(false, 16, 150 * 1024); NGM_KA(true, 16, 64 * 1024);
 #undef NGM_KA
     return e;
   }();
@@ -753,7 +770,8 @@ static int knn_stages(KnnArgs& a, bool build_grid, hipStream_t st) {
       else hipLaunchKernelGGL((k_knn_assign<false, KK_>), dim3(std::max(pb, 1)), dim3(256), a.hist_in_lds ? lds_h : 0, st, a); \
     } while (0)
     if (K == 1) NGM_KL(1); else if (K == 2) NGM_KL(2); else if (K == 3) NGM_KL(3); else if (K == 4) NGM_KL(4);
-    else if (K == 5) NGM_KL(5); else if (K == 6) NGM_KL(6); else if (K == 7) NGM_KL(7); else if (K == 8) NGM_KL(8); else return NGM_E_UNSUPPORTED;
+    else if (K == 5) NGM_KL(5); else if (K == 6) NGM_KL(6); else if (K == 7) NGM_KL(7); else if (K == 8) NGM_KL(8);
+    else if (K <= 16) NGM_KL(16); else return NGM_E_UNSUPPORTED;
 #undef NGM_KL
   }
   if (hipGetLastError() != hipSuccess) return NGM_E_HIP;      // an over-sized LDS request fails here, not four launches later

@@ -264,10 +264,12 @@ class NeuralFieldSet(torch.nn.Module):
             raise NotImplementedError("Only 2D and 3D spaces are supported.")      # models.py:236-243
         if scale_mode not in K.SCALE:
             raise NotImplementedError(f"{scale_mode=} is not available.")
-        if not 1 <= int(num_knn) <= 8:
+        if not 1 <= int(num_knn) <= 16:
             # the reference takes any num_knn (models.py:354-366: knn_points + a softmax over K); the assignment kernel keeps the K
-            # best in registers and is compiled for K = 1..8 (include/ngm_hip.h, ngm_field_eval_knn) -- fail here, not at the first render
-            raise NotImplementedError(f"num_knn={num_knn}: the kNN evaluation kernels are compiled for 1 <= K <= 8")
+            # best in registers: unrolled instances for K = 1..8, one 16-slot instance for K = 9..16 (include/ngm_hip.h,
+            # ngm_field_eval_knn; the one-call image path blends up to 8 and hands K > 8 to the staged entry points) -- fail here,
+            # not at the first render
+            raise NotImplementedError(f"num_knn={num_knn}: the kNN evaluation kernels are compiled for 1 <= K <= 16")
         self._scale_mode, self._field_radius, self._dim_points = scale_mode, field_radius, dim_points
         self._num_knn, self._distance_factor, self._outside_value = num_knn, distance_factor, outside_value
         self._prototype_field = str_to_object(field_type)(**field_kwargs)

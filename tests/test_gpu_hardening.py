@@ -134,7 +134,8 @@ def test_in_kernel_philox_equals_host_philox(n_c, n_g):
 
 # ------------------------------------------------------------------------------------------------ kNN evaluation, large maps
 @pytest.mark.parametrize("NF,K_,P,layout", [(10000, 2, 6000, "cover_grid"), (10000, 4, 4000, "random"), (5000, 2, 6000, "two_rooms"),
-                                            (40000, 2, 3000, "cover_grid"), (20000, 6, 3000, "cover_grid")])      # K > 4 with a histogram of more than 64 KB of LDS
+                                            (40000, 2, 3000, "cover_grid"), (20000, 6, 3000, "cover_grid"),      # K > 4 with a histogram of more than 64 KB of LDS
+                                            (3000, 11, 3000, "random"), (20000, 14, 2000, "cover_grid")])         # K = 9..16: run-time K in the 16-slot instance
 def test_knn_assignment_large_maps_vs_oracle(NF, K_, P, layout):
     """The nearest-field assignment bins the centres into a uniform grid on the device and grows the block of cells around a
     point until the K-th neighbour is provably exact -- no limit on the number of fields (round 3: 4096).  10 000 fields on
@@ -452,7 +453,7 @@ def test_stash_modes_bitwise_deterministic_and_close_to_full():
             assert torch.equal(g0[k], full[k]), k
 
 
-@pytest.mark.parametrize("num_knn,S", [(6, 64), (8, 640), (5, 40)])
+@pytest.mark.parametrize("num_knn,S", [(6, 64), (8, 640), (5, 40), (10, 64), (16, 40)])
 def test_image_path_with_more_than_four_neighbours(num_knn, S):
     """K = 5..8: assignment, evaluation and -- since the end of round 5 -- the blend inside the one-call image path's quadrature
     take up to 8 neighbours (whole-ray and generic quadrature kernels, two wave steps gathered at a time instead of five):
@@ -477,8 +478,19 @@ def test_image_path_with_more_than_four_neighbours(num_knn, S):
     r.eval()
     c2w = torch.eye(4, device=DEV)
     img, dv = r.render_image(c2w, seed=5)
-    assert r.last_eval_path.startswith("fused") and not r.eval_fallbacks
+    if num_knn <= 8:
+        assert r.last_eval_path.startswith("fused") and not r.eval_fallbacks
+    else:          # K = 9..16 (round 6): the one-call image path reports NGM_E_UNSUPPORTED once, the staged entry points serve the image
+        assert r.last_eval_path.startswith("staged") and len(r.eval_fallbacks) == 1 and "[1,8]" in r.eval_fallbacks[0]
     r.eval_fused = False
     img2, dv2 = r.render_image(c2w, seed=5)
     assert torch.equal(img, img2) and torch.equal(dv, dv2)
+    if num_knn > 8:                                  # ... and equals the oracle's blend of K neighbours on the same samples
+        from oracle import ngm_oracle as O
+        ospec = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)
+        pcpu = {k: v.cpu() for k, v in model.all_fields_params.items() if k != "_neus_sd"}
+        pts = torch.rand(4000, 3) * torch.tensor([3.0, 3.0, 1.5]) + torch.tensor([-1.5, -1.5, -3.0])
+        ref = O.field_set_forward_knn(pts, pos, quat, pcpu, ospec, num_knn=num_knn, distance_factor=10.0, outside_value=1.0, radius=0.6)
+        out = model(pts.to(DEV), pos.to(DEV), quat.to(DEV), None, False)
+        close(out, ref, rtol=3e-4, atol=3e-5)
     assert torch.isfinite(img).all() and float((img[..., :3] != 1.0).float().mean()) > 0.05      # the map is in view

@@ -1189,7 +1189,8 @@ def test_knn_blend_golden(mm):
     assert K.lib().ngm_debug_last_matmul(1) == K.MATMUL["f32" if mm == "f32" else "bf16x3"]       # the point evaluation too
 
 
-@pytest.mark.parametrize("NF,K_,P", [(1, 2, 300), (7, 3, 5000), (40, 2, 70000), (40, 5, 9000), (12, 8, 9000), (6, 8, 3000), (90, 7, 20000)])
+@pytest.mark.parametrize("NF,K_,P", [(1, 2, 300), (7, 3, 5000), (40, 2, 70000), (40, 5, 9000), (12, 8, 9000), (6, 8, 3000), (90, 7, 20000),
+                                     (40, 9, 9000), (60, 12, 6000), (30, 16, 5000), (11, 16, 2000)])     # K = 9..16: the 16-slot instance (round 6)
 def test_knn_blend_vs_oracle(NF, K_, P):
     torch.manual_seed(NF)
     fs = O.FieldSpec(encoding="fourier", dim_enc=32, num_layers=1)

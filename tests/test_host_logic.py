@@ -52,9 +52,10 @@ def test_unsupported_variants_raise():
     assert cat._linears[1].weight.shape == (64, 128) and cat._linears[2].weight.shape == (4, 128)
     with pytest.raises(ValueError):
         M.NeuralFieldSet(**{**SET_KW, "field_radius": None})
-    M.NeuralFieldSet(**{**SET_KW, "num_knn": 8})                  # K = 1..8 are compiled
-    with pytest.raises(NotImplementedError, match="1 <= K <= 8"):   # the reference takes any K; fail at construction, citing the limit
-        M.NeuralFieldSet(**{**SET_KW, "num_knn": 9})
+    M.NeuralFieldSet(**{**SET_KW, "num_knn": 8})                  # K = 1..8: unrolled neighbour lists
+    M.NeuralFieldSet(**{**SET_KW, "num_knn": 16})                 # K = 9..16: the 16-slot instance (round 6)
+    with pytest.raises(NotImplementedError, match="1 <= K <= 16"):  # the reference takes any K; fail at construction, citing the limit
+        M.NeuralFieldSet(**{**SET_KW, "num_knn": 17})
 
 
 def test_planar_field_sets_wiring(monkeypatch):

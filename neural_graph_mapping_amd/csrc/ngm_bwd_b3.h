@@ -274,6 +274,41 @@ __device__ __forceinline__ void build_dgrad_planes(const ngm_field_cfg& fc, cons
   }
 }
 
+// The same in two phases, for a prologue that has every global load of the workgroup in flight at once (round 6: built one
+// after the other -- constants, loss partials, two plane iterations per layer, each load waited for where it was issued -- the
+// prologue was ~9 serial memory round trips: 15.9 k clocks of a 300 k-clock kernel at the M1 batch, 11 k of 43 k at one field
+// x 512 rays x 24 samples).  planes_offsets / ngm_ldp_gather issue, planes_commit masks, splits and stores.
+// FWD: the forward orientation (build_fwd_planes) instead of the data-gradient one.
+template <bool FWD>
+__device__ __forceinline__ void planes_offsets(const ngm_field_cfg& fc, int l, int it, int (&off)[8]) {
+  const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
+  const int g = threadIdx.x + it * B3B_THREADS;
+  const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int o = FWD ? 32 * nt + n : 16 * kb + 8 * kh + e, c = FWD ? 16 * kb + 8 * kh + e : 32 * nt + n;
+    off[e] = (o < H && c < Din) ? o * Din + c : 0;
+  }
+}
+template <bool FWD>
+__device__ __forceinline__ void planes_commit(const ngm_field_cfg& fc, int l, int it, const float* xin, ngm_u32x4* P) {
+  const int Din = (l == 0) ? fc.dim_enc : fc.dim_hidden, H = fc.dim_hidden;
+  const int g = threadIdx.x + it * B3B_THREADS;
+  const int n = g & 31, kh = (g >> 5) & 1, kb = (g >> 6) & 3, nt = g >> 8;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int o = FWD ? 32 * nt + n : 16 * kb + 8 * kh + e, c = FWD ? 16 * kb + 8 * kh + e : 32 * nt + n;
+    x[e] = (o < H && c < Din) ? xin[e] : 0.f;
+  }
+  ngm_bf16x8 h, m, lo;
+  b3_split8(x, h, m, lo);
+  P[g] = __builtin_bit_cast(ngm_u32x4, h);
+  P[PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, m);
+  P[2 * PLANE_G + g] = __builtin_bit_cast(ngm_u32x4, lo);
+}
+static_assert(PLANE_G == 2 * B3B_THREADS, "two plane granules per thread");
+
 // HS: weight planes of layer l in the FORWARD orientation, for Y^T[s][32 nt + n] = sum_i X[s][i] W[32 nt + n][i] with the rows
 // of the X tile as A operand (same lane / k order as the data gradient's): granule (plane, nt, kb, kh, n) = W[32 nt + n][16 kb + 8 kh + e]
 __device__ __forceinline__ void build_fwd_planes(const ngm_field_cfg& fc, const ngm_params& pr, int64_t row, int l, ngm_u32x4* P) {

@@ -128,10 +128,18 @@ template <int L, bool NEED_COS, bool ENC_GRAD, bool FC = false, bool HS = false>
 __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = LdsB3b<L, ENC_GRAD, HS>;
+#ifdef NGM_PROLOGUE_TIMING   // clocks since kernel entry at the prologue's milestones (middle block, thread 0) -> debug_cycles[0..7]
+  unsigned long long ptk_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pt0_ = __builtin_readcyclecounter();
+#define PTK(i) ptk_[i] = __builtin_readcyclecounter() - pt0_
+#else
+#define PTK(i)
+#endif
   const int f = blockIdx.x % a.F, chunk = blockIdx.x / a.F;
   const int64_t row = a.pr.field_index ? a.pr.field_index[f] : f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, hi = lane >> 5;
+  PTK(0);
   ngm_u32x4* planes = reinterpret_cast<ngm_u32x4*>(sm);
   float* wl = sm + LY::PLANES + wave * LY::WAVE_TOTAL;
   float* inb = wl + LY::INB;
@@ -236,35 +244,78 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     if (L == 2) issue_tile32(fs.act[0], fs.gb, first, end, lane, wl_lds + LY::H1 * 4);
   }
   // per-feature constants (output-layer column, encoding row): LDS, re-read by the phase that needs them -- as
-  // loop-long register residents they were spilled to scratch, and a scratch reload waits on vmcnt, i.e. on the DMA
+  // loop-long register residents they were spilled to scratch, and a scratch reload waits on vmcnt, i.e. on the DMA.
+  // Round 6: every global load of the prologue -- constants, the forward's loss partials, the weights of all plane sets -- is
+  // ISSUED here, behind the first tile's transfers, and consumed below: one memory round trip instead of ~9 in a row.
   float4* cwout = reinterpret_cast<float4*>(sm + LY::CONSTS);
   float4* cenc = cwout + 64;
+  __shared__ float s_red[FC ? 16 : 1][17];
+  __shared__ float s_sums[NGM_NUM_LOSS_SUMS];
+  constexpr int NSETS = (ENC_GRAD ? 1 : 0) + (L == 2 ? 1 : 0) + (HS ? 1 : 0);       // plane sets, in build order
+  constexpr int NPX = NSETS > 0 ? NSETS * 16 : 1;
+  float px_[NPX];                      // 2 granules x 8 weights per set
+  {
+    int off_[NPX];
+    int si = 0;
+    if (ENC_GRAD) { planes_offsets<false>(a.fc, 0, 0, *reinterpret_cast<int(*)[8]>(off_ + 16 * si)); planes_offsets<false>(a.fc, 0, 1, *reinterpret_cast<int(*)[8]>(off_ + 16 * si + 8)); ++si; }
+    if (L == 2) { planes_offsets<false>(a.fc, 1, 0, *reinterpret_cast<int(*)[8]>(off_ + 16 * si)); planes_offsets<false>(a.fc, 1, 1, *reinterpret_cast<int(*)[8]>(off_ + 16 * si + 8)); ++si; }
+    if (HS) { planes_offsets<true>(a.fc, 1, 0, *reinterpret_cast<int(*)[8]>(off_ + 16 * si)); planes_offsets<true>(a.fc, 1, 1, *reinterpret_cast<int(*)[8]>(off_ + 16 * si + 8)); ++si; }
+    // one storage-type branch around all of them; layer 0's and layer 1's weights are different tensors: per-set base
+    si = 0;
+    if (ENC_GRAD) { ngm_ldp_gather<16>(a.pr.w[0], row * a.pr.w_stride[0], *reinterpret_cast<int(*)[16]>(off_ + 16 * si), a.pr.dtype, *reinterpret_cast<float(*)[16]>(px_ + 16 * si)); ++si; }
+    if (L == 2) { ngm_ldp_gather<16>(a.pr.w[1], row * a.pr.w_stride[1], *reinterpret_cast<int(*)[16]>(off_ + 16 * si), a.pr.dtype, *reinterpret_cast<float(*)[16]>(px_ + 16 * si)); ++si; }
+    if (HS) { ngm_ldp_gather<16>(a.pr.w[1], row * a.pr.w_stride[1], *reinterpret_cast<int(*)[16]>(off_ + 16 * si), a.pr.dtype, *reinterpret_cast<float(*)[16]>(px_ + 16 * si)); ++si; }
+  }
+  // the forward's loss partials: this thread's share (slot, every 16th partial), at most PMAX of them in registers
+  constexpr int PMAX = 20;
+  float pv_[FC ? PMAX : 1];
+  const int lslot = threadIdx.x & 15, lpart = threadIdx.x >> 4;
+  if constexpr (FC) {
+    if (a.loss_partials) {
+#pragma unroll
+      for (int q = 0; q < PMAX; ++q) {
+        const int b_ = lpart + 16 * q;
+        pv_[q] = (b_ < a.n_partials) ? a.loss_partials[(int64_t)b_ * NGM_NUM_LOSS_SUMS + lslot] : 0.f;
+      }
+    }
+  }
+  float4 cw_ = make_float4(0.f, 0.f, 0.f, 0.f), ce_ = make_float4(0.f, 0.f, 0.f, NGM_FK_ZERO);
+  float cb_ = 0.f;
   if (threadIdx.x < 64) {
     const int ft = threadIdx.x, H = a.fc.dim_hidden;
     const float* W = a.pr.w[L];
     const int64_t w0 = row * a.pr.w_stride[L];
-    cwout[ft] = (ft < H) ? make_float4(ngm_ldp(W, w0 + ft, a.pr.dtype), ngm_ldp(W, w0 + H + ft, a.pr.dtype),
-                                       ngm_ldp(W, w0 + 2 * H + ft, a.pr.dtype), ngm_ldp(W, w0 + 3 * H + ft, a.pr.dtype))
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-    cenc[ft] = enc_row_of(a.fc, a.pr, row, ft);
-    if constexpr (HS) sm[LY::CONSTS + 512 + ft] = (ft < H) ? ngm_ldp(a.pr.b[1], row * a.pr.b_stride[1] + ft, a.pr.dtype) : 0.f;
+    if (ft < H) cw_ = make_float4(ngm_ldp(W, w0 + ft, a.pr.dtype), ngm_ldp(W, w0 + H + ft, a.pr.dtype),
+                                  ngm_ldp(W, w0 + 2 * H + ft, a.pr.dtype), ngm_ldp(W, w0 + 3 * H + ft, a.pr.dtype));
+    ce_ = enc_row_of(a.fc, a.pr, row, ft);
+    if constexpr (HS) cb_ = (ft < H) ? ngm_ldp(a.pr.b[1], row * a.pr.b_stride[1] + ft, a.pr.dtype) : 0.f;
+  }
+  // ---- consumption
+  if (threadIdx.x < 64) {
+    cwout[threadIdx.x] = cw_;
+    cenc[threadIdx.x] = ce_;
+    if constexpr (HS) sm[LY::CONSTS + 512 + threadIdx.x] = cb_;
   }
   // FC: the global loss normalisers, as in k_stash_bwd (from the all-reduced sums, or summed here by every workgroup from
   // the forward's per-workgroup partials in k_loss_reduce's fixed order: identical everywhere, deterministic)
-  __shared__ float s_red[FC ? 16 : 1][17];
-  __shared__ float s_sums[NGM_NUM_LOSS_SUMS];
   if constexpr (FC) {
     if (a.loss_partials) {
-      const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
-      float s = 0.f;
-      for (int b = part; b < a.n_partials; b += 16) s += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
-      s_red[part][slot] = s;
+      float s_ = 0.f;
+#pragma unroll
+      for (int q = 0; q < PMAX; ++q) s_ += pv_[q];           // + 0 beyond the last partial: the same sum, the same order
+      for (int b_ = lpart + 16 * PMAX; b_ < a.n_partials; b_ += 16) s_ += a.loss_partials[(int64_t)b_ * NGM_NUM_LOSS_SUMS + lslot];
+      s_red[lpart][lslot] = s_;
     }
   }
-  if (ENC_GRAD) build_dgrad_planes(a.fc, a.pr, row, 0, planes + LY::plane_slot(0) * 3 * PLANE_G);
-  if (L == 2) build_dgrad_planes(a.fc, a.pr, row, 1, planes + LY::plane_slot(1) * 3 * PLANE_G);
-  if constexpr (HS) build_fwd_planes(a.fc, a.pr, row, 1, planes + LY::fwd_slot() * 3 * PLANE_G);
+  {
+    int si = 0;
+    if (ENC_GRAD) { planes_commit<false>(a.fc, 0, 0, px_ + 16 * si, planes + LY::plane_slot(0) * 3 * PLANE_G); planes_commit<false>(a.fc, 0, 1, px_ + 16 * si + 8, planes + LY::plane_slot(0) * 3 * PLANE_G); ++si; }
+    if (L == 2) { planes_commit<false>(a.fc, 1, 0, px_ + 16 * si, planes + LY::plane_slot(1) * 3 * PLANE_G); planes_commit<false>(a.fc, 1, 1, px_ + 16 * si + 8, planes + LY::plane_slot(1) * 3 * PLANE_G); ++si; }
+    if (HS) { planes_commit<true>(a.fc, 1, 0, px_ + 16 * si, planes + LY::fwd_slot() * 3 * PLANE_G); planes_commit<true>(a.fc, 1, 1, px_ + 16 * si + 8, planes + LY::fwd_slot() * 3 * PLANE_G); ++si; }
+  }
+  PTK(1);
   __syncthreads();
+  PTK(2);
   __shared__ __attribute__((aligned(16))) float s_k[8];   // FC: the five normalisers, re-read per tile (loop-long registers would spill)
   if constexpr (FC) {
     if (threadIdx.x < NGM_NUM_LOSS_SUMS) {
@@ -294,6 +345,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     }
     __syncthreads();
   }
+  PTK(3);
   float carryQ = 0.f;                 // FC: suffix value of the ray that continues into the next (= previous in memory) tile
   if constexpr (FC) {
     // the range ends with a tile, not necessarily with a ray: the recursion over the rest of the cut ray first
@@ -307,7 +359,9 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   for (int j = 0; j < 4; ++j) col[j] = (i >> 2) * 128 + (i & 3) + 4 * ((4 * hi + j) ^ (i >> 2));
 #define COL_OFF(m, r) ((m) * 1024 + col[(r) & 3] + 32 * ((r) >> 2))
 
+  PTK(4);
   DMA_WAIT(0);
+  PTK(5);
   TICK_DECL;
   TICK(0);
   for (uint32_t it = 0; it < ntiles; ++it) {
@@ -693,6 +747,7 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     WAVE_SYNC();
   }
 #undef COL_OFF
+  PTK(6);
   if constexpr (HS) {                 // the per-feature sums back into registers before the staging area takes all of LDS
     const float4 a0 = accl[0], a1 = accl[64], a2 = accl[128], f0 = accl[192], f1 = accl[256];
     dwo[0][0] = a0.x; dwo[0][1] = a0.y; dwo[0][2] = a0.z; dwo[0][3] = a0.w;
@@ -788,6 +843,15 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     for (int64_t p = enc_off + threadIdx.x; p < w_off[0]; p += B3B_THREADS) dst[p] = 0.f;
   TICK(11);
   TICK_REPORT
+#ifdef NGM_PROLOGUE_TIMING
+  PTK(7);
+  if (a.debug_cycles && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) a.debug_cycles[k] = ptk_[k];
+    for (int k = 8; k < 13; ++k) a.debug_cycles[k] = 0;
+    a.debug_cycles[12] = ptk_[7];
+  }
+#endif
+#undef PTK
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -321,6 +321,16 @@ def check_time(F=8, R=512, S_c=64, S_g=64, iters=10, hash_enc=False):
     H.synchronize()
     e = [H.Event() for _ in range(3)]
     tf = tb = 0.0
+    if os.environ.get("NGM_TWICE"):      # experiment: the same kernel twice in a row -- what a warm instruction cache / warm L2 is worth
+        ee = [H.Event() for _ in range(5)]
+        acc = [0.0] * 4
+        for _ in range(iters):
+            ee[0].record(); fwd(); ee[1].record(); fwd(); ee[2].record(); bwd(); ee[3].record(); bwd(); ee[4].record()
+            ee[4].synchronize()
+            for i in range(4):
+                acc[i] += ee[i].elapsed_ms(ee[i + 1])
+        print(f"[twice F={F} R={R} S={S_c + S_g}] fwd first/second us: {acc[0] / iters * 1e3:.1f} / {acc[1] / iters * 1e3:.1f}   "
+              f"bwd (+reduce) first/second us: {acc[2] / iters * 1e3:.1f} / {acc[3] / iters * 1e3:.1f}")
     for _ in range(iters):
         e[0].record(); fwd(); e[1].record(); bwd(); e[2].record()
         e[2].synchronize()

@@ -370,6 +370,19 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
         T0 = make_float4(Tp[0], Tp[1], Tp[2], Tp[3]); T1 = make_float4(Tp[4], Tp[5], Tp[6], Tp[7]);
         T2 = make_float4(Tp[8], Tp[9], Tp[10], Tp[11]);
       }
+      // the ray's targets too, before anything is stored: behind the ray-table stores below the compiler may not move these
+      // loads up (it cannot prove the tables apart), and they were one more memory round trip at the end of the set-up
+      float4 tgt4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned char tgt_dm = 0, tgt_tm = 0;
+      float tgt_tp = 0.f;
+      if (a.has_targets) {
+        tgt4 = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
+        tgt_dm = a.tg.depth_mask[ray];
+        const unsigned char* tmp = a.tg.term_mask ? a.tg.term_mask + ray : a.tg.depth_mask + ray;
+        const float* tpp = (a.tg.term_mask && a.tg.term_probs) ? a.tg.term_probs + ray : a.tg.rgbds;
+        tgt_tm = *tmp;
+        tgt_tp = *tpp;
+      }
       const RayGeom g = ray_geom(a.rc, a.rays, ray, guided);
       Vec3 dw{T0.x * g.dx + T0.y * g.dy + T0.z * g.dz, T1.x * g.dx + T1.y * g.dy + T1.z * g.dz,
               T2.x * g.dx + T2.y * g.dy + T2.z * g.dz};
@@ -390,12 +403,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       if (a.has_targets) {
         // the ray's targets ride along in the free table slots: the output phase at the end of the batch then
         // has no global load (and no memory latency) left in it
-        const float4 tg = reinterpret_cast<const float4*>(a.tg.rgbds)[ray];
-        const unsigned char dm = a.tg.depth_mask[ray];
-        const unsigned char* tmp = a.tg.term_mask ? a.tg.term_mask + ray : a.tg.depth_mask + ray;
-        const float* tpp = (a.tg.term_mask && a.tg.term_probs) ? a.tg.term_probs + ray : a.tg.rgbds;
-        const unsigned char tm = *tmp;
-        const float tp = *tpp;
+        const float4 tg = tgt4;
+        const unsigned char dm = tgt_dm, tm = tgt_tm;
+        const float tp = tgt_tp;
         rt[12] = tg.x; rt[13] = tg.y; rt[14] = tg.z; rt[15] = tg.w;
         wl.ra[lane][9] = dm ? 1.f : 0.f;
         wl.ra[lane][10] = (a.tg.term_mask && tm) ? 1.f : 0.f;

@@ -129,6 +129,20 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
     }
   };
   if (ntiles) issue(first);
+  // FC: this thread's share of the forward's loss partials, in flight together with the weights below (round 6: summed in a
+  // loop of its own after the planes were built, the prologue was two more memory round trips long)
+  constexpr int PMAX = 20;
+  float pv_[FC ? PMAX : 1];
+  if constexpr (FC) {
+    if (a.loss_partials && threadIdx.x < 256) {
+      const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
+#pragma unroll
+      for (int q = 0; q < PMAX; ++q) {
+        const int b_ = part + 16 * q;
+        pv_[q] = (b_ < a.n_partials) ? a.loss_partials[(int64_t)b_ * NGM_NUM_LOSS_SUMS + slot] : 0.f;
+      }
+    }
+  }
   // weight planes + per-unit constants while the first tile travels
   {
     const float* W = a.pr.w[0];
@@ -176,7 +190,9 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
     if (a.loss_partials && threadIdx.x < 256) {
       const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
       float sacc = 0.f;
-      for (int b = part; b < a.n_partials; b += 16) sacc += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
+#pragma unroll
+      for (int q = 0; q < PMAX; ++q) sacc += pv_[q];               // + 0 beyond the last partial: the same sum in the same order
+      for (int b = part + 16 * PMAX; b < a.n_partials; b += 16) sacc += a.loss_partials[(int64_t)b * NGM_NUM_LOSS_SUMS + slot];
       s_red[part][slot] = sacc;
     }
   }

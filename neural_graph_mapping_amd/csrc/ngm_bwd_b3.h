@@ -55,7 +55,8 @@ struct LdsB3b {
   static constexpr int ACCL = OB2 + 128;
   static constexpr int WAVE_TOTAL = ACCL + (HS ? 5 * 256 : 0);
   static constexpr int NT = 4 * L;                                   // 32x32 accumulator tiles per wave
-  static constexpr int EPI = B3B_WAVES * NT * 1024;
+  static constexpr int EPI_ACC = B3B_WAVES * NT * 1024;               // epilogue staging: the waves' accumulator tiles ...
+  static constexpr int EPI = EPI_ACC + B3B_WAVES * (2 * L + 18) * 64;  // ... and their per-feature vectors behind them
   static constexpr int BODY = PLANES + B3B_WAVES * WAVE_TOTAL;
   static constexpr int TOTAL = BODY > EPI ? BODY : EPI;
 };

@@ -758,9 +758,15 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
   }
   __syncthreads();
 
-  // ---- epilogue: the four waves' accumulators are summed in fixed wave order (all of LDS is free now)
+  // ---- epilogue: the four waves' accumulators are summed in fixed wave order (all of LDS is free now).
+  // Round 6: accumulator tiles AND per-feature vectors are staged before ONE barrier (they were two staging rounds with a
+  // barrier each), and the summing passes issue every LDS read of a thread before the first add (they were 8 + 3 dependent
+  // iterations): ~11 k clocks per workgroup -> see profiles/r06_small_batch_clocks.txt.
   float* stage = sm;
   constexpr int NT = LY::NT;
+  constexpr int NV = 2 * L + 8 + 6 + 4;
+  static_assert(LY::EPI_ACC + B3B_WAVES * NV * 64 <= LY::TOTAL, "the per-feature vectors are staged behind the accumulator tiles");
+  float* stagev = sm + LY::EPI_ACC;
   // staging layout [wave][tile][q = r >> 2][lane][4 floats]: 16-byte LDS accesses on both sides
 #pragma unroll
   for (int l = 0; l < L; ++l)
@@ -774,34 +780,9 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
           *reinterpret_cast<float4*>(stage + (((wave * NT + (l * 4 + mo * 2 + mi)) * 4 + q) * 64 + lane) * 4) =
               make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
         }
-  __syncthreads();
-  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
-  (void)ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
-  float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
-  const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
-  for (int e4 = threadIdx.x; e4 < NT * 256; e4 += B3B_THREADS) {
-    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int w = 0; w < B3B_WAVES; ++w) {                           // fixed wave order: deterministic
-      const float4 v = *reinterpret_cast<const float4*>(stage + (w * NT * 256 + e4) * 4);
-      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-    }
-    const int t = e4 >> 8, q = (e4 >> 6) & 3, ln = e4 & 63;
-    const int l = t >> 2, mo = (t >> 1) & 1, mi = t & 1;
-    const int o0 = 32 * mo + 8 * q + 4 * (ln >> 5), c = 32 * mi + (ln & 31), din = (l == 0) ? D : H;   // rows frow(4q + j, hi) = o0 + j
-    if (c < din) {
-      float* d = dst + w_off[l] + (int64_t)o0 * din + c;
-      if (o0 < H) d[0] = s4.x;
-      if (o0 + 1 < H) d[din] = s4.y;
-      if (o0 + 2 < H) d[2 * din] = s4.z;
-      if (o0 + 3 < H) d[3 * din] = s4.w;
-    }
-  }
-  __syncthreads();
   // per-feature vectors: lane (i, hi) holds the partial sums of feature 32 m + i over its half of the samples
-  constexpr int NV = 2 * L + 8 + 6 + 4;
   {
-    float* sw = stage + wave * NV * 64;
+    float* sw = stagev + wave * NV * 64;
     int k = 0;
 #pragma unroll
     for (int l = 0; l < L; ++l)
@@ -819,24 +800,71 @@ __global__ __launch_bounds__(B3B_THREADS) void k_field_bwd_b3(FieldBwdArgs a) {
     for (int c = 0; c < 4; ++c) sw[(k++) * 64 + lane] = wave_sum(dbo[c]);
   }
   __syncthreads();
+  int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
+  (void)ngm_param_offsets(&a.fc, &enc_off, w_off, b_off);
+  float* dst = a.partials + (int64_t)blockIdx.x * a.p_pad;
+  const int D = a.fc.dim_enc, H = a.fc.dim_hidden;
+  {
+    static_assert(NT * 256 % B3B_THREADS == 0, "whole passes");
+    constexpr int NIT = NT * 256 / B3B_THREADS;
+    float4 v4[NIT][B3B_WAVES];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int w = 0; w < B3B_WAVES; ++w)
+        v4[it][w] = *reinterpret_cast<const float4*>(stage + (w * NT * 256 + it * B3B_THREADS + threadIdx.x) * 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e4 = it * B3B_THREADS + threadIdx.x;
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < B3B_WAVES; ++w) {                           // fixed wave order: deterministic
+        s4.x += v4[it][w].x; s4.y += v4[it][w].y; s4.z += v4[it][w].z; s4.w += v4[it][w].w;
+      }
+      const int t = e4 >> 8, q = (e4 >> 6) & 3, ln = e4 & 63;
+      const int l = t >> 2, mo = (t >> 1) & 1, mi = t & 1;
+      const int o0 = 32 * mo + 8 * q + 4 * (ln >> 5), c = 32 * mi + (ln & 31), din = (l == 0) ? D : H;   // rows frow(4q + j, hi) = o0 + j
+      if (c < din) {
+        float* d = dst + w_off[l] + (int64_t)o0 * din + c;
+        if (o0 < H) d[0] = s4.x;
+        if (o0 + 1 < H) d[din] = s4.y;
+        if (o0 + 2 < H) d[2 * din] = s4.z;
+        if (o0 + 3 < H) d[3 * din] = s4.w;
+      }
+    }
+  }
   const bool fourier = ENC_GRAD && a.fc.encoding == NGM_ENC_FOURIER;
   const int n_raw = a.fc.raw_coords ? 3 : 0;
-  for (int e = threadIdx.x; e < NV * 32; e += B3B_THREADS) {
-    const int k = e >> 5, ii = e & 31;
-    float s0 = 0.f;
+  {
+    constexpr int NIV = (NV * 32 + B3B_THREADS - 1) / B3B_THREADS;
+    float sv[NIV];
 #pragma unroll
-    for (int w = 0; w < B3B_WAVES; ++w) s0 += stage[(w * NV + k) * 64 + ii] + stage[(w * NV + k) * 64 + 32 + ii];
-    if (k < 2 * L) {
-      const int l = k >> 1, ft = 32 * (k & 1) + ii;
-      if (ft < H) dst[b_off[l] + ft] = s0;
-    } else if (k < 2 * L + 8) {
-      const int u = k - 2 * L, ft = 32 * (u >> 2) + ii, c = u & 3;
-      if (ft < H) dst[w_off[L] + (int64_t)c * H + ft] = s0;
-    } else if (k < 2 * L + 14) {
-      const int u = k - 2 * L - 8, ft = 32 * (u / 3) + ii, c = u % 3;
-      if (fourier && ft < D && ft >= n_raw) dst[enc_off + (int64_t)(ft - n_raw) * 3 + c] = s0;
-    } else if (ii == 0) {
-      dst[b_off[L] + (k - 2 * L - 14)] = 0.5f * s0;     // wave_sum put the total into every lane: both halves counted it
+    for (int it = 0; it < NIV; ++it) {
+      const int e = it * B3B_THREADS + threadIdx.x;
+      const int k = min(e >> 5, NV - 1), ii = e & 31;
+      float s0 = 0.f;
+#pragma unroll
+      for (int w = 0; w < B3B_WAVES; ++w) s0 += stagev[(w * NV + k) * 64 + ii] + stagev[(w * NV + k) * 64 + 32 + ii];
+      sv[it] = s0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIV; ++it) {
+      const int e = it * B3B_THREADS + threadIdx.x;
+      if (e >= NV * 32) break;
+      const int k = e >> 5, ii = e & 31;
+      const float s0 = sv[it];
+      if (k < 2 * L) {
+        const int l = k >> 1, ft = 32 * (k & 1) + ii;
+        if (ft < H) dst[b_off[l] + ft] = s0;
+      } else if (k < 2 * L + 8) {
+        const int u = k - 2 * L, ft = 32 * (u >> 2) + ii, c = u & 3;
+        if (ft < H) dst[w_off[L] + (int64_t)c * H + ft] = s0;
+      } else if (k < 2 * L + 14) {
+        const int u = k - 2 * L - 8, ft = 32 * (u / 3) + ii, c = u % 3;
+        if (fourier && ft < D && ft >= n_raw) dst[enc_off + (int64_t)(ft - n_raw) * 3 + c] = s0;
+      } else if (ii == 0) {
+        dst[b_off[L] + (k - 2 * L - 14)] = 0.5f * s0;     // wave_sum put the total into every lane: both halves counted it
+      }
     }
   }
   if (!fourier)   // the encoding slot of the partial vector (if any) carries no gradient

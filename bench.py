@@ -230,12 +230,18 @@ def hash_rooflines(kern, n_local, scale_note="", pmc_scale=1.0):
     return out
 
 
-def shader_clock_under_load(step, n=1500):
-    """sclk as rocm-smi reports it WHILE the GPU works through n more (untimed) iterations; None if it cannot be read"""
+def shader_clock_under_load(step, n=1500, read=True):
+    """sclk as rocm-smi reports it WHILE the GPU works through n more (untimed) iterations; None if it cannot be read.
+    EVERY rank runs the n iterations (with a process group each of them holds the loss exchange: a rank that skipped them
+    would leave the others' collectives unmatched -- rounds 4-5 ran them on rank 0 alone, which no 1-GPU run could notice);
+    only the rank with read=True asks rocm-smi."""
     import subprocess
     try:
         for i in range(n):
             step(i)
+        if not read:
+            torch.cuda.synchronize()
+            return None
         r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
         torch.cuda.synchronize()
         js = json.loads(r.stdout[r.stdout.index("{"):])
@@ -664,7 +670,7 @@ def main():
             wins.append(window())
         wins = wins[:int(nw.item())]
     dt = sorted(wins)[len(wins) // 2] if len(wins) % 2 else 0.5 * (sorted(wins)[len(wins) // 2 - 1] + sorted(wins)[len(wins) // 2])
-    sclk = shader_clock_under_load(step) if rank == 0 else None
+    sclk = shader_clock_under_load(step, read=(rank == 0))
     loss = float(out["combined"])
 
     # per-kernel device time: HIP events recorded on the launch stream around every kernel launch

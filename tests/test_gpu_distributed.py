@@ -378,3 +378,20 @@ def test_peer_exchange_timeout_is_reported_not_swallowed(tmp_path):
     assert r0["partial"] is True                         # the sums of a timed-out exchange are NaN: the iteration is visibly dead
     assert r0["fast_after"][1] and r0["fast_after"][0] < 1.0     # 20 further exchanges: NaN without another 20 x 2 s of waiting
     assert r1["status"] == 0
+
+
+def test_bench_line_with_two_ranks_runs_to_the_end():
+    """bench.py --gpus 2 as the driver launches it (two ranks, here sharing the one GPU over gloo): every rank must issue the
+    same sequence of collectives from the first spin-up step to the last profiling step.  Rounds 4-5 read the shader clock by
+    running 1 500 more iterations on rank 0 ALONE -- each of them holds the loss all-reduce, so the other rank's next collective
+    met the wrong partner (gloo: size mismatch, abort; RCCL: a hang at the end of the run).  No 1-GPU run could notice."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGM_BENCH_SHARE_GPU="1", NGM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2",
+                        "--min-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["steps"] == 3 and line["value"] > 0

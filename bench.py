@@ -230,6 +230,18 @@ def hash_rooflines(kern, n_local, scale_note="", pmc_scale=1.0):
     return out
 
 
+def emit_line(d):
+    """the ONE JSON line of the contract, as the LAST thing on stdout: RCCL writes a version banner through C stdio, which
+    (stdout being a pipe) would otherwise be flushed at exit, i.e. behind the line"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(d), flush=True)
+
+
 def shader_clock_under_load(step, n=1500, read=True):
     """sclk as rocm-smi reports it WHILE the GPU works through n more (untimed) iterations; None if it cannot be read.
     EVERY rank runs the n iterations (with a process group each of them holds the loss exchange: a rank that skipped them
@@ -524,7 +536,7 @@ def scene_sim(args, rank, world, dev):
                 res["ms_per_step_vs_active_fields"] = sweep
             out["configs"][label] = res
     if rank == 0:
-        print(json.dumps(out))
+        emit_line(out)
 
 
 def main():
@@ -828,7 +840,7 @@ def main():
             res["aux_m2"] = aux_m2
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res))
+        emit_line(res)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -621,6 +621,59 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
   }
 }
 
+// Few partials per field (<= 8: 32 and more active fields on the chip): the four-quarter split above leaves each quarter
+// two loads and launches four times the workgroups the work needs (32 fields x 137 = 4 384 of them for the 64 + 2 x 64
+// network: 18.7 us, more than twice the 8-field launch).  Here a thread owns ONE parameter: its <= 8 partials in flight together,
+// summed in exactly the order of k_grad_reduce -- quarter i = p_i + p_(i+4), then ((q0 + q1) + q2) + q3 -- so the bits are the same.
+__global__ void __launch_bounds__(256) k_grad_reduce_flat(GradReduceK a) {
+  const int f = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.ptot) return;
+  int seg = -1;
+  for (int k = 0; k < a.nseg; ++k)
+    if (p >= a.seg[k].off && p < a.seg[k].off + a.seg[k].size) { seg = k; break; }
+  int64_t so = 0;
+  float pv = 0.f, m0 = 0.f, v0 = 0.f;
+  const bool adam = seg >= 0 && a.seg[seg].param;
+  if (adam) {
+    const int64_t row = a.field_index ? a.field_index[f] : f;
+    so = row * a.seg[seg].pstride + (p - a.seg[seg].off);
+    pv = a.seg[seg].param[so]; m0 = a.seg[seg].m[so]; v0 = a.seg[seg].v[so];
+  }
+  const float* src = a.partials + (int64_t)f * a.p_pad + p;
+  const int64_t cs = (int64_t)a.F * a.p_pad;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = (c < a.blocks_per_field) ? src[c * cs] : 0.f;
+  float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
+  if (adam) {
+    const double step = (double)(a.step_dev ? *a.step_dev : a.step);
+    lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
+  }
+  float q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+    if (i < a.blocks_per_field) s += v[i];
+    if (i + 4 < a.blocks_per_field) s += v[i + 4];
+    q[i] = s;
+  }
+  const float s = ((q[0] + q[1]) + q[2]) + q[3];
+  if (seg < 0) return;
+  const int64_t i = p - a.seg[seg].off;
+  if (a.seg[seg].dst) a.seg[seg].dst[(int64_t)f * a.seg[seg].stride + i] = s;
+  if (adam) {
+    const float g = s + a.wd * pv;
+    const float mn = a.beta1 * m0 + (1.0f - a.beta1) * g;
+    const float vn = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
+    a.seg[seg].m[so] = mn; a.seg[seg].v[so] = vn;
+    const float pn = pv - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.eps));
+    a.seg[seg].param[so] = pn;
+    if (a.seg[seg].lp) ngm_stp(a.seg[seg].lp, so, pn, a.seg[seg].lp_dt);
+  }
+}
+
 int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
   NgmProfScope prof_(NGM_K_GRAD_REDUCE, st);
   GradReduceK k;
@@ -650,6 +703,11 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
     }
     k.field_index = g.adam.field_index; k.step_dev = g.adam.step_dev; k.step = g.adam.step;
     k.lr = g.adam.lr; k.beta1 = g.adam.beta1; k.beta2 = g.adam.beta2; k.eps = g.adam.eps; k.wd = g.adam.wd;
+  }
+  if (k.blocks_per_field <= 8) {
+    dim3 grid((unsigned)((k.ptot + 255) / 256), (unsigned)g.F);
+    hipLaunchKernelGGL(k_grad_reduce_flat, grid, dim3(256), 0, st, k);
+    return 0;
   }
   dim3 grid((unsigned)((k.ptot + 63) / 64), (unsigned)g.F);
   hipLaunchKernelGGL(k_grad_reduce, grid, dim3(256), 0, st, k);

@@ -1,5 +1,7 @@
+"""Developer tool: the Level-1 training pair (ops.field_eval under autograd: ngm_field_eval_fwd_train + ngm_field_eval_bwd_stash) on 64 fields x
+65 536 points, for a rocprofv3 --kernel-trace --stats run (which kernels a backward really launches; round 6 found two 2 GB fills in it)."""
 import sys, os, torch, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neural_graph_mapping_amd import _capi as K, ops
 dev = torch.device("cuda:0")
 F, P = 64, 65536

@@ -137,7 +137,7 @@ def test_ops_are_registered_with_the_dispatcher(capi):
     ngm355 (schema + fake shapes + autograd formula) with a ROCm ("cuda") kernel only: no CPU registration."""
     from torch._subclasses.fake_tensor import FakeTensorMode
     from neural_graph_mapping_amd import mesh, ops  # noqa: F401
-    names = {"sample_rays", "field_eval", "field_eval_bwd", "field_eval_knn", "quadrature", "quadrature_bwd",
+    names = {"sample_rays", "field_eval", "field_eval_bwd", "field_eval_train", "field_eval_bwd_stash", "field_eval_knn", "quadrature", "quadrature_bwd",
              "composite_packed", "render_ijs", "render_ijs_bwd", "adam_sparse_", "marching_cubes", "render_eval_knn"}
     for n in names:
         assert hasattr(torch.ops.ngm355, n), n

@@ -566,6 +566,9 @@ int ngm_debug_last_bwd_variant(void);
  * per kernel and batch shape): which = 0 fused render forward (ngm_render_fwd), 1 point evaluation (ngm_field_eval_fwd),
  * 2 kNN evaluation (ngm_field_eval_knn).  Returns NGM_MATMUL_F32 or NGM_MATMUL_BF16X3, -1 before the first launch. */
 int ngm_debug_last_matmul(int which);
+/* 1 when the last fused render forward ran the instance whose wave step evaluates ONE 32-sample tile (batches of at most 32
+ * samples per wave: small per-rank batches), else 0 */
+int ngm_debug_last_fwd_one_tile(void);
 /* Debug: 1 when the last ngm_render_bwd / ngm_render_bwd_adam ran the compositing backward inside k_field_bwd_b3 (loss
  * seeds, pointwise geometry modes; no k_stash_bwd launch, the forward's colour / geometry stash stays intact), 0 when
  * k_stash_bwd ran.  Environment: NGM_NO_FUSED_COMP=1 forces the separate kernel. */

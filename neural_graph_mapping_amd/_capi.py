@@ -225,7 +225,7 @@ EXPORTED = ["ngm_abi_version", "ngm_last_error", "ngm_device_info", "ngm_permuto
             "ngm_composite_fwd", "ngm_composite_bwd", "ngm_render_workspace", "ngm_render_fwd",
             "ngm_render_bwd", "ngm_render_bwd_adam", "ngm_render_bwd_seeded", "ngm_render_bwd_seeded_vars", "ngm_render_read_samples", "ngm_adam_sparse",
             "ngm_field_eval_knn", "ngm_field_eval_knn_workspace", "ngm_render_eval_knn", "ngm_render_eval_knn_workspace", "ngm_adam_sparse_multi", "ngm_step_advance", "ngm_profile_enable", "ngm_profile_reset", "ngm_profile_read",
-            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_last_matmul", "ngm_debug_last_comp_fused", "ngm_debug_disable_fused_comp", "ngm_debug_stash_mode", "ngm_debug_last_stash_mode", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
+            "ngm_debug_phase_cycles", "ngm_debug_fwd_phase_cycles", "ngm_debug_last_bwd_variant", "ngm_debug_last_matmul", "ngm_debug_last_fwd_one_tile", "ngm_debug_last_comp_fused", "ngm_debug_disable_fused_comp", "ngm_debug_stash_mode", "ngm_debug_last_stash_mode", "ngm_target_visibility", "ngm_target_rays", "ngm_target_sv_intersect", "ngm_target_sv_rays",
             "ngm_peer_mailbox_bytes", "ngm_peer_alloc", "ngm_peer_free", "ngm_ipc_export", "ngm_ipc_open", "ngm_ipc_close", "ngm_loss_exchange", "ngm_peer_set_timeout",
             "ngm_marching_cubes_workspace", "ngm_marching_cubes_count", "ngm_marching_cubes_emit", "ngm_marching_cubes_tables"]
 

@@ -99,6 +99,7 @@ static int fail(int code, const char* msg) {
 #define NGM_FWD_DEBUG_WORDS (16 + 8 * 64)   // 16 summary slots + 8 waves x 64 timeline entries
 static unsigned long long* g_debug_cycles = nullptr;
 int g_ngm_last_matmul[3] = {-1, -1, -1};   // ngm_launch.h
+int g_ngm_last_fwd_one_tile = 0;
 static int g_last_bwd_variant = -1;   // 0: 32-sample tiles, 1: 16-sample tiles (recompute), 2: 16-sample tiles + activation stash, 3: bf16-split tiles + stash, 5: hash encoding + 1x32 MLP on the bf16 split
 static int g_no_fused_comp = 0;       // ngm_debug_disable_fused_comp
 static int g_last_stash_mode = -1;    // FieldBwdArgs::act_half of the last MLP backward that read an activation stash
@@ -333,6 +334,7 @@ int ngm_target_sv_rays(int32_t F, int32_t R, const float* field_pos_cam, float r
 
 int ngm_debug_last_bwd_variant(void) { return g_last_bwd_variant; }
 int ngm_debug_last_matmul(int which) { return (which >= 0 && which < 3) ? g_ngm_last_matmul[which] : -1; }
+int ngm_debug_last_fwd_one_tile(void) { return g_ngm_last_fwd_one_tile; }
 int ngm_debug_last_comp_fused(void) { return g_last_comp_fused; }
 int ngm_debug_disable_fused_comp(int on) { const int old = g_no_fused_comp; g_no_fused_comp = on ? 1 : 0; return old; }
 

@@ -993,6 +993,38 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
   return make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ONE 32-sample tile: the wave step of a batch that has at most 32 samples left (round 6).  The samples are those of lanes
+// 0..31; lanes 32..63 hold the other k-half of the same columns, as in tile 0 of eval_64, and every operation on that tile is
+// the one eval_64 performs (encode_pair_sin with the tile's point in both slots, the layers and the output layer with NT = 1):
+// the same bits for those samples, half the matrix and split work.  A rank of an 8-GPU run trains ~4 fields per iteration --
+// one 24-sample ray per wave at the reference's 8 + 16 samples --, where the second tile of eval_64 is pure overhead.
+// Sine-only table encodings, skip_mode no (the fused training forward's default instances).
+template <int MI, int MH, int L, bool B3>
+__device__ __forceinline__ float4 eval_32(const float* sm, int lane, float x, float y, float z, const ActStash* st,
+                                          const ngm_u32x4* b3w) {
+  using LY = FieldLds<MI, MH, L, false>;
+  const int hi = lane >> 5;
+  const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
+  f32x16 E[1][MI], Eo[MI];
+  {
+    const float tx = hi ? ox : x, ty = hi ? oy : y, tz = hi ? oz : z;      // the column's sample (lane & 31)
+    const ngm_v2f X = {tx, tx}, Y = {ty, ty}, Z = {tz, tz};
+    encode_pair_sin<MI>(sm + LY::ENCW, hi, X, Y, Z, E[0], Eo);
+  }
+  f32x16 Hl[1][MH];
+  mlp_fwd<MI, MH, L, 1, 0, B3>(sm, lane, E, Hl, st, nullptr, b3w);
+  float part[1][4];
+  out_layer_partial<MH, 1>(sm + LY::WOUT, hi, Hl, part);
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float recv = __shfl_xor(part[0][c], 32, 64);
+    // fixed summation order: low-feature half first (lanes 32..63 end up with the same sums; their samples do not exist)
+    o[c] = (hi ? (recv + part[0][c]) : (part[0][c] + recv)) + sm[LY::BOUT + c];
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // dispatch helper: logical (D,H,L) -> compiled (MI,MH,L) instantiation
 struct FieldShape { int MI, MH, L; };
 static inline FieldShape field_shape(const ngm_field_cfg* fc) {

@@ -320,7 +320,10 @@ __device__ __forceinline__ int fdiv_idx(int idx, float inv_s, int S) {
   return q;
 }
 
-template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false, bool NEUS = false>
+// HALF (round 6): the instance for batches of at most 32 samples per wave (a rank of an 8-GPU run: one 24-sample ray per wave):
+// the wave step evaluates ONE 32-sample tile (eval_32) where the batch allows it.  A separate instance, chosen by the launcher,
+// so that the default instance's code and register allocation stay what they were (in-line it cost the M1 forward 0.9 us).
+template <int MI, int MH, int L, bool NEED_COS, int HASH, int SKIP, bool B3 = false, bool NEUS = false, bool HALF = false>
 __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   using LY = FieldLds<MI, MH, L, SKIP == 2>;
@@ -541,7 +544,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
 #ifdef NGM_PHASE_TIMING
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, pc, b3w, &tc);
 #else
-      const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
+      float4 o;
+      if constexpr (HALF && B3 && HASH == 0 && !NEED_COS && SKIP == 0 && !NEUS) {
+        // (wave-uniform) at most 32 samples left in the batch: one tile instead of two (ngm_field.h eval_32)
+        if (nsamp - base <= 32) o = eval_32<MI, MH, L, B3>(sm, lane, x, y, z, &ast, b3w);
+        else o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
+      } else {
+        o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
+      }
 #endif
 #endif
       const float c0 = cf * o.x, c1 = cf * o.y, c2 = cf * o.z;
@@ -789,6 +799,16 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
         const size_t lds = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float) + (size_t)B3Lds<MI, MH, L>::TOTAL * 16;
         if (lds > 160 * 1024) return NGM_E_UNSUPPORTED;
         g_ngm_last_matmul[0] = NGM_MATMUL_BF16X3;
+        // every wave's batches hold at most 32 samples (rays per wave x samples per ray): the one-tile instance
+        const int per_wave = (a.rays_per_block + a.waves_per_block - 1) / a.waves_per_block;
+        static const bool no_half = getenv("NGM_NO_HALF_STEP") != nullptr;          // developer A/B switch
+        g_ngm_last_fwd_one_tile = (per_wave * a.S <= 32 && !no_half) ? 1 : 0;
+        if (per_wave * a.S <= 32 && !no_half) {
+          (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 0, 0, true, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 0, 0, true, false, true>), dim3(blocks), blk, lds, st, a);
+          return 0;
+        }
         (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 0, 0, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 0, 0, true>), dim3(blocks), blk, lds, st, a);

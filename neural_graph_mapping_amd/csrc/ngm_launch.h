@@ -178,6 +178,7 @@ struct StashBwdArgs {
 // which arithmetic the last launch of each forward-type kernel resolved to (ngm_debug_last_matmul): 0 = the fused render
 // forward, 1 = the point evaluation, 2 = the kNN evaluation; values NGM_MATMUL_F32 / NGM_MATMUL_BF16X3, -1 = none yet
 extern int g_ngm_last_matmul[3];
+extern int g_ngm_last_fwd_one_tile;      // the last fused render forward ran the one-tile wave step instance (k_render_fwd<.., HALF>)
 int ngm_launch_points_fwd(const PointsFwdArgs& a, int blocks, hipStream_t st);
 int64_t ngm_encode_bwd_fourier_scratch(int F, int64_t P);
 int ngm_launch_encode_bwd_fourier(const ngm_field_cfg& fc, const ngm_params& pr, int F, int64_t P, const float* points,

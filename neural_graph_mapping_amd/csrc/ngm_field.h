@@ -999,20 +999,27 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 // the same bits for those samples, half the matrix and split work.  A rank of an 8-GPU run trains ~4 fields per iteration --
 // one 24-sample ray per wave at the reference's 8 + 16 samples --, where the second tile of eval_64 is pure overhead.
 // Sine-only table encodings, skip_mode no (the fused training forward's default instances).
-template <int MI, int MH, int L, bool B3>
+// HASH = 1: the permutohedral encoding of the tile (one encode_hash instead of two: the simplex searches and table gathers are a
+// third of the default network's forward), its stash, one hidden-layer pass on fp32 MFMA.
+template <int MI, int MH, int L, bool B3, int HASH = 0>
 __device__ __forceinline__ float4 eval_32(const float* sm, int lane, float x, float y, float z, const ActStash* st,
-                                          const ngm_u32x4* b3w) {
+                                          const ngm_u32x4* b3w, const HashCtx* hc = nullptr) {
   using LY = FieldLds<MI, MH, L, false>;
   const int hi = lane >> 5;
   const float ox = __shfl_xor(x, 32, 64), oy = __shfl_xor(y, 32, 64), oz = __shfl_xor(z, 32, 64);
-  f32x16 E[1][MI], Eo[MI];
-  {
-    const float tx = hi ? ox : x, ty = hi ? oy : y, tz = hi ? oz : z;      // the column's sample (lane & 31)
+  f32x16 E[1][MI];
+  const float tx = hi ? ox : x, ty = hi ? oy : y, tz = hi ? oz : z;      // the column's sample (lane & 31)
+  if constexpr (HASH == 1) {
+    static_assert(HASH != 1 || MI == 1, "hash encoding: 2*levels <= 32 features");
+    encode_hash(sm + LY::ENCW, *hc, hi, tx, ty, tz, E[0][0]);
+    if (st && st->base) act_store<MI, 1>(*st, 0, lane, E);
+  } else {
+    f32x16 Eo[MI];
     const ngm_v2f X = {tx, tx}, Y = {ty, ty}, Z = {tz, tz};
     encode_pair_sin<MI>(sm + LY::ENCW, hi, X, Y, Z, E[0], Eo);
   }
   f32x16 Hl[1][MH];
-  mlp_fwd<MI, MH, L, 1, 0, B3>(sm, lane, E, Hl, st, nullptr, b3w);
+  mlp_fwd<MI, MH, L, 1, 0, B3>(sm, lane, E, Hl, HASH == 1 ? nullptr : st, nullptr, b3w);
   float part[1][4];
   out_layer_partial<MH, 1>(sm + LY::WOUT, hi, Hl, part);
   float o[4];

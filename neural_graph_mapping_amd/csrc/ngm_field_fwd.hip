@@ -545,9 +545,9 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
       const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, pc, b3w, &tc);
 #else
       float4 o;
-      if constexpr (HALF && B3 && HASH == 0 && !NEED_COS && SKIP == 0 && !NEUS) {
+      if constexpr (HALF && ((B3 && HASH == 0) || (!B3 && HASH == 1)) && !NEED_COS && SKIP == 0 && !NEUS) {
         // (wave-uniform) at most 32 samples left in the batch: one tile instead of two (ngm_field.h eval_32)
-        if (nsamp - base <= 32) o = eval_32<MI, MH, L, B3>(sm, lane, x, y, z, &ast, b3w);
+        if (nsamp - base <= 32) o = eval_32<MI, MH, L, B3, HASH>(sm, lane, x, y, z, &ast, b3w, &hc);
         else o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
       } else {
         o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, &ast, nullptr, b3w, &tc);
@@ -782,6 +782,7 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
   const size_t wave_lds = (size_t)a.waves_per_block * RenderWaveLds::floats(a.maxs);
   const dim3 blk(64 * a.waves_per_block);
   g_ngm_last_matmul[0] = NGM_MATMUL_F32;
+  g_ngm_last_fwd_one_tile = 0;
   if (a.rc.geometry_mode == NGM_GEO_NEUS) {
     // neus in the fused kernel (two-pass compositing over the wave's LDS planes): Fourier / no encoding, skip no, fp32 MFMA
     if (a.fc.skip_mode != NGM_SKIP_NO || (a.fc.encoding != NGM_ENC_FOURIER && a.fc.encoding != NGM_ENC_NONE) || !a.neus_sd)
@@ -818,7 +819,20 @@ static int launch_render(const RenderFwdArgs& a, int blocks, hipStream_t st) {
     return NGM_E_UNSUPPORTED;
   }
   if (a.fc.encoding == NGM_ENC_PERMUTO) {
-    if constexpr (MI == 1) NGM_LAUNCH_VARIANT(k_render_fwd, false, 1, blocks, blk, 0, wave_lds);
+    if constexpr (MI == 1) {
+      // the reference's default network on small per-rank batches: the one-tile instance (see the split path above)
+      const int per_wave = (a.rays_per_block + a.waves_per_block - 1) / a.waves_per_block;
+      static const bool no_half = getenv("NGM_NO_HALF_STEP") != nullptr;
+      if (per_wave * a.S <= 32 && !no_half && a.fc.skip_mode == NGM_SKIP_NO) {
+        const size_t lds_ = (FieldLds<MI, MH, L>::TOTAL + wave_lds) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)k_render_fwd<MI, MH, L, false, 1, 0, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);
+        hipLaunchKernelGGL((k_render_fwd<MI, MH, L, false, 1, 0, false, false, true>), dim3(blocks), blk, lds_, st, a);
+        g_ngm_last_fwd_one_tile = 1;
+        return 0;
+      }
+      NGM_LAUNCH_VARIANT(k_render_fwd, false, 1, blocks, blk, 0, wave_lds);
+    }
     else return NGM_E_UNSUPPORTED;
   } else if (a.fc.encoding == NGM_ENC_TRIPLANE) NGM_LAUNCH_VARIANT(k_render_fwd, false, 2, blocks, blk, 0, wave_lds); else if (a.fc.encoding == NGM_ENC_NERF) NGM_LAUNCH_VARIANT(k_render_fwd, true, 0, blocks, blk, 0, wave_lds);
   else NGM_LAUNCH_VARIANT(k_render_fwd, false, 0, blocks, blk, 0, wave_lds);

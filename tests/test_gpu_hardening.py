@@ -500,19 +500,19 @@ _ONE_TILE_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 from gpu_common import DEV, make_renderer, make_target, synth_target
-from test_gpu_configs import FOURIER, _perturb
+from test_gpu_configs import FOURIER, HASH, _perturb
 out = {}
-for n_c, n_g, F in ((8, 16, 1), (16, 16, 4), (5, 0, 2)):
+for n_c, n_g, F, net in ((8, 16, 1, FOURIER), (16, 16, 4, FOURIER), (5, 0, 2, FOURIER), (8, 16, 4, HASH), (3, 7, 1, HASH)):
     R = 512
     torch.manual_seed(1234 + n_c)          # the prototype's initialisation: the same network in both processes
-    r = make_renderer(FOURIER, dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g), F)
+    r = make_renderer(net, dict(num_samples_coarse=n_c, num_samples_depth_guided=n_g), F)
     _perturb(r)
     pos, quat, t = synth_target(F, R, seed=31 + n_c)
     r.set_field_poses(pos.to(DEV), quat.to(DEV))
     o = r.optimization_iteration(make_target(t, torch.arange(F)), seed=9, update=False)
     p = o["prediction"]
     from neural_graph_mapping_amd import _capi as K
-    out[(n_c, n_g, F)] = dict(one_tile=torch.tensor(K.lib().ngm_debug_last_fwd_one_tile()), rgbds=p.rgbds.cpu(), cv=p.color_vars.cpu(), dv=p.depth_vars.cpu(), term=p.term_probs.cpu(),
+    out[(n_c, n_g, F, net["encoding"])] = dict(one_tile=torch.tensor(K.lib().ngm_debug_last_fwd_one_tile()), rgbds=p.rgbds.cpu(), cv=p.color_vars.cpu(), dv=p.depth_vars.cpu(), term=p.term_probs.cpu(),
                              loss=o["combined"].cpu(), **{"g::" + k: v.cpu() for k, v in o["grads"].items()})
 torch.save(out, sys.argv[3])
 """
@@ -522,7 +522,8 @@ def test_one_tile_wave_step_equals_the_two_tile_step_bitwise(tmp_path):
     """Round 6: batches of at most 32 samples per wave (one field x 512 rays x 24 samples: a 24-sample ray per wave; what a rank of
     an 8-GPU run sees) run the k_render_fwd instance whose wave step evaluates ONE 32-sample tile (eval_32).  The same iteration
     with that instance switched off (NGM_NO_HALF_STEP=1, read once per process: two child processes) must give the same BITS:
-    predictions, loss, every gradient (the activation stash the backward reads is written by the step in question)."""
+    predictions, loss, every gradient (the activation stash the backward reads is written by the step in question) -- for the
+    Fourier network on the bf16 split and for the reference's default hash network (one encode_hash per step instead of two)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -536,7 +537,7 @@ def test_one_tile_wave_step_equals_the_two_tile_step_bitwise(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(pth))
     a, b = outs
-    assert a.keys() == b.keys() and len(a) == 3
+    assert a.keys() == b.keys() and len(a) == 5
     for case in a:
         assert int(a[case]["one_tile"]) == 1 and int(b[case]["one_tile"]) == 0, case      # the switch did select the other instance
         for k in a[case]:

@@ -1018,17 +1018,21 @@ static int render_bwd_common(const ngm_field_cfg* fcfg, const ngm_render_cfg* rc
   e = check_launch("ngm_field_bwd");
   if (e) return e;
   if (fcfg->encoding == NGM_ENC_TRIPLANE) { ngm_launch_tri_finish(a, st); e = check_launch("ngm_tri_finish"); if (e) return e; }
-  if (fcfg->encoding == NGM_ENC_PERMUTO) {
-    if (lattice_adam) a.lattice_adam = *lattice_adam;
-    e = ngm_launch_hash_grad(a, st, lattice_adam_applied);
-    if (e) return fail(e, "permutohedral backward: hash table too large for the LDS-staged scatter");
-    e = check_launch("ngm_hash_grad");
-    if (e) return e;
-  }
   GradReduceArgs g;
   memset(&g.adam, 0, sizeof(g.adam));
   if (adam) g.adam = *adam;
   g.fc = *fcfg; g.gr = *grads; g.F = rays->F; g.blocks_per_field = a.blocks_per_field; g.partials = a.partials; g.p_pad = a.p_pad;
+  bool mlp_reduced = false;
+  if (fcfg->encoding == NGM_ENC_PERMUTO) {
+    if (lattice_adam) a.lattice_adam = *lattice_adam;
+    // the MLP's reduction + Adam rides along in the table-gradient launch (both depend on the MLP backward only)
+    e = ngm_launch_hash_grad(a, st, lattice_adam_applied, &g, &mlp_reduced);
+    if (e == NGM_E_INVALID) return fail(e, "render_bwd_adam: adam tensors do not match the parameter segments");
+    if (e) return fail(e, "permutohedral backward: hash table too large for the LDS-staged scatter");
+    e = check_launch("ngm_hash_grad");
+    if (e) return e;
+  }
+  if (mlp_reduced) return NGM_OK;
   if (ngm_launch_grad_reduce(g, st)) return fail(NGM_E_INVALID, "render_bwd_adam: adam tensors do not match the parameter segments");
   return check_launch("ngm_grad_reduce");
 }

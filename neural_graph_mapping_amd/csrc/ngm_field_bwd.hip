@@ -9,6 +9,7 @@
 // registers for the whole kernel; every workgroup writes ONE partial gradient vector, reduced (in a
 // fixed order -> deterministic) by k_grad_reduce.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include "ngm_field.h"
 #include "ngm_launch.h"
@@ -625,9 +626,9 @@ __global__ void __launch_bounds__(256) k_grad_reduce(GradReduceK a) {
 // two loads and launches four times the workgroups the work needs (32 fields x 137 = 4 384 of them for the 64 + 2 x 64
 // network: 18.7 us, more than twice the 8-field launch).  Here a thread owns ONE parameter: its <= 8 partials in flight together,
 // summed in exactly the order of k_grad_reduce -- quarter i = p_i + p_(i+4), then ((q0 + q1) + q2) + q3 -- so the bits are the same.
-__global__ void __launch_bounds__(256) k_grad_reduce_flat(GradReduceK a) {
-  const int f = blockIdx.y;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// One parameter p of field f: its partials summed in exactly k_grad_reduce's order -- quarter i = partials i, i + 4, i + 8, ... in
+// that order, then ((q0 + q1) + q2) + q3 -- and the sparse Adam update.  <= 8 partials: all in flight together.
+__device__ __forceinline__ void grad_reduce_one(const GradReduceK& a, int f, int64_t p) {
   if (p >= a.ptot) return;
   int seg = -1;
   for (int k = 0; k < a.nseg; ++k)
@@ -642,22 +643,33 @@ __global__ void __launch_bounds__(256) k_grad_reduce_flat(GradReduceK a) {
   }
   const float* src = a.partials + (int64_t)f * a.p_pad + p;
   const int64_t cs = (int64_t)a.F * a.p_pad;
-  float v[8];
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.blocks_per_field <= 8) {
+    float v[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = (c < a.blocks_per_field) ? src[c * cs] : 0.f;
+    for (int c = 0; c < 8; ++c) v[c] = (c < a.blocks_per_field) ? src[c * cs] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+      if (i < a.blocks_per_field) s += v[i];
+      if (i + 4 < a.blocks_per_field) s += v[i + 4];
+      q[i] = s;
+    }
+  } else {
+    for (int c0 = 0; c0 < a.blocks_per_field; c0 += 16) {          // 16 loads in flight; every quarter keeps its own order
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (c0 + u < a.blocks_per_field) ? src[(int64_t)(c0 + u) * cs] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (c0 + u < a.blocks_per_field) q[u & 3] += v[u];
+    }
+  }
   float lr_bc1 = 0.f, inv_sqrt_bc2 = 1.f;
   if (adam) {
     const double step = (double)(a.step_dev ? *a.step_dev : a.step);
     lr_bc1 = (float)((double)a.lr / (1.0 - pow((double)a.beta1, step)));
     inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, step)));
-  }
-  float q[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float s = 0.f;
-    if (i < a.blocks_per_field) s += v[i];
-    if (i + 4 < a.blocks_per_field) s += v[i + 4];
-    q[i] = s;
   }
   const float s = ((q[0] + q[1]) + q[2]) + q[3];
   if (seg < 0) return;
@@ -673,10 +685,11 @@ __global__ void __launch_bounds__(256) k_grad_reduce_flat(GradReduceK a) {
     if (a.seg[seg].lp) ngm_stp(a.seg[seg].lp, so, pn, a.seg[seg].lp_dt);
   }
 }
+__global__ void __launch_bounds__(256) k_grad_reduce_flat(GradReduceK a) {
+  grad_reduce_one(a, blockIdx.y, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
 
-int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
-  NgmProfScope prof_(NGM_K_GRAD_REDUCE, st);
-  GradReduceK k;
+static int build_grad_reduce(const GradReduceArgs& g, GradReduceK& k) {
   k.F = g.F; k.blocks_per_field = g.blocks_per_field; k.partials = g.partials; k.p_pad = g.p_pad;
   int64_t enc_off, w_off[NGM_MAX_LAYERS + 1], b_off[NGM_MAX_LAYERS + 1];
   k.ptot = ngm_param_offsets(&g.fc, &enc_off, w_off, b_off);
@@ -704,6 +717,13 @@ int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
     k.field_index = g.adam.field_index; k.step_dev = g.adam.step_dev; k.step = g.adam.step;
     k.lr = g.adam.lr; k.beta1 = g.adam.beta1; k.beta2 = g.adam.beta2; k.eps = g.adam.eps; k.wd = g.adam.wd;
   }
+  return 0;
+}
+int ngm_launch_grad_reduce(const GradReduceArgs& g, hipStream_t st) {
+  NgmProfScope prof_(NGM_K_GRAD_REDUCE, st);
+  GradReduceK k;
+  const int rc = build_grad_reduce(g, k);
+  if (rc) return rc;
   if (k.blocks_per_field <= 8) {
     dim3 grid((unsigned)((k.ptot + 255) / 256), (unsigned)g.F);
     hipLaunchKernelGGL(k_grad_reduce_flat, grid, dim3(256), 0, st, k);
@@ -796,6 +816,11 @@ struct HashGradArgs {
   float* ad_param; float* ad_m; float* ad_v; int64_t ad_stride; void* ad_lp; int ad_lp_dt;
   const int64_t* ad_field_index; const int64_t* ad_step_dev; int64_t ad_step;
   float ad_lr, ad_beta1, ad_beta2, ad_eps, ad_wd;
+  // Round 6: the MLP's gradient reduction + Adam (k_grad_reduce's work, a few KB per field) rides along as extra workgroups
+  // behind the hash_blocks table workgroups: it depends on the MLP backward only, like this kernel, and as a launch of its own
+  // it was 8 us of latency chain + boundary in a 195 us iteration.  mlp_bx = 0: none.
+  int hash_blocks, mlp_bx;
+  GradReduceK mlp;
 };
 
 // FLT = false (NGM_HASH_ATOMICS_EXACT, the default): Q23.40 fixed point in LDS -- integer LDS atomics run at full bank rate
@@ -819,9 +844,14 @@ __global__ __launch_bounds__(NT) void k_hash_grad(HashGradArgs a) {
   using acc_t = typename HashAcc<FLT>::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char tab_raw[];
   acc_t* tab = reinterpret_cast<acc_t*>(tab_raw);
+  if ((int)blockIdx.x >= a.hash_blocks) {          // the MLP reduction riding along: one thread per parameter (grad_reduce_one)
+    const int id = (int)blockIdx.x - a.hash_blocks;
+    grad_reduce_one(a.mlp, id / a.mlp_bx, (int64_t)(id % a.mlp_bx) * blockDim.x + threadIdx.x);
+    return;
+  }
   int chunk, f, level[NL];
   {
-    const int nlev = a.fc.nr_levels, total = gridDim.x, id = blockIdx.x;
+    const int nlev = a.fc.nr_levels, total = a.hash_blocks, id = blockIdx.x;
     if constexpr (NL == 2) {
       chunk = id % a.chunks;
       const int r = id / a.chunks, lh = r % (nlev / 2);
@@ -1046,8 +1076,12 @@ __global__ void k_hash_reduce(HashGradArgs a) {
   }
 }
 
-int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_applied) {
+int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_applied, const GradReduceArgs* mlp_reduce,
+                         bool* mlp_reduced) {
   HashGradArgs a;
+  a.hash_blocks = 0; a.mlp_bx = 0;
+  memset(&a.mlp, 0, sizeof(a.mlp));
+  if (mlp_reduced) *mlp_reduced = false;
   a.fc = fb.fc; a.pr = fb.pr; a.F = fb.F; a.P = fb.P; a.dE = fb.hash_dE; a.xyz = fb.hash_xyz;
   a.gtab = fb.lattice_grad; a.gstride = fb.lattice_grad_stride;
   const int T = 1 << fb.fc.log2_hashmap_size;
@@ -1097,12 +1131,21 @@ int ngm_launch_hash_grad(const FieldBwdArgs& fb, hipStream_t st, bool* adam_appl
       a.ad_eps = fb.lattice_adam.eps; a.ad_wd = fb.lattice_adam.wd;
     }
   }
+  a.hash_blocks = chunks * units;
+  static const bool no_ride = getenv("NGM_NO_REDUCE_RIDE") != nullptr;          // developer A/B switch
+  if (mlp_reduce && !no_ride) {
+    if (build_grad_reduce(*mlp_reduce, a.mlp)) return NGM_E_INVALID;
+    const int nt = (pair || (getenv("NGM_HASH_THREADS") != nullptr && atoi(getenv("NGM_HASH_THREADS")) == 1024)) ? 1024 : 512;
+    a.mlp_bx = (int)((a.mlp.ptot + nt - 1) / nt);
+    if (mlp_reduced) *mlp_reduced = true;
+  }
+  const int grid_x = a.hash_blocks + a.mlp_bx * (int)fb.F;
   {
     NgmProfScope prof_(NGM_K_HASH_GRAD, st);
 #define NGM_HG(FLT_, NL_, NT_)                                                                                                  \
     do {                                                                                                                        \
       (void)hipFuncSetAttribute((const void*)k_hash_grad<FLT_, NL_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_hash_grad<FLT_, NL_, NT_>), dim3(chunks * units), dim3(NT_), lds, st, a);                            \
+      hipLaunchKernelGGL((k_hash_grad<FLT_, NL_, NT_>), dim3(grid_x), dim3(NT_), lds, st, a);                                    \
     } while (0)
     // Round 6 A/B on one box (profiles/r06_hash_ablation.txt), M1 hash batch at 2397 MHz: one level per workgroup, 512 threads
     // (two resident workgroups = 4 waves per SIMD) 76.7 us; 1024 threads (8 waves per SIMD) 84.9 us; level pairs 78.8 us.  More

@@ -111,7 +111,11 @@ struct FieldBwdArgs {
 };
 bool ngm_field_bwd_b3_applies(const FieldBwdArgs& a);   // would ngm_launch_field_bwd_b3 take this problem
 bool ngm_hash_mlp_bwd_applies(const FieldBwdArgs& a);   // would ngm_launch_hash_mlp_bwd (given positions, or fused_comp)
-int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr);
+struct GradReduceArgs;
+// mlp_reduce (optional): the MLP's gradient reduction (+ Adam) to run as extra workgroups of the same launch; *mlp_reduced tells
+// the caller that it did (no ngm_launch_grad_reduce needed then)
+int ngm_launch_hash_grad(const FieldBwdArgs& a, hipStream_t st, bool* adam_applied = nullptr, const GradReduceArgs* mlp_reduce = nullptr,
+                         bool* mlp_reduced = nullptr);
 
 struct GradReduceArgs {
   ngm_field_cfg fc;

@@ -839,7 +839,16 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
           typedef float v4f __attribute__((ext_vector_type(4)));
           const v4f val = {H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]};
           const int pos = r ^ ((2 * g4 + hi) & 7);                       // chunk = 8 m + 2 g4 + hi
-          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));   // streamed: read once, by the backward
+#ifdef NGM_STASH_NT    // rounds 1-5: non-temporal stores (the lines stay in the writing XCD's L2 until evicted, dirty)
+          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));
+#else
+          // Round 6: WRITE-THROUGH stores (sc1).  The stash is read once, by the NEXT kernel, from whichever XCD its workgroup
+          // lands on: written through, nothing of it sits dirty in the writer's L2 at the kernel boundary and the backward's
+          // transfers are served by the memory side directly.  Same-box A/B at the M1 batch: forward 82.3 -> 80.8 us,
+          // BACKWARD 142.5 -> 138.9 us, step 0.2324 -> 0.2266 ms (MI355X_MICROARCH.md, "publish-large": write-through wins for
+          // tens of KB per workgroup handed to another kernel).
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos)), "v"(val));
+#endif
         }
     }
   }

@@ -494,8 +494,14 @@ __global__ __launch_bounds__(512) void k_render_fwd(RenderFwdArgs a) {
           typedef float v2f __attribute__((ext_vector_type(2)));
           const v4f sa = {c0, c1, c2, geom};
           const v2f sb = {t, T_excl};
+#ifdef NGM_STASH_NT      // rounds 1-5: non-temporal
           __builtin_nontemporal_store(sa, reinterpret_cast<v4f*>(a.stashA + gs));   // read once, by the next kernel
           __builtin_nontemporal_store(sb, reinterpret_cast<v2f*>(a.stashB + gs));
+#else                    // round 6: written through (sc1), like the activation stash (ngm_field.h act_store): the backward reads these
+                         // rows from another CU, most often another XCD -- M1 backward 141.4 -> 137.7 us, k_hash_mlp_bwd 37.3 -> 33.8 us
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<v4f*>(a.stashA + gs)), "v"(sa));
+          asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(reinterpret_cast<v2f*>(a.stashB + gs)), "v"(sb));
+#endif
         }
       }
       float sc[5] = {w * c0, w * c1, w * c2, w * depth, w};      // five segmented sums over the same rays: one fused scan

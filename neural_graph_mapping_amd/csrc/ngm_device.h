@@ -211,6 +211,21 @@ __device__ __forceinline__ ngm_v2f ngm_sinf2(ngm_v2f x) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Write-through (sc1) stores for data one kernel hands to the NEXT launch (round 6).  A consumer workgroup lands on any XCD;
+// written through, the data is at the memory side when the producer ends (nothing dirty left in its L2 for the boundary to
+// flush) and the consumer's loads are served from there.  16- and 8-byte forms only: narrower write-through stores are one
+// fabric write each (MI355X_MICROARCH.md, stores of each flavour).
+// ------------------------------------------------------------------------------------------------
+typedef float ngm_v4f_ __attribute__((ext_vector_type(4)));
+typedef float ngm_v2f_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ngm_store_wt(float4* p, const float4& v) {
+  const ngm_v4f_ x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x));
+}
+__device__ __forceinline__ void ngm_store_wt(ngm_v4f_* p, ngm_v4f_ x) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x)); }
+__device__ __forceinline__ void ngm_store_wt(ngm_v2f_* p, ngm_v2f_ x) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x)); }
+
+// ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (used when the caller passes no explicit torch.rand draws)
 // ------------------------------------------------------------------------------------------------
 // One block = counter (ctr low 32, ctr high 32, stream id, offset low 32) under key (seed low 32, seed high 32) -> four words.

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
         if (valid) {                             // the position k_hash_grad searches the simplex of (the forward's own fmaf)
           typedef float v4f __attribute__((ext_vector_type(4)));
           const v4f pxyz = {fmaf(t, r0.w, r0.x), fmaf(t, r1.x, r0.y), fmaf(t, r1.y, r0.z), 0.f};
-          __builtin_nontemporal_store(pxyz, reinterpret_cast<v4f*>(a.hash_xyz + g0 + n));
+          ngm_store_wt(reinterpret_cast<ngm_v4f_*>(a.hash_xyz + g0 + n), pxyz);      // written through: read by k_hash_grad (another launch)
         }
       }
       WAVE_SYNC();
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_hash_mlp_bwd(FieldBwdArgs a) {
           if (lv + 2 * hi < nlev) {
             typedef float v2f __attribute__((ext_vector_type(2)));
             const v2f v = {dE[4 * q + 2 * p], dE[4 * q + 2 * p + 1]};
-            __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(dst + (int64_t)lv * NP));      // read once, by k_hash_grad
+            ngm_store_wt(reinterpret_cast<ngm_v2f_*>(dst + (int64_t)lv * NP), v);      // read once, by k_hash_grad: written through (k_hash_grad 80.5 -> 76.7 us)
           }
         }
     }

@@ -821,7 +821,10 @@ __device__ __forceinline__ void out_layer_partial(const float* sm_wout, int hi, 
 
 // C layout: lane (n = lane & 31, hi) holds, for sample column n of tile nt, features
 // 32m + 8g + 4hi + {0..3} in registers 4g..4g+3 -> chunk 8m + 2g + hi, one 16-byte store per (nt, m, g).
-template <int MH, int NT>
+// WT: write-through stores (the fused training forward, whose consumer is the next kernel of a short iteration) or non-temporal
+// ones (the point evaluation's training forward: gigabytes of stash per call -- written through, that kernel was 7 % slower and
+// its backward no faster; same-box A/B, round 6)
+template <int MH, int NT, bool WT = true>
 __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lane, const f32x16 (&H)[NT][MH]) {
   const int n = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -840,15 +843,20 @@ __device__ __forceinline__ void act_store(const ActStash& st, int layer, int lan
           const v4f val = {H[nt][m][4 * g4], H[nt][m][4 * g4 + 1], H[nt][m][4 * g4 + 2], H[nt][m][4 * g4 + 3]};
           const int pos = r ^ ((2 * g4 + hi) & 7);                       // chunk = 8 m + 2 g4 + hi
 #ifdef NGM_STASH_NT    // rounds 1-5: non-temporal stores (the lines stay in the writing XCD's L2 until evicted, dirty)
-          __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));
+          constexpr bool wt_ = false;
 #else
+          constexpr bool wt_ = WT;
+#endif
+          if constexpr (!wt_) {
+            __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos));
+          } else {
           // Round 6: WRITE-THROUGH stores (sc1).  The stash is read once, by the NEXT kernel, from whichever XCD its workgroup
           // lands on: written through, nothing of it sits dirty in the writer's L2 at the kernel boundary and the backward's
           // transfers are served by the memory side directly.  Same-box A/B at the M1 batch: forward 82.3 -> 80.8 us,
           // BACKWARD 142.5 -> 138.9 us, step 0.2324 -> 0.2266 ms (MI355X_MICROARCH.md, "publish-large": write-through wins for
           // tens of KB per workgroup handed to another kernel).
           asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<v4f*>(p + (8 * m + 2 * g4) * 128 + 4 * pos)), "v"(val));
-#endif
+          }
         }
     }
   }
@@ -872,7 +880,7 @@ __device__ __forceinline__ void skip_add(f32x16 (&H)[NT][MH], const f32x16 (&E)[
 
 // SKIP (0 no, 1 add, 2 concat) is a template parameter on purpose: as a run-time flag it kept the encoding registers
 // alive through every layer of the default path as well and cost the fused forward 14 us.
-template <int MI, int MH, int L, int NT, int SKIP = 0, bool B3 = false>
+template <int MI, int MH, int L, int NT, int SKIP = 0, bool B3 = false, bool WT = true>
 __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 (&E)[NT][MI], f32x16 (&Hlast)[NT][MH],
                                         const ActStash* st = nullptr, PhaseClock* pc = nullptr,
                                         const ngm_u32x4* b3w = nullptr) {
@@ -882,7 +890,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
   else layer_fwd<MI, MH, NT>(sm + LY::w_off(0), sm + LY::b_off(0), lane, E, Hlast);
   if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
   PTICK(pc, 5);
-  if (st && st->base) act_store<MH, NT>(*st, 0, lane, Hlast);
+  if (st && st->base) act_store<MH, NT, WT>(*st, 0, lane, Hlast);
   PTICK(pc, 6);
 #pragma unroll
   for (int l = 1; l < L; ++l) {
@@ -909,7 +917,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
       for (int m = 0; m < MH; ++m) Hlast[nt][m] = T[nt][m];
     if constexpr (SKIP == 1) skip_add<MI, MH, NT>(Hlast, E);
     PTICK(pc, 5);
-    if (st && st->base && l < st->nlayers) act_store<MH, NT>(*st, l, lane, Hlast);
+    if (st && st->base && l < st->nlayers) act_store<MH, NT, WT>(*st, l, lane, Hlast);
     PTICK(pc, 6);
   }
 }
@@ -917,7 +925,7 @@ __device__ __forceinline__ void mlp_fwd(const float* sm, int lane, const f32x16 
 // Evaluate the field MLP for the 64 samples owned by the 64 lanes of a wave.
 // (x,y,z) = this lane's sample in scaled field-local coordinates.  Returns the 4 raw outputs.
 // HASH: 0 = encoding from the per-feature table (raw / sin / cos), 1 = permutohedral hash, 2 = triplane (tc)
-template <int MI, int MH, int L, bool NEED_COS, int HASH = 0, int SKIP = 0, bool B3 = false>
+template <int MI, int MH, int L, bool NEED_COS, int HASH = 0, int SKIP = 0, bool B3 = false, bool WT = true>
 __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, float y, float z, const HashCtx* hc = nullptr,
                                           const ActStash* st = nullptr, PhaseClock* pc = nullptr,
                                           const ngm_u32x4* b3w = nullptr, const TriCtx* tc = nullptr) {
@@ -935,7 +943,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
     encode_hash(sm + LY::ENCW, *hc, hi, hi ? x : ox, hi ? y : oy, hi ? z : oz, E[1][0]);
     // training: the encoding itself is what the backward cannot cheaply recompute (simplex search + 64 table
     // gathers per sample) -> stash it (128 B per sample); the one hidden layer is recomputed there
-    if (st && st->base) act_store<MI, 2>(*st, 0, lane, E);
+    if (st && st->base) act_store<MI, 2, WT>(*st, 0, lane, E);
 #ifdef NGM_ABLF_HASHCELLS   // timing ablation (results meaningless): what stashing the lattice search for k_hash_grad would cost the
                             // forward -- 24 bytes (4 x 16-bit slots + 4 fp32 weights) per (sample, level), level-major, written over
                             // the encoding stash's memory (wrapped: the backward then reads garbage)
@@ -977,7 +985,7 @@ __device__ __forceinline__ float4 eval_64(const float* sm, int lane, float x, fl
 #pragma unroll
     for (int m = 0; m < MH; ++m) Hl[nt][m] = E[nt][m % MI];
 #else
-  mlp_fwd<MI, MH, L, 2, SKIP, B3>(sm, lane, E, Hl, HASH == 1 ? nullptr : st, pc, b3w);
+  mlp_fwd<MI, MH, L, 2, SKIP, B3, WT>(sm, lane, E, Hl, HASH == 1 ? nullptr : st, pc, b3w);
 #endif
   float part[2][4];
   out_layer_partial<MH, 2>(sm + LY::WOUT, hi, Hl, part);

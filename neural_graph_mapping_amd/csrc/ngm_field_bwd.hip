@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(NT) void k_hash_grad(HashGradArgs a) {
             pp[c] = pp[c] - lr_bc1 * (mn / (sqrtf(vn) * inv_sqrt_bc2 + a.ad_eps));
           }
           reinterpret_cast<float4*>(a.ad_m)[o4] = m; reinterpret_cast<float4*>(a.ad_v)[o4] = v;
-          reinterpret_cast<float4*>(a.ad_param)[o4] = p;
+          reinterpret_cast<float4*>(a.ad_param)[o4] = p;      // (written through: no measurable difference, round 6)
           if (a.ad_lp) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) ngm_stp(a.ad_lp, 4 * o4 + c, pp[c], a.ad_lp_dt);

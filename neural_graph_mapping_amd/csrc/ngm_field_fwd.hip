@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NT) void k_field_points_fwd(PointsFwdArgs a) {
     ActStash ast;
     ast.base = (HASH == 0 && MH == 2 && SKIP == 0) ? a.act : nullptr; ast.layer_stride = a.act_layer_stride;
     ast.g0 = (int64_t)f * a.P + base; ast.nvalid = (int)min((int64_t)64, end - base); ast.nlayers = NGM_MAX_LAYERS;
-    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3>(sm, lane, x, y, z, &hc, ast.base ? &ast : nullptr, nullptr, b3w, &tc);
+    const float4 o = eval_64<MI, MH, L, NEED_COS, HASH, SKIP, B3, false>(sm, lane, x, y, z, &hc, ast.base ? &ast : nullptr, nullptr, b3w, &tc);
     if (valid) reinterpret_cast<float4*>(a.out)[(int64_t)f * a.P + idx] = o;
   }
 }

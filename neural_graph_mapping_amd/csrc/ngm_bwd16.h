@@ -59,6 +59,10 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+// cache policy of the streamed (read-once) transfers: non-temporal by default; -DNGM_DMA_HINT='""' / '"sc1"' for A/B runs
+#ifndef NGM_DMA_HINT
+#define NGM_DMA_HINT "nt"
+#endif
 __device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint32_t lds_base) {
 #ifdef NGM_ABLS_NODMA   // timing ablation: no activation DMA at all (results meaningless)
   return;
@@ -68,7 +72,7 @@ __device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint3
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2 nt\n\t"
+      "global_load_lds_dwordx4 %1, %2 " NGM_DMA_HINT "\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_base)

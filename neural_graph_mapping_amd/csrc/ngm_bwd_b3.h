@@ -83,10 +83,10 @@ __device__ __forceinline__ void dma16_x4(const char* sb, uint32_t voff, uint32_t
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2 nt\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+      "global_load_lds_dwordx4 %1, %2 " NGM_DMA_HINT "\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024 " NGM_DMA_HINT "\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:2048 " NGM_DMA_HINT "\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:3072 " NGM_DMA_HINT "\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(sb), "s"(lds_base)
